@@ -1,0 +1,152 @@
+"""ctypes binding of libbdf_hip.so (include/bdf.h).
+
+The library is the product: there is no Python/CPU fallback for anything it computes.  A missing
+library raises at import of this module's `lib()`; a missing GPU raises at context creation.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbdf_hip.so")
+
+BDF_MAX_MODES = 4
+BDF_MAX_TERMS = 4
+BDF_MAX_D = 64
+
+P_ROW, P_BETA_E1, P_BETA_E2, P_NW_NORMAL, P_GAMMA_N, P_GAMMA_U, P_NW_MEAN = 1, 2, 3, 4, 5, 6, 7
+
+
+class ArgumentError(ValueError):
+    """The reference's ArgumentError."""
+
+
+class DimensionMismatch(ValueError):
+    """The reference's DimensionMismatch."""
+
+
+class BoundsError(IndexError):
+    """The reference's BoundsError."""
+
+
+class HipError(RuntimeError):
+    pass
+
+
+class NotPositiveDefinite(ArithmeticError):
+    pass
+
+
+class NoGpuError(RuntimeError):
+    pass
+
+
+_ERR = {-1: ArgumentError, -2: BoundsError, -3: HipError, -4: NotPositiveDefinite, -5: NoGpuError}
+
+c_dp = C.POINTER(C.c_double)
+c_i64p = C.POINTER(C.c_int64)
+c_i32p = C.POINTER(C.c_int32)
+
+
+class Term(C.Structure):
+    """bdf_term"""
+    _fields_ = [("rel", C.c_void_p), ("mode", C.c_int32), ("_pad", C.c_int32), ("alpha", C.c_double),
+                ("mean_value", C.c_double), ("linear_values", C.c_void_p), ("factors", C.c_void_p * BDF_MAX_MODES)]
+
+
+_SIGS = {
+    # name: (restype, argtypes)
+    "bdf_last_error": (C.c_char_p, []),
+    "bdf_version": (C.c_int, []),
+    "bdf_ctx_create": (C.c_int, [C.c_int, C.c_void_p, C.c_uint64, C.POINTER(C.c_void_p)]),
+    "bdf_ctx_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_ctx_set_sweep": (C.c_int, [C.c_void_p, C.c_uint32]),
+    "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
+    "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
+    "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "bdf_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bdf_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "bdf_index_build": (C.c_int, [C.c_int, c_i64p, C.c_int64, C.c_void_p, C.c_int, C.POINTER(c_i64p), C.POINTER(c_i64p)]),
+    "bdf_relation_create": (C.c_int, [C.c_void_p, C.c_int, c_i64p, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
+    "bdf_relation_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_relation_index": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(c_i64p), C.POINTER(c_i64p)]),
+    "bdf_relation_value_mean": (C.c_int, [C.c_void_p, c_dp]),
+    "bdf_relation_order": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
+    "bdf_sample_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
+                                  C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p]),
+    "bdf_row_system": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
+                                 C.c_void_p, C.c_void_p]),
+    "bdf_normals": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
+    "bdf_philox": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "bdf_hyper_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_hyper_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                   C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
+    "bdf_pairs_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),
+    "bdf_predict_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_int, C.c_double,
+                                     C.c_double, C.c_double, C.c_void_p]),
+    "bdf_pairs_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i64p]),
+    "bdf_feat_create_dense": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, c_dp, C.POINTER(C.c_void_p)]),
+    "bdf_feat_create_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_dp, C.POINTER(C.c_void_p)]),
+    "bdf_feat_create_bin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_void_p)]),
+    "bdf_feat_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_feat_size": (C.c_int, [C.c_void_p, c_i64p, c_i64p, c_i64p]),
+    "bdf_feat_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
+    "bdf_feat_AtA_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),
+    "bdf_uhat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_hyper_feature_terms": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_sample_beta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                  C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
+                                  C.c_void_p]),
+}
+
+_LIB = None
+
+
+def _preload_torch_hip_runtime():
+    """torch ships its own libamdhip64.so (soname libamdhip64.so.7, the same soname as /opt/rocm's).  If this
+    library pulled in the system copy first, a later `import torch` would load a second HIP runtime into the
+    process and one of the two would see no device.  Loading torch's copy first makes both resolve to it; hosts
+    without torch (e.g. Julia) simply use the system runtime."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return
+    path = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        C.CDLL(path, mode=C.RTLD_GLOBAL)
+
+
+def lib():
+    """The loaded library; raises if it has not been built (python __graft_entry__.py build)."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: the HIP library is the product and has no fallback. "
+                              "Build it with `make -C bayesiandatafusion.jl_amd/csrc` (hipcc --offload-arch=gfx950).")
+        _preload_torch_hip_runtime()
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(L, name)          # AttributeError if the library lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = L
+    return _LIB
+
+
+def declared_symbols():
+    return sorted(_SIGS)
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().bdf_last_error().decode("utf-8", "replace")
+        exc = _ERR.get(rc, RuntimeError)
+        if exc is ArgumentError and "DimensionMismatch" in msg:
+            exc = DimensionMismatch
+        raise exc(msg)
+    return rc

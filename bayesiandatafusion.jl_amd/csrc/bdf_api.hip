@@ -1,0 +1,428 @@
+// bdf_api.hip -- C-ABI entry points: context, device memory, IndexedDF -> device CSR, row sampling front-end
+#include "bdf_common.h"
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+static thread_local char g_err[512] = "";
+
+void bdf_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *bdf_last_error(void) { return g_err; }
+extern "C" int bdf_version(void) { return 100; }
+
+// ---- context -----------------------------------------------------------------------------
+extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx **out)
+{
+    BDF_REQUIRE(out != nullptr, BDF_ERR_ARG, "bdf_ctx_create: out is NULL");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        bdf_set_error("bdf_ctx_create: no HIP device visible (this library has no CPU path)");
+        return BDF_ERR_NOGPU;
+    }
+    BDF_REQUIRE(device >= 0 && device < ndev, BDF_ERR_ARG, "bdf_ctx_create: device %d out of range (0..%d)", device, ndev - 1);
+    BDF_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    BDF_HIP(hipGetDeviceProperties(&prop, device));
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        bdf_set_error("bdf_ctx_create: device %d is %s; this library is built for gfx950 only", device, prop.gcnArchName);
+        return BDF_ERR_NOGPU;
+    }
+    bdf_ctx *c = new bdf_ctx();
+    c->device = device;
+    c->seed = seed;
+    c->own_stream = false;
+    c->stream = (hipStream_t)stream;          // NULL is the device's default stream
+    BDF_HIP(hipMalloc((void **)&c->sweep_dev, sizeof(uint32_t)));
+    BDF_HIP(hipMalloc((void **)&c->flag_dev, sizeof(int)));
+    BDF_HIP(hipMemsetAsync(c->sweep_dev, 0, sizeof(uint32_t), c->stream));
+    BDF_HIP(hipMemsetAsync(c->flag_dev, 0, sizeof(int), c->stream));
+    c->sweep_host = 0;
+    c->scratch = nullptr;
+    c->scratch_bytes = 0;
+    *out = c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
+{
+    if (!ctx) return BDF_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    if (ctx->scratch) hipFree(ctx->scratch);
+    hipFree(ctx->sweep_dev);
+    hipFree(ctx->flag_dev);
+    if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return BDF_OK;
+}
+
+int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->scratch_bytes) {
+        // growing frees the old block: wait for work that may still read it
+        BDF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch) BDF_HIP(hipFree(ctx->scratch));
+        size_t nb = std::max(bytes, ctx->scratch_bytes * 2);
+        nb = (nb + 255) & ~(size_t)255;
+        BDF_HIP(hipMalloc(&ctx->scratch, nb));
+        ctx->scratch_bytes = nb;
+    }
+    *out = ctx->scratch;
+    return BDF_OK;
+}
+
+__global__ void k_set_u32(uint32_t *p, uint32_t v) { *p = v; }
+__global__ void k_inc_u32(uint32_t *p) { *p = *p + 1; }
+
+extern "C" int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_set_sweep: ctx is NULL");
+    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, ctx->sweep_dev, sweep);
+    BDF_HIP(hipGetLastError());
+    ctx->sweep_host = sweep;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_advance_sweep(bdf_ctx *ctx)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_advance_sweep: ctx is NULL");
+    hipLaunchKernelGGL(k_inc_u32, dim3(1), dim3(1), 0, ctx->stream, ctx->sweep_dev);
+    BDF_HIP(hipGetLastError());
+    ctx->sweep_host++;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_sync: ctx is NULL");
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    int flag = 0;
+    BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag) {
+        BDF_HIP(hipMemset(ctx->flag_dev, 0, sizeof(int)));
+        bdf_set_error("a matrix that must be positive definite was not (flag %d)", flag);
+        return BDF_ERR_NOTPD;
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr)
+{
+    BDF_REQUIRE(ctx && dptr, BDF_ERR_ARG, "bdf_dev_alloc: NULL argument");
+    BDF_HIP(hipSetDevice(ctx->device));
+    BDF_HIP(hipMalloc(dptr, bytes ? bytes : 8));
+    return BDF_OK;
+}
+
+extern "C" int bdf_dev_free(bdf_ctx *ctx, void *dptr)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_dev_free: ctx is NULL");
+    if (dptr) {
+        BDF_HIP(hipStreamSynchronize(ctx->stream));
+        BDF_HIP(hipFree(dptr));
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_h2d(bdf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    BDF_REQUIRE(ctx && (bytes == 0 || (dst && src)), BDF_ERR_ARG, "bdf_h2d: NULL argument");
+    if (bytes) {
+        BDF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+        BDF_HIP(hipStreamSynchronize(ctx->stream));   // src is caller-owned for the call only
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_d2h(bdf_ctx *ctx, void *dst, const void *src, size_t bytes)
+{
+    BDF_REQUIRE(ctx && (bytes == 0 || (dst && src)), BDF_ERR_ARG, "bdf_d2h: NULL argument");
+    if (bytes) {
+        BDF_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        BDF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return BDF_OK;
+}
+
+template <typename T>
+static int upload(bdf_ctx *ctx, const std::vector<T> &v, T **dptr)
+{
+    size_t bytes = std::max<size_t>(v.size() * sizeof(T), 8);
+    BDF_HIP(hipMalloc((void **)dptr, bytes));
+    if (!v.empty()) BDF_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BDF_OK;
+}
+
+// ---- a1: IndexedDF / FastIDF ------------------------------------------------------------
+// IndexedDF.jl:10-19 pushes COO row i onto index[mode][id] in row order: a stable counting sort.
+static inline int64_t id_at(const void *ids, int id_bytes, int64_t nnz, int64_t i, int m)
+{
+    size_t off = (size_t)m * (size_t)nnz + (size_t)i;
+    return id_bytes == 8 ? ((const int64_t *)ids)[off] : (int64_t)((const int32_t *)ids)[off];
+}
+
+extern "C" int bdf_index_build(int n_modes, const int64_t *dims, int64_t nnz, const void *ids, int id_bytes,
+                               int64_t *const *rowptr, int64_t *const *rowids)
+{
+    BDF_REQUIRE(dims && rowptr && rowids, BDF_ERR_ARG, "bdf_index_build: NULL argument");
+    BDF_REQUIRE(n_modes >= 1 && n_modes <= BDF_MAX_MODES, BDF_ERR_ARG, "bdf_index_build: n_modes=%d must be in 1..%d", n_modes, BDF_MAX_MODES);
+    BDF_REQUIRE(id_bytes == 4 || id_bytes == 8, BDF_ERR_ARG, "bdf_index_build: id_bytes must be 4 or 8");
+    BDF_REQUIRE(nnz >= 0 && (nnz == 0 || ids), BDF_ERR_ARG, "bdf_index_build: ids NULL");
+    for (int m = 0; m < n_modes; m++) {
+        const int64_t N = dims[m];
+        BDF_REQUIRE(N >= 0 && rowptr[m] && (nnz == 0 || rowids[m]), BDF_ERR_ARG, "bdf_index_build: bad mode %d", m);
+        int64_t *rp = rowptr[m], *ri = rowids[m];
+        for (int64_t j = 0; j <= N; j++) rp[j] = 0;
+        for (int64_t i = 0; i < nnz; i++) {
+            int64_t j = id_at(ids, id_bytes, nnz, i, m);
+            if (j < 1 || j > N) {
+                bdf_set_error("id %lld of mode %d at row %lld outside 1..%lld (BoundsError)", (long long)j, m + 1,
+                              (long long)(i + 1), (long long)N);
+                return BDF_ERR_BOUNDS;
+            }
+            rp[j]++;
+        }
+        for (int64_t j = 0; j < N; j++) rp[j + 1] += rp[j];
+        std::vector<int64_t> cursor(rp, rp + N);
+        for (int64_t i = 0; i < nnz; i++) ri[cursor[(size_t)id_at(ids, id_bytes, nnz, i, m) - 1]++] = i + 1;
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz,
+                                   const void *ids, int id_bytes, const double *values, bdf_rel **out)
+{
+    BDF_REQUIRE(ctx && dims && out, BDF_ERR_ARG, "bdf_relation_create: NULL argument");
+    BDF_REQUIRE(n_modes >= 2 && n_modes <= BDF_MAX_MODES, BDF_ERR_ARG,
+                "bdf_relation_create: n_modes=%d must be in 2..%d", n_modes, BDF_MAX_MODES);
+    BDF_REQUIRE(id_bytes == 4 || id_bytes == 8, BDF_ERR_ARG, "bdf_relation_create: id_bytes must be 4 or 8");
+    BDF_REQUIRE(nnz >= 0 && nnz < (int64_t)0x7fffffff, BDF_ERR_ARG, "bdf_relation_create: nnz=%lld unsupported", (long long)nnz);
+    BDF_REQUIRE(nnz == 0 || (ids && values), BDF_ERR_ARG, "bdf_relation_create: ids/values NULL");
+    for (int m = 0; m < n_modes; m++)
+        BDF_REQUIRE(dims[m] >= 0 && dims[m] < (int64_t)0x7fffffff, BDF_ERR_ARG, "bdf_relation_create: dims[%d]=%lld unsupported", m, (long long)dims[m]);
+    BDF_HIP(hipSetDevice(ctx->device));
+    auto idat = [&](int64_t i, int m) -> int64_t { return id_at(ids, id_bytes, nnz, i, m); };
+
+    bdf_rel *r = new bdf_rel();
+    r->ctx = ctx;
+    r->n_modes = n_modes;
+    r->nnz = nnz;
+    for (int m = 0; m < n_modes; m++) r->dims[m] = dims[m];
+    double s = 0.0;
+    for (int64_t i = 0; i < nnz; i++) s += values[i];
+    r->value_mean = nnz ? s / (double)nnz : NAN;
+
+    {
+        int64_t *rps[BDF_MAX_MODES], *ris[BDF_MAX_MODES];
+        for (int m = 0; m < n_modes; m++) {
+            r->idx[m].rowptr.assign((size_t)dims[m] + 1, 0);
+            r->idx[m].rowids.assign((size_t)std::max<int64_t>(nnz, 1), 0);
+            rps[m] = r->idx[m].rowptr.data();
+            ris[m] = r->idx[m].rowids.data();
+        }
+        int rc = bdf_index_build(n_modes, dims, nnz, ids, id_bytes, rps, ris);
+        if (rc) { delete r; return rc; }
+    }
+    for (int m = 0; m < n_modes; m++) {
+        bdf_mode_index &ix = r->idx[m];
+        const int64_t N = dims[m];
+        std::vector<int32_t> colidx((size_t)nnz * (size_t)(n_modes - 1));
+        std::vector<double> vals((size_t)nnz);
+        std::vector<int32_t> perm((size_t)nnz);
+        for (int64_t q = 0; q < nnz; q++) {
+            int64_t i = ix.rowids[(size_t)q] - 1;
+            perm[(size_t)q] = (int32_t)i;
+            vals[(size_t)q] = values[i];
+            int plane = 0;
+            for (int k = 0; k < n_modes; k++) {
+                if (k == m) continue;
+                colidx[(size_t)plane * (size_t)nnz + (size_t)q] = (int32_t)(idat(i, k) - 1);
+                plane++;
+            }
+        }
+        ix.order.resize((size_t)N);
+        std::iota(ix.order.begin(), ix.order.end(), 0);
+        std::stable_sort(ix.order.begin(), ix.order.end(), [&](int32_t x, int32_t y) {
+            return (ix.rowptr[(size_t)x + 1] - ix.rowptr[(size_t)x]) > (ix.rowptr[(size_t)y + 1] - ix.rowptr[(size_t)y]);
+        });
+        int rc;
+        if ((rc = upload(ctx, ix.rowptr, &ix.rowptr_dev))) return rc;
+        if ((rc = upload(ctx, colidx, &ix.colidx_dev))) return rc;
+        if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
+        if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
+        if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
+    }
+    *out = r;
+    return BDF_OK;
+}
+
+extern "C" int bdf_relation_destroy(bdf_rel *rel)
+{
+    if (!rel) return BDF_OK;
+    hipSetDevice(rel->ctx->device);
+    hipStreamSynchronize(rel->ctx->stream);
+    for (int m = 0; m < rel->n_modes; m++) {
+        bdf_mode_index &ix = rel->idx[m];
+        hipFree(ix.rowptr_dev); hipFree(ix.colidx_dev); hipFree(ix.vals_dev); hipFree(ix.perm_dev); hipFree(ix.order_dev);
+    }
+    delete rel;
+    return BDF_OK;
+}
+
+extern "C" int bdf_relation_index(const bdf_rel *rel, int mode, const int64_t **rowptr, const int64_t **rowids)
+{
+    BDF_REQUIRE(rel && rowptr && rowids, BDF_ERR_ARG, "bdf_relation_index: NULL argument");
+    BDF_REQUIRE(mode >= 0 && mode < rel->n_modes, BDF_ERR_ARG, "bdf_relation_index: mode %d out of range", mode);
+    *rowptr = rel->idx[mode].rowptr.data();
+    *rowids = rel->idx[mode].rowids.data();
+    return BDF_OK;
+}
+
+extern "C" int bdf_relation_value_mean(const bdf_rel *rel, double *mean)
+{
+    BDF_REQUIRE(rel && mean, BDF_ERR_ARG, "bdf_relation_value_mean: NULL argument");
+    *mean = rel->value_mean;
+    return BDF_OK;
+}
+
+extern "C" int bdf_relation_order(const bdf_rel *rel, int mode, int32_t *order_host)
+{
+    BDF_REQUIRE(rel && order_host, BDF_ERR_ARG, "bdf_relation_order: NULL argument");
+    BDF_REQUIRE(mode >= 0 && mode < rel->n_modes, BDF_ERR_ARG, "bdf_relation_order: mode %d out of range", mode);
+    memcpy(order_host, rel->idx[mode].order.data(), rel->idx[mode].order.size() * sizeof(int32_t));
+    return BDF_OK;
+}
+
+// ---- a3-a7: rows ---------------------------------------------------------------------------
+static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_terms, const bdf_term *terms,
+                     const double *mu, int mu_is_matrix, const double *Lambda, SampleArgs &a)
+{
+    BDF_REQUIRE(ctx && terms && mu && Lambda, BDF_ERR_ARG, "%s: NULL argument", who);
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "%s: num_latent=%d must be in 1..%d", who, D, BDF_MAX_D);
+    BDF_REQUIRE(n_terms >= 1 && n_terms <= BDF_MAX_TERMS, BDF_ERR_ARG, "%s: n_terms=%d must be in 1..%d", who, n_terms, BDF_MAX_TERMS);
+    memset(&a, 0, sizeof(a));
+    for (int r = 0; r < n_terms; r++) {
+        const bdf_term &t = terms[r];
+        BDF_REQUIRE(t.rel != nullptr, BDF_ERR_ARG, "%s: terms[%d].rel is NULL", who, r);
+        BDF_REQUIRE(t.rel->ctx == ctx, BDF_ERR_ARG, "%s: terms[%d].rel belongs to another context", who, r);
+        BDF_REQUIRE(t.mode >= 0 && t.mode < t.rel->n_modes, BDF_ERR_ARG, "%s: terms[%d].mode=%d out of range", who, r, t.mode);
+        BDF_REQUIRE(t.rel->dims[t.mode] == N, BDF_ERR_ARG,
+                    "%s: entity has %lld instances, relation %d has data for %lld (ArgumentError)", who, (long long)N, r,
+                    (long long)t.rel->dims[t.mode]);
+        const bdf_mode_index &ix = t.rel->idx[t.mode];
+        TermDev &T = a.t[r];
+        T.rowptr = ix.rowptr_dev;
+        T.colidx = ix.colidx_dev;
+        T.vals = ix.vals_dev;
+        T.perm = ix.perm_dev;
+        T.linear = t.linear_values;
+        T.nnz = t.rel->nnz;
+        T.n_other = t.rel->n_modes - 1;
+        int plane = 0;
+        for (int k = 0; k < t.rel->n_modes; k++) {
+            if (k == t.mode) continue;
+            BDF_REQUIRE(t.factors[k] != nullptr, BDF_ERR_ARG, "%s: terms[%d].factors[%d] is NULL", who, r, k);
+            T.fac[plane++] = t.factors[k];
+        }
+        T.alpha = t.alpha;
+        T.mean = t.mean_value;
+    }
+    a.n_terms = n_terms;
+    a.D = D;
+    a.mu = mu;
+    a.mu_is_matrix = mu_is_matrix;
+    a.Lambda = Lambda;
+    a.sweep = ctx->sweep_dev;
+    a.seed = ctx->seed;
+    a.flag = ctx->flag_dev;
+    return BDF_OK;
+}
+
+extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
+                               const double *mu, int mu_is_matrix, const double *Lambda,
+                               uint32_t entity_tag, const int32_t *rowlist, int64_t n_rows, double *out)
+{
+    SampleArgs a;
+    int rc = fill_args(ctx, "bdf_sample_rows", D, N, n_terms, terms, mu, mu_is_matrix, Lambda, a);
+    if (rc) return rc;
+    BDF_REQUIRE(out != nullptr, BDF_ERR_ARG, "bdf_sample_rows: out is NULL");
+    for (int r = 0; r < n_terms; r++)
+        for (int k = 0; k < terms[r].rel->n_modes; k++)
+            BDF_REQUIRE(k == terms[r].mode || terms[r].factors[k] != out, BDF_ERR_ARG,
+                        "bdf_sample_rows: out aliases terms[%d].factors[%d]", r, k);
+    if (rowlist) {
+        BDF_REQUIRE(n_rows >= 0 && n_rows <= N, BDF_ERR_ARG, "bdf_sample_rows: n_rows=%lld outside 0..N", (long long)n_rows);
+        a.rowlist = rowlist;
+        a.nrows = n_rows;
+    } else {
+        a.rowlist = terms[0].rel->idx[terms[0].mode].order_dev;
+        a.nrows = N;
+    }
+    a.entity_tag = entity_tag;
+    a.out = out;
+    return bdf_launch_sample_rows(ctx, a, false);
+}
+
+extern "C" int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
+                              const double *mu, int mu_is_matrix, const double *Lambda,
+                              double *P_out, double *b_out)
+{
+    SampleArgs a;
+    int rc = fill_args(ctx, "bdf_row_system", D, N, n_terms, terms, mu, mu_is_matrix, Lambda, a);
+    if (rc) return rc;
+    BDF_REQUIRE(P_out && b_out, BDF_ERR_ARG, "bdf_row_system: NULL output");
+    a.rowlist = nullptr;
+    a.nrows = N;
+    a.P_dump = P_out;
+    a.b_dump = b_out;
+    return bdf_launch_sample_rows(ctx, a, true);
+}
+
+__global__ void k_normals(uint64_t seed, const uint32_t *sweep, uint32_t purpose, uint32_t entity,
+                          int64_t row_begin, int64_t n_rows, int n, double *out)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_rows * n) return;
+    int64_t r = idx / n;
+    int e = (int)(idx % n);
+    out[idx] = bdf_normal(seed, *sweep, purpose, entity, (uint64_t)(row_begin + r), e);
+}
+
+extern "C" int bdf_normals(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, int64_t row_begin,
+                           int64_t n_rows, int n, double *out)
+{
+    BDF_REQUIRE(ctx && out && n >= 1 && n_rows >= 0, BDF_ERR_ARG, "bdf_normals: bad argument");
+    int64_t total = n_rows * n;
+    if (total == 0) return BDF_OK;
+    hipLaunchKernelGGL(k_normals, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seed,
+                       ctx->sweep_dev, purpose, entity_tag, row_begin, n_rows, n, out);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+__global__ void k_philox(uint64_t seed, const uint32_t *sweep, uint32_t purpose, uint32_t entity, uint64_t row,
+                         uint32_t pair, uint32_t *out)
+{
+    u32x4 o = bdf_draw(seed, *sweep, purpose, entity, row, pair);
+    out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w;
+}
+
+extern "C" int bdf_philox(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, uint64_t row, uint32_t pair,
+                          uint32_t out_host[4])
+{
+    BDF_REQUIRE(ctx && out_host, BDF_ERR_ARG, "bdf_philox: NULL argument");
+    void *s;
+    int rc = bdf_scratch(ctx, 256, &s);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_philox, dim3(1), dim3(1), 0, ctx->stream, ctx->seed, ctx->sweep_dev, purpose, entity_tag, row,
+                       pair, (uint32_t *)s);
+    BDF_HIP(hipGetLastError());
+    return bdf_d2h(ctx, out_host, s, 4 * sizeof(uint32_t));
+}

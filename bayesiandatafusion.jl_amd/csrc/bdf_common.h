@@ -1,0 +1,202 @@
+// bdf_common.h -- internal declarations shared by the HIP translation units of libbdf_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstdarg>
+#include <cstring>
+#include <vector>
+#include "../../include/bdf.h"
+
+void bdf_set_error(const char *fmt, ...);
+
+#define BDF_HIP(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            bdf_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e__), __FILE__, __LINE__); \
+            return BDF_ERR_HIP;                                                            \
+        }                                                                                  \
+    } while (0)
+
+#define BDF_REQUIRE(cond, code, ...)                                                       \
+    do {                                                                                   \
+        if (!(cond)) { bdf_set_error(__VA_ARGS__); return (code); }                        \
+    } while (0)
+
+struct bdf_ctx {
+    int device;
+    hipStream_t stream;
+    bool own_stream;
+    uint64_t seed;
+    uint32_t *sweep_dev;       // Gibbs iteration counter in device memory
+    uint32_t sweep_host;       // mirror of the last bdf_ctx_set_sweep / advance
+    // scratch (grown on demand, never shrunk)
+    void *scratch;
+    size_t scratch_bytes;
+    int *flag_dev;             // not-positive-definite flag
+};
+
+int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
+
+struct bdf_mode_index {
+    std::vector<int64_t> rowptr;   // host, dims+1
+    std::vector<int64_t> rowids;   // host, nnz, 1-based COO row numbers (IndexedDF.index)
+    std::vector<int32_t> order;    // host, rows by descending degree (stable)
+    int64_t *rowptr_dev;           // dims+1
+    int32_t *colidx_dev;           // (n_modes-1) planes of nnz: 0-based ids of the other modes, mode order
+    double  *vals_dev;             // nnz values in mode order
+    int32_t *perm_dev;             // nnz: 0-based COO row number in mode order
+    int32_t *order_dev;
+};
+
+struct bdf_rel {
+    bdf_ctx *ctx;
+    int n_modes;
+    int64_t dims[BDF_MAX_MODES];
+    int64_t nnz;
+    double value_mean;
+    bdf_mode_index idx[BDF_MAX_MODES];
+};
+
+struct bdf_pairs {
+    bdf_ctx *ctx;
+    int n_modes;
+    int64_t n;
+    int32_t *ids_dev;     // n_modes planes of n, 0-based
+    double *values_dev;   // n
+    double *avg_dev, *sq_dev;
+    double count;         // counter_prob (macau.jl:171-183)
+};
+
+struct bdf_feat {
+    bdf_ctx *ctx;
+    int kind;             // 0 dense, 1 csr (real), 2 binary
+    int64_t m, n, nnz;
+    double *dense_dev;    // m x n column-major
+    // CSR (rows) and CSC (= CSR of F') so that neither product needs atomics
+    int64_t *rowptr_dev; int32_t *colind_dev; double *rvals_dev;
+    int64_t *colptr_dev; int32_t *rowind_dev; double *cvals_dev;
+    double *FF_dev;       // n x n (F'F), built on first use_ff
+};
+
+// ---------------------------------------------------------------------------------------
+// Philox4x32-10 + Box-Muller (host+device).  Counter layout: DESIGN.md "RNG contract".
+// ---------------------------------------------------------------------------------------
+struct u32x4 { uint32_t x, y, z, w; };
+
+__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
+{
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c.x;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c.z;
+        u32x4 n;
+        n.x = (uint32_t)(p1 >> 32) ^ c.y ^ k0;
+        n.y = (uint32_t)p1;
+        n.z = (uint32_t)(p0 >> 32) ^ c.w ^ k1;
+        n.w = (uint32_t)p0;
+        c = n;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c;
+}
+
+__host__ __device__ inline u32x4 bdf_draw(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+                                          uint64_t row, uint32_t pair)
+{
+    u32x4 c;
+    c.x = (uint32_t)row;
+    c.y = (uint32_t)((row >> 32) & 0xffffu) | (pair << 16);
+    c.z = sweep;
+    c.w = (purpose << 24) | (entity & 0xffffffu);
+    return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+}
+
+__host__ __device__ inline double bdf_u01(uint32_t lo, uint32_t hi)
+{
+    uint64_t x = ((uint64_t)hi << 32) | lo;
+    return ((double)(x >> 11) + 0.5) * 0x1.0p-53;
+}
+
+// standard normal number `n` (0-based) of stream (purpose, entity, row): pair n/2, element n%2
+__device__ inline double bdf_normal(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+                                    uint64_t row, int n)
+{
+    u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, (uint32_t)(n >> 1));
+    double u1 = bdf_u01(o.x, o.y), u2 = bdf_u01(o.z, o.w);
+    double r = sqrt(-2.0 * log(u1));
+    double t = 6.283185307179586476925286766559 * u2;
+    return (n & 1) ? r * sin(t) : r * cos(t);
+}
+
+__device__ inline double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+                                     uint64_t row, uint32_t pair)
+{
+    u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, pair);
+    return bdf_u01(o.x, o.y);
+}
+
+// Gamma(a, 1), Marsaglia-Tsang; variate index g addresses the stream, the attempt is the pair
+__device__ inline double bdf_gamma(uint64_t seed, uint32_t sweep, uint32_t entity, uint64_t g, double a)
+{
+    double boost = 1.0;
+    if (a < 1.0) {
+        boost = pow(bdf_uniform(seed, sweep, BDF_P_GAMMA_U, entity, g, 0xffffu), 1.0 / a);
+        a += 1.0;
+    }
+    double d = a - 1.0 / 3.0, c = 1.0 / sqrt(9.0 * d);
+    for (uint32_t t = 0; t < 256; t++) {
+        double x = bdf_normal(seed, sweep, BDF_P_GAMMA_N, entity, g, (int)(2 * t));
+        double v = 1.0 + c * x;
+        if (v <= 0.0) continue;
+        v = v * v * v;
+        double u = bdf_uniform(seed, sweep, BDF_P_GAMMA_U, entity, g, t);
+        if (u < 1.0 - 0.0331 * (x * x) * (x * x)) return boost * d * v;
+        if (log(u) < 0.5 * x * x + d * (1.0 - v + log(v))) return boost * d * v;
+    }
+    return boost * d;
+}
+
+// ---------------------------------------------------------------------------------------
+// wave-level helpers (wave = 64 lanes)
+// ---------------------------------------------------------------------------------------
+__device__ inline double readlane_f64(double v, int lane)   // lane must be wave-uniform
+{
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+// kernel launch argument blocks ------------------------------------------------------------
+struct TermDev {
+    const int64_t *rowptr;
+    const int32_t *colidx;
+    const double *vals;
+    const int32_t *perm;
+    const double *linear;
+    const double *fac[BDF_MAX_MODES - 1];
+    int64_t nnz;
+    int32_t n_other;
+    int32_t _pad;
+    double alpha, mean;
+};
+
+struct SampleArgs {
+    TermDev t[BDF_MAX_TERMS];
+    int32_t n_terms, D;
+    const int32_t *rowlist;
+    int64_t nrows;
+    const double *mu;
+    int32_t mu_is_matrix, _pad;
+    const double *Lambda;
+    const uint32_t *sweep;
+    uint64_t seed;
+    uint32_t entity_tag, _pad2;
+    double *out;
+    double *P_dump, *b_dump;
+    int *flag;
+};
+
+int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, bool dump);

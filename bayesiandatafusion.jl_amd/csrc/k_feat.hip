@@ -1,0 +1,648 @@
+// k_feat.hip -- K2..K5: the side-information (Entity.F) operators and the beta update.
+//
+//   Entity.F operator contract: F*B, At_mul_B(F,B), AtA_mul_B! for dense F, SparseMatrixCSR
+//   (src/parallel_csr.jl:36-54) and binary sparse F (src/sparsebin_csr.jl:22-63, src/parallel_matrix.jl:19-24,
+//   242-267).  Sparse operators keep the CSR of F and the CSR of F' so that both products are row gathers with
+//   no atomics (the reference's COO At_mul_B! scatters, parallel_matrix.jl:258-267).
+//   uhat = (F beta)'                                   F_mul_beta, src/RelationData.jl:314-320; macau.jl:103,112
+//   rhs  = F'((sample - mu)' + E1) + sqrt(lb) E2       sample_beta, src/sampling.jl:298-300
+//   beta = (F'F + lb I) \ rhs                          solve_full :314-320 | solve_cg2 parallel_matrix.jl:488-507
+//   all D conjugate-gradient solves advance together, each column keeping the reference's own stopping rule
+//   (cg_AtA, src/parallel_cg.jl:63-94: stop when ||r|| < tol ||b||, checked before an iteration; maxiter).
+//   lambda_beta ~ Gamma                                sample_lambda_beta, src/sampling.jl:136-142
+#include "bdf_common.h"
+#include "wave_linalg.h"
+#include <algorithm>
+#include <cmath>
+
+namespace {
+
+// ---- strided dense GEMM: C(i,j) = sum_k A(i,k) B(k,j), optional second output C2 = C + bias[j] -------------
+constexpr int TM = 32, TN = 32, TK = 16;
+
+struct GemmArgs {
+    int64_t M, N, K;
+    const double *A; int64_t ars, acs;
+    const double *B; int64_t brs, bcs;
+    double *C; int64_t crs, ccs;
+    const double *bias; double *C2;
+};
+
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
+{
+    __shared__ double As[TK][TM + 1];
+    __shared__ double Bs[TK][TN + 1];
+    const int tid = threadIdx.x;
+    const int tx = tid % 16, ty = tid / 16;
+    const int64_t i0 = (int64_t)blockIdx.x * TM, j0 = (int64_t)blockIdx.y * TN;
+    double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
+    const bool a_fast_i = g.ars <= g.acs, b_fast_k = g.brs <= g.bcs;
+    for (int64_t k0 = 0; k0 < g.K; k0 += TK) {
+        for (int e = tid; e < TM * TK; e += 256) {
+            const int ii = a_fast_i ? e % TM : e / TK, kk = a_fast_i ? e / TM : e % TK;
+            const int64_t i = i0 + ii, k = k0 + kk;
+            As[kk][ii] = (i < g.M && k < g.K) ? g.A[i * g.ars + k * g.acs] : 0.0;
+        }
+        for (int e = tid; e < TN * TK; e += 256) {
+            const int kk = b_fast_k ? e % TK : e / TN, jj = b_fast_k ? e / TK : e % TN;
+            const int64_t k = k0 + kk, j = j0 + jj;
+            Bs[kk][jj] = (k < g.K && j < g.N) ? g.B[k * g.brs + j * g.bcs] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < TK; kk++) {
+            const double a0 = As[kk][tx], a1 = As[kk][tx + 16];
+            const double b0 = Bs[kk][ty], b1 = Bs[kk][ty + 16];
+            acc[0][0] = fma(a0, b0, acc[0][0]); acc[0][1] = fma(a0, b1, acc[0][1]);
+            acc[1][0] = fma(a1, b0, acc[1][0]); acc[1][1] = fma(a1, b1, acc[1][1]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int v = 0; v < 2; v++) {
+            const int64_t i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
+            if (i < g.M && j < g.N) {
+                g.C[i * g.crs + j * g.ccs] = acc[u][v];
+                if (g.C2) g.C2[i * g.crs + j * g.ccs] = acc[u][v] + g.bias[j];
+            }
+        }
+}
+
+int gemm(bdf_ctx *ctx, const GemmArgs &g)
+{
+    if (g.M == 0 || g.N == 0) return BDF_OK;
+    dim3 grid((unsigned)((g.M + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN));
+    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+// ---- sparse (CSR) x dense: Y(r,c) = sum_q val_q B(col_q, c); vals == NULL means implicit 1.0 ------------------
+struct SpmmArgs {
+    int64_t m; int ncol;
+    const int64_t *rowptr; const int32_t *colind; const double *vals;
+    const double *B; int64_t brs, bcs;
+    double *Y; int64_t yrs, ycs;
+    const double *bias; double *Y2;
+};
+
+__global__ __launch_bounds__(256) void k_spmm(SpmmArgs s)
+{
+    // 32 lanes walk the columns of the dense operand, 8 rows per block
+    const int c0 = threadIdx.x % 32;
+    const int64_t r = (int64_t)blockIdx.x * 8 + threadIdx.x / 32;
+    if (r >= s.m) return;
+    const int64_t beg = s.rowptr[r], end = s.rowptr[r + 1];
+    for (int c = c0; c < s.ncol; c += 32) {
+        double acc = 0.0;
+        for (int64_t q = beg; q < end; q++) {
+            const double v = s.vals ? s.vals[q] : 1.0;
+            acc = fma(v, s.B[(int64_t)s.colind[q] * s.brs + c * s.bcs], acc);
+        }
+        s.Y[r * s.yrs + c * s.ycs] = acc;
+        if (s.Y2) s.Y2[r * s.yrs + c * s.ycs] = acc + s.bias[c];
+    }
+}
+
+int spmm(bdf_ctx *ctx, const SpmmArgs &s)
+{
+    if (s.m == 0 || s.ncol == 0) return BDF_OK;
+    hipLaunchKernelGGL(k_spmm, dim3((unsigned)((s.m + 7) / 8)), dim3(256), 0, ctx->stream, s);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+// Y = op(F) B for any feature kind.  B(i,c) at B[i*brs + c*bcs], Y(r,c) at Y[r*yrs + c*ycs].
+int feat_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B, int64_t brs, int64_t bcs, int ncol,
+               double *Y, int64_t yrs, int64_t ycs, const double *bias = nullptr, double *Y2 = nullptr)
+{
+    if (f->kind == 0) {
+        GemmArgs g;
+        g.M = transpose ? f->n : f->m; g.N = ncol; g.K = transpose ? f->m : f->n;
+        g.A = f->dense_dev;
+        g.ars = transpose ? f->m : 1; g.acs = transpose ? 1 : f->m;
+        g.B = B; g.brs = brs; g.bcs = bcs; g.C = Y; g.crs = yrs; g.ccs = ycs; g.bias = bias; g.C2 = Y2;
+        return gemm(ctx, g);
+    }
+    SpmmArgs s;
+    s.m = transpose ? f->n : f->m; s.ncol = ncol;
+    s.rowptr = transpose ? f->colptr_dev : f->rowptr_dev;
+    s.colind = transpose ? f->rowind_dev : f->colind_dev;
+    s.vals = f->kind == 1 ? (transpose ? f->cvals_dev : f->rvals_dev) : nullptr;
+    s.B = B; s.brs = brs; s.bcs = bcs; s.Y = Y; s.yrs = yrs; s.ycs = ycs; s.bias = bias; s.Y2 = Y2;
+    return spmm(ctx, s);
+}
+
+// ---- elementwise helpers -------------------------------------------------------------------------------------
+__global__ void k_axpy_lambda(int64_t n, double lambda, const double *x, double *y)   // y += lambda x
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fma(lambda, x[i], y[i]);
+}
+
+// ---- noise rows e ~ N(0, Lambda^-1) = chol(inv(Lambda))' z  (sampling.jl:298-300) ----------------------------------
+// step 1 (one wave): L~ = chol of index-reversed Lambda; stored row-major with 1/diag in Lr[DP*DP .. DP*DP+DP)
+template <int DP>
+__global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, double *Lr, int *flag)
+{
+    const int lane = threadIdx.x;
+    const int ej = D - 1 - lane;
+    double col[DP];
+#pragma unroll
+    for (int i = 0; i < DP; i++) {
+        const int ei = D - 1 - i;
+        double w = (i == lane) ? 1.0 : 0.0;
+        if (ei >= 0 && ej >= 0) {
+            const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;    // Symmetric(Lambda): upper triangle
+            w = Lambda[lo + (int64_t)hi * D];
+        }
+        col[i] = w;
+    }
+    double rinv_own;
+    if (wl_chol_rows<DP>(col, rinv_own, lane) && lane == 0) atomicOr(flag, 4);
+    if (lane < DP) {
+#pragma unroll
+        for (int k = 0; k < DP; k++) Lr[lane * DP + k] = col[k];
+        Lr[DP * DP + lane] = rinv_own;
+    }
+}
+
+// step 2: T[:,i] = (sample[:,i] - mu) + e_i   (sample == NULL: T[:,i] = scale * e_i), one thread per row i;
+// e solves U' e = z, i.e. L~' e~ = z~ in reversed coordinates (backward substitution)
+template <int DP>
+__global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const double *Lr, const double *sample,
+                                                     const double *mu, const double *scale_sq, uint64_t seed,
+                                                     const uint32_t *sweep_p, uint32_t purpose, uint32_t entity, double *T)
+{
+    __shared__ double sL[DP * DP + DP];
+    for (int e = threadIdx.x; e < DP * DP + DP; e += blockDim.x) sL[e] = Lr[e];
+    __syncthreads();
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sweep = *sweep_p;
+    double e[DP];
+#pragma unroll
+    for (int j = DP - 1; j >= 0; j--) {
+        const int ej = D - 1 - j;
+        double s = (ej >= 0) ? bdf_normal(seed, sweep, purpose, entity, (uint64_t)i, ej) : 0.0;
+#pragma unroll
+        for (int m = j + 1; m < DP; m++) s = fma(-sL[m * DP + j], e[m], s);
+        e[j] = s * sL[DP * DP + j];
+    }
+    const double scale = scale_sq ? sqrt(*scale_sq) : 1.0;
+#pragma unroll
+    for (int j = 0; j < DP; j++) {
+        const int ej = D - 1 - j;
+        if (ej >= 0) {
+            const int64_t off = i * D + ej;
+            T[off] = sample ? (sample[off] - mu[ej]) + e[j] : scale * e[j];
+        }
+    }
+}
+
+template <int DP>
+int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr, const double *sample, const double *mu,
+               const double *scale_sq, uint32_t purpose, uint32_t entity, double *T, bool prep)
+{
+    if (prep) {
+        hipLaunchKernelGGL(k_noise_prep<DP>, dim3(1), dim3(64), 0, ctx->stream, D, Lambda, Lr, ctx->flag_dev);
+        BDF_HIP(hipGetLastError());
+    }
+    if (n > 0) {
+        hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, D, n, Lr,
+                           sample, mu, scale_sq, ctx->seed, ctx->sweep_dev, purpose, entity, T);
+        BDF_HIP(hipGetLastError());
+    }
+    return BDF_OK;
+}
+
+// rhs(f,d) = FtT(f,d) + E2s(d,f)   (E2s is D x numF: row f of the noise is contiguous)
+__global__ void k_add_e2(int64_t numF, int D, const double *E2s, double *rhs)
+{
+    int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= numF * D) return;
+    const int64_t f = idx % numF;
+    const int d = (int)(idx / numF);
+    rhs[idx] += E2s[f * D + d];
+}
+
+// ---- batched CG --------------------------------------------------------------------------------------------------
+struct CgState {
+    int64_t n; int D;
+    double *X, *R, *P, *Z;               // n x D column-major
+    double *bknum, *bkden, *tolb;        // D
+    int *active, *iters, *nactive;
+};
+
+__device__ inline double block_sum(double v, double *red)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double s = 0.0;
+    for (int w = 0; w < (int)(blockDim.x >> 6); w++) s += red[w];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_cg_init(CgState s, const double *rhs, double tol)
+{
+    __shared__ double red[4];
+    const int d = blockIdx.x;
+    const int64_t off = (int64_t)d * s.n;
+    double nb = 0.0;
+    for (int64_t i = threadIdx.x; i < s.n; i += blockDim.x) {
+        const double b = rhs[off + i];
+        s.X[off + i] = 0.0; s.R[off + i] = b; s.P[off + i] = b;
+        nb = fma(b, b, nb);
+    }
+    nb = block_sum(nb, red);
+    if (threadIdx.x == 0) {
+        s.tolb[d] = tol * sqrt(nb);      // tol = tol * norm(b), parallel_cg.jl:65
+        s.bkden[d] = 0.0; s.active[d] = 1; s.iters[d] = 0;
+        if (d == 0) *s.nactive = s.D;
+    }
+}
+
+// top of iteration `iter` (1-based): residual check, direction update (parallel_cg.jl:74-83)
+__global__ __launch_bounds__(256) void k_cg_pre(CgState s, int iter)
+{
+    __shared__ double red[4];
+    __shared__ int go;
+    const int d = blockIdx.x;
+    if (!s.active[d]) return;
+    const int64_t off = (int64_t)d * s.n;
+    double bknum = 0.0;
+    for (int64_t i = threadIdx.x; i < s.n; i += blockDim.x) bknum = fma(s.R[off + i], s.R[off + i], bknum);
+    bknum = block_sum(bknum, red);
+    if (threadIdx.x == 0) {
+        go = !(sqrt(bknum) < s.tolb[d]);
+        if (!go) { s.active[d] = 0; atomicSub(s.nactive, 1); }
+    }
+    __syncthreads();
+    if (!go) return;
+    if (iter > 1) {
+        const double bk = bknum / s.bkden[d];
+        for (int64_t i = threadIdx.x; i < s.n; i += blockDim.x) s.P[off + i] = fma(bk, s.P[off + i], s.R[off + i]);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) { s.bkden[d] = bknum; s.bknum[d] = bknum; s.iters[d] = iter; }
+}
+
+// bottom of the iteration: z = Z + lambda p; ak = bknum / (z.p); x += ak p; r -= ak z (parallel_cg.jl:85-91)
+__global__ __launch_bounds__(256) void k_cg_post(CgState s, const double *lambda_p, int iter)
+{
+    __shared__ double red[4];
+    const int d = blockIdx.x;
+    if (!s.active[d] || s.iters[d] != iter) return;
+    const double lambda = *lambda_p;
+    const int64_t off = (int64_t)d * s.n;
+    double zp = 0.0;
+    for (int64_t i = threadIdx.x; i < s.n; i += blockDim.x) {
+        const double p = s.P[off + i];
+        const double z = fma(lambda, p, s.Z[off + i]);
+        s.Z[off + i] = z;
+        zp = fma(z, p, zp);
+    }
+    zp = block_sum(zp, red);
+    const double ak = s.bknum[d] / zp;
+    for (int64_t i = threadIdx.x; i < s.n; i += blockDim.x) {
+        s.X[off + i] = fma(ak, s.P[off + i], s.X[off + i]);
+        s.R[off + i] = fma(-ak, s.Z[off + i], s.R[off + i]);
+    }
+}
+
+// ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
+// G = beta' beta (D x D) by one block
+__global__ __launch_bounds__(256) void k_btb(int D, int64_t numF, const double *beta, double *G)
+{
+    for (int e = threadIdx.x; e < D * D; e += blockDim.x) {
+        const int i = e % D, j = e / D;
+        double s = 0.0;
+        for (int64_t f = 0; f < numF; f++) s = fma(beta[f + (int64_t)i * numF], beta[f + (int64_t)j * numF], s);
+        G[e] = s;
+    }
+}
+
+__global__ void k_tinv_feat(int D, const double *G, const double *WI, const double *lambda_beta, double *Tinv)
+{
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e < D * D) Tinv[e] = WI[e] + G[e] * (*lambda_beta);      // Tinv += beta'beta * lambda_beta, macau.jl:128
+}
+
+__global__ __launch_bounds__(64) void k_lambda_beta(int D, int64_t numF, const double *G, const double *Lambda, double nu,
+                                                    double mu, uint64_t seed, const uint32_t *sweep, uint32_t entity,
+                                                    double *lambda_beta)
+{
+    // trace((beta'beta) Lambda) = sum_ij G[i][j] Lambda[j][i]
+    double tr = 0.0;
+    for (int e = threadIdx.x; e < D * D; e += 64) {
+        const int i = e % D, j = e / D;
+        tr = fma(G[i + j * D], Lambda[j + i * D], tr);
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) tr += __shfl_xor(tr, off);
+    if (threadIdx.x == 0) {
+        const double nux = nu + (double)numF * (double)D;
+        const double mux = mu * nux / (nu + mu * tr);
+        *lambda_beta = bdf_gamma(seed, *sweep, entity, (uint64_t)D, 0.5 * nux) * (2.0 * mux / nux);
+    }
+}
+
+// ---- direct solve for numF <= 64: (FF + lambda I) X = RHS on one wave (solve_full, sampling.jl:314-320) -------------
+template <int DP>
+__global__ __launch_bounds__(64) void k_solve_small(int n, int ncol, const double *FF, const double *lambda_p,
+                                                    const double *rhs, double *X, int *flag)
+{
+    __shared__ double tb[DP * WL_TLD];
+    const int lane = threadIdx.x;
+    const double lambda = *lambda_p;
+    double col[DP];
+#pragma unroll
+    for (int i = 0; i < DP; i++) {
+        double w = (i == lane) ? 1.0 : 0.0;
+        if (i < n && lane < n) w = FF[i + (int64_t)lane * n] + ((i == lane) ? lambda : 0.0);
+        col[i] = w;
+    }
+    double rinv_own;
+    if (wl_chol_rows<DP>(col, rinv_own, lane) && lane == 0) atomicOr(flag, 8);
+    double rowsL[DP];
+#pragma unroll
+    for (int k = 0; k < DP; k++) rowsL[k] = col[k];
+    wl_rows_to_cols<DP>(col, tb, lane);
+    for (int c = 0; c < ncol; c++) {
+        double b = (lane < n) ? rhs[lane + (int64_t)c * n] : 0.0;
+        b = wl_fwd_rows<DP>(rowsL, rinv_own, b, lane);
+        b = wl_bwd_cols<DP>(col, rinv_own, b, lane);
+        if (lane < n) X[lane + (int64_t)c * n] = b;
+    }
+}
+
+int ensure_dense(bdf_feat *f)
+{
+    if (f->dense_dev) return BDF_OK;
+    bdf_ctx *ctx = f->ctx;
+    BDF_REQUIRE((double)f->m * (double)f->n * 8.0 <= 4e9, BDF_ERR_ARG,
+                "FF path needs F'F of a sparse F with %lld x %lld entries: too large, use the CG path (compute_ff_size)",
+                (long long)f->m, (long long)f->n);
+    // densify by applying F to the identity: dense(:, j) = F e_j
+    size_t nn = (size_t)f->n * (size_t)f->n;
+    double *eye;
+    BDF_HIP(hipMalloc((void **)&eye, std::max<size_t>(nn * sizeof(double), 8)));
+    std::vector<double> h(nn, 0.0);
+    for (int64_t j = 0; j < f->n; j++) h[(size_t)j * f->n + j] = 1.0;
+    BDF_HIP(hipMemcpy(eye, h.data(), nn * sizeof(double), hipMemcpyHostToDevice));
+    double *dense;
+    BDF_HIP(hipMalloc((void **)&dense, std::max<size_t>((size_t)f->m * f->n * sizeof(double), 8)));
+    int rc = feat_apply(ctx, f, false, eye, 1, f->n, (int)f->n, dense, 1, f->m);
+    if (rc) return rc;
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    BDF_HIP(hipFree(eye));
+    f->dense_dev = dense;
+    return BDF_OK;
+}
+
+int ensure_FF(bdf_feat *f)
+{
+    if (f->FF_dev) return BDF_OK;
+    bdf_ctx *ctx = f->ctx;
+    int rc = ensure_dense(f);
+    if (rc) return rc;
+    BDF_HIP(hipMalloc((void **)&f->FF_dev, std::max<size_t>((size_t)f->n * f->n * sizeof(double), 8)));
+    GemmArgs g;                          // FF = full(At_mul_B(F, F)), RelationData.jl:338
+    g.M = f->n; g.N = f->n; g.K = f->m;
+    g.A = f->dense_dev; g.ars = f->m; g.acs = 1;
+    g.B = f->dense_dev; g.brs = 1; g.bcs = f->m;
+    g.C = f->FF_dev; g.crs = 1; g.ccs = f->n; g.bias = nullptr; g.C2 = nullptr;
+    return gemm(ctx, g);
+}
+
+template <typename T>
+int upload_vec(const std::vector<T> &v, T **dptr)
+{
+    BDF_HIP(hipMalloc((void **)dptr, std::max<size_t>(v.size() * sizeof(T), 8)));
+    if (!v.empty()) BDF_HIP(hipMemcpy(*dptr, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BDF_OK;
+}
+
+int create_sparse(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows, const int32_t *cols,
+                  const double *vals, bdf_feat **out)
+{
+    BDF_REQUIRE(ctx && out, BDF_ERR_ARG, "bdf_feat_create: NULL argument");
+    BDF_REQUIRE(m >= 0 && n >= 0 && nnz >= 0 && (nnz == 0 || (rows && cols)), BDF_ERR_ARG, "bdf_feat_create: bad argument");
+    for (int64_t q = 0; q < nnz; q++) {
+        BDF_REQUIRE(rows[q] >= 1 && rows[q] <= m && cols[q] >= 1 && cols[q] <= n, BDF_ERR_BOUNDS,
+                    "bdf_feat_create: entry %lld (%d,%d) outside %lld x %lld", (long long)q, rows[q], cols[q], (long long)m, (long long)n);
+    }
+    BDF_HIP(hipSetDevice(ctx->device));
+    auto build = [&](const int32_t *major, const int32_t *minor, int64_t nmajor, std::vector<int64_t> &ptr,
+                     std::vector<int32_t> &ind, std::vector<double> &v) {
+        ptr.assign((size_t)nmajor + 1, 0);
+        for (int64_t q = 0; q < nnz; q++) ptr[(size_t)major[q]]++;
+        for (int64_t j = 0; j < nmajor; j++) ptr[(size_t)j + 1] += ptr[(size_t)j];
+        std::vector<int64_t> cur(ptr.begin(), ptr.end() - 1);
+        ind.assign((size_t)nnz, 0);
+        if (vals) v.assign((size_t)nnz, 0.0);
+        for (int64_t q = 0; q < nnz; q++) {          // stable in input order (sortperm, sparsebin_csr.jl:23)
+            int64_t dst = cur[(size_t)major[q] - 1]++;
+            ind[(size_t)dst] = minor[q] - 1;
+            if (vals) v[(size_t)dst] = vals[q];
+        }
+    };
+    bdf_feat *f = new bdf_feat();
+    memset(f, 0, sizeof(*f));
+    f->ctx = ctx; f->kind = vals ? 1 : 2; f->m = m; f->n = n; f->nnz = nnz;
+    std::vector<int64_t> ptr; std::vector<int32_t> ind; std::vector<double> v;
+    int rc;
+    build(rows, cols, m, ptr, ind, v);
+    if ((rc = upload_vec(ptr, &f->rowptr_dev)) || (rc = upload_vec(ind, &f->colind_dev))) return rc;
+    if (vals && (rc = upload_vec(v, &f->rvals_dev))) return rc;
+    build(cols, rows, n, ptr, ind, v);
+    if ((rc = upload_vec(ptr, &f->colptr_dev)) || (rc = upload_vec(ind, &f->rowind_dev))) return rc;
+    if (vals && (rc = upload_vec(v, &f->cvals_dev))) return rc;
+    *out = f;
+    return BDF_OK;
+}
+
+}  // namespace
+
+extern "C" int bdf_feat_create_dense(bdf_ctx *ctx, int64_t m, int64_t n, const double *F, bdf_feat **out)
+{
+    BDF_REQUIRE(ctx && out && m >= 0 && n >= 0 && (m * n == 0 || F), BDF_ERR_ARG, "bdf_feat_create_dense: bad argument");
+    BDF_HIP(hipSetDevice(ctx->device));
+    bdf_feat *f = new bdf_feat();
+    memset(f, 0, sizeof(*f));
+    f->ctx = ctx; f->kind = 0; f->m = m; f->n = n; f->nnz = m * n;
+    BDF_HIP(hipMalloc((void **)&f->dense_dev, std::max<size_t>((size_t)m * n * sizeof(double), 8)));
+    if (m * n) BDF_HIP(hipMemcpy(f->dense_dev, F, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));
+    *out = f;
+    return BDF_OK;
+}
+
+extern "C" int bdf_feat_create_csr(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows,
+                                   const int32_t *cols, const double *vals, bdf_feat **out)
+{
+    BDF_REQUIRE(nnz == 0 || vals, BDF_ERR_ARG, "bdf_feat_create_csr: vals is NULL");
+    static const double one = 1.0;
+    return create_sparse(ctx, m, n, nnz, rows, cols, nnz ? vals : &one, out);
+}
+
+extern "C" int bdf_feat_create_bin(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows,
+                                   const int32_t *cols, bdf_feat **out)
+{
+    return create_sparse(ctx, m, n, nnz, rows, cols, nullptr, out);
+}
+
+extern "C" int bdf_feat_destroy(bdf_feat *f)
+{
+    if (!f) return BDF_OK;
+    hipSetDevice(f->ctx->device);
+    hipStreamSynchronize(f->ctx->stream);
+    hipFree(f->dense_dev); hipFree(f->rowptr_dev); hipFree(f->colind_dev); hipFree(f->rvals_dev);
+    hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev);
+    delete f;
+    return BDF_OK;
+}
+
+extern "C" int bdf_feat_size(const bdf_feat *f, int64_t *m, int64_t *n, int64_t *nnz)
+{
+    BDF_REQUIRE(f && m && n && nnz, BDF_ERR_ARG, "bdf_feat_size: NULL argument");
+    *m = f->m; *n = f->n; *nnz = f->nnz;
+    return BDF_OK;
+}
+
+extern "C" int bdf_feat_mul(bdf_ctx *ctx, const bdf_feat *f, const double *B, int ncol, double *out, int transpose)
+{
+    BDF_REQUIRE(ctx && f && B && out && ncol >= 1, BDF_ERR_ARG, "bdf_feat_mul: bad argument");
+    const int64_t kin = transpose ? f->m : f->n, kout = transpose ? f->n : f->m;
+    return feat_apply(ctx, f, transpose != 0, B, 1, kin, ncol, out, 1, kout);
+}
+
+extern "C" int bdf_feat_AtA_mul(bdf_ctx *ctx, const bdf_feat *f, const double *X, int ncol, double lambda, double *out)
+{
+    BDF_REQUIRE(ctx && f && X && out && ncol >= 1, BDF_ERR_ARG, "bdf_feat_AtA_mul: bad argument");
+    void *tmp;
+    int rc = bdf_scratch(ctx, (size_t)f->m * ncol * sizeof(double), &tmp);
+    if (rc) return rc;
+    if ((rc = feat_apply(ctx, f, false, X, 1, f->n, ncol, (double *)tmp, 1, f->m))) return rc;
+    if ((rc = feat_apply(ctx, f, true, (const double *)tmp, 1, f->m, ncol, out, 1, f->n))) return rc;
+    const int64_t tot = f->n * ncol;
+    hipLaunchKernelGGL(k_axpy_lambda, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, ctx->stream, tot, lambda, X, out);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_uhat(bdf_ctx *ctx, const bdf_feat *f, int D, const double *beta, const double *mu,
+                        double *uhat_out, double *mu_matrix_out)
+{
+    BDF_REQUIRE(ctx && f && beta && uhat_out, BDF_ERR_ARG, "bdf_uhat: NULL argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_uhat: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    BDF_REQUIRE(!mu_matrix_out || mu, BDF_ERR_ARG, "bdf_uhat: mu is NULL");
+    // (F beta)(i,d) written at uhat[d + i*D]
+    return feat_apply(ctx, f, false, beta, 1, f->n, D, uhat_out, D, 1, mu, mu_matrix_out);
+}
+
+extern "C" int bdf_hyper_feature_terms(bdf_ctx *ctx, int D, int64_t numF, const double *beta, const double *WI,
+                                       const double *lambda_beta_dev, double *Tinv_out)
+{
+    BDF_REQUIRE(ctx && beta && WI && lambda_beta_dev && Tinv_out, BDF_ERR_ARG, "bdf_hyper_feature_terms: NULL argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_feature_terms: bad num_latent");
+    void *G;
+    int rc = bdf_scratch(ctx, (size_t)D * D * sizeof(double), &G);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, beta, (double *)G);
+    hipLaunchKernelGGL(k_tinv_feat, dim3((D * D + 255) / 256), dim3(256), 0, ctx->stream, D, (const double *)G, WI,
+                       lambda_beta_dev, Tinv_out);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const double *sample, const double *mu,
+                               const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
+                               int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
+                               double *beta_out, double *rhs_out, int32_t *iters_out)
+{
+    BDF_REQUIRE(ctx && fc && sample && mu && Lambda && lambda_beta_dev && beta_out, BDF_ERR_ARG, "bdf_sample_beta: NULL argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_sample_beta: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    bdf_feat *f = const_cast<bdf_feat *>(fc);
+    const int64_t N = f->m, numF = f->n;
+    if (std::isnan(tol)) tol = 2.220446049250313e-16 * (double)numF;       // eps()*numF, sampling.jl:294-296
+    if (maxiter <= 0) maxiter = (int)numF;
+    const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
+
+    // scratch layout (doubles): Lr | T (D x N) | E2s (D x numF) | rhs | R P Z Tm | scalars
+    size_t nLr = (size_t)DP * DP + DP, nT = (size_t)D * N, nE2 = (size_t)D * numF, nB = (size_t)numF * D, nTm = (size_t)N * D;
+    size_t total = nLr + nT + nE2 + nB * 4 + nTm + 3 * (size_t)D + 64 + (size_t)D * D;
+    void *sv;
+    int rc = bdf_scratch(ctx, total * sizeof(double) + (2 * (size_t)D + 16) * sizeof(int), &sv);
+    if (rc) return rc;
+    double *Lr = (double *)sv, *T = Lr + nLr, *E2s = T + nT, *rhs = E2s + nE2, *R = rhs + nB, *P = R + nB, *Z = P + nB,
+           *Tm = Z + nB, *scal = Tm + nTm, *G = scal + 3 * D + 64;
+    int *ints = (int *)(G + (size_t)D * D);
+
+    // rhs = F'((sample - mu)' + E1) + sqrt(lb) E2
+#define NOISE(DPV)                                                                                                      \
+    do {                                                                                                                \
+        if ((rc = noise_rows<DPV>(ctx, D, N, Lambda, Lr, sample, mu, nullptr, BDF_P_BETA_E1, entity_tag, T, true))) return rc; \
+        if ((rc = noise_rows<DPV>(ctx, D, numF, Lambda, Lr, nullptr, nullptr, lambda_beta_dev, BDF_P_BETA_E2, entity_tag, E2s, false))) return rc; \
+    } while (0)
+    if (DP == 16) NOISE(16); else if (DP == 32) NOISE(32); else NOISE(64);
+#undef NOISE
+    // T holds (target)' as D x N: element (i,d) at T[i*D + d]
+    if ((rc = feat_apply(ctx, f, true, T, D, 1, D, rhs, 1, numF))) return rc;
+    if (numF * D > 0) {
+        hipLaunchKernelGGL(k_add_e2, dim3((unsigned)((numF * D + 255) / 256)), dim3(256), 0, ctx->stream, numF, D, E2s, rhs);
+        BDF_HIP(hipGetLastError());
+    }
+    if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, rhs, nB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+
+    bool direct = use_ff && numF <= 64;
+    if (use_ff && (rc = ensure_FF(f))) return rc;
+    if (direct) {
+        // solve_full (sampling.jl:314-320) by Cholesky on one wave
+        if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
+        else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
+        else hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
+        BDF_HIP(hipGetLastError());
+        if (iters_out) BDF_HIP(hipMemsetAsync(iters_out, 0, D * sizeof(int32_t), ctx->stream));
+    } else {
+        // D simultaneous cg_AtA solves; with use_ff the operator is the precomputed F'F (same system, numF > 64)
+        CgState s;
+        s.n = numF; s.D = D; s.X = beta_out; s.R = R; s.P = P; s.Z = Z;
+        s.bknum = scal; s.bkden = scal + D; s.tolb = scal + 2 * D;
+        s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
+        hipLaunchKernelGGL(k_cg_init, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)rhs, tol);
+        BDF_HIP(hipGetLastError());
+        for (int iter = 1; iter <= maxiter; iter++) {
+            hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, iter);
+            if (use_ff) {
+                GemmArgs g;
+                g.M = numF; g.N = D; g.K = numF; g.A = f->FF_dev; g.ars = 1; g.acs = numF;
+                g.B = P; g.brs = 1; g.bcs = numF; g.C = Z; g.crs = 1; g.ccs = numF; g.bias = nullptr; g.C2 = nullptr;
+                if ((rc = gemm(ctx, g))) return rc;
+            } else {
+                if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, 1, N))) return rc;
+                if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
+            }
+            hipLaunchKernelGGL(k_cg_post, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter);
+            BDF_HIP(hipGetLastError());
+            if (iter % 8 == 0 || iter == maxiter) {
+                int nact = 0;
+                BDF_HIP(hipMemcpyAsync(&nact, s.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+                BDF_HIP(hipStreamSynchronize(ctx->stream));
+                if (nact == 0) break;
+            }
+        }
+        if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, s.iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    if (sample_lambda) {
+        hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, (const double *)beta_out, G);
+        hipLaunchKernelGGL(k_lambda_beta, dim3(1), dim3(64), 0, ctx->stream, D, numF, (const double *)G, Lambda, lb_nu, lb_mu,
+                           ctx->seed, ctx->sweep_dev, entity_tag, lambda_beta_dev);
+        BDF_HIP(hipGetLastError());
+    }
+    return BDF_OK;
+}

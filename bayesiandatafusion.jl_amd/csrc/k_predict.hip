@@ -1,0 +1,183 @@
+// k_predict.hip -- K7: test-set prediction and the running posterior mean of macau.jl:142-203.
+//
+// pred(r, test_vec) = udot(r, test_vec) + mean_value (src/sampling.jl:9-14); udot is the sum over the latent
+// dimension of the product of the modes' factor rows (src/sampling.jl:30-45).  16 lanes share one test pair so
+// that each gathered factor row is read as whole 128-byte segments.
+#include "bdf_common.h"
+
+namespace {
+
+constexpr int LPP = 16;    // lanes per pair
+
+struct PredArgs {
+    int D, n_modes;
+    int64_t n;
+    const int32_t *ids;            // n_modes planes of n, 0-based
+    const double *fac[BDF_MAX_MODES];
+    double mean;
+    const double *values;
+    double *out;                   // nullable: raw predictions
+    double *avg, *sq;              // running state (update mode)
+    int phase;                     // -1: predict only
+    double count, clamp_lo, clamp_hi, cut;
+    double *stats;
+};
+
+__device__ inline double clampv(double x, double lo, double hi)
+{
+    if (lo > hi) return x;
+    return x < lo ? lo : (x > hi ? hi : x);
+}
+
+__global__ __launch_bounds__(256) void k_predict(PredArgs a)
+{
+    const int tid = threadIdx.x;
+    const int sub = tid % LPP;
+    const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + tid) / LPP;
+    double s = 0.0;
+    if (pair < a.n) {
+        for (int e = sub; e < a.D; e += LPP) {
+            double p = 1.0;
+            for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
+            s += p;
+        }
+    }
+#pragma unroll
+    for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    double st[4] = {0.0, 0.0, 0.0, 0.0};
+    if (pair < a.n && sub == 0) {
+        const double p = s + a.mean;
+        if (a.out) a.out[pair] = p;
+        if (a.phase >= 0) {
+            double avg;
+            if (a.phase == 0) { avg = p; }
+            else if (a.phase == 1) { avg = p; a.sq[pair] = p * p; }
+            else { avg = (a.count * a.avg[pair] + p) / (a.count + 1.0); a.sq[pair] += p * p; }
+            a.avg[pair] = avg;
+            const double y = a.values[pair];
+            const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
+            const bool label = y < a.cut;
+            st[0] = ea * ea; st[1] = ep * ep;
+            st[2] = (label == (avg < a.cut)) ? 1.0 : 0.0;
+            st[3] = (label == (p < a.cut)) ? 1.0 : 0.0;
+        }
+    }
+    if (a.phase >= 0) {
+        __shared__ double red[4][256 / 64];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            double v = st[q];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+            if ((tid & 63) == 0) red[q][tid >> 6] = v;
+        }
+        __syncthreads();
+        if (tid < 4) {
+            double v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+            atomicAdd(&a.stats[tid], v);
+        }
+    }
+}
+
+int launch_predict(bdf_ctx *ctx, const PredArgs &a)
+{
+    if (a.n == 0) return BDF_OK;
+    int64_t threads = a.n * LPP;
+    hipLaunchKernelGGL(k_predict, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+int fill(const char *who, bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, PredArgs &a)
+{
+    BDF_REQUIRE(ctx && p && factors, BDF_ERR_ARG, "%s: NULL argument", who);
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "%s: num_latent=%d must be in 1..%d", who, D, BDF_MAX_D);
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.n_modes = p->n_modes; a.n = p->n; a.ids = p->ids_dev; a.values = p->values_dev;
+    for (int k = 0; k < p->n_modes; k++) {
+        BDF_REQUIRE(factors[k] != nullptr, BDF_ERR_ARG, "%s: factors[%d] is NULL", who, k);
+        a.fac[k] = factors[k];
+    }
+    a.phase = -1;
+    return BDF_OK;
+}
+
+}  // namespace
+
+extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void *ids, int id_bytes,
+                                const double *values, bdf_pairs **out)
+{
+    BDF_REQUIRE(ctx && out, BDF_ERR_ARG, "bdf_pairs_create: NULL argument");
+    BDF_REQUIRE(n_modes >= 2 && n_modes <= BDF_MAX_MODES, BDF_ERR_ARG, "bdf_pairs_create: n_modes=%d must be in 2..%d", n_modes, BDF_MAX_MODES);
+    BDF_REQUIRE(id_bytes == 4 || id_bytes == 8, BDF_ERR_ARG, "bdf_pairs_create: id_bytes must be 4 or 8");
+    BDF_REQUIRE(n >= 0 && (n == 0 || (ids && values)), BDF_ERR_ARG, "bdf_pairs_create: ids/values NULL");
+    BDF_HIP(hipSetDevice(ctx->device));
+    std::vector<int32_t> h((size_t)n * n_modes);
+    for (size_t q = 0; q < h.size(); q++) {
+        int64_t v = id_bytes == 8 ? ((const int64_t *)ids)[q] : (int64_t)((const int32_t *)ids)[q];
+        BDF_REQUIRE(v >= 1 && v < (int64_t)0x7fffffff, BDF_ERR_BOUNDS, "bdf_pairs_create: id %lld out of range", (long long)v);
+        h[q] = (int32_t)(v - 1);
+    }
+    bdf_pairs *p = new bdf_pairs();
+    p->ctx = ctx; p->n_modes = n_modes; p->n = n; p->count = 0.0;
+    size_t nb = std::max<size_t>((size_t)n * sizeof(double), 8);
+    BDF_HIP(hipMalloc((void **)&p->ids_dev, std::max<size_t>(h.size() * sizeof(int32_t), 8)));
+    BDF_HIP(hipMalloc((void **)&p->values_dev, nb));
+    BDF_HIP(hipMalloc((void **)&p->avg_dev, nb));
+    BDF_HIP(hipMalloc((void **)&p->sq_dev, nb));
+    if (n) {
+        BDF_HIP(hipMemcpy(p->ids_dev, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        BDF_HIP(hipMemcpy(p->values_dev, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
+    }
+    BDF_HIP(hipMemset(p->avg_dev, 0, nb));
+    BDF_HIP(hipMemset(p->sq_dev, 0, nb));
+    *out = p;
+    return BDF_OK;
+}
+
+extern "C" int bdf_pairs_destroy(bdf_pairs *p)
+{
+    if (!p) return BDF_OK;
+    hipSetDevice(p->ctx->device);
+    hipStreamSynchronize(p->ctx->stream);
+    hipFree(p->ids_dev); hipFree(p->values_dev); hipFree(p->avg_dev); hipFree(p->sq_dev);
+    delete p;
+    return BDF_OK;
+}
+
+extern "C" int bdf_predict(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors,
+                           double mean_value, double *out)
+{
+    PredArgs a;
+    int rc = fill("bdf_predict", ctx, p, D, factors, a);
+    if (rc) return rc;
+    BDF_REQUIRE(out != nullptr, BDF_ERR_ARG, "bdf_predict: out is NULL");
+    a.mean = mean_value; a.out = out;
+    return launch_predict(ctx, a);
+}
+
+extern "C" int bdf_predict_update(bdf_ctx *ctx, bdf_pairs *p, int D, const double *const *factors,
+                                  double mean_value, int phase, double clamp_lo, double clamp_hi,
+                                  double class_cut, double *stats_out)
+{
+    PredArgs a;
+    int rc = fill("bdf_predict_update", ctx, p, D, factors, a);
+    if (rc) return rc;
+    BDF_REQUIRE(stats_out != nullptr, BDF_ERR_ARG, "bdf_predict_update: stats_out is NULL");
+    BDF_REQUIRE(phase >= 0 && phase <= 2, BDF_ERR_ARG, "bdf_predict_update: phase must be 0, 1 or 2");
+    a.mean = mean_value; a.avg = p->avg_dev; a.sq = p->sq_dev; a.phase = phase; a.count = p->count;
+    a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi; a.cut = class_cut; a.stats = stats_out;
+    BDF_HIP(hipMemsetAsync(stats_out, 0, 4 * sizeof(double), ctx->stream));
+    rc = launch_predict(ctx, a);
+    if (rc) return rc;
+    if (phase == 1) p->count = 1.0;
+    else if (phase == 2) p->count += 1.0;
+    return BDF_OK;
+}
+
+extern "C" int bdf_pairs_state(const bdf_pairs *p, double **avg, double **sq, int64_t *n)
+{
+    BDF_REQUIRE(p && avg && sq && n, BDF_ERR_ARG, "bdf_pairs_state: NULL argument");
+    *avg = p->avg_dev; *sq = p->sq_dev; *n = p->n;
+    return BDF_OK;
+}

@@ -1,0 +1,425 @@
+"""GibbsEngine -- host-side orchestration of one macau() run on one MI355X (one process per GPU).
+
+Everything numeric is a call into libbdf_hip.so (include/bdf.h).  torch is used for what the task calls plumbing:
+device allocations (tensors), the HIP stream, and -- when torch.distributed is initialised -- the RCCL all-gather of a
+freshly sampled factor matrix (reference: sample_latent_all2! ships every factor to every worker each half-sweep,
+src/sampling.jl:155-167).
+
+Layout: an entity's sample is the reference's D x N column-major matrix == a contiguous torch tensor of shape (N, D).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import features as feat
+from ._lib import ArgumentError, Term, check, lib
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+class Context:
+    """bdf_ctx bound to a torch device and torch's current stream."""
+
+    def __init__(self, device=None, seed=0):
+        if not torch.cuda.is_available():
+            raise _lib.NoGpuError("no GPU visible: bayesiandatafusion.jl_amd has no CPU path (the reference is the CPU path)")
+        self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        torch.cuda.set_device(self.device)
+        self.stream = torch.cuda.current_stream(self.device)
+        self.handle = C.c_void_p()
+        check(lib().bdf_ctx_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.c_uint64(int(seed) & (2 ** 64 - 1)),
+                                   C.byref(self.handle)))
+        self.seed = int(seed)
+
+    def set_sweep(self, i):
+        check(lib().bdf_ctx_set_sweep(self.handle, C.c_uint32(int(i))))
+
+    def advance_sweep(self):
+        check(lib().bdf_ctx_advance_sweep(self.handle))
+
+    def sync(self):
+        check(lib().bdf_ctx_sync(self.handle))
+
+    def zeros(self, *shape, dtype=torch.float64):
+        return torch.zeros(*shape, dtype=dtype, device=self.device)
+
+    def tensor(self, a, dtype=torch.float64):
+        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+
+    def close(self):
+        if self.handle:
+            lib().bdf_ctx_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DeviceRelation:
+    """bdf_rel: Relation.data (IndexedDF) as per-mode CSR in HBM."""
+
+    def __init__(self, ctx, idf):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        dims = np.asarray(idf.dims, dtype=np.int64)
+        vals = np.ascontiguousarray(idf.values, dtype=np.float64)
+        ids = idf.ids
+        check(lib().bdf_relation_create(ctx.handle, len(idf.dims), dims.ctypes.data_as(_lib.c_i64p), idf.nnz(),
+                                        ids.ctypes.data_as(C.c_void_p), ids.dtype.itemsize, vals.ctypes.data_as(_lib.c_dp),
+                                        C.byref(self.handle)))
+        self.dims = list(idf.dims)
+        self.nnz = idf.nnz()
+
+    def index(self, mode0):
+        rp, ri = _lib.c_i64p(), _lib.c_i64p()
+        check(lib().bdf_relation_index(self.handle, mode0, C.byref(rp), C.byref(ri)))
+        return (np.ctypeslib.as_array(rp, shape=(self.dims[mode0] + 1,)).copy(),
+                np.ctypeslib.as_array(ri, shape=(max(self.nnz, 1),))[:self.nnz].copy())
+
+    def value_mean(self):
+        m = C.c_double()
+        check(lib().bdf_relation_value_mean(self.handle, C.byref(m)))
+        return m.value
+
+    def order(self, mode0):
+        out = np.zeros(self.dims[mode0], dtype=np.int32)
+        check(lib().bdf_relation_order(self.handle, mode0, out.ctypes.data_as(_lib.c_i32p)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().bdf_relation_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class DevicePairs:
+    """bdf_pairs: test_vec (or the training table) with its running prediction state."""
+
+    def __init__(self, ctx, ids, values):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        ids = np.asfortranarray(np.asarray(ids, dtype=np.int64))
+        values = np.ascontiguousarray(values, dtype=np.float64)
+        self.n, self.n_modes = ids.shape
+        check(lib().bdf_pairs_create(ctx.handle, self.n_modes, self.n, ids.ctypes.data_as(C.c_void_p), 8,
+                                     values.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
+        self.stats = ctx.zeros(4)
+
+    def _facs(self, factors):
+        return (C.c_void_p * len(factors))(*[f.data_ptr() for f in factors])
+
+    def predict(self, D, factors, mean_value):
+        out = self.ctx.zeros(self.n)
+        check(lib().bdf_predict(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, _ptr(out)))
+        return out
+
+    def update(self, D, factors, mean_value, phase, clamp, class_cut):
+        lo, hi = (clamp[0], clamp[1]) if len(clamp) else (1.0, -1.0)
+        check(lib().bdf_predict_update(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, phase, lo, hi,
+                                       class_cut, _ptr(self.stats)))
+        return self.stats
+
+    def state(self):
+        """(avg, sq) as host arrays"""
+        a, s, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().bdf_pairs_state(self.handle, C.byref(a), C.byref(s), C.byref(n)))
+        avg, sq = np.zeros(n.value), np.zeros(n.value)
+        if n.value:
+            check(lib().bdf_d2h(self.ctx.handle, avg.ctypes.data_as(C.c_void_p), a, n.value * 8))
+            check(lib().bdf_d2h(self.ctx.handle, sq.ctypes.data_as(C.c_void_p), s, n.value * 8))
+        return avg, sq
+
+    def close(self):
+        if self.handle:
+            lib().bdf_pairs_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class FeatOperator:
+    """bdf_feat: the Entity.F operator on the device (dense / CSR / binary)."""
+
+    def __init__(self, ctx, F):
+        self.ctx = ctx
+        self.handle = C.c_void_p()
+        L = lib()
+        if isinstance(F, feat.SparseMatrixCSR):
+            self.kind = "csr"
+            check(L.bdf_feat_create_csr(ctx.handle, F.m, F.n, len(F.rows), F.rows.ctypes.data_as(_lib.c_i32p),
+                                        F.cols.ctypes.data_as(_lib.c_i32p), F.vals.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
+            self.m, self.n = F.m, F.n
+        elif isinstance(F, feat.SparseBinMatrix):
+            self.kind = "bin"
+            check(L.bdf_feat_create_bin(ctx.handle, F.m, F.n, len(F.rows), F.rows.ctypes.data_as(_lib.c_i32p),
+                                        F.cols.ctypes.data_as(_lib.c_i32p), C.byref(self.handle)))
+            self.m, self.n = F.m, F.n
+        elif hasattr(F, "tocoo"):
+            coo = F.tocoo()
+            rows = np.ascontiguousarray(coo.row + 1, dtype=np.int32)
+            cols = np.ascontiguousarray(coo.col + 1, dtype=np.int32)
+            vals = np.ascontiguousarray(coo.data, dtype=np.float64)
+            self.kind = "csr"
+            check(L.bdf_feat_create_csr(ctx.handle, coo.shape[0], coo.shape[1], len(rows), rows.ctypes.data_as(_lib.c_i32p),
+                                        cols.ctypes.data_as(_lib.c_i32p), vals.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
+            self.m, self.n = int(coo.shape[0]), int(coo.shape[1])
+        else:
+            A = np.asfortranarray(np.asarray(F, dtype=np.float64))
+            if A.ndim != 2:
+                raise ArgumentError("feature matrix must be two-dimensional")
+            self.kind = "dense"
+            check(L.bdf_feat_create_dense(ctx.handle, A.shape[0], A.shape[1], A.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
+            self.m, self.n = int(A.shape[0]), int(A.shape[1])
+
+    # B, out: torch tensors holding column-major matrices, i.e. shape (ncol, rows)
+    def mul(self, B, transpose=False):
+        ncol = B.shape[0]
+        out = self.ctx.zeros(ncol, self.n if transpose else self.m)
+        check(lib().bdf_feat_mul(self.ctx.handle, self.handle, _ptr(B), ncol, _ptr(out), int(transpose)))
+        return out
+
+    def AtA_mul(self, X, lam):
+        out = self.ctx.zeros(X.shape[0], self.n)
+        check(lib().bdf_feat_AtA_mul(self.ctx.handle, self.handle, _ptr(X), X.shape[0], float(lam), _ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            lib().bdf_feat_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class EntityState:
+    """Device-resident EntityModel (RelationData.jl:14-40, initModel! :66-90)."""
+
+    def __init__(self, ctx, en, D, tag):
+        self.ctx, self.D, self.N, self.tag = ctx, D, en.count, tag
+        self.sample = ctx.zeros(en.count, D)
+        self.mu = ctx.zeros(D)
+        self.Lambda = (5.0 * torch.eye(D, dtype=torch.float64)).to(ctx.device)
+        self.mu0 = ctx.zeros(D)
+        self.b0 = 2.0
+        self.WI = torch.eye(D, dtype=torch.float64).to(ctx.device)
+        self.nu0 = float(D)
+        self.sumU = ctx.zeros(D)
+        self.UUt = ctx.zeros(D, D)
+        self.params = ctx.zeros(D + D * D)
+        self.F = None
+        self.numF = 0
+        self.beta = ctx.zeros(D, 0)
+        self.uhat = None
+        self.mu_matrix = None
+        self.Tinv = None
+        self.lambda_beta = None
+        self.cg_iters = None
+        if not feat.isempty(en.F):
+            self.F = FeatOperator(ctx, en.F)
+            if self.F.m != en.count:
+                raise ArgumentError(f"Entity {en.name} has {en.count} instances but its feature matrix has {self.F.m} rows")
+            self.numF = self.F.n
+            self.beta = ctx.zeros(D, self.numF)          # numF x D column-major
+            self.uhat = ctx.zeros(en.count, D)
+            self.mu_matrix = ctx.zeros(en.count, D)
+            self.Tinv = ctx.zeros(D, D)
+            self.lambda_beta = ctx.tensor([en.lambda_beta])
+            self.cg_iters = torch.zeros(D, dtype=torch.int32, device=ctx.device)
+
+    def host(self, name):
+        t = getattr(self, name)
+        if t is None:
+            return np.zeros((0, 0))
+        a = t.detach().cpu().numpy()
+        return a.T.copy() if a.ndim == 2 else a.copy()
+
+
+class GibbsEngine:
+    """Device state of a RelationData and the per-iteration steps of macau.jl:80-140."""
+
+    def __init__(self, data, num_latent, seed=0, device=None, lambda_beta=float("nan"), compute_ff_size=6500,
+                 full_lambda_u=True, tol=float("nan"), shard=None):
+        if not (1 <= num_latent <= _lib.BDF_MAX_D):
+            raise ArgumentError(f"num_latent={num_latent} must be in 1..{_lib.BDF_MAX_D}")
+        self.data, self.D = data, int(num_latent)
+        self.ctx = Context(device, seed)
+        self.full_lambda_u = bool(full_lambda_u)
+        self.tol = float(tol)
+        self.compute_ff_size = compute_ff_size
+        self.rank, self.world = (0, 1) if shard is None else shard
+        self._rowlists = {}
+        # ---- reset! (RelationData.jl:331-355)
+        self.ent = []
+        for j, en in enumerate(data.entities):
+            if not np.isnan(lambda_beta):
+                en.lambda_beta = float(lambda_beta)
+            st = EntityState(self.ctx, en, self.D, j + 1)
+            en.modes = [[e is en for e in r.entities].index(True) + 1 for r in en.relations]
+            en.modes_other = [[k + 1 for k, e in enumerate(r.entities) if e is not en] for r in en.relations]
+            if st.F is not None:
+                en.use_FF = st.numF <= compute_ff_size
+            from .relation_data import EntityModel
+            en.model = EntityModel()
+            en.model._dev = st
+            self.ent.append(st)
+        self.rel = []
+        for r in data.relations:
+            if len(r.entities) != len(r.data.dims):
+                raise ArgumentError(f"Relation {r.name} has {len(r.entities)} entities but its data implies {r.data.size()}.")
+            dr = DeviceRelation(self.ctx, r.data)
+            r.model.mean_value = dr.value_mean()
+            r._dev = dr
+            self.rel.append(dr)
+            if not feat.isempty(r.F):
+                raise NotImplementedError("relation-level side information (sample_beta_rel, sampling.jl:322-337) is not on the GPU path yet")
+        self._test_pairs = None
+        self._train_pairs = None
+
+    # ---- helpers ----------------------------------------------------------------------------------------
+    def _entity_index(self, en):
+        return [e is en for e in self.data.entities].index(True)
+
+    def _terms(self, j):
+        en = self.data.entities[j]
+        terms = (Term * len(en.relations))()
+        for t, r in enumerate(en.relations):
+            ri = [x is r for x in self.data.relations].index(True)
+            terms[t].rel = self.rel[ri].handle
+            terms[t].mode = en.modes[t] - 1
+            terms[t].alpha = r.model.alpha
+            terms[t].mean_value = r.model.mean_value
+            terms[t].linear_values = None
+            for k, e2 in enumerate(r.entities):
+                terms[t].factors[k] = self.ent[self._entity_index(e2)].sample.data_ptr()
+        return terms
+
+    def _rowlist(self, j):
+        """rows of entity j owned by this rank: positions rank, rank+world, ... of the degree-descending order
+        (the reference partitions rows i:P:N for balance, sampling.jl:154)"""
+        if self.world == 1:
+            return None, self.ent[j].N
+        if j not in self._rowlists:
+            en = self.data.entities[j]
+            r0 = en.relations[0]
+            ri = [x is r0 for x in self.data.relations].index(True)
+            order = self.rel[ri].order(en.modes[0] - 1)
+            parts = [order[p::self.world] for p in range(self.world)]
+            self._rowlists[j] = ([self.ctx.tensor(p, dtype=torch.int32) for p in parts], [len(p) for p in parts])
+        lists, counts = self._rowlists[j]
+        return lists[self.rank], counts[self.rank]
+
+    # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
+    def sample_entity(self, j):
+        en, st = self.data.entities[j], self.ent[j]
+        if not en.relations:
+            raise ArgumentError(f"Entity {en.name} takes part in no relation")
+        terms = self._terms(j)
+        mu, is_matrix = st.mu, 0
+        if st.F is not None:
+            check(lib().bdf_uhat(self.ctx.handle, st.F.handle, self.D, _ptr(st.beta), _ptr(st.mu), _ptr(st.uhat), _ptr(st.mu_matrix)))
+            mu, is_matrix = st.mu_matrix, 1
+        rowlist, nrows = self._rowlist(j)
+        check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
+                                    st.tag, _ptr(rowlist), nrows, _ptr(st.sample)))
+        if self.world > 1:
+            self._allgather(j)
+
+    def _allgather(self, j):
+        """RCCL all-gather of the rows each rank sampled (C1). Shards are padded to equal length."""
+        import torch.distributed as dist
+        st = self.ent[j]
+        lists, counts = self._rowlists[j]
+        nmax = max(counts)
+        send = torch.zeros(nmax, self.D, dtype=torch.float64, device=self.ctx.device)
+        send[:counts[self.rank]] = st.sample.index_select(0, lists[self.rank].long())
+        recv = torch.empty(self.world * nmax, self.D, dtype=torch.float64, device=self.ctx.device)
+        dist.all_gather_into_tensor(recv, send)
+        for p in range(self.world):
+            if p != self.rank:
+                st.sample.index_copy_(0, lists[p].long(), recv[p * nmax:p * nmax + counts[p]])
+
+    # ---- macau.jl:119-134: hyperprior of entity j ----------------------------------------------------------------
+    def update_prior(self, j):
+        en, st = self.data.entities[j], self.ent[j]
+        L = lib()
+        check(L.bdf_hyper_sums(self.ctx.handle, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
+                               _ptr(st.sumU), _ptr(st.UUt)))
+        nu, Tinv = st.nu0, st.WI
+        if st.F is not None and self.full_lambda_u:
+            nu += st.numF
+            check(L.bdf_hyper_feature_terms(self.ctx.handle, self.D, st.numF, _ptr(st.beta), _ptr(st.WI), _ptr(st.lambda_beta),
+                                            _ptr(st.Tinv)))
+            Tinv = st.Tinv
+        check(L.bdf_hyper_sample(self.ctx.handle, self.D, st.N, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
+                                 nu, st.tag, _ptr(st.mu), _ptr(st.Lambda), _ptr(st.params)))
+
+    # ---- macau.jl:138-140: beta of entity j ----------------------------------------------------------------
+    def update_beta(self, j):
+        en, st = self.data.entities[j], self.ent[j]
+        if st.F is None:
+            return
+        check(lib().bdf_sample_beta(self.ctx.handle, st.F.handle, self.D, _ptr(st.sample), _ptr(st.mu), _ptr(st.Lambda),
+                                    _ptr(st.lambda_beta), int(en.use_FF), self.tol, 0, int(en.lambda_beta_sample),
+                                    en.nu, en.mu, st.tag, _ptr(st.beta), None, _ptr(st.cg_iters)))
+
+    def sync_host_scalars(self):
+        for en, st in zip(self.data.entities, self.ent):
+            if st.lambda_beta is not None:
+                en.lambda_beta = float(st.lambda_beta.item())
+
+    # ---- one Gibbs iteration without reporting (the timed unit of bench.py) ---------------------------------------
+    def sweep(self, i):
+        self.ctx.set_sweep(i)
+        for j in range(len(self.ent)):
+            self.sample_entity(j)
+            self.update_prior(j)
+        for j in range(len(self.ent)):
+            self.update_beta(j)
+
+    # ---- predictions ------------------------------------------------------------------------------------------
+    def factors_of(self, r):
+        return [self.ent[self._entity_index(e)].sample for e in r.entities]
+
+    def test_pairs(self):
+        r = self.data.relations[0]
+        if self._test_pairs is None:
+            self._test_pairs = DevicePairs(self.ctx, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
+        return self._test_pairs
+
+    def train_pairs(self):
+        r = self.data.relations[0]
+        if self._train_pairs is None:
+            self._train_pairs = DevicePairs(self.ctx, r.data.ids, r.data.values)
+        return self._train_pairs
+
+    def close(self):
+        for p in (self._test_pairs, self._train_pairs):
+            if p is not None:
+                p.close()
+        for st in self.ent:
+            if st.F is not None:
+                st.F.close()
+        for dr in self.rel:
+            dr.close()
+        self.ctx.close()

@@ -1,0 +1,203 @@
+/*
+ * bdf.h -- C ABI of libbdf_hip.so: the MI355X (gfx950) implementation of the Gibbs-sweep
+ * hot path of BayesianDataFusion.jl (latent-row sampler + hyperprior + side-information
+ * beta update + test-set prediction).
+ *
+ * The reference has no FFI for this path (pure Julia, multiple dispatch); the entry points
+ * below are the seams a maintainer would `ccall` from the reference's own functions.  Each
+ * declaration cites the reference interface (file:line under the reference tree) it replaces.
+ * INTEGRATION.md shows the Julia-side binding.
+ *
+ * Conventions
+ *   - every function returns BDF_OK (0) or a negative BDF_ERR_* code; bdf_last_error() gives
+ *     the message (the reference throws ArgumentError / DimensionMismatch / BoundsError).
+ *   - no exceptions, no C++ types, no torch types cross this boundary.
+ *   - "dev" pointers are device (HBM) addresses on the context's GPU; "host" pointers are
+ *     caller-owned host memory valid for the duration of the call only.
+ *   - matrices are column-major as in Julia: an entity's sample matrix is D x N (one column
+ *     of D doubles per entity instance), beta is numF x D, a dense F is N x numF.
+ *   - ids crossing the boundary from the reference's data model (relation / test pairs) are
+ *     1-based like the DataFrame holds them; row lists and ranges are 0-based.
+ *   - one host thread per context (macau.jl runs the Gibbs loop on one task); all work is
+ *     enqueued on the context's HIP stream, asynchronously unless stated.
+ */
+#ifndef BDF_H
+#define BDF_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDF_OK           0
+#define BDF_ERR_ARG     (-1)  /* ArgumentError / DimensionMismatch in the reference */
+#define BDF_ERR_BOUNDS  (-2)  /* BoundsError: id outside 1..dims                     */
+#define BDF_ERR_HIP     (-3)  /* HIP runtime error                                  */
+#define BDF_ERR_NOTPD   (-4)  /* a matrix that must be positive definite is not     */
+#define BDF_ERR_NOGPU   (-5)  /* no usable gfx950 device                            */
+
+#define BDF_MAX_MODES 4       /* modes per relation (matrix = 2, tensors up to 4)  */
+#define BDF_MAX_TERMS 4       /* relations summed per entity row                   */
+#define BDF_MAX_D     64      /* num_latent                                        */
+
+/* RNG stream purposes (DESIGN.md "RNG contract"); Philox4x32-10 counters are
+ * (row, pair | row_hi, sweep, purpose<<24 | entity_tag), key = seed. */
+#define BDF_P_ROW       1
+#define BDF_P_BETA_E1   2
+#define BDF_P_BETA_E2   3
+#define BDF_P_NW_NORMAL 4
+#define BDF_P_GAMMA_N   5
+#define BDF_P_GAMMA_U   6
+#define BDF_P_NW_MEAN   7
+
+typedef struct bdf_ctx   bdf_ctx;    /* device, stream, seed, sweep counter, scratch        */
+typedef struct bdf_rel   bdf_rel;    /* Relation.data :: IndexedDF / FastIDF on the device  */
+typedef struct bdf_pairs bdf_pairs;  /* Relation.test_vec (+ running prediction state)      */
+typedef struct bdf_feat  bdf_feat;   /* Entity.F operator (dense / CSR / binary CSR / COO)  */
+
+const char *bdf_last_error(void);
+int bdf_version(void);
+
+/* ---- context ------------------------------------------------------------------------ */
+/* stream: a hipStream_t the caller owns (e.g. torch's current stream); NULL is the device's
+ * default stream.  seed keys every random draw of the context. */
+int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx **out);
+int bdf_ctx_destroy(bdf_ctx *ctx);
+/* Gibbs iteration number (macau.jl:80 loop variable); lives in device memory so that a
+ * captured hipGraph of one sweep can be replayed: bdf_ctx_advance_sweep enqueues ++sweep. */
+int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
+int bdf_ctx_advance_sweep(bdf_ctx *ctx);
+int bdf_ctx_sync(bdf_ctx *ctx);
+/* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
+int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);
+int bdf_dev_free(bdf_ctx *ctx, void *dptr);
+int bdf_h2d(bdf_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int bdf_d2h(bdf_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);  /* synchronises */
+
+/* ---- a1: IndexedDF / FastIDF  (src/IndexedDF.jl:10-21, 46-70) ----------------------- */
+/* Host-only (needs no GPU): the IndexedDF constructor's index (IndexedDF.jl:10-19).  ids: nnz x n_modes
+ * column-major, 1-based, id_bytes 4|8.  rowptr[m]: caller array of dims[m]+1 (0-based offsets);
+ * rowids[m]: caller array of nnz (1-based COO row numbers, in original row order).
+ * Errors: BDF_ERR_BOUNDS for an id outside 1..dims[m]. */
+int bdf_index_build(int n_modes, const int64_t *dims, int64_t nnz, const void *ids, int id_bytes,
+                    int64_t *const *rowptr, int64_t *const *rowids);
+/* ids: nnz x n_modes column-major, 1-based, id_bytes = 4 (Int32) or 8 (Int64); values: nnz.
+ * Builds, per mode, the adjacency index in ORIGINAL COO order (bit-exact with
+ * IndexedDF.index) and its device CSR.  Errors: BDF_ERR_BOUNDS for an id outside 1..dims. */
+int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz,
+                        const void *ids, int id_bytes, const double *values, bdf_rel **out);
+int bdf_relation_destroy(bdf_rel *rel);
+/* host view of index[mode]: rowptr[dims[mode]+1] (0-based offsets) and rowids[nnz] (1-based
+ * COO row numbers), for getData/getCount/getI (IndexedDF.jl:41-43, 67-70) */
+int bdf_relation_index(const bdf_rel *rel, int mode, const int64_t **rowptr, const int64_t **rowids);
+/* valueMean (IndexedDF.jl:26) */
+int bdf_relation_value_mean(const bdf_rel *rel, double *mean);
+/* host copy of the degree-descending launch order of `mode` (0-based row numbers, n = dims[mode]) */
+int bdf_relation_order(const bdf_rel *rel, int mode, int32_t *order_host);
+
+/* ---- a3-a7: latent rows ---------------------------------------------------------------
+ * One relation's contribution to the rows of the entity being sampled:
+ * sample_user_basic (src/sampling.jl:200-212 matrix, :215-234 tensor) and the per-relation
+ * body of sample_user2 (src/sampling.jl:270-283). */
+typedef struct {
+    const bdf_rel *rel;
+    int32_t mode;                 /* 0-based mode of the sampled entity in rel              */
+    int32_t _pad;
+    double alpha;                 /* rel.model.alpha                                         */
+    double mean_value;            /* rel.model.mean_value                                    */
+    const double *linear_values;  /* dev, nullable: rel.temp.linear_values in COO order      */
+    const double *factors[BDF_MAX_MODES]; /* dev: D x N_k sample of every mode of rel; [mode] ignored */
+} bdf_term;
+
+/* sample_latent_all2! (src/sampling.jl:149-172) and sample_user2_all! (:251-264):
+ * for every listed row i:  P_i = Lambda + sum_r alpha_r sum_obs w w',  b_i = Lambda mu_i + sum_r alpha_r
+ * sum_obs w (y - base),  out[:,i] = chol(inv(P_i))' z + inv(P_i) b_i  with z from stream
+ * (BDF_P_ROW, entity_tag, i).  mu: dev, D doubles (shared prior mean) or D x N (mu_is_matrix,
+ * macau.jl:103-105).  rowlist: dev int32 row numbers (0-based) or NULL = all rows of the entity in the
+ * relation's degree order.  out: dev D x N; only listed rows are written; must not alias any
+ * terms[].factors[k] with k != mode. */
+int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
+                    const double *mu, int mu_is_matrix, const double *Lambda,
+                    uint32_t entity_tag, const int32_t *rowlist, int64_t n_rows, double *out);
+/* parity hook: the deterministic part only.  P_out: dev D x D x N, b_out: dev D x N */
+int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
+                   const double *mu, int mu_is_matrix, const double *Lambda,
+                   double *P_out, double *b_out);
+/* parity hook: n standard normals per row of stream (purpose, entity_tag, row) -> dev n x n_rows */
+int bdf_normals(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, int64_t row_begin,
+                int64_t n_rows, int n, double *out);
+/* parity hook: raw Philox4x32-10 block for (purpose, entity_tag, row, pair) at the current sweep */
+int bdf_philox(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, uint64_t row, uint32_t pair,
+               uint32_t out_host[4]);
+
+/* ---- a15: hyperprior  (src/sampling.jl:116-127, src/normal_wishart.jl:38-42, macau.jl:120-134) */
+/* sumU (dev D) = sum_i U[:,i], UUt (dev D x D) = U U' with U = sample - uhat (uhat nullable);
+ * deterministic summation order. */
+int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *sample, const double *uhat,
+                   double *sumU, double *UUt);
+/* ConditionalNormalWishart + rand(::NormalWishart): draws (mu, Lambda) on the device from the sums.
+ * mu0 (dev D), Tinv (dev D x D), b0, nu: the hyper-prior AFTER the feature terms of macau.jl:124-129.
+ * params_out (dev, nullable): mu_N (D) followed by inv(T_N) (D x D, the matrix sampling.jl:124 inverts)
+ * for parity checks. */
+int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *sumU, const double *UUt,
+                     const double *mu0, double b0, const double *Tinv, double nu,
+                     uint32_t entity_tag, double *mu_out, double *Lambda_out, double *params_out);
+
+/* ---- f2: test-set prediction (src/sampling.jl:9-45, macau.jl:142-203, 231-241) -------- */
+/* ids: n x n_modes column-major 1-based (test_vec[:,1:end-1]); values: n (test_vec[:,end]) */
+int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void *ids, int id_bytes,
+                     const double *values, bdf_pairs **out);
+int bdf_pairs_destroy(bdf_pairs *p);
+/* pred(r, test_vec) = udot + mean_value -> out (dev n) */
+int bdf_predict(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors,
+                double mean_value, double *out);
+/* one macau.jl:142-203 reporting step: p = pred; phase 0 (burn-in): avg = p; phase 1 (first
+ * posterior sample): avg = p, sq = p^2, count = 1; phase 2: running mean / sum of squares.
+ * stats_out (dev 4 doubles): sum (y-clamp(avg))^2, sum (y-clamp(p))^2, #correct(avg), #correct(p).
+ * clamp_lo > clamp_hi means no clamping. */
+int bdf_predict_update(bdf_ctx *ctx, bdf_pairs *p, int D, const double *const *factors,
+                       double mean_value, int phase, double clamp_lo, double clamp_hi,
+                       double class_cut, double *stats_out);
+/* running state: avg (dev n), sq (dev n) */
+int bdf_pairs_state(const bdf_pairs *p, double **avg, double **sq, int64_t *n);
+
+/* ---- a8-a14: side information (Entity.F operator contract) ------------- */
+/* dense: F host N x numF column-major (RelationData.jl:66-90 `F`) */
+int bdf_feat_create_dense(bdf_ctx *ctx, int64_t m, int64_t n, const double *F, bdf_feat **out);
+/* SparseMatrixCSR (src/parallel_csr.jl:36-54): COO triplets, 1-based */
+int bdf_feat_create_csr(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows,
+                        const int32_t *cols, const double *vals, bdf_feat **out);
+/* SparseBinMatrixCSR / SparseBinMatrix (src/sparsebin_csr.jl:22-37, src/parallel_matrix.jl:19-24):
+ * implicit 1.0 values; 1-based Int32 rows/cols */
+int bdf_feat_create_bin(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows,
+                        const int32_t *cols, bdf_feat **out);
+int bdf_feat_destroy(bdf_feat *f);
+int bdf_feat_size(const bdf_feat *f, int64_t *m, int64_t *n, int64_t *nnz);
+/* F*B (transpose=0: B n x ncol -> out m x ncol) or At_mul_B(F,B) (transpose=1: B m x ncol -> out
+ * n x ncol); B, out dev column-major (RelationData.jl:314-329, parallel_matrix.jl:520-561) */
+int bdf_feat_mul(bdf_ctx *ctx, const bdf_feat *f, const double *B, int ncol, double *out, int transpose);
+/* AtA_mul_B! for ncol vectors at once: out = (F'F + lambda I) X (src/parallel_cg.jl:7-14) */
+int bdf_feat_AtA_mul(bdf_ctx *ctx, const bdf_feat *f, const double *X, int ncol, double lambda, double *out);
+/* uhat = (F beta)' : D x N (F_mul_beta, RelationData.jl:314-320; macau.jl:103,112) and, if
+ * mu_matrix_out != NULL, mu_matrix = mu .+ uhat (macau.jl:104,113) */
+int bdf_uhat(bdf_ctx *ctx, const bdf_feat *f, int D, const double *beta, const double *mu,
+             double *uhat_out, double *mu_matrix_out);
+/* hyper-prior feature terms (macau.jl:124-129): Tinv_out = WI + beta' beta * lambda_beta */
+int bdf_hyper_feature_terms(bdf_ctx *ctx, int D, int64_t numF, const double *beta, const double *WI,
+                            const double *lambda_beta_dev, double *Tinv_out);
+/* sample_beta + update_beta! (src/sampling.jl:291-312, 361-370): rhs = F'((sample - mu)' + E1) +
+ * sqrt(lb) E2; beta = (F'F + lb I) \ rhs by Cholesky of FF (use_ff, solve_full :314-320) or D
+ * simultaneous cg_AtA solves (solve_cg2, parallel_matrix.jl:488-507; cg_AtA parallel_cg.jl:63-94)
+ * with per-column stopping ||r|| < tol ||b||, maxiter (<=0: numF).  tol NaN => eps()*numF.
+ * lambda_beta lives on the device (lambda_beta_dev, 1 double) so that sample_lambda_beta
+ * (sampling.jl:136-142; nu, mu hyper-parameters; enabled by sample_lambda) can update it in place.
+ * rhs_out (dev numF x D, nullable), iters_out (dev int32 D, nullable). */
+int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *f, int D, const double *sample, const double *mu,
+                    const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
+                    int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
+                    double *beta_out, double *rhs_out, int32_t *iters_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BDF_H */

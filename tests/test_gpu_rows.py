@@ -1,0 +1,327 @@
+"""GPU parity of the latent-row sampler (K1), RNG, hyperprior (K6) and prediction (K7) against the CPU oracle.
+
+Every call goes through the C ABI (include/bdf.h).  Tolerances: integer / counter outputs bit-exact; the row system
+(P_i, b_i) to 1e-12 relative; sampled rows to 1e-8 relative for the same normals (the oracle follows the reference's
+inv + chol(covar), the device factors the precision once -- see k_sample_rows.hip); normals to 1e-13.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SEED = 1234
+
+
+def _problem(rng, dims, nnz, D, empty_rows=True):
+    n_modes = len(dims)
+    ids = np.stack([rng.integers(1, d + 1, nnz) for d in dims], axis=1).astype(np.int64)
+    if empty_rows and dims[0] > 3:
+        ids[ids[:, 0] == 2, 0] = 1          # entity 2 of mode 1 has no observations
+    vals = rng.standard_normal(nnz)
+    facs = [rng.standard_normal((d, D)) for d in dims]
+    A = rng.standard_normal((D, D))
+    Lam = A @ A.T / D + np.eye(D)
+    mu = rng.standard_normal(D)
+    return ids, vals, facs, Lam, mu
+
+
+def _dev_terms(B, ctx, rels):
+    """rels: list of (DeviceRelation, mode0, alpha, mean, [factor tensors], linear tensor|None)"""
+    from bdf_amd._lib import Term
+    terms = (Term * len(rels))()
+    for t, (dr, mode0, alpha, mean, facs, lin) in enumerate(rels):
+        terms[t].rel = dr.handle
+        terms[t].mode = mode0
+        terms[t].alpha = alpha
+        terms[t].mean_value = mean
+        terms[t].linear_values = lin.data_ptr() if lin is not None else None
+        for k, f in enumerate(facs):
+            terms[t].factors[k] = f.data_ptr() if f is not None else None
+    return terms
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, tag, out_t, rowlist=None, nrows=0):
+    from bdf_amd._lib import check, lib
+    check(lib().bdf_sample_rows(ctx.handle, D, N, len(terms), terms, _p(mu_t), int(mu_t.dim() == 2), _p(Lam_t), tag,
+                                _p(rowlist), nrows, _p(out_t)))
+    ctx.sync()
+
+
+def test_philox_known_answer_and_stream(B, O, ctx):
+    from bdf_amd._lib import check, lib
+    out = (C.c_uint32 * 4)()
+    # seed 0, sweep 0, purpose 0, entity 0, row 0, pair 0 == counter 0 / key 0: Random123 known answer
+    c0 = B.Context(seed=0)
+    c0.set_sweep(0)
+    check(lib().bdf_philox(c0.handle, 0, 0, 0, 0, out))
+    assert [hex(x) for x in out] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    c0.close()
+    ctx.set_sweep(77)
+    for (purpose, entity, row, pair) in [(1, 1, 0, 0), (1, 2, 123456789012, 31), (4, 0xabcdef, 7, 65535), (6, 3, 2 ** 40 + 5, 9)]:
+        check(lib().bdf_philox(ctx.handle, purpose, entity, row, pair, out))
+        assert list(out) == list(O.draw(SEED, 77, purpose, entity, row, pair))
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 32, 64])
+def test_normals_match_oracle(B, O, ctx, n):
+    from bdf_amd._lib import check, lib
+    ctx.set_sweep(5)
+    rows = 300
+    out = ctx.zeros(rows, n)
+    check(lib().bdf_normals(ctx.handle, 1, 9, 1000, rows, n, _p(out)))
+    ctx.sync()
+    got = out.cpu().numpy()
+    exp = np.stack([O.normals(SEED, 5, 1, 9, 1000 + r, n) for r in range(rows)])
+    np.testing.assert_allclose(got, exp, rtol=1e-13, atol=1e-14)
+
+
+@pytest.mark.parametrize("D", [1, 5, 10, 16, 17, 30, 32, 33, 64])
+def test_row_system_and_sample_matrix(B, O, ctx, D):
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(D)
+    dims = [57, 41]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 900, D)
+    idf = B.IndexedDF((ids, vals), dims)
+    dr = B.DeviceRelation(ctx, idf)
+    ft = [ctx.tensor(f) for f in facs]
+    for mode0 in (0, 1):
+        N = dims[mode0]
+        alpha, mean = 1.7, 0.25
+        fl = [None if k == mode0 else ft[k] for k in range(2)]
+        terms = _dev_terms(B, ctx, [(dr, mode0, alpha, mean, fl, None)])
+        Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
+        P_t, b_t = ctx.zeros(N, D, D), ctx.zeros(N, D)
+        check(lib().bdf_row_system(ctx.handle, D, N, 1, terms, _p(mu_t), 0, _p(Lam_t), _p(P_t), _p(b_t)))
+        ctx.sync()
+        P, b = P_t.cpu().numpy(), b_t.cpu().numpy()
+        ot = O.Term(ids, vals, dims, mode0, alpha, mean, [None if k == mode0 else facs[k] for k in range(2)])
+        for row in range(N):
+            Pe, be = O.row_system(D, [ot], row, mu, Lam)
+            np.testing.assert_allclose(P[row].T, Pe, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(b[row], be, rtol=1e-12, atol=1e-12)
+        # full draw, same stream
+        ctx.set_sweep(3)
+        out_t = ctx.zeros(N, D)
+        _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 11, out_t)
+        exp = O.sample_rows(D, N, [ot], mu, Lam, SEED, 3, 11)
+        np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    dr.close()
+
+
+def test_rows_tensor_multi_relation_mu_matrix_linear(B, O, ctx):
+    """3-mode relation (Hadamard gather, sampling.jl:215-234) + a 2-mode relation sharing the entity
+    (sum over relations, :270-283), per-row prior mean (macau.jl:104) and linear_values (:273)"""
+    D = 12
+    rng = np.random.default_rng(5)
+    dimsA, dimsB = [23, 9, 6], [23, 14]
+    idsA, valsA, facsA, Lam, mu = _problem(rng, dimsA, 700, D)
+    idsB, valsB, facsB, _, _ = _problem(rng, dimsB, 300, D)
+    facsB[0] = facsA[0]
+    linB = rng.standard_normal(len(valsB))
+    mu_mat = rng.standard_normal((23, D))
+    idfA, idfB = B.IndexedDF((idsA, valsA), dimsA), B.IndexedDF((idsB, valsB), dimsB)
+    drA, drB = B.DeviceRelation(ctx, idfA), B.DeviceRelation(ctx, idfB)
+    fA = [ctx.tensor(f) for f in facsA]
+    fB = [fA[0], ctx.tensor(facsB[1])]
+    lin_t = ctx.tensor(linB)
+    terms = _dev_terms(B, ctx, [(drA, 0, 2.0, 0.1, [None, fA[1], fA[2]], None), (drB, 0, 0.7, -0.3, [None, fB[1]], lin_t)])
+    Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu_mat)
+    ctx.set_sweep(9)
+    out_t = ctx.zeros(23, D)
+    _run_rows(B, ctx, D, 23, terms, mu_t, Lam_t, 2, out_t)
+    oA = O.Term(idsA, valsA, dimsA, 0, 2.0, 0.1, [None, facsA[1], facsA[2]])
+    oB = O.Term(idsB, valsB, dimsB, 0, 0.7, -0.3, [None, facsB[1]], linear_values=linB)
+    exp = O.sample_rows(D, 23, [oA, oB], mu_mat, Lam, SEED, 9, 2)
+    np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    # middle mode of the tensor
+    terms = _dev_terms(B, ctx, [(drA, 1, 2.0, 0.1, [fA[0], None, fA[2]], None)])
+    out_t = ctx.zeros(9, D)
+    mu1_t = ctx.tensor(mu)
+    _run_rows(B, ctx, D, 9, terms, mu1_t, Lam_t, 3, out_t)
+    oA1 = O.Term(idsA, valsA, dimsA, 1, 2.0, 0.1, [facsA[0], None, facsA[2]])
+    exp = O.sample_rows(D, 9, [oA1], mu, Lam, SEED, 9, 3)
+    np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    drA.close(); drB.close()
+
+
+def test_rowlist_writes_only_listed_rows(B, O, ctx):
+    import torch
+    D = 8
+    rng = np.random.default_rng(8)
+    dims = [40, 30]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 500, D)
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    ft = [ctx.tensor(f) for f in facs]
+    terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, ft[1]], None)])
+    ctx.set_sweep(1)
+    out_t = ctx.zeros(40, D) + 777.0
+    rows = np.array([5, 0, 39, 17], dtype=np.int32)
+    rl = ctx.tensor(rows, dtype=torch.int32)
+    mu_t, Lam_t = ctx.tensor(mu), ctx.tensor(Lam)
+    _run_rows(B, ctx, D, 40, terms, mu_t, Lam_t, 1, out_t, rl, len(rows))
+    got = out_t.cpu().numpy()
+    exp = O.sample_rows(D, 40, [O.Term(ids, vals, dims, 0, 1.0, 0.0, [None, facs[1]])], mu, Lam, SEED, 1, 1)
+    mask = np.zeros(40, dtype=bool)
+    mask[rows] = True
+    np.testing.assert_allclose(got[mask], exp[mask], rtol=1e-8, atol=1e-9)
+    assert np.all(got[~mask] == 777.0)
+    # the degree order the library launches with is a permutation sorted by descending count
+    order = dr.order(0)
+    counts = np.bincount(ids[:, 0] - 1, minlength=40)
+    assert sorted(order.tolist()) == list(range(40))
+    assert np.all(np.diff(counts[order]) <= 0)
+    dr.close()
+
+
+def test_row_moments(B, O, ctx):
+    """sampled moments of one row over many sweeps: mean within 5 sigma/sqrt(n), covariance within 5% (Frobenius)"""
+    D = 6
+    rng = np.random.default_rng(21)
+    dims = [4, 12]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 40, D, empty_rows=False)
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    ft = [ctx.tensor(f) for f in facs]
+    terms = _dev_terms(B, ctx, [(dr, 0, 2.0, 0.1, [None, ft[1]], None)])
+    Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
+    n = 20000
+    draws = np.zeros((n, D))
+    out_t = ctx.zeros(4, D)
+    from bdf_amd._lib import check, lib
+    for s in range(n):
+        ctx.set_sweep(s + 1)
+        check(lib().bdf_sample_rows(ctx.handle, D, 4, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, None, 0, _p(out_t)))
+        draws[s] = out_t[1].cpu().numpy()
+    P, b = O.row_system(D, [O.Term(ids, vals, dims, 0, 2.0, 0.1, [None, facs[1]])], 1, mu, Lam)
+    cov = np.linalg.inv(P)
+    mean = cov @ b
+    se = np.sqrt(np.diag(cov) / n)
+    assert np.all(np.abs(draws.mean(0) - mean) < 5 * se)
+    emp = np.cov(draws.T)
+    assert np.linalg.norm(emp - cov) / np.linalg.norm(cov) < 0.05
+    dr.close()
+
+
+def test_not_positive_definite_is_reported(B, ctx):
+    D = 4
+    rng = np.random.default_rng(3)
+    dims = [5, 5]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 20, D, empty_rows=False)
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    ft = [ctx.tensor(f) for f in facs]
+    terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, ft[1]], None)])
+    bad_t, mu_t = ctx.tensor(-np.eye(D) * 1e6), ctx.tensor(mu)
+    out_t = ctx.zeros(5, D)
+    from bdf_amd._lib import check, lib
+    check(lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu_t), 0, _p(bad_t), 1, None, 0, _p(out_t)))
+    with pytest.raises(B.NotPositiveDefinite):
+        ctx.sync()
+    ctx.sync()      # flag is cleared
+    dr.close()
+
+
+def test_argument_errors(B, ctx):
+    from bdf_amd._lib import lib
+    D = 4
+    dims = [5, 6]
+    ids = np.array([[1, 1], [5, 6]])
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, np.ones(2)), dims))
+    f1, f2 = ctx.zeros(5, D), ctx.zeros(6, D)
+    terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, f2], None)])
+    mu, Lam = ctx.zeros(D), ctx.tensor(np.eye(D))
+    # entity count disagrees with the relation (ArgumentError, RelationData.jl:399)
+    assert lib().bdf_sample_rows(ctx.handle, D, 7, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f1)) == -1
+    # num_latent out of range
+    assert lib().bdf_sample_rows(ctx.handle, 65, 5, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f1)) == -1
+    # output aliasing a gathered factor
+    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f2)) == -1
+    with pytest.raises(B.BoundsError):
+        B.DeviceRelation(ctx, type("X", (), {"dims": [2, 2], "values": np.ones(1), "ids": np.asfortranarray(np.array([[3, 1]])),
+                                             "nnz": lambda self: 1})())
+    dr.close()
+
+
+def test_device_index_is_the_reference_index(B, O, ctx):
+    rng = np.random.default_rng(0)
+    dims = [13, 7, 5]
+    ids = np.stack([rng.integers(1, d + 1, 400) for d in dims], axis=1)
+    idf = B.IndexedDF((ids, rng.standard_normal(400)), dims)
+    dr = B.DeviceRelation(ctx, idf)
+    ref = O.index_build(ids, dims)
+    for m in range(3):
+        rp, ri = dr.index(m)
+        assert np.array_equal(rp, ref[m][0]) and np.array_equal(ri, ref[m][1])
+    assert abs(dr.value_mean() - idf.valueMean()) < 1e-15
+    dr.close()
+
+
+@pytest.mark.parametrize("D,N,with_uhat", [(3, 10, False), (10, 1000, True), (32, 6040, False), (64, 777, True)])
+def test_hyper_sums_and_normal_wishart(B, O, ctx, D, N, with_uhat):
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(D + N)
+    S = rng.standard_normal((N, D)) * 0.7 + rng.standard_normal(D)
+    uh = rng.standard_normal((N, D)) * 0.1 if with_uhat else None
+    U = S - uh if with_uhat else S
+    S_t = ctx.tensor(S)
+    uh_t = ctx.tensor(uh) if with_uhat else None
+    sumU, UUt = ctx.zeros(D), ctx.zeros(D, D)
+    check(lib().bdf_hyper_sums(ctx.handle, D, N, _p(S_t), _p(uh_t), _p(sumU), _p(UUt)))
+    ctx.sync()
+    np.testing.assert_allclose(sumU.cpu().numpy(), U.sum(0), rtol=1e-12, atol=1e-10)
+    np.testing.assert_allclose(UUt.cpu().numpy(), U.T @ U, rtol=1e-12, atol=1e-10)
+    # Normal-Wishart: parameters and draw against the oracle on the same streams
+    mu0 = rng.standard_normal(D) * 0.1
+    A = rng.standard_normal((D, D))
+    Tinv = A @ A.T / D + np.eye(D)
+    b0, nu = 2.0, D + 3.0
+    ctx.set_sweep(12)
+    mu_t, Lam_t, par_t = ctx.zeros(D), ctx.zeros(D, D), ctx.zeros(D + D * D)
+    mu0_t, Tinv_t = ctx.tensor(mu0), ctx.tensor(Tinv)      # keep alive until the kernel has run
+    check(lib().bdf_hyper_sample(ctx.handle, D, N, _p(sumU), _p(UUt), _p(mu0_t), b0, _p(Tinv_t), nu, 5,
+                                 _p(mu_t), _p(Lam_t), _p(par_t)))
+    ctx.sync()
+    mu_N, beta_N, T_N, nu_N = O.hyper_params(U, mu0, b0, Tinv, nu)
+    par = par_t.cpu().numpy()
+    np.testing.assert_allclose(par[:D], mu_N, rtol=1e-11, atol=1e-12)
+    W = par[D:].reshape(D, D)
+    np.testing.assert_allclose(np.triu(W), np.triu(np.linalg.inv(T_N)), rtol=1e-8, atol=1e-8)
+    mu_e, Lam_e = O.hyper_draw(mu_N, beta_N, T_N, nu_N, SEED, 12, 5)
+    np.testing.assert_allclose(Lam_t.cpu().numpy(), Lam_e, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(mu_t.cpu().numpy(), mu_e, rtol=1e-7, atol=1e-9)
+
+
+def test_predict_and_running_mean(B, O, ctx):
+    D = 10
+    rng = np.random.default_rng(4)
+    dims = [30, 20, 4]
+    n = 1000
+    ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
+    y = rng.standard_normal(n) + 3
+    pairs = B.DevicePairs(ctx, ids, y)
+    clamp, cut = [2.0, 4.0], 3.0
+    avg = sq = None
+    for it, phase in enumerate([0, 0, 1, 2, 2, 2]):
+        facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
+        ft = [ctx.tensor(f) for f in facs]
+        p = O.predict(ids, facs, 3.0)
+        got = pairs.predict(D, ft, 3.0).cpu().numpy()
+        np.testing.assert_allclose(got, p, rtol=1e-12, atol=1e-12)
+        stats = pairs.update(D, ft, 3.0, phase, clamp, cut).cpu().numpy()
+        if phase == 0:
+            avg = p
+        elif phase == 1:
+            avg, sq, cnt = p, p ** 2, 1
+        else:
+            avg = (cnt * avg + p) / (cnt + 1); sq = sq + p ** 2; cnt += 1
+        ca, cp = np.clip(avg, *clamp), np.clip(p, *clamp)
+        exp = [np.sum((y - ca) ** 2), np.sum((y - cp) ** 2), np.sum((y < cut) == (avg < cut)), np.sum((y < cut) == (p < cut))]
+        np.testing.assert_allclose(stats, exp, rtol=1e-10)
+    a, s = pairs.state()
+    np.testing.assert_allclose(a, avg, rtol=1e-12)
+    np.testing.assert_allclose(s, sq, rtol=1e-12)
+    pairs.close()
