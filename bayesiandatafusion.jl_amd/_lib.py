@@ -62,6 +62,7 @@ _SIGS = {
     "bdf_ctx_set_sweep": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
     "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
+    "bdf_ctx_set_item_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "bdf_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
@@ -73,7 +74,7 @@ _SIGS = {
     "bdf_relation_value_mean": (C.c_int, [C.c_void_p, c_dp]),
     "bdf_relation_order": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
     "bdf_sample_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
-                                  C.c_uint32, C.c_void_p, C.c_int64, C.c_void_p]),
+                                  C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
     "bdf_row_system": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "bdf_normals": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),

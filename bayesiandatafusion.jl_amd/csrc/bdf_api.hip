@@ -3,6 +3,7 @@
 #include <algorithm>
 #include <cmath>
 #include <numeric>
+#include <atomic>
 
 static thread_local char g_err[512] = "";
 
@@ -46,6 +47,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
+    c->item_size = 128;
     *out = c;
     return BDF_OK;
 }
@@ -55,6 +57,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (!ctx) return BDF_OK;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    bdf_plans_release(ctx, 0);
     if (ctx->scratch) hipFree(ctx->scratch);
     hipFree(ctx->sweep_dev);
     hipFree(ctx->flag_dev);
@@ -96,6 +99,13 @@ extern "C" int bdf_ctx_advance_sweep(bdf_ctx *ctx)
     hipLaunchKernelGGL(k_inc_u32, dim3(1), dim3(1), 0, ctx->stream, ctx->sweep_dev);
     BDF_HIP(hipGetLastError());
     ctx->sweep_host++;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations)
+{
+    BDF_REQUIRE(ctx && observations >= 8 && observations <= (1 << 20), BDF_ERR_ARG, "bdf_ctx_set_item_size: 8..2^20 observations");
+    ctx->item_size = observations;
     return BDF_OK;
 }
 
@@ -210,8 +220,10 @@ extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dim
     BDF_HIP(hipSetDevice(ctx->device));
     auto idat = [&](int64_t i, int m) -> int64_t { return id_at(ids, id_bytes, nnz, i, m); };
 
+    static std::atomic<uint64_t> next_serial{1};
     bdf_rel *r = new bdf_rel();
     r->ctx = ctx;
+    r->serial = next_serial.fetch_add(1);
     r->n_modes = n_modes;
     r->nnz = nnz;
     for (int m = 0; m < n_modes; m++) r->dims[m] = dims[m];
@@ -268,6 +280,7 @@ extern "C" int bdf_relation_destroy(bdf_rel *rel)
     if (!rel) return BDF_OK;
     hipSetDevice(rel->ctx->device);
     hipStreamSynchronize(rel->ctx->stream);
+    bdf_plans_release(rel->ctx, rel->serial);
     for (int m = 0; m < rel->n_modes; m++) {
         bdf_mode_index &ix = rel->idx[m];
         hipFree(ix.rowptr_dev); hipFree(ix.colidx_dev); hipFree(ix.vals_dev); hipFree(ix.perm_dev); hipFree(ix.order_dev);
@@ -347,27 +360,25 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
 
 extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                                const double *mu, int mu_is_matrix, const double *Lambda,
-                               uint32_t entity_tag, const int32_t *rowlist, int64_t n_rows, double *out)
+                               uint32_t entity_tag, int shard, int n_shards, double *out)
 {
     SampleArgs a;
     int rc = fill_args(ctx, "bdf_sample_rows", D, N, n_terms, terms, mu, mu_is_matrix, Lambda, a);
     if (rc) return rc;
     BDF_REQUIRE(out != nullptr, BDF_ERR_ARG, "bdf_sample_rows: out is NULL");
-    for (int r = 0; r < n_terms; r++)
+    BDF_REQUIRE(n_shards >= 1 && shard >= 0 && shard < n_shards, BDF_ERR_ARG, "bdf_sample_rows: shard %d of %d", shard, n_shards);
+    const bdf_rel *rels[BDF_MAX_TERMS];
+    int modes[BDF_MAX_TERMS];
+    for (int r = 0; r < n_terms; r++) {
+        rels[r] = terms[r].rel;
+        modes[r] = terms[r].mode;
         for (int k = 0; k < terms[r].rel->n_modes; k++)
             BDF_REQUIRE(k == terms[r].mode || terms[r].factors[k] != out, BDF_ERR_ARG,
                         "bdf_sample_rows: out aliases terms[%d].factors[%d]", r, k);
-    if (rowlist) {
-        BDF_REQUIRE(n_rows >= 0 && n_rows <= N, BDF_ERR_ARG, "bdf_sample_rows: n_rows=%lld outside 0..N", (long long)n_rows);
-        a.rowlist = rowlist;
-        a.nrows = n_rows;
-    } else {
-        a.rowlist = terms[0].rel->idx[terms[0].mode].order_dev;
-        a.nrows = N;
     }
     a.entity_tag = entity_tag;
     a.out = out;
-    return bdf_launch_sample_rows(ctx, a, false);
+    return bdf_launch_sample_rows(ctx, a, rels, modes, shard, n_shards, false);
 }
 
 extern "C" int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
@@ -378,11 +389,12 @@ extern "C" int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const
     int rc = fill_args(ctx, "bdf_row_system", D, N, n_terms, terms, mu, mu_is_matrix, Lambda, a);
     if (rc) return rc;
     BDF_REQUIRE(P_out && b_out, BDF_ERR_ARG, "bdf_row_system: NULL output");
-    a.rowlist = nullptr;
-    a.nrows = N;
+    const bdf_rel *rels[BDF_MAX_TERMS];
+    int modes[BDF_MAX_TERMS];
+    for (int r = 0; r < n_terms; r++) { rels[r] = terms[r].rel; modes[r] = terms[r].mode; }
     a.P_dump = P_out;
     a.b_dump = b_out;
-    return bdf_launch_sample_rows(ctx, a, true);
+    return bdf_launch_sample_rows(ctx, a, rels, modes, 0, 1, true);
 }
 
 __global__ void k_normals(uint64_t seed, const uint32_t *sweep, uint32_t purpose, uint32_t entity,

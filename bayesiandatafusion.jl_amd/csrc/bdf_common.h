@@ -35,6 +35,7 @@ struct bdf_ctx {
     void *scratch;
     size_t scratch_bytes;
     int *flag_dev;             // not-positive-definite flag
+    int item_size;             // K1: observations per work item (rows longer than this are split)
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
@@ -52,6 +53,7 @@ struct bdf_mode_index {
 
 struct bdf_rel {
     bdf_ctx *ctx;
+    uint64_t serial;           // unique per created relation (keys the K1 plan cache)
     int n_modes;
     int64_t dims[BDF_MAX_MODES];
     int64_t nnz;
@@ -186,8 +188,6 @@ struct TermDev {
 struct SampleArgs {
     TermDev t[BDF_MAX_TERMS];
     int32_t n_terms, D;
-    const int32_t *rowlist;
-    int64_t nrows;
     const double *mu;
     int32_t mu_is_matrix, _pad;
     const double *Lambda;
@@ -199,4 +199,6 @@ struct SampleArgs {
     int *flag;
 };
 
-int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, bool dump);
+int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
+                           int n_shards, bool dump);
+void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);   // rel_serial 0: every plan of the context

@@ -68,16 +68,23 @@ __global__ __launch_bounds__(HS_THREADS) void k_hyper_partial(int D, int64_t N, 
 }
 
 // ---- stage 2: fixed-order sum of the partials -----------------------------------------------------------------
-__global__ void k_hyper_final(int D, int nblocks, const double *__restrict__ partial, double *__restrict__ sumU,
-                              double *__restrict__ UUt)
+// one wave per 16 output elements: lane (b4, e) sums partials b4, b4+4, ... of element e, then the four partial sums
+// are combined in lane order -- a fixed order, so the result does not depend on scheduling
+__global__ __launch_bounds__(64) void k_hyper_final(int D, int nblocks, const double *__restrict__ partial,
+                                                    double *__restrict__ sumU, double *__restrict__ UUt)
 {
     const int DD = D * D;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= DD + D) return;
+    const int e = blockIdx.x * 16 + (threadIdx.x & 15);
+    const int b4 = threadIdx.x >> 4;
     double s = 0.0;
-    for (int b = 0; b < nblocks; b++) s += partial[(int64_t)b * (DD + D) + e];
-    if (e < DD) UUt[e] = s;
-    else sumU[e - DD] = s;
+    if (e < DD + D)
+        for (int b = b4; b < nblocks; b += 4) s += partial[(int64_t)b * (DD + D) + e];
+    const double s1 = __shfl_down(s, 16), s2 = __shfl_down(s, 32), s3 = __shfl_down(s, 48);
+    if (b4 == 0 && e < DD + D) {
+        const double t = ((s + s1) + s2) + s3;
+        if (e < DD) UUt[e] = t;
+        else sumU[e - DD] = t;
+    }
 }
 
 // ---- Normal-Wishart draw on one wavefront -------------------------------------------------------------------
@@ -206,7 +213,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
-    int nblocks = (int)std::min<int64_t>(1024, (N + 63) / 64);
+    int nblocks = (int)std::min<int64_t>(512, (N + 127) / 128);
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (N + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;
@@ -217,7 +224,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
                        (double *)scratch);
     BDF_HIP(hipGetLastError());
     int tot = D * D + D;
-    hipLaunchKernelGGL(k_hyper_final, dim3((tot + 255) / 256), dim3(256), 0, ctx->stream, D, nblocks,
+    hipLaunchKernelGGL(k_hyper_final, dim3((tot + 15) / 16), dim3(64), 0, ctx->stream, D, nblocks,
                        (const double *)scratch, sumU, UUt);
     BDF_HIP(hipGetLastError());
     return BDF_OK;

@@ -4,6 +4,7 @@
 // dimension of the product of the modes' factor rows (src/sampling.jl:30-45).  16 lanes share one test pair so
 // that each gathered factor row is read as whole 128-byte segments.
 #include "bdf_common.h"
+#include <algorithm>
 
 namespace {
 
@@ -21,6 +22,7 @@ struct PredArgs {
     int phase;                     // -1: predict only
     double count, clamp_lo, clamp_hi, cut;
     double *stats;
+    double *partial;               // per-block statistics
 };
 
 __device__ inline double clampv(double x, double lo, double hi)
@@ -33,19 +35,20 @@ __global__ __launch_bounds__(256) void k_predict(PredArgs a)
 {
     const int tid = threadIdx.x;
     const int sub = tid % LPP;
-    const int64_t pair = ((int64_t)blockIdx.x * blockDim.x + tid) / LPP;
+    double st[4] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPP);
+    // the 16 lanes of a group share `pair`, so a group enters and leaves the loop together (the shuffles below
+    // only cross lanes of one group)
+    for (int64_t pair = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; pair < a.n; pair += stride) {
     double s = 0.0;
-    if (pair < a.n) {
-        for (int e = sub; e < a.D; e += LPP) {
-            double p = 1.0;
-            for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
-            s += p;
-        }
+    for (int e = sub; e < a.D; e += LPP) {
+        double p = 1.0;
+        for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
+        s += p;
     }
 #pragma unroll
     for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    double st[4] = {0.0, 0.0, 0.0, 0.0};
-    if (pair < a.n && sub == 0) {
+    if (sub == 0) {
         const double p = s + a.mean;
         if (a.out) a.out[pair] = p;
         if (a.phase >= 0) {
@@ -57,10 +60,11 @@ __global__ __launch_bounds__(256) void k_predict(PredArgs a)
             const double y = a.values[pair];
             const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
             const bool label = y < a.cut;
-            st[0] = ea * ea; st[1] = ep * ep;
-            st[2] = (label == (avg < a.cut)) ? 1.0 : 0.0;
-            st[3] = (label == (p < a.cut)) ? 1.0 : 0.0;
+            st[0] += ea * ea; st[1] += ep * ep;
+            st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
+            st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
         }
+    }
     }
     if (a.phase >= 0) {
         __shared__ double red[4][256 / 64];
@@ -72,18 +76,43 @@ __global__ __launch_bounds__(256) void k_predict(PredArgs a)
             if ((tid & 63) == 0) red[q][tid >> 6] = v;
         }
         __syncthreads();
-        if (tid < 4) {
-            double v = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-            atomicAdd(&a.stats[tid], v);
-        }
+        if (tid < 4) a.partial[blockIdx.x * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
     }
 }
 
-int launch_predict(bdf_ctx *ctx, const PredArgs &a)
+// fixed-order sum of the per-block statistics
+__global__ __launch_bounds__(256) void k_predict_final(int nblocks, const double *partial, double *stats)
+{
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] += partial[b * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double x = v[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        if ((tid & 63) == 0) red[q][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 4) stats[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+int launch_predict(bdf_ctx *ctx, PredArgs &a)
 {
     if (a.n == 0) return BDF_OK;
-    int64_t threads = a.n * LPP;
-    hipLaunchKernelGGL(k_predict, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, ctx->stream, a);
+    const int64_t need = (a.n * LPP + 255) / 256;
+    const int nblocks = (int)std::min<int64_t>(need, 2048);
+    if (a.phase >= 0) {
+        void *sc;
+        int rc = bdf_scratch(ctx, (size_t)nblocks * 4 * sizeof(double), &sc);
+        if (rc) return rc;
+        a.partial = (double *)sc;
+    }
+    hipLaunchKernelGGL(k_predict, dim3(nblocks), dim3(256), 0, ctx->stream, a);
+    if (a.phase >= 0) hipLaunchKernelGGL(k_predict_final, dim3(1), dim3(256), 0, ctx->stream, nblocks, (const double *)a.partial, a.stats);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -167,7 +196,6 @@ extern "C" int bdf_predict_update(bdf_ctx *ctx, bdf_pairs *p, int D, const doubl
     BDF_REQUIRE(phase >= 0 && phase <= 2, BDF_ERR_ARG, "bdf_predict_update: phase must be 0, 1 or 2");
     a.mean = mean_value; a.avg = p->avg_dev; a.sq = p->sq_dev; a.phase = phase; a.count = p->count;
     a.clamp_lo = clamp_lo; a.clamp_hi = clamp_hi; a.cut = class_cut; a.stats = stats_out;
-    BDF_HIP(hipMemsetAsync(stats_out, 0, 4 * sizeof(double), ctx->stream));
     rc = launch_predict(ctx, a);
     if (rc) return rc;
     if (phase == 1) p->count = 1.0;

@@ -4,7 +4,7 @@
 // (src/sampling.jl:266-289, sum over the entity's relations) of the reference, for every row of an
 // entity at once (sample_latent_all2! :149-172, sample_user2_all! :251-264).
 //
-// Per row i (one 64-lane wavefront per row):
+// Per row i:
 //   S   = sum over the row's observations of w w',  w = Hadamard product of the other modes' factor rows
 //   P_i = Lambda + sum_r alpha_r S_r          b_i = Lambda mu_i + sum_r alpha_r sum w (y - base)
 //   x_i = chol(inv(P_i))' z + inv(P_i) b_i    (the reference's map from z to the sample)
@@ -17,161 +17,628 @@
 // All of it runs in index-reversed coordinates (e -> D-1-e), where U U' becomes an ordinary lower
 // Cholesky L L' and the two solves become forward then backward substitution.
 //
-// Data flow: CSR of the relation in this mode (rowptr / other-mode ids / values, coalesced) -> gathered
-// factor rows staged through LDS -> D x D accumulator in registers (lane = column) -> in-wave Cholesky
-// (v_readlane broadcasts, no LDS) -> forward solve -> LDS transpose -> backward solve -> D doubles out.
+// Work decomposition (ragged rows: MovieLens rows have 0..1668 observations):
+//   * a row's observations are cut into ITEMS of at most T observations; one wavefront accumulates one item.
+//   * a row with a single item is DIRECT: the wave that accumulated it also factors, solves and draws.
+//   * a row with several items (long rows, or several relations) is SPLIT: its items write partial (S, b) to a
+//     scratch slab, and a second launch (k_rows_finish) adds a row's partials in slot order and finishes it.
+//   so no wave ever owns more than T observations and results do not depend on scheduling.
+//
+// Accumulation: the rank-4 update S += W W' (W = D x 4 gathered factor rows) is one v_mfma_f64_16x16x4_f64 per
+// 16x16 block of the lower block-triangle.  The MFMA A/B operand of lane l is element (l & 15) of observation
+// (l >> 4): exactly what a coalesced 128-byte-per-16-lanes gather of the factor row delivers, so operands go from
+// global memory to the matrix pipe with no LDS staging and no cross-lane traffic (measured on MI355X: 64 cycles
+// per MFMA, 77 TFLOP/s chip-wide against 64 TFLOP/s for v_fma_f64 which would also need every operand broadcast).
+//
+// Finishing: G = 64/DP rows at a time per wave (lane group = row, lane in group = column of P~ held in registers).
+// Cholesky keeps the matrix fully symmetric so row k of a lane's column doubles as A[c][k]; step k broadcasts row k
+// through LDS once (ds_write_b64 + broadcast ds_reads) and updates the trailing rows with one fma per element.
 #include "bdf_common.h"
-#include "wave_linalg.h"
+#include <algorithm>
+#include <map>
+#include <mutex>
+
+#ifndef BDF_K1_WAVES
+#define BDF_K1_WAVES 2
+#endif
 
 namespace {
 
-constexpr int G = 16;   // observations staged per chunk
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+struct Item {             // one wave's accumulation work
+    int32_t row;          // entity row (-1: padding)
+    int32_t term;
+    int64_t q_begin;      // first observation (index into the term's CSR arrays)
+    int32_t count;        // observations in this item
+    int32_t slot;         // partial slot, or -1 for a direct row
+};
+
+struct SplitRow {
+    int32_t row;
+    int32_t slot_begin, n_slots;
+    int32_t _pad;
+};
+
+struct PlanDev {
+    const Item *direct;   int32_t n_direct;      // padded to a multiple of G
+    const Item *split;    int32_t n_split;
+    const SplitRow *rows; int32_t n_split_rows;  // padded to a multiple of G
+    double *partials;                            // n_split * PSZ doubles
+};
 
 template <int DP>
 struct Geo {
-    static constexpr int NH = 64 / DP;        // lane groups per wave (DP=64:1, 32:2, 16:4)
-    static constexpr int RPL = DP / NH;       // accumulator rows per lane (64, 16, 4)
+    static constexpr int G = 64 / DP;                  // rows finished together by one wave
+    static constexpr int DB = DP / 16;                 // 16-wide blocks per dimension
+    static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
+    static constexpr int LD = DP + 1;                  // padded leading dimension of the LDS images
+    static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
+    static constexpr int WAVE_LDS = DP * LD + 2 * 64 + 64;   // image + double-buffered broadcast row + 1/diag
+    static constexpr int WPB = (DP == 64) ? 1 : 4;     // waves per workgroup (static LDS must stay under 64 KB)
 };
 
-template <int DP, bool DUMP>
-__global__ __launch_bounds__(64) void k_sample_rows(SampleArgs a)
+__device__ inline void wave_sync()
 {
-    constexpr int NH = Geo<DP>::NH, RPL = Geo<DP>::RPL;
-    constexpr int STAGE = G * DP;
-    constexpr int TBUF = DP * WL_TLD;
-    __shared__ double smem[(STAGE + G > TBUF) ? (STAGE + G) : TBUF];
-    double *srow = smem;            // [G][DP] staged w vectors (index-reversed)
-    double *srr = smem + STAGE;     // [G] residuals y - base
+    // orders this wave's LDS writes before its later LDS reads (the LDS pipe is in-order per wave; this only
+    // stops the compiler from moving accesses across it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
 
-    const int lane = threadIdx.x;
-    const int c = lane % DP;        // column owned during accumulation (reversed coordinates)
-    const int h = lane / DP;
+__device__ inline double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+__device__ inline double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * 0.5, e, y);
+}
+
+// ---- accumulate one item: acc (MFMA C layout, lower block-triangle) and bred (the item's part of b) -----------------
+// Software pipeline over "trips" of 4*KS observations: the other-mode ids and values of trip t+2 and the gathered
+// factor rows of trip t+1 are in flight while the MFMAs of trip t issue.  Lane (j = l & 15, h = l >> 4) handles
+// observations h, h+4, h+8, ... of the item and elements 16 I + j of their factor rows (index-reversed).
+template <int DP, int NO>
+__device__ inline void accumulate(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                  double (&bred)[Geo<DP>::DB])
+{
+    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
+    constexpr int KS = (NO == 1) ? 4 : 2;                 // k-steps (of 4 observations) per trip
+    const TermDev &T = a.t[it.term];
     const int D = a.D;
-    const int64_t row = a.rowlist ? (int64_t)a.rowlist[blockIdx.x] : (int64_t)blockIdx.x;
-    const int ec = D - 1 - c;       // natural index of reversed column c (negative => padding)
+    const int j = lane & 15, h = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    double bpart[DB];
+    int ec[DB];                               // natural element index of reversed element 16*I + j (negative: padding)
+#pragma unroll
+    for (int I = 0; I < DB; I++) { bpart[I] = 0.0; ec[I] = D - 1 - (16 * I + j); }
+    const int n = it.count;
+    const int ntrips = (n + 4 * KS - 1) / (4 * KS);
+    const int64_t qb = it.q_begin;
 
-    double tot[RPL];
-#pragma unroll
-    for (int t = 0; t < RPL; t++) tot[t] = 0.0;
-    double btot = 0.0;
+    int32_t ix_n[KS][NO], ix_nn[KS][NO];
+    double rr_n[KS], rr_nn[KS];
+    double w_n[KS][NO][DB];
 
-    for (int r = 0; r < a.n_terms; r++) {
-        const TermDev &T = a.t[r];
-        const int64_t beg = T.rowptr[row], end = T.rowptr[row + 1];
-        double acc[RPL];
+#define LOAD_IDX(t, IX, RR)                                                                     \
+    _Pragma("unroll") for (int k = 0; k < KS; k++) {                                            \
+        const int o = (t) * 4 * KS + 4 * k + h;                                                 \
+        const bool valid = o < n;                                                               \
+        const int64_t q = qb + (valid ? o : 0);                                                 \
+        _Pragma("unroll") for (int m = 0; m < NO; m++) IX[k][m] = T.colidx[(int64_t)m * T.nnz + q]; \
+        const double base = T.linear ? T.linear[T.perm[q]] : T.mean;                            \
+        RR[k] = valid ? T.vals[q] - base : 0.0;                                                 \
+    }
+#define LOAD_DATA(t, IX)                                                                        \
+    _Pragma("unroll") for (int k = 0; k < KS; k++) {                                            \
+        const bool valid = (t) * 4 * KS + 4 * k + h < n;                                        \
+        _Pragma("unroll") for (int m = 0; m < NO; m++) {                                        \
+            const double *f = T.fac[m] + (int64_t)IX[k][m] * D;                                 \
+            _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
+                w_n[k][m][I] = (valid && ec[I] >= 0) ? f[ec[I]] : 0.0;                          \
+        }                                                                                       \
+    }
+
+    if (ntrips > 0) {
+        LOAD_IDX(0, ix_n, rr_n)
+        if (ntrips > 1) { LOAD_IDX(1, ix_nn, rr_nn) }
+        LOAD_DATA(0, ix_n)
+    }
+    for (int t = 0; t < ntrips; t++) {
+        double w_c[KS][DB], rr_c[KS];
 #pragma unroll
-        for (int t = 0; t < RPL; t++) acc[t] = 0.0;
-        double bacc = 0.0;
-        for (int64_t q0 = beg; q0 < end; q0 += G) {
-            const int g = (int)((end - q0 < G) ? (end - q0) : G);
-            // ---- stage: lane (c,h) loads element ec of observations h, h+NH, ...
+        for (int k = 0; k < KS; k++) {
+            rr_c[k] = rr_n[k];
 #pragma unroll
-            for (int s = 0; s < G / NH; s++) {
-                const int o = h + NH * s;
-                double w = 0.0;
-                if (o < g && ec >= 0) {
-                    const int64_t q = q0 + o;
-                    w = T.fac[0][(int64_t)T.colidx[q] * D + ec];
-                    for (int k = 1; k < T.n_other; k++)
-                        w *= T.fac[k][(int64_t)T.colidx[(int64_t)k * T.nnz + q] * D + ec];
-                }
-                srow[o * DP + c] = w;
-            }
-            if (lane < g) {
-                const int64_t q = q0 + lane;
-                const double base = T.linear ? T.linear[T.perm[q]] : T.mean;
-                srr[lane] = T.vals[q] - base;
-            }
-            __syncthreads();
-            // ---- rank-1 updates: acc[t] = S[h*RPL+t][c]
-            for (int o = 0; o < g; o++) {
-                const double vc = srow[o * DP + c];
-                const double *vr = srow + o * DP + h * RPL;
+            for (int I = 0; I < DB; I++) {
+                double v = w_n[k][0][I];
 #pragma unroll
-                for (int t = 0; t < RPL; t++) acc[t] = fma(vr[t], vc, acc[t]);
-                bacc = fma(vc, srr[o], bacc);
+                for (int m = 1; m < NO; m++) v *= w_n[k][m][I];      // Hadamard product (sampling.jl:225-227, 277-280)
+                w_c[k][I] = v;
             }
-            __syncthreads();
         }
 #pragma unroll
-        for (int t = 0; t < RPL; t++) tot[t] = fma(T.alpha, acc[t], tot[t]);
-        btot = fma(T.alpha, bacc, btot);
-    }
-
-    // ---- prior: P += Lambda, b += Lambda mu_i (reversed coordinates; identity padding)
-    const double *mu_i = a.mu_is_matrix ? a.mu + row * D : a.mu;
+        for (int k = 0; k < KS; k++) {
+            rr_n[k] = rr_nn[k];
 #pragma unroll
-    for (int t = 0; t < RPL; t++) {
-        const int i = h * RPL + t;
-        const int ei = D - 1 - i;
-        double lam = 0.0;
-        if (ei >= 0 && ec >= 0) lam = a.Lambda[ei + (int64_t)ec * D];
-        else if (i == c) lam = 1.0;
-        tot[t] += lam;
+            for (int m = 0; m < NO; m++) ix_n[k][m] = ix_nn[k][m];
+        }
+        if (t + 1 < ntrips) { LOAD_DATA(t + 1, ix_n) }
+        if (t + 2 < ntrips) { LOAD_IDX(t + 2, ix_nn, rr_nn) }
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            int b = 0;
+#pragma unroll
+            for (int I = 0; I < DB; I++) {
+#pragma unroll
+                for (int J = 0; J <= I; J++) {
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0);
+                    b++;
+                }
+                bpart[I] = fma(w_c[k][I], rr_c[k], bpart[I]);
+            }
+        }
     }
-    if (ec >= 0) {
-        double s = 0.0;
-        for (int j = 0; j < D; j++) s = fma(a.Lambda[ec + (int64_t)j * D], mu_i[j], s);
-        btot += s;
-    } else {
-        btot = 0.0;
+#undef LOAD_IDX
+#undef LOAD_DATA
+    // scale by alpha; reduce b over the four observation groups (lanes j, j+16, j+32, j+48)
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        double v = bpart[I] * T.alpha;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        bred[I] = v;
     }
+}
+
+// dispatch on the number of other modes of the item's relation (wave-uniform)
+template <int DP>
+__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                      double (&bred)[Geo<DP>::DB])
+{
+    const int no = a.t[it.term].n_other;
+    if (no == 1) accumulate<DP, 1>(a, it, lane, acc, bred);
+    else if (no == 2) accumulate<DP, 2>(a, it, lane, acc, bred);
+    else accumulate<DP, 3>(a, it, lane, acc, bred);
+}
+
+// ---- spread an accumulator (C layout) as a full symmetric image P~[i][c] at img[i*LD + c] ----------------------------
+// C layout of block (I,J): lane l, register r holds element (row 16I + (l>>4) + 4r, column 16J + (l&15)).
+template <int DP>
+__device__ inline void acc_to_image(const d4 (&acc)[Geo<DP>::NB], double *img, int lane)
+{
+    constexpr int DB = Geo<DP>::DB, LD = Geo<DP>::LD;
+    const int j = lane & 15, h = lane >> 4;
+    int b = 0;
+#pragma unroll
+    for (int I = 0; I < DB; I++)
+#pragma unroll
+        for (int J = 0; J <= I; J++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * I + h + 4 * r, colm = 16 * J + j;
+                img[row * LD + colm] = acc[b][r];
+                if (I != J) img[colm * LD + row] = acc[b][r];
+            }
+            b++;
+        }
+}
+
+// ---- finish G rows at once: lane group grp = lane / DP owns row rows[grp]; col[] = column c of P~ (with the prior) ----
+template <int DP, bool DUMP>
+__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double *wl, int lane)
+{
+    constexpr int G = Geo<DP>::G, LD = Geo<DP>::LD;
+    const int D = a.D;
+    const int grp = lane / DP, c = lane % DP;
+    const int ec = D - 1 - c;
+    double *img = wl;                       // DP x LD image (conversion / transposition buffer), shared by the groups in turn
+    double *fb = wl + DP * LD;              // [2][64] broadcast rows (double-buffered)
+    double *rdiag = fb + 2 * 64;            // [64] 1 / L[c][c]
 
     if (DUMP) {
-        if (ec >= 0) {
+        if (myrow >= 0 && ec >= 0) {
 #pragma unroll
-            for (int t = 0; t < RPL; t++) {
-                const int ei = D - 1 - (h * RPL + t);
-                if (ei >= 0) a.P_dump[(row * D + ec) * D + ei] = tot[t];
+            for (int i = 0; i < DP; i++) {
+                const int ei = D - 1 - i;
+                if (ei >= 0) a.P_dump[(myrow * D + ec) * D + ei] = col[i];
             }
-            if (h == 0) a.b_dump[row * D + ec] = btot;
+            a.b_dump[myrow * D + ec] = bj;
         }
         return;
     }
 
-    // ---- gather the full column c into lanes 0..DP-1
-    double col[DP];
+    // ---- factorisation P~ = Lh diag(p) Lh' kept UNSCALED: after step k, col[k] = Ah[c][k] = Lh[c][k] * p_k
+    //      (p_k = pivot).  One LDS round trip per step: row k is broadcast and the trailing rows take one fma each.
+    //      The Cholesky factor is L = Ah diag(1/sqrt(p)); the solves below are written in terms of Ah, 1/p and
+    //      one 1/sqrt(p_c) per lane, so no square root sits on the step-to-step critical path.
+    bool notpd = false;
+    double p_own = 1.0, rp_own = 1.0;
 #pragma unroll
-    for (int hh = 0; hh < NH; hh++)
+    for (int k = 0; k < DP; k++) {
+        double *row = fb + (k & 1) * 64 + grp * DP;
+        row[c] = col[k];                                  // A[k][c] = A[c][k]
+        wave_sync();
+        const double pk = row[k];
+        if (!(pk > 0.0)) notpd = true;
+        const double rp = fast_rcp(pk);
+        const double g = col[k] * rp;                     // A[c][k] / A[k][k]
 #pragma unroll
-        for (int t = 0; t < RPL; t++) col[hh * RPL + t] = __shfl(tot[t], c + hh * DP);
-    double bj = __shfl(btot, c);     // lanes >= DP mirror lane c (harmless)
+        for (int i = k + 1; i < DP; i++) col[i] = fma(-row[i], g, col[i]);
+        if (c == k) { p_own = pk; rp_own = rp; }
+    }
+    if (notpd && myrow >= 0) atomicOr(a.flag, 1);
+    rdiag[lane] = rp_own;
+    const double rs_own = fast_rsqrt(p_own);              // 1 / L[c][c]
+    const double sq_own = p_own * rs_own;                 // L[c][c]
+    wave_sync();
 
-    // ---- in-wave Cholesky: afterwards lane j holds row j of L in col[0..j]
-    double rinv_own;
-    if (wl_chol_rows<DP>(col, rinv_own, lane) && lane == 0) atomicOr(a.flag, 1);
+    // ---- forward solve L w = b  <=>  Ah wh = b with wh = w / sqrt(p):  wh_k = b'_k / p_k
+#pragma unroll
+    for (int k = 0; k < DP; k++) {
+        const double wk = __shfl(bj, grp * DP + k) * rdiag[grp * DP + k];
+        if (c > k) bj = fma(-col[k], wk, bj);
+        else if (c == k) bj = wk;
+    }
 
-    // ---- forward solve L w = b
-    bj = wl_fwd_rows<DP>(col, rinv_own, bj, lane);
-
-    // ---- y = w + z  (z in reversed coordinates: lane j takes normal number D-1-j)
-    const uint32_t sweep = *a.sweep;
+    // ---- y = w + z, carried as yh = y * sqrt(p) = wh * p + z * sqrt(p)
+    //      (z in reversed coordinates: column c takes normal number D-1-c of the row's stream)
     double yj = 0.0;
-    if (lane < DP && ec >= 0) yj = bj + bdf_normal(a.seed, sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, ec);
+    if (myrow >= 0 && ec >= 0)
+        yj = fma(bj, p_own, bdf_normal(a.seed, *a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec) * sq_own);
 
-    // ---- transpose L through LDS, then backward solve L' x = y
-    wl_rows_to_cols<DP>(col, smem, lane);
-    yj = wl_bwd_cols<DP>(col, rinv_own, yj, lane);
+    // ---- rows -> columns through the image, one group at a time: afterwards col[i] = Ah[i][c] (i >= c)
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        wave_sync();
+        if (grp == g) {
+#pragma unroll
+            for (int k = 0; k < DP; k++) img[c * LD + k] = col[k];
+        }
+        wave_sync();
+        if (grp == g) {
+#pragma unroll
+            for (int i = 0; i < DP; i++) col[i] = img[i * LD + c];
+        }
+    }
 
-    if (lane < DP && ec >= 0) a.out[row * D + ec] = yj;
+    // ---- backward solve L' x = y  <=>  Ah' x = yh:  x_i = yh'_i / p_i
+#pragma unroll
+    for (int i = DP - 1; i >= 0; i--) {
+        const double xi = __shfl(yj, grp * DP + i) * rdiag[grp * DP + i];
+        if (c < i) yj = fma(-col[i], xi, yj);
+        else if (c == i) yj = xi;
+    }
+    if (myrow >= 0 && ec >= 0) a.out[myrow * D + ec] = yj;
+}
+
+// column c of the prior in reversed coordinates: Lambda~[i][c] (identity padding) and (Lambda mu_i)~[c]
+template <int DP>
+__device__ inline void add_prior(const SampleArgs &a, int64_t myrow, int c, double (&col)[DP], double &bj)
+{
+    const int D = a.D;
+    const int ec = D - 1 - c;
+    if (ec >= 0 && myrow >= 0) {
+        const double *mu_i = a.mu_is_matrix ? a.mu + myrow * D : a.mu;
+        double s = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; i++) {
+            const int ei = D - 1 - i;
+            if (ei >= 0) {
+                const double lam = a.Lambda[ei + (int64_t)ec * D];
+                col[i] += lam;
+                s = fma(lam, mu_i[ei], s);        // (Lambda mu)[ec] = sum_ei Lambda[ec][ei] mu[ei] (Lambda symmetric)
+            }
+        }
+        bj += s;
+    } else {
+#pragma unroll
+        for (int i = 0; i < DP; i++) col[i] = (i == c) ? 1.0 : 0.0;
+        bj = 0.0;
+    }
+}
+
+// ---- launch 1: accumulate every item; finish the direct rows -------------------------------------------------------
+template <int DP, bool DUMP>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows_accum(SampleArgs a, PlanDev p)
+{
+    constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
+    constexpr int WPB = Geo<DP>::WPB;
+    __shared__ double lds[WPB * Geo<DP>::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *wl = lds + wave * Geo<DP>::WAVE_LDS;
+    const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+    d4 acc[NB];
+    double bred[DB];
+
+    if (wid < p.n_split) {
+        // a split item: partial to the slab, slot layout [block*4 + r][lane] then b[I][j]
+        const Item it = p.split[wid];
+        accumulate_any<DP>(a, it, lane, acc, bred);
+        double *dst = p.partials + (int64_t)it.slot * PSZ;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
+        if (lane < 16) {
+#pragma unroll
+            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bred[I];
+        }
+        return;
+    }
+    const int64_t first = (wid - p.n_split) * G;
+    if (first >= p.n_direct) return;
+    const int grp = lane / DP, c = lane % DP;
+    // accumulate the G rows of this wave one after the other; their accumulators stay in registers (NB*4 doubles
+    // each) until all are done, so that the column array of the finishing phase is not live during the gathers
+    d4 accg[G][NB];
+    double bredg[G][DB];
+    int64_t rows[G];
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const Item it = p.direct[first + g];
+        rows[g] = it.row;
+#pragma unroll
+        for (int b = 0; b < NB; b++) accg[g][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int I = 0; I < DB; I++) bredg[g][I] = 0.0;
+#ifndef BDF_EXP_SKIP_ACCUM
+        if (it.row >= 0 && it.count > 0) accumulate_any<DP>(a, it, lane, accg[g], bredg[g]);    // wave-uniform branch
+#endif
+    }
+    double col[DP];
+    double bj = 0.0;
+    int64_t myrow = -1;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        if (rows[g] >= 0) {
+            wave_sync();
+            acc_to_image<DP>(accg[g], wl, lane);
+            if (lane < 16) {
+#pragma unroll
+                for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bredg[g][I];
+            }
+            wave_sync();
+            if (grp == g) {
+#pragma unroll
+                for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
+                bj = wl[DP * LD + c];
+                myrow = rows[g];
+            }
+        }
+    }
+    wave_sync();
+    add_prior<DP>(a, myrow, c, col, bj);
+#ifdef BDF_EXP_SKIP_FINISH
+    if (myrow >= 0 && a.D - 1 - c >= 0) a.out[myrow * a.D + (a.D - 1 - c)] = col[0] + bj;
+    return;
+#endif
+    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane);
+}
+
+// ---- launch 2: add the partials of the split rows in slot order and finish them --------------------------------------
+template <int DP, bool DUMP>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows_finish(SampleArgs a, PlanDev p)
+{
+    constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
+    constexpr int WPB = Geo<DP>::WPB;
+    __shared__ double lds[WPB * Geo<DP>::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double *wl = lds + wave * Geo<DP>::WAVE_LDS;
+    const int64_t first = ((int64_t)blockIdx.x * WPB + wave) * G;
+    if (first >= p.n_split_rows) return;
+    const int grp = lane / DP, c = lane % DP;
+    double col[DP];
+    double bj = 0.0;
+    int64_t myrow = -1;
+#pragma unroll
+    for (int g = 0; g < G; g++) {
+        const SplitRow sr = p.rows[first + g];
+        if (sr.row >= 0) {
+            d4 acc[NB];
+            double bred[DB];
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < DB; I++) bred[I] = 0.0;
+            for (int s = 0; s < sr.n_slots; s++) {
+                const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[b][r] += src[(b * 4 + r) * 64 + lane];
+#pragma unroll
+                for (int I = 0; I < DB; I++) bred[I] += src[NB * 4 * 64 + I * 16 + (lane & 15)];
+            }
+            wave_sync();
+            acc_to_image<DP>(acc, wl, lane);
+            if (lane < 16) {
+#pragma unroll
+                for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bred[I];
+            }
+            wave_sync();
+            if (grp == g) {
+#pragma unroll
+                for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
+                bj = wl[DP * LD + c];
+                myrow = sr.row;
+            }
+        }
+    }
+    wave_sync();
+    add_prior<DP>(a, myrow, c, col, bj);
+    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane);
+}
+
+// ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
+struct PlanKey {
+    uint64_t rel[BDF_MAX_TERMS];      // relation serials
+    int mode[BDF_MAX_TERMS];
+    int n_terms, DP, T;
+    int shard, n_shards;
+    bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
+};
+
+struct Plan {
+    PlanDev dev;
+    Item *direct_dev = nullptr, *split_dev = nullptr;
+    SplitRow *rows_dev = nullptr;
+    double *partials_dev = nullptr;
+};
+
+struct PlanCache {
+    std::map<PlanKey, Plan> plans;
+};
+
+std::mutex g_cache_mutex;
+std::map<bdf_ctx *, PlanCache> g_caches;
+
+template <typename T>
+int to_device(const std::vector<T> &v, T **out)
+{
+    BDF_HIP(hipMalloc((void **)out, std::max<size_t>(v.size() * sizeof(T), 8)));
+    if (!v.empty()) BDF_HIP(hipMemcpy(*out, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return BDF_OK;
+}
+
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, const std::vector<int32_t> &rows, int G,
+               int psz, Plan &plan)
+{
+    const int T = key.T;
+    std::vector<Item> direct, split;
+    std::vector<SplitRow> srows;
+    for (int32_t row : rows) {
+        int n_items = 0;
+        for (int r = 0; r < key.n_terms; r++) {
+            const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
+            const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
+            n_items += (int)((n + T - 1) / T);
+        }
+        if (n_items <= 1) {
+            Item it{row, 0, 0, 0, -1};
+            for (int r = 0; r < key.n_terms; r++) {
+                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
+                const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
+                if (n > 0) { it.term = r; it.q_begin = rp[(size_t)row]; it.count = (int32_t)n; }
+            }
+            direct.push_back(it);
+        } else {
+            SplitRow sr{row, (int32_t)split.size(), n_items, 0};
+            for (int r = 0; r < key.n_terms; r++) {
+                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
+                const int64_t beg = rp[(size_t)row], n = rp[(size_t)row + 1] - beg;
+                const int pieces = (int)((n + T - 1) / T);
+                for (int s = 0; s < pieces; s++) {
+                    // equal pieces rather than T, T, ..., remainder
+                    const int64_t b0 = beg + n * s / pieces, b1 = beg + n * (s + 1) / pieces;
+                    split.push_back(Item{row, r, b0, (int32_t)(b1 - b0), (int32_t)split.size()});
+                }
+            }
+            srows.push_back(sr);
+        }
+    }
+    while (direct.size() % (size_t)G) direct.push_back(Item{-1, 0, 0, 0, -1});
+    while (srows.size() % (size_t)G) srows.push_back(SplitRow{-1, 0, 0, 0});
+    int rc;
+    if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
+        (rc = to_device(srows, &plan.rows_dev)))
+        return rc;
+    BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
+    plan.dev.direct = plan.direct_dev; plan.dev.n_direct = (int32_t)direct.size();
+    plan.dev.split = plan.split_dev;   plan.dev.n_split = (int32_t)split.size();
+    plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
+    plan.dev.partials = plan.partials_dev;
+    return BDF_OK;
 }
 
 template <int DP>
-int launch(bdf_ctx *ctx, const SampleArgs &a, bool dump)
+int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
-    dim3 grid((unsigned)a.nrows), block(64);
-    if (dump) hipLaunchKernelGGL((k_sample_rows<DP, true>), grid, block, 0, ctx->stream, a);
-    else      hipLaunchKernelGGL((k_sample_rows<DP, false>), grid, block, 0, ctx->stream, a);
-    BDF_HIP(hipGetLastError());
+    constexpr int G = Geo<DP>::G, WPB = Geo<DP>::WPB;
+    const int64_t waves1 = (int64_t)p.n_split + p.n_direct / G;
+    if (waves1 > 0) {
+        dim3 grid((unsigned)((waves1 + WPB - 1) / WPB)), block(64 * WPB);
+        if (dump) hipLaunchKernelGGL((k_rows_accum<DP, true>), grid, block, 0, ctx->stream, a, p);
+        else      hipLaunchKernelGGL((k_rows_accum<DP, false>), grid, block, 0, ctx->stream, a, p);
+        BDF_HIP(hipGetLastError());
+    }
+    const int64_t waves2 = p.n_split_rows / G;
+    if (waves2 > 0) {
+        dim3 grid((unsigned)((waves2 + WPB - 1) / WPB)), block(64 * WPB);
+        if (dump) hipLaunchKernelGGL((k_rows_finish<DP, true>), grid, block, 0, ctx->stream, a, p);
+        else      hipLaunchKernelGGL((k_rows_finish<DP, false>), grid, block, 0, ctx->stream, a, p);
+        BDF_HIP(hipGetLastError());
+    }
     return BDF_OK;
 }
 
 }  // namespace
 
-int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, bool dump)
+void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
 {
-    if (a.nrows == 0) return BDF_OK;
-    if (a.D <= 16) return launch<16>(ctx, a, dump);
-    if (a.D <= 32) return launch<32>(ctx, a, dump);
-    return launch<64>(ctx, a, dump);
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_caches.find(ctx);
+    if (it == g_caches.end()) return;
+    auto &plans = it->second.plans;
+    for (auto kv = plans.begin(); kv != plans.end();) {
+        bool hit = rel_serial == 0;
+        for (int r = 0; r < kv->first.n_terms; r++) hit = hit || kv->first.rel[r] == rel_serial;
+        if (hit) {
+            hipFree(kv->second.direct_dev); hipFree(kv->second.split_dev); hipFree(kv->second.rows_dev);
+            hipFree(kv->second.partials_dev);
+            kv = plans.erase(kv);
+        } else {
+            ++kv;
+        }
+    }
+    if (rel_serial == 0) g_caches.erase(it);
+}
+
+int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
+                           int n_shards, bool dump)
+{
+    const int DP = a.D <= 16 ? 16 : (a.D <= 32 ? 32 : 64);
+    const int G = 64 / DP;
+    const int DB = DP / 16, NB = DB * (DB + 1) / 2;
+    const int psz = NB * 4 * 64 + DB * 16;
+    PlanKey key;
+    memset(&key, 0, sizeof(key));
+    for (int r = 0; r < a.n_terms; r++) { key.rel[r] = rels[r]->serial; key.mode[r] = modes[r]; }
+    key.n_terms = a.n_terms; key.DP = DP; key.T = ctx->item_size; key.shard = shard; key.n_shards = n_shards;
+
+    Plan *plan;
+    {
+        std::lock_guard<std::mutex> lock(g_cache_mutex);
+        PlanCache &cache = g_caches[ctx];
+        auto it = cache.plans.find(key);
+        if (it == cache.plans.end()) {
+            // rows of this shard: positions shard, shard + n_shards, ... of the degree-descending order of the first
+            // relation (the reference deals rows i:P:N to its P workers for the same balance, sampling.jl:154)
+            const std::vector<int32_t> &order = rels[0]->idx[modes[0]].order;
+            std::vector<int32_t> rows;
+            for (size_t pos = (size_t)shard; pos < order.size(); pos += (size_t)n_shards) rows.push_back(order[pos]);
+            Plan np;
+            int rc = build_plan(ctx, key, rels, rows, G, psz, np);
+            if (rc) return rc;
+            it = cache.plans.emplace(key, np).first;
+        }
+        plan = &it->second;
+    }
+    if (DP == 16) return launch<16>(ctx, a, plan->dev, dump);
+    if (DP == 32) return launch<32>(ctx, a, plan->dev, dump);
+    return launch<64>(ctx, a, plan->dev, dump);
 }

@@ -35,6 +35,9 @@ class Context:
                                    C.byref(self.handle)))
         self.seed = int(seed)
 
+    def set_item_size(self, observations):
+        check(lib().bdf_ctx_set_item_size(self.handle, int(observations)))
+
     def set_sweep(self, i):
         check(lib().bdf_ctx_set_sweep(self.handle, C.c_uint32(int(i))))
 
@@ -295,6 +298,16 @@ class GibbsEngine:
                 raise NotImplementedError("relation-level side information (sample_beta_rel, sampling.jl:322-337) is not on the GPU path yet")
         self._test_pairs = None
         self._train_pairs = None
+        self.k1_events = None     # bench.py: list of (entity, start, end) HIP events around each K1 launch
+
+    def k1_algorithmic_bytes(self, j):
+        """bytes one K1 launch over all rows of entity j must move, summed over its relations:
+        nnz*((4 + 8D)*(n_modes-1) + 8) + N*(8D + 8) [+ N*8D per-row prior mean] + 8D^2 + 8D"""
+        en, st, D = self.data.entities[j], self.ent[j], self.D
+        b = st.N * (8 * D + 8) + 8 * D * D + 8 * D + (st.N * 8 * D if st.F is not None else 0)
+        for r in en.relations:
+            b += r.data.nnz() * ((4 + 8 * D) * (len(r.entities) - 1) + 8)
+        return b
 
     # ---- helpers ----------------------------------------------------------------------------------------
     def _entity_index(self, en):
@@ -315,10 +328,8 @@ class GibbsEngine:
         return terms
 
     def _rowlist(self, j):
-        """rows of entity j owned by this rank: positions rank, rank+world, ... of the degree-descending order
-        (the reference partitions rows i:P:N for balance, sampling.jl:154)"""
-        if self.world == 1:
-            return None, self.ent[j].N
+        """rows of entity j owned by each rank: positions rank, rank+world, ... of the degree-descending order
+        (the reference partitions rows i:P:N for balance, sampling.jl:154); needed to pack the all-gather"""
         if j not in self._rowlists:
             en = self.data.entities[j]
             r0 = en.relations[0]
@@ -339,9 +350,14 @@ class GibbsEngine:
         if st.F is not None:
             check(lib().bdf_uhat(self.ctx.handle, st.F.handle, self.D, _ptr(st.beta), _ptr(st.mu), _ptr(st.uhat), _ptr(st.mu_matrix)))
             mu, is_matrix = st.mu_matrix, 1
-        rowlist, nrows = self._rowlist(j)
+        if self.k1_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(self.ctx.stream)
         check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
-                                    st.tag, _ptr(rowlist), nrows, _ptr(st.sample)))
+                                    st.tag, self.rank, self.world, _ptr(st.sample)))
+        if self.k1_events is not None:
+            e1.record(self.ctx.stream)
+            self.k1_events.append((j, e0, e1))
         if self.world > 1:
             self._allgather(j)
 
@@ -349,6 +365,7 @@ class GibbsEngine:
         """RCCL all-gather of the rows each rank sampled (C1). Shards are padded to equal length."""
         import torch.distributed as dist
         st = self.ent[j]
+        self._rowlist(j)
         lists, counts = self._rowlists[j]
         nmax = max(counts)
         send = torch.zeros(nmax, self.D, dtype=torch.float64, device=self.ctx.device)

@@ -67,7 +67,9 @@ int bdf_ctx_destroy(bdf_ctx *ctx);
  * captured hipGraph of one sweep can be replayed: bdf_ctx_advance_sweep enqueues ++sweep. */
 int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
 int bdf_ctx_advance_sweep(bdf_ctx *ctx);
-int bdf_ctx_sync(bdf_ctx *ctx);
+int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
+/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 128 */
+int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 /* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
 int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);
 int bdf_dev_free(bdf_ctx *ctx, void *dptr);
@@ -113,12 +115,13 @@ typedef struct {
  * for every listed row i:  P_i = Lambda + sum_r alpha_r sum_obs w w',  b_i = Lambda mu_i + sum_r alpha_r
  * sum_obs w (y - base),  out[:,i] = chol(inv(P_i))' z + inv(P_i) b_i  with z from stream
  * (BDF_P_ROW, entity_tag, i).  mu: dev, D doubles (shared prior mean) or D x N (mu_is_matrix,
- * macau.jl:103-105).  rowlist: dev int32 row numbers (0-based) or NULL = all rows of the entity in the
- * relation's degree order.  out: dev D x N; only listed rows are written; must not alias any
- * terms[].factors[k] with k != mode. */
+ * macau.jl:103-105).  (shard, n_shards): the rows sampled are positions shard, shard + n_shards, ... of
+ * bdf_relation_order(terms[0].rel, terms[0].mode) -- the reference deals rows i:P:N to its P workers
+ * (sampling.jl:154); (0, 1) = every row.  out: dev D x N; only this shard's rows are written; must not
+ * alias any terms[].factors[k] with k != mode. */
 int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                     const double *mu, int mu_is_matrix, const double *Lambda,
-                    uint32_t entity_tag, const int32_t *rowlist, int64_t n_rows, double *out);
+                    uint32_t entity_tag, int shard, int n_shards, double *out);
 /* parity hook: the deterministic part only.  P_out: dev D x D x N, b_out: dev D x N */
 int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                    const double *mu, int mu_is_matrix, const double *Lambda,

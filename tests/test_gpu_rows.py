@@ -46,10 +46,10 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, tag, out_t, rowlist=None, nrows=0):
+def _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, tag, out_t, shard=0, n_shards=1):
     from bdf_amd._lib import check, lib
     check(lib().bdf_sample_rows(ctx.handle, D, N, len(terms), terms, _p(mu_t), int(mu_t.dim() == 2), _p(Lam_t), tag,
-                                _p(rowlist), nrows, _p(out_t)))
+                                shard, n_shards, _p(out_t)))
     ctx.sync()
 
 
@@ -150,8 +150,9 @@ def test_rows_tensor_multi_relation_mu_matrix_linear(B, O, ctx):
     drA.close(); drB.close()
 
 
-def test_rowlist_writes_only_listed_rows(B, O, ctx):
-    import torch
+def test_shard_writes_only_its_rows(B, O, ctx):
+    """(shard, n_shards) = positions shard::n_shards of the degree-descending order (the reference's i:P:N deal,
+    sampling.jl:154); the union of the shards equals the unsharded result"""
     D = 8
     rng = np.random.default_rng(8)
     dims = [40, 30]
@@ -160,23 +161,44 @@ def test_rowlist_writes_only_listed_rows(B, O, ctx):
     ft = [ctx.tensor(f) for f in facs]
     terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, ft[1]], None)])
     ctx.set_sweep(1)
-    out_t = ctx.zeros(40, D) + 777.0
-    rows = np.array([5, 0, 39, 17], dtype=np.int32)
-    rl = ctx.tensor(rows, dtype=torch.int32)
     mu_t, Lam_t = ctx.tensor(mu), ctx.tensor(Lam)
-    _run_rows(B, ctx, D, 40, terms, mu_t, Lam_t, 1, out_t, rl, len(rows))
-    got = out_t.cpu().numpy()
     exp = O.sample_rows(D, 40, [O.Term(ids, vals, dims, 0, 1.0, 0.0, [None, facs[1]])], mu, Lam, SEED, 1, 1)
-    mask = np.zeros(40, dtype=bool)
-    mask[rows] = True
-    np.testing.assert_allclose(got[mask], exp[mask], rtol=1e-8, atol=1e-9)
-    assert np.all(got[~mask] == 777.0)
-    # the degree order the library launches with is a permutation sorted by descending count
     order = dr.order(0)
     counts = np.bincount(ids[:, 0] - 1, minlength=40)
     assert sorted(order.tolist()) == list(range(40))
     assert np.all(np.diff(counts[order]) <= 0)
+    for n_shards in (2, 3):
+        for shard in range(n_shards):
+            out_t = ctx.zeros(40, D) + 777.0
+            _run_rows(B, ctx, D, 40, terms, mu_t, Lam_t, 1, out_t, shard, n_shards)
+            got = out_t.cpu().numpy()
+            mask = np.zeros(40, dtype=bool)
+            mask[order[shard::n_shards]] = True
+            np.testing.assert_allclose(got[mask], exp[mask], rtol=1e-8, atol=1e-9)
+            assert np.all(got[~mask] == 777.0)
     dr.close()
+
+
+@pytest.mark.parametrize("item", [8, 16, 1000])
+def test_item_size_does_not_change_results(B, O, ctx, item):
+    """rows longer than the item size are split over wavefronts and re-assembled in slot order"""
+    D = 32
+    rng = np.random.default_rng(77)
+    dims = [12, 50]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 2500, D, empty_rows=True)
+    c2 = B.Context(seed=SEED)
+    c2.set_item_size(item)
+    dr = B.DeviceRelation(c2, B.IndexedDF((ids, vals), dims))
+    ft = [c2.tensor(f) for f in facs]
+    terms = _dev_terms(B, c2, [(dr, 0, 1.3, 0.2, [None, ft[1]], None)])
+    c2.set_sweep(4)
+    mu_t, Lam_t = c2.tensor(mu), c2.tensor(Lam)
+    out_t = c2.zeros(12, D)
+    _run_rows(B, c2, D, 12, terms, mu_t, Lam_t, 6, out_t)
+    exp = O.sample_rows(D, 12, [O.Term(ids, vals, dims, 0, 1.3, 0.2, [None, facs[1]])], mu, Lam, SEED, 4, 6)
+    np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    dr.close()
+    c2.close()
 
 
 def test_row_moments(B, O, ctx):
@@ -195,7 +217,7 @@ def test_row_moments(B, O, ctx):
     from bdf_amd._lib import check, lib
     for s in range(n):
         ctx.set_sweep(s + 1)
-        check(lib().bdf_sample_rows(ctx.handle, D, 4, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, None, 0, _p(out_t)))
+        check(lib().bdf_sample_rows(ctx.handle, D, 4, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, 0, 1, _p(out_t)))
         draws[s] = out_t[1].cpu().numpy()
     P, b = O.row_system(D, [O.Term(ids, vals, dims, 0, 2.0, 0.1, [None, facs[1]])], 1, mu, Lam)
     cov = np.linalg.inv(P)
@@ -218,7 +240,7 @@ def test_not_positive_definite_is_reported(B, ctx):
     bad_t, mu_t = ctx.tensor(-np.eye(D) * 1e6), ctx.tensor(mu)
     out_t = ctx.zeros(5, D)
     from bdf_amd._lib import check, lib
-    check(lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu_t), 0, _p(bad_t), 1, None, 0, _p(out_t)))
+    check(lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu_t), 0, _p(bad_t), 1, 0, 1, _p(out_t)))
     with pytest.raises(B.NotPositiveDefinite):
         ctx.sync()
     ctx.sync()      # flag is cleared
@@ -235,11 +257,13 @@ def test_argument_errors(B, ctx):
     terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, f2], None)])
     mu, Lam = ctx.zeros(D), ctx.tensor(np.eye(D))
     # entity count disagrees with the relation (ArgumentError, RelationData.jl:399)
-    assert lib().bdf_sample_rows(ctx.handle, D, 7, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f1)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, D, 7, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1)) == -1
     # num_latent out of range
-    assert lib().bdf_sample_rows(ctx.handle, 65, 5, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f1)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, 65, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1)) == -1
     # output aliasing a gathered factor
-    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, None, 0, _p(f2)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f2)) == -1
+    # shard outside 0..n_shards-1
+    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 2, 2, _p(f1)) == -1
     with pytest.raises(B.BoundsError):
         B.DeviceRelation(ctx, type("X", (), {"dims": [2, 2], "values": np.ones(1), "ids": np.asfortranarray(np.array([[3, 1]])),
                                              "nnz": lambda self: 1})())
