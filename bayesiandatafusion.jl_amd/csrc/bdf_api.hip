@@ -47,7 +47,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
-    c->item_size = 128;
+    c->item_size = 512;
     *out = c;
     return BDF_OK;
 }

@@ -143,41 +143,44 @@ __global__ void k_axpy_lambda(int64_t n, double lambda, const double *x, double 
 }
 
 // ---- noise rows e ~ N(0, Lambda^-1) = chol(inv(Lambda))' z  (sampling.jl:298-300) ----------------------------------
-// step 1 (one wave): L~ = chol of index-reversed Lambda; stored row-major with 1/diag in Lr[DP*DP .. DP*DP+DP)
+// step 1 (one wave): factor the index-reversed Lambda (wave_linalg.h): Lr = [Ah rows, masked | 1/p | sqrt(p)]
 template <int DP>
 __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, double *Lr, int *flag)
 {
+    __shared__ double fb[64], piv[64];
     const int lane = threadIdx.x;
-    const int ej = D - 1 - lane;
+    const int c = lane % DP;
+    const int ej = D - 1 - c;
     double col[DP];
 #pragma unroll
     for (int i = 0; i < DP; i++) {
         const int ei = D - 1 - i;
-        double w = (i == lane) ? 1.0 : 0.0;
+        double w = (i == c) ? 1.0 : 0.0;
         if (ei >= 0 && ej >= 0) {
             const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;    // Symmetric(Lambda): upper triangle
             w = Lambda[lo + (int64_t)hi * D];
         }
         col[i] = w;
     }
-    double rinv_own;
-    if (wl_chol_rows<DP>(col, rinv_own, lane) && lane == 0) atomicOr(flag, 4);
+    double p_own;
+    if (wl_factor<DP>(col, p_own, fb, piv, lane) && lane == 0) atomicOr(flag, 4);
     if (lane < DP) {
 #pragma unroll
-        for (int k = 0; k < DP; k++) Lr[lane * DP + k] = col[k];
-        Lr[DP * DP + lane] = rinv_own;
+        for (int k = 0; k < DP; k++) Lr[c * DP + k] = col[k];
+        Lr[DP * DP + c] = piv[lane];
+        Lr[DP * DP + DP + c] = p_own * fast_rsqrt(p_own);
     }
 }
 
 // step 2: T[:,i] = (sample[:,i] - mu) + e_i   (sample == NULL: T[:,i] = scale * e_i), one thread per row i;
-// e solves U' e = z, i.e. L~' e~ = z~ in reversed coordinates (backward substitution)
+// e solves U' e = z, i.e. L~' e~ = z~ in reversed coordinates:  e~_j = (sqrt(p_j) z~_j - sum_{m>j} Ah[m][j] e~_m) / p_j
 template <int DP>
 __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const double *Lr, const double *sample,
                                                      const double *mu, const double *scale_sq, uint64_t seed,
                                                      const uint32_t *sweep_p, uint32_t purpose, uint32_t entity, double *T)
 {
-    __shared__ double sL[DP * DP + DP];
-    for (int e = threadIdx.x; e < DP * DP + DP; e += blockDim.x) sL[e] = Lr[e];
+    __shared__ double sL[DP * DP + 2 * DP];
+    for (int e = threadIdx.x; e < DP * DP + 2 * DP; e += blockDim.x) sL[e] = Lr[e];
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
 #pragma unroll
     for (int j = DP - 1; j >= 0; j--) {
         const int ej = D - 1 - j;
-        double s = (ej >= 0) ? bdf_normal(seed, sweep, purpose, entity, (uint64_t)i, ej) : 0.0;
+        double s = (ej >= 0) ? bdf_normal(seed, sweep, purpose, entity, (uint64_t)i, ej) * sL[DP * DP + DP + j] : 0.0;
 #pragma unroll
         for (int m = j + 1; m < DP; m++) s = fma(-sL[m * DP + j], e[m], s);
         e[j] = s * sL[DP * DP + j];
@@ -357,27 +360,27 @@ template <int DP>
 __global__ __launch_bounds__(64) void k_solve_small(int n, int ncol, const double *FF, const double *lambda_p,
                                                     const double *rhs, double *X, int *flag)
 {
-    __shared__ double tb[DP * WL_TLD];
+    __shared__ double img[DP * (DP + 1)], fb[64], piv[64];
     const int lane = threadIdx.x;
+    const int c = lane % DP;
     const double lambda = *lambda_p;
-    double col[DP];
+    double rowm[DP], colm[DP];
 #pragma unroll
     for (int i = 0; i < DP; i++) {
-        double w = (i == lane) ? 1.0 : 0.0;
-        if (i < n && lane < n) w = FF[i + (int64_t)lane * n] + ((i == lane) ? lambda : 0.0);
-        col[i] = w;
+        double w = (i == c) ? 1.0 : 0.0;
+        if (i < n && c < n) w = FF[i + (int64_t)c * n] + ((i == c) ? lambda : 0.0);
+        rowm[i] = w;
     }
-    double rinv_own;
-    if (wl_chol_rows<DP>(col, rinv_own, lane) && lane == 0) atomicOr(flag, 8);
-    double rowsL[DP];
+    double p_own;
+    if (wl_factor<DP>(rowm, p_own, fb, piv, lane) && lane == 0) atomicOr(flag, 8);
 #pragma unroll
-    for (int k = 0; k < DP; k++) rowsL[k] = col[k];
-    wl_rows_to_cols<DP>(col, tb, lane);
-    for (int c = 0; c < ncol; c++) {
-        double b = (lane < n) ? rhs[lane + (int64_t)c * n] : 0.0;
-        b = wl_fwd_rows<DP>(rowsL, rinv_own, b, lane);
-        b = wl_bwd_cols<DP>(col, rinv_own, b, lane);
-        if (lane < n) X[lane + (int64_t)c * n] = b;
+    for (int k = 0; k < DP; k++) colm[k] = rowm[k];
+    wl_transpose<DP>(colm, img, lane);
+    for (int q = 0; q < ncol; q++) {
+        double b = (lane < DP && c < n) ? rhs[c + (int64_t)q * n] : 0.0;
+        b = wl_forward<DP>(rowm, b, piv, lane);          // b' = wh p;  yh = w sqrt(p) = b'
+        b = wl_backward<DP>(colm, b, piv, lane);
+        if (lane < DP && c < n) X[c + (int64_t)q * n] = b;
     }
 }
 
@@ -574,7 +577,7 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
     const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
 
     // scratch layout (doubles): Lr | T (D x N) | E2s (D x numF) | rhs | R P Z Tm | scalars
-    size_t nLr = (size_t)DP * DP + DP, nT = (size_t)D * N, nE2 = (size_t)D * numF, nB = (size_t)numF * D, nTm = (size_t)N * D;
+    size_t nLr = (size_t)DP * DP + 2 * DP, nT = (size_t)D * N, nE2 = (size_t)D * numF, nB = (size_t)numF * D, nTm = (size_t)N * D;
     size_t total = nLr + nT + nE2 + nB * 4 + nTm + 3 * (size_t)D + 64 + (size_t)D * D;
     void *sv;
     int rc = bdf_scratch(ctx, total * sizeof(double) + (2 * (size_t)D + 16) * sizeof(int), &sv);

@@ -3,7 +3,7 @@
 //  bdf_hyper_sums   : N, sum_i U_i and U U' (src/sampling.jl:117-119) with U = sample - uhat (macau.jl:123),
 //                     two-stage deterministic reduction.
 //  bdf_hyper_sample : ConditionalNormalWishart (src/sampling.jl:116-127) + rand(::NormalWishart)
-//                     (src/normal_wishart.jl:38-42) on ONE wavefront, so the D x D work never leaves the device.
+//                     (src/normal_wishart.jl:38-42) in ONE workgroup, so the D x D work never leaves the device.
 //
 // The Normal-Wishart draw, in the reference's terms:
 //     W    = Tinv + UU' + b0 mu0 mu0' - beta_N mu_N mu_N'         (= inv(T_N))
@@ -100,109 +100,123 @@ struct NWArgs {
     int *flag;
 };
 
+// One workgroup of 256 threads.  Wave 0 runs the two factorisations; all four waves draw the Bartlett matrix and form
+// Lam~ = Z~ Z~'.  LDS images are row-major with leading dimension DP + 1.
 template <int DP>
-__global__ __launch_bounds__(64) void k_hyper_sample(NWArgs a)
+__global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
 {
     constexpr int LD = DP + 1;
-    __shared__ double sA[DP * LD];     // L~ rows, then Z~ (row-major, padded)
-    __shared__ double sT[DP * WL_TLD];
-    __shared__ double s_muN[DP];
-    const int lane = threadIdx.x;
+    __shared__ double sA[DP * LD];      // Bartlett A~ = J A, then Z~
+    __shared__ double sL[DP * LD];      // masked rows of Ah (factor of W~), later Lam~, later transposition image
+    __shared__ double s_rp[64], s_sq[64], s_fb[64], s_piv[64], s_muN[64];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
-    const int ej = D - 1 - lane;       // natural index of reversed index `lane` (negative => padding)
     const uint32_t sweep = *a.sweep;
     const double beta_N = a.b0 + a.N;
     const double nu_N = a.nu + a.N;
-
-    if (lane < DP) s_muN[lane] = (ej >= 0) ? (a.b0 * a.mu0[ej] + a.sumU[ej]) / beta_N : 0.0;
+    if (tid == 0) s_bad = 0;
+    if (tid < 64) {
+        const int e = D - 1 - tid;
+        s_muN[tid] = (e >= 0) ? (a.b0 * a.mu0[e] + a.sumU[e]) / beta_N : 0.0;      // reversed: s_muN[c] = mu_N[D-1-c]
+    }
     __syncthreads();
 
-    // W~ column `lane`; Symmetric(...) reads the upper triangle of the natural-order matrix
-    double col[DP];
-#pragma unroll
-    for (int i = 0; i < DP; i++) {
-        const int ei = D - 1 - i;
-        double w = (i == lane) ? 1.0 : 0.0;
-        if (ei >= 0 && ej >= 0) {
-            const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;     // element (lo, hi) of the upper triangle
-            w = a.Tinv[lo + (int64_t)hi * D] + a.UUt[lo + (int64_t)hi * D] + a.b0 * a.mu0[lo] * a.mu0[hi] -
-                beta_N * s_muN[D - 1 - lo] * s_muN[D - 1 - hi];
-        }
-        col[i] = w;
-    }
-    if (a.params_out && lane < DP && ej >= 0) {
-        a.params_out[ej] = s_muN[lane];
+    if (wave == 0) {
+        // ---- W~ = J W J, W = Tinv + UU' + b0 mu0 mu0' - beta_N mu_N mu_N' (Symmetric(): upper triangle), factorised
+        const int c = lane % DP, ej = D - 1 - c;
+        double col[DP];
 #pragma unroll
         for (int i = 0; i < DP; i++) {
             const int ei = D - 1 - i;
-            if (ei >= 0) a.params_out[D + ei + (int64_t)ej * D] = col[i];
+            double w = (i == c) ? 1.0 : 0.0;
+            if (ei >= 0 && ej >= 0) {
+                const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;
+                w = a.Tinv[lo + (int64_t)hi * D] + a.UUt[lo + (int64_t)hi * D] + a.b0 * a.mu0[lo] * a.mu0[hi] -
+                    beta_N * s_muN[D - 1 - lo] * s_muN[D - 1 - hi];
+            }
+            col[i] = w;
+        }
+        if (a.params_out && lane < DP && ej >= 0) {
+            a.params_out[ej] = s_muN[c];
+#pragma unroll
+            for (int i = 0; i < DP; i++) {
+                const int ei = D - 1 - i;
+                if (ei >= 0) a.params_out[D + ei + (int64_t)ej * D] = col[i];
+            }
+        }
+        double p_own;
+        if (wl_factor<DP>(col, p_own, s_fb, s_piv, lane) && lane == 0) s_bad = 1;
+        if (lane < DP) {
+#pragma unroll
+            for (int k = 0; k < DP; k++) sL[c * LD + k] = col[k];         // Ah[c][k], k < c (else 0)
+            s_rp[c] = s_piv[lane];
+            s_sq[c] = p_own * fast_rsqrt(p_own);
+        }
+    } else {
+        // ---- Bartlett matrix, reversed rows: sA[i][c] = A[D-1-i][c];  A[r][c]: c < r normal, c == r sqrt(chi2(nu_N - r))
+        for (int e = tid - 64; e < DP * DP; e += 192) {
+            const int i = e / DP, c = e % DP;
+            const int arow = D - 1 - i;
+            double v = 0.0;
+            if (arow >= 0 && c < D) {
+                if (c < arow) v = bdf_normal(a.seed, sweep, BDF_P_NW_NORMAL, a.entity_tag, (uint64_t)arow, c);
+                else if (c == arow) v = sqrt(2.0 * bdf_gamma(a.seed, sweep, a.entity_tag, (uint64_t)arow, 0.5 * (nu_N - (double)arow)));
+            }
+            sA[i * LD + c] = v;
         }
     }
-
-    double rinv_own;
-    bool bad = wl_chol_rows<DP>(col, rinv_own, lane);       // lane j: row j of L~
-
-    // L~ to LDS (row-major): sA[j*LD + k] = L~[j][k]
-    if (lane < DP) {
-#pragma unroll
-        for (int k = 0; k < DP; k++) sA[lane * LD + k] = col[k];
-    }
     __syncthreads();
 
-    // Bartlett column c = lane of A~ = J A:  A~[i][c] = A[D-1-i][c]; A[a][c]: c < a normal, c == a sqrt(chi2), else 0
-    // then backward substitution L~' Z~[:,c] = A~[:,c]
-    double zc[DP];
+    // ---- Z~ = L~^-T A~  <=>  Ah' Z~ = diag(sqrt(p)) A~ : one thread per column, backward substitution
+    if (tid < DP) {
+        double z[DP];
 #pragma unroll
-    for (int i = DP - 1; i >= 0; i--) {
-        const int arow = D - 1 - i;                          // natural row of A
-        double rhs = 0.0;
-        if (arow >= 0 && lane < D) {
-            if (lane < arow) rhs = bdf_normal(a.seed, sweep, BDF_P_NW_NORMAL, a.entity_tag, (uint64_t)arow, lane);
-            else if (lane == arow)
-                rhs = sqrt(2.0 * bdf_gamma(a.seed, sweep, a.entity_tag, (uint64_t)arow, 0.5 * (nu_N - (double)arow)));
+        for (int i = DP - 1; i >= 0; i--) {
+            double s = s_sq[i] * sA[i * LD + tid];
+#pragma unroll
+            for (int m = i + 1; m < DP; m++) s = fma(-sL[m * LD + i], z[m], s);
+            z[i] = s * s_rp[i];
         }
-        double s = rhs;
 #pragma unroll
-        for (int m = i + 1; m < DP; m++) s = fma(-sA[m * LD + i], zc[m], s);
-        zc[i] = s * readlane_f64(rinv_own, i);
+        for (int i = 0; i < DP; i++) sA[i * LD + tid] = z[i];
     }
     __syncthreads();
-    // Z~ to LDS row-major: sA[i*LD + c] = Z~[i][c]
-    if (lane < DP) {
-#pragma unroll
-        for (int i = 0; i < DP; i++) sA[i * LD + lane] = zc[i];
-    }
-    __syncthreads();
-    // Lam~ column `lane`: Lam~[i][j] = sum_c Z~[i][c] Z~[j][c]   (zc reused for row `lane` of Z~)
-    if (lane < DP) {
-#pragma unroll
-        for (int c = 0; c < DP; c++) zc[c] = sA[lane * LD + c];
-    }
-#pragma unroll
-    for (int i = 0; i < DP; i++) {
+
+    // ---- Lam~ = Z~ Z~' (identity on the padding), stored reversed in sL and natural in Lambda_out
+    for (int e = tid; e < DP * DP; e += 256) {
+        const int i = e / DP, j = e % DP;
+        const int ei = D - 1 - i, ej = D - 1 - j;
         double s = 0.0;
-#pragma unroll
-        for (int c = 0; c < DP; c++) s = fma(sA[i * LD + c], zc[c], s);
-        const int ei = D - 1 - i;
-        if (ei < 0 || ej < 0) s = (i == lane) ? 1.0 : 0.0;   // identity padding
-        col[i] = s;
-    }
-    if (lane < DP && ej >= 0) {
-#pragma unroll
-        for (int i = 0; i < DP; i++) {
-            const int ei = D - 1 - i;
-            if (ei >= 0) a.Lambda_out[ei + (int64_t)ej * D] = col[i];
+        if (ei >= 0 && ej >= 0) {
+            // fixed summation order in c; (i,j) and (j,i) multiply the same pairs: the result is exactly symmetric
+            for (int c = 0; c < DP; c++) s = fma(sA[i * LD + c], sA[j * LD + c], s);
+            a.Lambda_out[ei + (int64_t)ej * D] = s;
+        } else {
+            s = (i == j) ? 1.0 : 0.0;
         }
+        sL[i * LD + j] = s;
     }
+    __syncthreads();
 
-    // mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N)
-    bad = wl_chol_rows<DP>(col, rinv_own, lane) || bad;
-    wl_rows_to_cols<DP>(col, sT, lane);
-    double y = 0.0;
-    if (lane < DP && ej >= 0) y = bdf_normal(a.seed, sweep, BDF_P_NW_MEAN, a.entity_tag, 0, ej);
-    y = wl_bwd_cols<DP>(col, rinv_own, y, lane);
-    if (lane < DP && ej >= 0) a.mu_out[ej] = s_muN[lane] + y / sqrt(beta_N);
-    if (bad && lane == 0) atomicOr(a.flag, 2);
+    // ---- mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
+    if (wave == 0) {
+        const int c = lane % DP, ej = D - 1 - c;
+        double col[DP];
+#pragma unroll
+        for (int i = 0; i < DP; i++) col[i] = sL[i * LD + c];
+        wave_sync();
+        double p_own;
+        if (wl_factor<DP>(col, p_own, s_fb, s_piv, lane) && lane == 0) s_bad = 1;
+        wl_transpose<DP>(col, sL, lane);
+        double yh = 0.0;
+        if (lane < DP && ej >= 0)
+            yh = bdf_normal(a.seed, sweep, BDF_P_NW_MEAN, a.entity_tag, 0, ej) * (p_own * fast_rsqrt(p_own));
+        const double x = wl_backward<DP>(col, yh, s_piv, lane);
+        if (lane < DP && ej >= 0) a.mu_out[ej] = s_muN[c] + x / sqrt(beta_N);
+        wave_sync();
+        if (lane == 0 && s_bad) atomicOr(a.flag, 2);
+    }
 }
 
 }  // namespace
@@ -240,9 +254,9 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.D = D; a.N = (double)N; a.sumU = sumU; a.UUt = UUt; a.mu0 = mu0; a.Tinv = Tinv; a.b0 = b0; a.nu = nu;
     a.seed = ctx->seed; a.sweep = ctx->sweep_dev; a.entity_tag = entity_tag;
     a.mu_out = mu_out; a.Lambda_out = Lambda_out; a.params_out = params_out; a.flag = ctx->flag_dev;
-    if (D <= 16) hipLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(64), 0, ctx->stream, a);
-    else if (D <= 32) hipLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(64), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(64), 0, ctx->stream, a);
+    if (D <= 16) hipLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, a);
+    else if (D <= 32) hipLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, a);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }

@@ -34,7 +34,9 @@
 // Cholesky keeps the matrix fully symmetric so row k of a lane's column doubles as A[c][k]; step k broadcasts row k
 // through LDS once (ds_write_b64 + broadcast ds_reads) and updates the trailing rows with one fma per element.
 #include "bdf_common.h"
+#include "wave_linalg.h"
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 
@@ -45,6 +47,8 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
 
 struct Item {             // one wave's accumulation work
     int32_t row;          // entity row (-1: padding)
@@ -74,43 +78,29 @@ struct Geo {
     static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
     static constexpr int LD = DP + 1;                  // padded leading dimension of the LDS images
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
-    static constexpr int WAVE_LDS = DP * LD + 2 * 64 + 64;   // image + double-buffered broadcast row + 1/diag
     static constexpr int WPB = (DP == 64) ? 1 : 4;     // waves per workgroup (static LDS must stay under 64 KB)
+    // LDS-DMA gather ring: a slot holds the 4 gathered factor rows of one MFMA k-step
+    static constexpr int LPR = (DP == 64) ? 32 : 16;   // lanes (16 bytes each) per gathered row
+    static constexpr int ROWB = LPR * 16;              // bytes between rows in a slot
+    static constexpr int IPK = 4 * LPR / 64;           // DMA instructions per k-step and other mode
+    static constexpr int SLOTB = 4 * ROWB;             // bytes per slot
+    static constexpr int RING_SLOTS = 8192 / SLOTB;    // 8 (DP <= 32) or 4 (DP = 64) slots, shared by the other modes
+    static constexpr int TMAX = 128;                   // observations per item on the DMA path
+    static constexpr int STAGE_B = 2 * TMAX * 4 + TMAX * 8;   // ids of up to 2 other modes + values
+    // per-wave LDS (doubles): the finishing area [img | fb | piv] aliases the gather area [ring | stage]
+    static constexpr int FIN_D = DP * LD + 64 + 64;
+    static constexpr int GAT_D = (8192 + STAGE_B) / 8;
+    static constexpr int WAVE_LDS = FIN_D > GAT_D ? FIN_D : GAT_D;
 };
 
-__device__ inline void wave_sync()
-{
-    // orders this wave's LDS writes before its later LDS reads (the LDS pipe is in-order per wave; this only
-    // stops the compiler from moving accesses across it)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
 
-__device__ inline double fast_rcp(double x)
-{
-    double y = __builtin_amdgcn_rcp(x);
-    double e = fma(-x, y, 1.0);
-    y = fma(y, e, y);
-    e = fma(-x, y, 1.0);
-    return fma(y, e, y);
-}
-
-__device__ inline double fast_rsqrt(double x)
-{
-    double y = __builtin_amdgcn_rsq(x);
-    double e = fma(-x * y, y, 1.0);
-    y = fma(y * 0.5, e, y);
-    e = fma(-x * y, y, 1.0);
-    return fma(y * 0.5, e, y);
-}
-
-// ---- accumulate one item: acc (MFMA C layout, lower block-triangle) and bred (the item's part of b) -----------------
+// ---- accumulate one item, register path (any D, per-observation baselines): acc (MFMA C layout, lower block-triangle)
+// and bred (the item's part of b) ------------------------------------------------------------------------------------
 // Software pipeline over "trips" of 4*KS observations: the other-mode ids and values of trip t+2 and the gathered
 // factor rows of trip t+1 are in flight while the MFMAs of trip t issue.  Lane (j = l & 15, h = l >> 4) handles
 // observations h, h+4, h+8, ... of the item and elements 16 I + j of their factor rows (index-reversed).
 template <int DP, int NO>
-__device__ inline void accumulate(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+__device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                   double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
@@ -205,15 +195,142 @@ __device__ inline void accumulate(const SampleArgs &a, const Item &it, int lane,
     }
 }
 
-// dispatch on the number of other modes of the item's relation (wave-uniform)
-template <int DP>
-__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+// ---- accumulate one item, LDS-DMA path (even D, shared baseline), in passes of at most TMAX observations -----------
+// The item's other-mode ids and values are staged in LDS by DMA once; then a ring of RING_SLOTS k-step slots is kept
+// full by global_load_lds gathers (per-lane source address = chunk (l % LPR) of factor row ids[l / LPR], lane-linear LDS
+// destination), P = slots/NO - 1 k-steps ahead of the MFMAs.  Nothing but DMAs uses the vector-memory counter inside
+// the loop, so the waits are exact: `s_waitcnt vmcnt((P-1) * NO * IPK)` retires precisely the oldest k-step.
+template <int DP, int NO>
+__device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int lane, double *wl, d4 (&acc)[Geo<DP>::NB],
                                       double (&bred)[Geo<DP>::DB])
 {
-    const int no = a.t[it.term].n_other;
-    if (no == 1) accumulate<DP, 1>(a, it, lane, acc, bred);
-    else if (no == 2) accumulate<DP, 2>(a, it, lane, acc, bred);
-    else accumulate<DP, 3>(a, it, lane, acc, bred);
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB, NB = GG::NB, LPR = GG::LPR, ROWB = GG::ROWB, IPK = GG::IPK, SLOTB = GG::SLOTB;
+    constexpr int R = GG::RING_SLOTS / NO;                // ring depth in k-steps
+    constexpr int P = R - 1;                              // k-steps in flight
+    static_assert(R >= 2, "ring too small");
+    constexpr int TMAX = GG::TMAX;
+    const TermDev &T = a.t[it.term];
+    const int D = a.D;
+    const int j = lane & 15, h = lane >> 4;
+    char *ring = (char *)wl;
+    int32_t *sidx = (int32_t *)(ring + 8192);             // [NO][TMAX]
+    double *svals = (double *)(ring + 8192 + 2 * TMAX * 4);
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    double bpart[DB];
+    int eoff[DB];                                         // byte offset in a gathered row of reversed element 16 I + j
+    bool eok[DB];
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        bpart[I] = 0.0;
+        const int ec = D - 1 - (16 * I + j);
+        eok[I] = ec >= 0;
+        eoff[I] = (ec >= 0 ? ec : 0) * 8;
+    }
+    const int rowbytes = D * 8;
+    const int chunk = lane % LPR;
+    const int coff = (chunk * 16 < rowbytes) ? chunk * 16 : rowbytes - 16;   // lanes past the row re-read its last chunk
+    for (int pass0 = 0; pass0 < it.count; pass0 += TMAX) {
+    const int n = (it.count - pass0 < TMAX) ? it.count - pass0 : TMAX;       // observations of this pass
+    const int64_t qb = it.q_begin + pass0;
+    // ---- stage ids (4 bytes per lane) and values (as dwords) of the pass
+    {
+        const int last = n - 1;
+#pragma unroll
+        for (int m = 0; m < NO; m++)
+#pragma unroll
+            for (int part = 0; part < TMAX / 64; part++) {
+                const int o = part * 64 + lane;
+                const int32_t *src = T.colidx + (int64_t)m * T.nnz + qb + (o < n ? o : last);
+                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sidx + m * TMAX + part * 64), 4, 0, 0);
+            }
+#pragma unroll
+        for (int part = 0; part < 2 * TMAX / 64; part++) {
+            const int w = part * 64 + lane;               // dword index into the values
+            const int32_t *src = (const int32_t *)(T.vals + qb) + (w < 2 * n ? w : 2 * last + (w & 1));
+            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)((int32_t *)svals + part * 64), 4, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const int nks = (n + 3) >> 2;
+
+    auto issue = [&](int ks) {
+        // gather the 4 factor rows of k-step ks (clamped into the pass) of every other mode into slot ks % R
+        char *slot = ring + (ks % R) * (NO * SLOTB);
+#pragma unroll
+        for (int m = 0; m < NO; m++)
+#pragma unroll
+            for (int q = 0; q < IPK; q++) {
+                int o = 4 * ks + q * (64 / LPR) + lane / LPR;
+                o = o < n ? o : n - 1;
+                const char *src = (const char *)(T.fac[m] + (int64_t)sidx[m * TMAX + o] * D) + coff;
+                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot + m * SLOTB + q * 1024), 16, 0, 0);
+            }
+    };
+#pragma unroll
+    for (int s = 0; s < P; s++) issue(s);
+    for (int ks = 0; ks < nks; ks++) {
+        // exactly P k-steps are outstanding here: ks .. ks+P-1; retire the oldest
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NO * IPK) : "memory");
+        const char *slot = ring + (ks % R) * (NO * SLOTB) + h * ROWB;
+        double w[DB];
+#pragma unroll
+        for (int I = 0; I < DB; I++) {
+            double v = *(const double *)(slot + eoff[I]);
+#pragma unroll
+            for (int m = 1; m < NO; m++) v *= *(const double *)(slot + m * SLOTB + eoff[I]);    // Hadamard product
+            w[I] = v;
+        }
+        const int o = 4 * ks + h;
+        const bool valid = o < n;
+        const double rr = valid ? svals[valid ? o : 0] - T.mean : 0.0;
+#pragma unroll
+        for (int I = 0; I < DB; I++) w[I] = (valid && eok[I]) ? w[I] : 0.0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // operands are in registers before their slot is reused
+        issue(ks + P);
+        int b = 0;
+#pragma unroll
+        for (int I = 0; I < DB; I++) {
+#pragma unroll
+            for (int J = 0; J <= I; J++) {
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[I], w[J], acc[b], 0, 0, 0);
+                b++;
+            }
+            bpart[I] = fma(w[I], rr, bpart[I]);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the run-ahead gathers before the stage is rewritten
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the run-ahead gathers before the LDS is reused
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        double v = bpart[I] * T.alpha;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        bred[I] = v;
+    }
+}
+
+// path and other-mode count are wave-uniform
+template <int DP>
+__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, double *wl, d4 (&acc)[Geo<DP>::NB],
+                                      double (&bred)[Geo<DP>::DB])
+{
+    const TermDev &T = a.t[it.term];
+    const int no = T.n_other;
+    const bool dma = (a.D % 2 == 0) && T.linear == nullptr;
+    if (dma && no == 1) {
+        accumulate_dma<DP, 1>(a, it, lane, wl, acc, bred);
+    } else if (dma && no == 2) {
+        accumulate_dma<DP, 2>(a, it, lane, wl, acc, bred);
+    } else {
+        if (no == 1) accumulate_reg<DP, 1>(a, it, lane, acc, bred);
+        else if (no == 2) accumulate_reg<DP, 2>(a, it, lane, acc, bred);
+        else accumulate_reg<DP, 3>(a, it, lane, acc, bred);
+    }
 }
 
 // ---- spread an accumulator (C layout) as a full symmetric image P~[i][c] at img[i*LD + c] ----------------------------
@@ -238,17 +355,17 @@ __device__ inline void acc_to_image(const d4 (&acc)[Geo<DP>::NB], double *img, i
         }
 }
 
-// ---- finish G rows at once: lane group grp = lane / DP owns row rows[grp]; col[] = column c of P~ (with the prior) ----
+// ---- finish G rows at once: lane group grp = lane / DP owns row myrow; col[] = column c of P~ (prior included) --------
 template <int DP, bool DUMP>
 __device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double *wl, int lane)
 {
-    constexpr int G = Geo<DP>::G, LD = Geo<DP>::LD;
+    constexpr int LD = Geo<DP>::LD;
     const int D = a.D;
-    const int grp = lane / DP, c = lane % DP;
+    const int c = lane % DP;
     const int ec = D - 1 - c;
-    double *img = wl;                       // DP x LD image (conversion / transposition buffer), shared by the groups in turn
-    double *fb = wl + DP * LD;              // [2][64] broadcast rows (double-buffered)
-    double *rdiag = fb + 2 * 64;            // [64] 1 / L[c][c]
+    double *img = wl;                       // DP x LD image (conversion / transposition buffer)
+    double *fb = wl + DP * LD;              // [64] broadcast row
+    double *piv = fb + 64;                  // [64] 1 / pivot
 
     if (DUMP) {
         if (myrow >= 0 && ec >= 0) {
@@ -261,69 +378,17 @@ __device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&
         }
         return;
     }
-
-    // ---- factorisation P~ = Lh diag(p) Lh' kept UNSCALED: after step k, col[k] = Ah[c][k] = Lh[c][k] * p_k
-    //      (p_k = pivot).  One LDS round trip per step: row k is broadcast and the trailing rows take one fma each.
-    //      The Cholesky factor is L = Ah diag(1/sqrt(p)); the solves below are written in terms of Ah, 1/p and
-    //      one 1/sqrt(p_c) per lane, so no square root sits on the step-to-step critical path.
-    bool notpd = false;
-    double p_own = 1.0, rp_own = 1.0;
-#pragma unroll
-    for (int k = 0; k < DP; k++) {
-        double *row = fb + (k & 1) * 64 + grp * DP;
-        row[c] = col[k];                                  // A[k][c] = A[c][k]
-        wave_sync();
-        const double pk = row[k];
-        if (!(pk > 0.0)) notpd = true;
-        const double rp = fast_rcp(pk);
-        const double g = col[k] * rp;                     // A[c][k] / A[k][k]
-#pragma unroll
-        for (int i = k + 1; i < DP; i++) col[i] = fma(-row[i], g, col[i]);
-        if (c == k) { p_own = pk; rp_own = rp; }
-    }
-    if (notpd && myrow >= 0) atomicOr(a.flag, 1);
-    rdiag[lane] = rp_own;
-    const double rs_own = fast_rsqrt(p_own);              // 1 / L[c][c]
-    const double sq_own = p_own * rs_own;                 // L[c][c]
-    wave_sync();
-
-    // ---- forward solve L w = b  <=>  Ah wh = b with wh = w / sqrt(p):  wh_k = b'_k / p_k
-#pragma unroll
-    for (int k = 0; k < DP; k++) {
-        const double wk = __shfl(bj, grp * DP + k) * rdiag[grp * DP + k];
-        if (c > k) bj = fma(-col[k], wk, bj);
-        else if (c == k) bj = wk;
-    }
-
-    // ---- y = w + z, carried as yh = y * sqrt(p) = wh * p + z * sqrt(p)
-    //      (z in reversed coordinates: column c takes normal number D-1-c of the row's stream)
-    double yj = 0.0;
+    double p_own;
+    if (wl_factor<DP>(col, p_own, fb, piv, lane) && myrow >= 0) atomicOr(a.flag, 1);
+    const double sq_own = p_own * fast_rsqrt(p_own);                 // L[c][c] = sqrt(p_c)
+    // L w = b, y = w + z, carried as yh = y sqrt(p) = b' + z sqrt(p)   (z reversed: column c takes normal number D-1-c)
+    const double bp = wl_forward<DP>(col, bj, piv, lane);
+    double yh = 0.0;
     if (myrow >= 0 && ec >= 0)
-        yj = fma(bj, p_own, bdf_normal(a.seed, *a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec) * sq_own);
-
-    // ---- rows -> columns through the image, one group at a time: afterwards col[i] = Ah[i][c] (i >= c)
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        wave_sync();
-        if (grp == g) {
-#pragma unroll
-            for (int k = 0; k < DP; k++) img[c * LD + k] = col[k];
-        }
-        wave_sync();
-        if (grp == g) {
-#pragma unroll
-            for (int i = 0; i < DP; i++) col[i] = img[i * LD + c];
-        }
-    }
-
-    // ---- backward solve L' x = y  <=>  Ah' x = yh:  x_i = yh'_i / p_i
-#pragma unroll
-    for (int i = DP - 1; i >= 0; i--) {
-        const double xi = __shfl(yj, grp * DP + i) * rdiag[grp * DP + i];
-        if (c < i) yj = fma(-col[i], xi, yj);
-        else if (c == i) yj = xi;
-    }
-    if (myrow >= 0 && ec >= 0) a.out[myrow * D + ec] = yj;
+        yh = fma(bdf_normal(a.seed, *a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec), sq_own, bp);
+    wl_transpose<DP>(col, img, lane);
+    const double x = wl_backward<DP>(col, yh, piv, lane);            // L' x = y
+    if (myrow >= 0 && ec >= 0) a.out[myrow * D + ec] = x;
 }
 
 // column c of the prior in reversed coordinates: Lambda~[i][c] (identity padding) and (Lambda mu_i)~[c]
@@ -358,17 +423,20 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
 {
     constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
     constexpr int WPB = Geo<DP>::WPB;
-    __shared__ double lds[WPB * Geo<DP>::WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *wl = lds + wave * Geo<DP>::WAVE_LDS;
     const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
-    d4 acc[NB];
-    double bred[DB];
 
-    if (wid < p.n_split) {
-        // a split item: partial to the slab, slot layout [block*4 + r][lane] then b[I][j]
-        const Item it = p.split[wid];
-        accumulate_any<DP>(a, it, lane, acc, bred);
+    const int64_t n_dwaves = p.n_direct / G;
+    if (wid >= n_dwaves) {
+        // a split item (launched after the direct rows, so that the short items fill the tail of the launch):
+        // partial to the slab, slot layout [block*4 + r][lane] then b[I][j]
+        if (wid - n_dwaves >= p.n_split) return;
+        d4 acc[NB];
+        double bred[DB];
+        const Item it = p.split[wid - n_dwaves];
+        accumulate_any<DP>(a, it, lane, wl, acc, bred);
         double *dst = p.partials + (int64_t)it.slot * PSZ;
 #pragma unroll
         for (int b = 0; b < NB; b++)
@@ -380,8 +448,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
         }
         return;
     }
-    const int64_t first = (wid - p.n_split) * G;
-    if (first >= p.n_direct) return;
+    const int64_t first = wid * G;
     const int grp = lane / DP, c = lane % DP;
     // accumulate the G rows of this wave one after the other; their accumulators stay in registers (NB*4 doubles
     // each) until all are done, so that the column array of the finishing phase is not live during the gathers
@@ -396,9 +463,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
         for (int b = 0; b < NB; b++) accg[g][b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int I = 0; I < DB; I++) bredg[g][I] = 0.0;
-#ifndef BDF_EXP_SKIP_ACCUM
-        if (it.row >= 0 && it.count > 0) accumulate_any<DP>(a, it, lane, accg[g], bredg[g]);    // wave-uniform branch
-#endif
+        if (it.row >= 0 && it.count > 0) accumulate_any<DP>(a, it, lane, wl, accg[g], bredg[g]);    // wave-uniform branch
     }
     double col[DP];
     double bj = 0.0;
@@ -423,11 +488,32 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
     }
     wave_sync();
     add_prior<DP>(a, myrow, c, col, bj);
-#ifdef BDF_EXP_SKIP_FINISH
-    if (myrow >= 0 && a.D - 1 - c >= 0) a.out[myrow * a.D + (a.D - 1 - c)] = col[0] + bj;
-    return;
-#endif
     finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane);
+}
+
+// ---- items-only launch (every row split): accumulate items to the slab, nothing else -------------------------------------
+template <int DP>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB) void k_rows_items(SampleArgs a, PlanDev p)
+{
+    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, PSZ = Geo<DP>::PSZ, WPB = Geo<DP>::WPB;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::GAT_D];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double *wl = lds + wave * Geo<DP>::GAT_D;
+    const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+    if (wid >= p.n_split) return;
+    d4 acc[NB];
+    double bred[DB];
+    const Item it = p.split[wid];
+    accumulate_any<DP>(a, it, lane, wl, acc, bred);
+    double *dst = p.partials + (int64_t)it.slot * PSZ;
+#pragma unroll
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
+    if (lane < 16) {
+#pragma unroll
+        for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bred[I];
+    }
 }
 
 // ---- launch 2: add the partials of the split rows in slot order and finish them --------------------------------------
@@ -436,8 +522,8 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
 {
     constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
     constexpr int WPB = Geo<DP>::WPB;
-    __shared__ double lds[WPB * Geo<DP>::WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *wl = lds + wave * Geo<DP>::WAVE_LDS;
     const int64_t first = ((int64_t)blockIdx.x * WPB + wave) * G;
     if (first >= p.n_split_rows) return;
@@ -455,14 +541,29 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
             for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int I = 0; I < DB; I++) bred[I] = 0.0;
-            for (int s = 0; s < sr.n_slots; s++) {
-                const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
+            // slot order is fixed; four slots are loaded per trip so that their latencies overlap
+            for (int s0 = 0; s0 < sr.n_slots; s0 += 4) {
+                double v[4][NB * 4 + DB];
 #pragma unroll
-                for (int b = 0; b < NB; b++)
+                for (int u = 0; u < 4; u++) {
+                    const int s = (s0 + u < sr.n_slots) ? s0 + u : sr.n_slots - 1;
+                    const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
 #pragma unroll
-                    for (int r = 0; r < 4; r++) acc[b][r] += src[(b * 4 + r) * 64 + lane];
+                    for (int e = 0; e < NB * 4; e++) v[u][e] = src[e * 64 + lane];
 #pragma unroll
-                for (int I = 0; I < DB; I++) bred[I] += src[NB * 4 * 64 + I * 16 + (lane & 15)];
+                    for (int I = 0; I < DB; I++) v[u][NB * 4 + I] = src[NB * 4 * 64 + I * 16 + (lane & 15)];
+                }
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if (s0 + u < sr.n_slots) {
+#pragma unroll
+                        for (int b = 0; b < NB; b++)
+#pragma unroll
+                            for (int r = 0; r < 4; r++) acc[b][r] += v[u][b * 4 + r];
+#pragma unroll
+                        for (int I = 0; I < DB; I++) bred[I] += v[u][NB * 4 + I];
+                    }
+                }
             }
             wave_sync();
             acc_to_image<DP>(acc, wl, lane);
@@ -528,7 +629,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
             n_items += (int)((n + T - 1) / T);
         }
-        if (n_items <= 1) {
+        static const bool all_split = getenv("BDF_ALL_SPLIT") != nullptr;
+        if (n_items <= 1 && !all_split) {
             Item it{row, 0, 0, 0, -1};
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
@@ -537,6 +639,11 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             }
             direct.push_back(it);
         } else {
+            if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
+                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size()});
+                srows.push_back(SplitRow{row, (int32_t)split.size() - 1, 1, 0});
+                continue;
+            }
             SplitRow sr{row, (int32_t)split.size(), n_items, 0};
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
@@ -570,7 +677,11 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
     constexpr int G = Geo<DP>::G, WPB = Geo<DP>::WPB;
     const int64_t waves1 = (int64_t)p.n_split + p.n_direct / G;
-    if (waves1 > 0) {
+    if (p.n_direct == 0 && p.n_split > 0) {
+        dim3 grid((unsigned)((p.n_split + WPB - 1) / WPB)), block(64 * WPB);
+        hipLaunchKernelGGL((k_rows_items<DP>), grid, block, 0, ctx->stream, a, p);
+        BDF_HIP(hipGetLastError());
+    } else if (waves1 > 0) {
         dim3 grid((unsigned)((waves1 + WPB - 1) / WPB)), block(64 * WPB);
         if (dump) hipLaunchKernelGGL((k_rows_accum<DP, true>), grid, block, 0, ctx->stream, a, p);
         else      hipLaunchKernelGGL((k_rows_accum<DP, false>), grid, block, 0, ctx->stream, a, p);

@@ -1,78 +1,125 @@
-// wave_linalg.h -- D x D (D <= 64) symmetric positive-definite linear algebra on ONE wavefront.
+// wave_linalg.h -- D x D (D <= 64) symmetric positive-definite linear algebra on ONE wavefront, G = 64/DP matrices at a
+// time (DP = 16, 32, 64 is the padded dimension): lane = grp * DP + c, lane (grp, c) holds column c of matrix grp in
+// registers, col[i] = A[i][c].  The matrix is kept fully symmetric so that row k of a lane's column doubles as A[c][k].
 //
-// Layout: lane j owns column j of the matrix in registers col[0..DP-1] (col[i] = A[i][j]); the matrix is kept
-// fully symmetric so that row k of a lane's column doubles as A[j][k].  Every loop is unrolled so that register
-// indices are static; cross-lane traffic is v_readlane broadcasts of a wave-uniform lane (no LDS).
+// Factorisation A = Ah diag(1/p) Ah' with Ah = L diag(sqrt(p)) (L the Cholesky factor, p the pivots): kept UNSCALED so
+// that no square root sits on the step-to-step critical path.  Step k broadcasts row k of the current Schur complement
+// through LDS (one ds_write_b64 + broadcast reads) and updates every trailing row with one fma per element.
+// The triangular solves are written in terms of Ah and 1/p:
+//     L w = b   <=>  Ah wh = b,   wh = w / sqrt(p)
+//     L' x = y  <=>  Ah' x = yh,  yh = y * sqrt(p)
+// and run on MASKED columns (strict lower part, zeros elsewhere) so that their inner step is one unconditional fma.
+//
+// LDS needs per wave (doubles): fb[64] broadcast row, piv[64] pivots then 1/pivots, img[DP * (DP + 1)] transposition.
 #pragma once
 #include "bdf_common.h"
 
-constexpr int WL_TLD = 33;   // leading dimension of the LDS transpose buffer (32 columns per pass + 1 pad)
-
-// Cholesky A = L L'.  On exit lane j holds ROW j of L: col[k] = L[j][k] for k <= j (col[k], k > j: undefined),
-// rinv_own = 1 / L[j][j].  Returns true in every lane if a pivot was not positive.
-template <int DP>
-__device__ inline bool wl_chol_rows(double (&col)[DP], double &rinv_own, int lane)
+__device__ inline void wave_sync()
 {
+    // orders this wave's LDS writes before its later LDS reads (the LDS pipe is in-order per wave; this only stops the
+    // compiler from moving accesses across it)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+__device__ inline double fast_rcp(double x)
+{
+    double y = __builtin_amdgcn_rcp(x);
+    double e = fma(-x, y, 1.0);
+    y = fma(y, e, y);
+    e = fma(-x, y, 1.0);
+    return fma(y, e, y);
+}
+
+__device__ inline double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    double e = fma(-x * y, y, 1.0);
+    y = fma(y * 0.5, e, y);
+    e = fma(-x * y, y, 1.0);
+    return fma(y * 0.5, e, y);
+}
+
+// In : col[i] = A[i][c] (symmetric, all rows).
+// Out: col[k] = Ah[c][k] for k < c, 0 for k >= c (strict lower part of row c, masked); p_own = pivot p_c;
+//      piv[lane] = 1 / p_c (for the solves).  Returns true (in every lane of the group) if a pivot was not positive.
+template <int DP>
+__device__ inline bool wl_factor(double (&col)[DP], double &p_own, double *fb, double *piv, int lane)
+{
+    const int grp = lane / DP, c = lane % DP;
+    double *row = fb + grp * DP;
     bool notpd = false;
-    rinv_own = 1.0;
+    p_own = 1.0;
 #pragma unroll
     for (int k = 0; k < DP; k++) {
-        const double pk = readlane_f64(col[k], k);
+        row[c] = col[k];                                  // A[k][c] = A[c][k]
+        wave_sync();
+        const double pk = row[k];
         if (!(pk > 0.0)) notpd = true;
-        const double rinv = 1.0 / sqrt(pk);
-        const double f = col[k] * rinv;            // lane j: A[k][j]/sqrt(pk) = L[j][k]  (j >= k)
-        col[k] = f;
-        if (lane == k) rinv_own = rinv;
+        const double g = col[k] * fast_rcp(pk);           // A[c][k] / A[k][k]
 #pragma unroll
-        for (int i = k + 1; i < DP; i++) col[i] = fma(-readlane_f64(f, i), f, col[i]);
+        for (int i = k + 1; i < DP; i++) col[i] = fma(-row[i], g, col[i]);
+        p_own = (c == k) ? pk : p_own;
+        wave_sync();                                      // row[] is rewritten by the next step (compiler barrier only)
     }
+    piv[lane] = fast_rcp(p_own);
+#pragma unroll
+    for (int k = 0; k < DP; k++) col[k] = (k < c) ? col[k] : 0.0;
+    wave_sync();
     return notpd;
 }
 
-// forward substitution L w = b with lane j holding row j of L (wl_chol_rows layout) and b_j; returns w_j
-template <int DP>
-__device__ inline double wl_fwd_rows(const double (&col)[DP], double rinv_own, double bj, int lane)
+__device__ inline double wl_bcast(double v, int src_lane)
 {
+    return __shfl(v, src_lane);
+}
+
+// forward solve Ah wh = b on masked rows (lane c holds row c).  Returns b'_c = wh_c * p_c (the reduced right-hand side).
+template <int DP>
+__device__ inline double wl_forward(const double (&rowm)[DP], double b, const double *piv, int lane)
+{
+    const int base = (lane / DP) * DP;
 #pragma unroll
     for (int k = 0; k < DP; k++) {
-        const double wk = readlane_f64(bj, k) * readlane_f64(rinv_own, k);
-        if (lane > k) bj = fma(-col[k], wk, bj);
-        else if (lane == k) bj = wk;
+        const double wk = wl_bcast(b, base + k) * piv[base + k];
+        b = fma(-rowm[k], wk, b);
     }
-    return bj;
+    return b;
 }
 
-// rows -> columns through LDS (tb: DP * WL_TLD doubles), 32 columns per pass.
-// in : lane j holds row j (col[k] = L[j][k], k <= j).  out: lane j holds column j (col[i] = L[i][j], i >= j).
-// Must be called by all 64 lanes of a single-wave workgroup.
+// masked rows -> masked columns through the image (img: DP * (DP+1) doubles), one group at a time.
+// in: rowm[k] = Ah[c][k] (k < c, else 0).  out: colm[i] = Ah[i][c] (i > c, else 0).
 template <int DP>
-__device__ inline void wl_rows_to_cols(double (&col)[DP], double *tb, int lane)
+__device__ inline void wl_transpose(double (&col)[DP], double *img, int lane)
 {
+    constexpr int G = 64 / DP, LD = DP + 1;
+    const int grp = lane / DP, c = lane % DP;
 #pragma unroll
-    for (int pass = 0; pass < (DP + 31) / 32; pass++) {
-        const int k0 = pass * 32;
-        __syncthreads();
-        if (lane < DP) {
+    for (int g = 0; g < G; g++) {
+        wave_sync();
+        if (grp == g) {
 #pragma unroll
-            for (int k = 0; k < 32 && k0 + k < DP; k++) tb[lane * WL_TLD + k] = col[k0 + k];
+            for (int k = 0; k < DP; k++) img[c * LD + k] = col[k];
         }
-        __syncthreads();
-        if (lane >= k0 && lane < k0 + 32 && lane < DP) {
+        wave_sync();
+        if (grp == g) {
 #pragma unroll
-            for (int i = 0; i < DP; i++) col[i] = tb[i * WL_TLD + (lane - k0)];
+            for (int i = 0; i < DP; i++) col[i] = img[i * LD + c];
         }
     }
+    wave_sync();
 }
 
-// backward substitution L' x = y with lane j holding COLUMN j of L (col[i] = L[i][j], i >= j) and y_j; returns x_j
+// backward solve Ah' x = yh on masked columns (lane c holds column c).  Returns x_c.
 template <int DP>
-__device__ inline double wl_bwd_cols(const double (&col)[DP], double rinv_own, double yj, int lane)
+__device__ inline double wl_backward(const double (&colm)[DP], double yh, const double *piv, int lane)
 {
+    const int base = (lane / DP) * DP;
 #pragma unroll
     for (int i = DP - 1; i >= 0; i--) {
-        const double xi = readlane_f64(yj, i) * readlane_f64(rinv_own, i);
-        if (lane < i) yj = fma(-col[i], xi, yj);
-        else if (lane == i) yj = xi;
+        const double xi = wl_bcast(yh, base + i) * piv[base + i];
+        yh = fma(-colm[i], xi, yh);
     }
-    return yj;
+    return yh * piv[lane];
 }

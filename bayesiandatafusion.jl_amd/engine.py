@@ -8,6 +8,7 @@ src/sampling.jl:155-167).
 Layout: an entity's sample is the reference's D x N column-major matrix == a contiguous torch tensor of shape (N, D).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -267,6 +268,8 @@ class GibbsEngine:
             raise ArgumentError(f"num_latent={num_latent} must be in 1..{_lib.BDF_MAX_D}")
         self.data, self.D = data, int(num_latent)
         self.ctx = Context(device, seed)
+        if os.environ.get("BDF_ITEM_SIZE"):
+            self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size

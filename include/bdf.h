@@ -68,7 +68,7 @@ int bdf_ctx_destroy(bdf_ctx *ctx);
 int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
 int bdf_ctx_advance_sweep(bdf_ctx *ctx);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
-/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 128 */
+/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 512 */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 /* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
 int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);
