@@ -378,8 +378,26 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     }
     a.entity_tag = entity_tag;
     a.out = out;
+#ifdef BDF_K1_STAMPS
+    {   // diagnostic build only: per-wave phase stamps (16 x u64 per wave) readable through bdf_debug_stamps
+        extern void *g_bdf_stamp_buf;
+        if (!g_bdf_stamp_buf) { BDF_HIP(hipMalloc(&g_bdf_stamp_buf, 16 * 8 * 65536)); }
+        BDF_HIP(hipMemsetAsync(g_bdf_stamp_buf, 0, 16 * 8 * 65536, ctx->stream));
+        a.b_dump = (double *)g_bdf_stamp_buf;
+    }
+#endif
     return bdf_launch_sample_rows(ctx, a, rels, modes, shard, n_shards, false);
 }
+
+#ifdef BDF_K1_STAMPS
+void *g_bdf_stamp_buf = nullptr;
+extern "C" int bdf_debug_stamps(bdf_ctx *ctx, unsigned long long *host, int nwaves)
+{
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    BDF_HIP(hipMemcpy(host, g_bdf_stamp_buf, (size_t)nwaves * 16 * 8, hipMemcpyDeviceToHost));
+    return BDF_OK;
+}
+#endif
 
 extern "C" int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                               const double *mu, int mu_is_matrix, const double *Lambda,

@@ -195,6 +195,7 @@ struct SampleArgs {
     uint64_t seed;
     uint32_t entity_tag, _pad2;
     double *out;
+    const double *prior_b;     // Lambda mu (D) or Lambda mu_i (D x N), filled by the launch front-end
     double *P_dump, *b_dump;
     int *flag;
 };

@@ -147,7 +147,7 @@ __global__ void k_axpy_lambda(int64_t n, double lambda, const double *x, double 
 template <int DP>
 __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, double *Lr, int *flag)
 {
-    __shared__ double fb[64], piv[64];
+    __shared__ double tri[WL<DP>::TRI + 64];
     const int lane = threadIdx.x;
     const int c = lane % DP;
     const int ej = D - 1 - c;
@@ -162,12 +162,12 @@ __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, 
         }
         col[i] = w;
     }
-    double p_own;
-    if (wl_factor<DP>(col, p_own, fb, piv, lane) && lane == 0) atomicOr(flag, 4);
+    double p_own, rp_own;
+    if (wl_factor<DP, true>(col, p_own, rp_own, tri, lane) && lane == 0) atomicOr(flag, 4);
     if (lane < DP) {
 #pragma unroll
         for (int k = 0; k < DP; k++) Lr[c * DP + k] = col[k];
-        Lr[DP * DP + c] = piv[lane];
+        Lr[DP * DP + c] = rp_own;
         Lr[DP * DP + DP + c] = p_own * fast_rsqrt(p_own);
     }
 }
@@ -360,26 +360,23 @@ template <int DP>
 __global__ __launch_bounds__(64) void k_solve_small(int n, int ncol, const double *FF, const double *lambda_p,
                                                     const double *rhs, double *X, int *flag)
 {
-    __shared__ double img[DP * (DP + 1)], fb[64], piv[64];
+    __shared__ double tri[WL<DP>::TRI + 64];
     const int lane = threadIdx.x;
     const int c = lane % DP;
     const double lambda = *lambda_p;
-    double rowm[DP], colm[DP];
+    double rowm[DP];
 #pragma unroll
     for (int i = 0; i < DP; i++) {
         double w = (i == c) ? 1.0 : 0.0;
         if (i < n && c < n) w = FF[i + (int64_t)c * n] + ((i == c) ? lambda : 0.0);
         rowm[i] = w;
     }
-    double p_own;
-    if (wl_factor<DP>(rowm, p_own, fb, piv, lane) && lane == 0) atomicOr(flag, 8);
-#pragma unroll
-    for (int k = 0; k < DP; k++) colm[k] = rowm[k];
-    wl_transpose<DP>(colm, img, lane);
+    double p_own, rp_own;
+    if (wl_factor<DP, true>(rowm, p_own, rp_own, tri, lane) && lane == 0) atomicOr(flag, 8);
     for (int q = 0; q < ncol; q++) {
         double b = (lane < DP && c < n) ? rhs[c + (int64_t)q * n] : 0.0;
-        b = wl_forward<DP>(rowm, b, piv, lane);          // b' = wh p;  yh = w sqrt(p) = b'
-        b = wl_backward<DP>(colm, b, piv, lane);
+        b = wl_forward<DP>(rowm, b, rp_own, lane);       // b' = wh p;  yh = w sqrt(p) = b'
+        b = wl_backward<DP, true>(tri, b, rp_own, lane);
         if (lane < DP && c < n) X[c + (int64_t)q * n] = b;
     }
 }

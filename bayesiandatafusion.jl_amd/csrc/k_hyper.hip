@@ -108,7 +108,8 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
     constexpr int LD = DP + 1;
     __shared__ double sA[DP * LD];      // Bartlett A~ = J A, then Z~
     __shared__ double sL[DP * LD];      // masked rows of Ah (factor of W~), later Lam~, later transposition image
-    __shared__ double s_rp[64], s_sq[64], s_fb[64], s_piv[64], s_muN[64];
+    __shared__ double s_rp[64], s_sq[64], s_muN[64];
+    __shared__ double s_tri[WL<DP>::TRI + 64];
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
@@ -145,12 +146,12 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
                 if (ei >= 0) a.params_out[D + ei + (int64_t)ej * D] = col[i];
             }
         }
-        double p_own;
-        if (wl_factor<DP>(col, p_own, s_fb, s_piv, lane) && lane == 0) s_bad = 1;
+        double p_own, rp_own;
+        if (wl_factor<DP, true>(col, p_own, rp_own, s_tri, lane) && lane == 0) s_bad = 1;
         if (lane < DP) {
 #pragma unroll
             for (int k = 0; k < DP; k++) sL[c * LD + k] = col[k];         // Ah[c][k], k < c (else 0)
-            s_rp[c] = s_piv[lane];
+            s_rp[c] = rp_own;
             s_sq[c] = p_own * fast_rsqrt(p_own);
         }
     } else {
@@ -206,13 +207,12 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
 #pragma unroll
         for (int i = 0; i < DP; i++) col[i] = sL[i * LD + c];
         wave_sync();
-        double p_own;
-        if (wl_factor<DP>(col, p_own, s_fb, s_piv, lane) && lane == 0) s_bad = 1;
-        wl_transpose<DP>(col, sL, lane);
+        double p_own, rp_own;
+        if (wl_factor<DP, true>(col, p_own, rp_own, s_tri, lane) && lane == 0) s_bad = 1;
         double yh = 0.0;
         if (lane < DP && ej >= 0)
             yh = bdf_normal(a.seed, sweep, BDF_P_NW_MEAN, a.entity_tag, 0, ej) * (p_own * fast_rsqrt(p_own));
-        const double x = wl_backward<DP>(col, yh, s_piv, lane);
+        const double x = wl_backward<DP, true>(s_tri, yh, rp_own, lane);
         if (lane < DP && ej >= 0) a.mu_out[ej] = s_muN[c] + x / sqrt(beta_N);
         wave_sync();
         if (lane == 0 && s_bad) atomicOr(a.flag, 2);
@@ -227,7 +227,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
-    int nblocks = (int)std::min<int64_t>(512, (N + 127) / 128);
+    int nblocks = (int)std::min<int64_t>(1024, (N + 31) / 32);
     if (nblocks < 1) nblocks = 1;
     int64_t rpb = (N + nblocks - 1) / nblocks;
     if (rpb < 1) rpb = 1;

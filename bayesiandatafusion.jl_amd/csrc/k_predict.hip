@@ -1,14 +1,14 @@
 // k_predict.hip -- K7: test-set prediction and the running posterior mean of macau.jl:142-203.
 //
 // pred(r, test_vec) = udot(r, test_vec) + mean_value (src/sampling.jl:9-14); udot is the sum over the latent
-// dimension of the product of the modes' factor rows (src/sampling.jl:30-45).  16 lanes share one test pair so
-// that each gathered factor row is read as whole 128-byte segments.
+// dimension of the product of the modes' factor rows (src/sampling.jl:30-45).  8 lanes share one test pair and read
+// 32 bytes each, so that a gathered factor row is read as whole 128-byte segments.
 #include "bdf_common.h"
 #include <algorithm>
 
 namespace {
 
-constexpr int LPP = 16;    // lanes per pair
+constexpr int LPP = 8;     // lanes per pair
 
 struct PredArgs {
     int D, n_modes;
@@ -31,40 +31,67 @@ __device__ inline double clampv(double x, double lo, double hi)
     return x < lo ? lo : (x > hi ? hi : x);
 }
 
+// one test pair per group of LPP lanes; a group handles two pairs per trip so that their gathers overlap
+__device__ inline double pair_dot(const PredArgs &a, int64_t pair, int sub)
+{
+    double s = 0.0;
+    if ((a.D & 3) == 0) {
+        for (int e = sub * 4; e < a.D; e += LPP * 4) {
+            double4 p = *(const double4 *)(a.fac[0] + (int64_t)a.ids[pair] * a.D + e);
+            for (int k = 1; k < a.n_modes; k++) {
+                const double4 q = *(const double4 *)(a.fac[k] + (int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e);
+                p.x *= q.x; p.y *= q.y; p.z *= q.z; p.w *= q.w;
+            }
+            s += (p.x + p.y) + (p.z + p.w);
+        }
+    } else {
+        for (int e = sub; e < a.D; e += LPP) {
+            double p = 1.0;
+            for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
+            s += p;
+        }
+    }
+#pragma unroll
+    for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    return s;
+}
+
+__device__ inline void pair_update(const PredArgs &a, int64_t pair, double s, double (&st)[4])
+{
+    const double p = s + a.mean;
+    if (a.out) a.out[pair] = p;
+    if (a.phase >= 0) {
+        double avg;
+        if (a.phase == 0) { avg = p; }
+        else if (a.phase == 1) { avg = p; a.sq[pair] = p * p; }
+        else { avg = (a.count * a.avg[pair] + p) / (a.count + 1.0); a.sq[pair] += p * p; }
+        a.avg[pair] = avg;
+        const double y = a.values[pair];
+        const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
+        const bool label = y < a.cut;
+        st[0] += ea * ea; st[1] += ep * ep;
+        st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
+        st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
+    }
+}
+
 __global__ __launch_bounds__(256) void k_predict(PredArgs a)
 {
     const int tid = threadIdx.x;
     const int sub = tid % LPP;
     double st[4] = {0.0, 0.0, 0.0, 0.0};
-    const int64_t stride = (int64_t)gridDim.x * (256 / LPP);
-    // the 16 lanes of a group share `pair`, so a group enters and leaves the loop together (the shuffles below
-    // only cross lanes of one group)
-    for (int64_t pair = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; pair < a.n; pair += stride) {
-    double s = 0.0;
-    for (int e = sub; e < a.D; e += LPP) {
-        double p = 1.0;
-        for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
-        s += p;
-    }
-#pragma unroll
-    for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (sub == 0) {
-        const double p = s + a.mean;
-        if (a.out) a.out[pair] = p;
-        if (a.phase >= 0) {
-            double avg;
-            if (a.phase == 0) { avg = p; }
-            else if (a.phase == 1) { avg = p; a.sq[pair] = p * p; }
-            else { avg = (a.count * a.avg[pair] + p) / (a.count + 1.0); a.sq[pair] += p * p; }
-            a.avg[pair] = avg;
-            const double y = a.values[pair];
-            const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
-            const bool label = y < a.cut;
-            st[0] += ea * ea; st[1] += ep * ep;
-            st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
-            st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
+    const int64_t ngroups = (int64_t)gridDim.x * (256 / LPP);
+    // the lanes of a group share their pairs, so a group enters and leaves the loop together (the shuffles only cross
+    // lanes of one group)
+    for (int64_t p0 = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; p0 < a.n; p0 += 2 * ngroups) {
+        const int64_t p1 = p0 + ngroups;
+        const bool has1 = p1 < a.n;
+        const double s0 = pair_dot(a, p0, sub);
+        const double s1 = pair_dot(a, has1 ? p1 : p0, sub);
+        if (sub == 0) {
+            pair_update(a, p0, s0, st);
+            if (has1) pair_update(a, p1, s1, st);
         }
-    }
     }
     if (a.phase >= 0) {
         __shared__ double red[4][256 / 64];
@@ -104,7 +131,7 @@ int launch_predict(bdf_ctx *ctx, PredArgs &a)
 {
     if (a.n == 0) return BDF_OK;
     const int64_t need = (a.n * LPP + 255) / 256;
-    const int nblocks = (int)std::min<int64_t>(need, 2048);
+    const int nblocks = (int)std::min<int64_t>((need + 1) / 2, 8192);
     if (a.phase >= 0) {
         void *sc;
         int rc = bdf_scratch(ctx, (size_t)nblocks * 4 * sizeof(double), &sc);

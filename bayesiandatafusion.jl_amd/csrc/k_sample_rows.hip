@@ -21,7 +21,8 @@
 //   * a row's observations are cut into ITEMS of at most T observations; one wavefront accumulates one item.
 //   * a row with a single item is DIRECT: the wave that accumulated it also factors, solves and draws.
 //   * a row with several items (long rows, or several relations) is SPLIT: its items write partial (S, b) to a
-//     scratch slab, and a second launch (k_rows_finish) adds a row's partials in slot order and finishes it.
+//     scratch slab and count themselves in; the wave whose arrival completes the row adds the row's partials in slot
+//     order and finishes it, inside the same launch.
 //   so no wave ever owns more than T observations and results do not depend on scheduling.
 //
 // Accumulation: the rank-4 update S += W W' (W = D x 4 gathered factor rows) is one v_mfma_f64_16x16x4_f64 per
@@ -40,8 +41,17 @@
 #include <map>
 #include <mutex>
 
+#ifndef BDF_K1_WPB
+#define BDF_K1_WPB 4
+#endif
 #ifndef BDF_K1_WAVES
-#define BDF_K1_WAVES 2
+#define BDF_K1_WAVES 3
+#endif
+
+#ifdef BDF_K1_STAMPS
+#define STAMP(slot) do { if (lane == 0 && a.b_dump) ((unsigned long long *)a.b_dump)[wid * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define STAMP(slot) do { } while (0)
 #endif
 
 namespace {
@@ -56,6 +66,8 @@ struct Item {             // one wave's accumulation work
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
     int32_t slot;         // partial slot, or -1 for a direct row
+    int32_t srow;         // index of the row in the split-row table (split items)
+    int32_t _pad;
 };
 
 struct SplitRow {
@@ -67,8 +79,9 @@ struct SplitRow {
 struct PlanDev {
     const Item *direct;   int32_t n_direct;      // padded to a multiple of G
     const Item *split;    int32_t n_split;
-    const SplitRow *rows; int32_t n_split_rows;  // padded to a multiple of G
+    const SplitRow *rows; int32_t n_split_rows;
     double *partials;                            // n_split * PSZ doubles
+    int32_t *arrived;                            // per split row: items that have published their partial (self-resetting)
 };
 
 template <int DP>
@@ -78,18 +91,21 @@ struct Geo {
     static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
     static constexpr int LD = DP + 1;                  // padded leading dimension of the LDS images
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
-    static constexpr int WPB = (DP == 64) ? 1 : 4;     // waves per workgroup (static LDS must stay under 64 KB)
+    static constexpr int WPB = (DP == 64) ? 1 : BDF_K1_WPB;   // waves per workgroup (static LDS must stay under 64 KB)
     // LDS-DMA gather ring: a slot holds the 4 gathered factor rows of one MFMA k-step
     static constexpr int LPR = (DP == 64) ? 32 : 16;   // lanes (16 bytes each) per gathered row
     static constexpr int ROWB = LPR * 16;              // bytes between rows in a slot
     static constexpr int IPK = 4 * LPR / 64;           // DMA instructions per k-step and other mode
     static constexpr int SLOTB = 4 * ROWB;             // bytes per slot
     static constexpr int RING_SLOTS = 8192 / SLOTB;    // 8 (DP <= 32) or 4 (DP = 64) slots, shared by the other modes
-    static constexpr int TMAX = 128;                   // observations per item on the DMA path
-    static constexpr int STAGE_B = 2 * TMAX * 4 + TMAX * 8;   // ids of up to 2 other modes + values
+    static constexpr int TMAX = 192;                   // observations staged per pass on the DMA path
+    // stage of one item: [values TMAX x 8][ids of other mode 0, TMAX x 4][ids of other mode 1, TMAX x 4]; consecutive
+    // stages are STAGE_B apart, so an item with two other modes needs the room of the following stage as well
+    static constexpr int STAGE_B = TMAX * 12;
+    static constexpr int NSTAGE = (G >= 2) ? 2 : 1;    // items of a wave staged ahead (matrix relations only)
     // per-wave LDS (doubles): the finishing area [img | fb | piv] aliases the gather area [ring | stage]
-    static constexpr int FIN_D = DP * LD + 64 + 64;
-    static constexpr int GAT_D = (8192 + STAGE_B) / 8;
+    static constexpr int FIN_D = (DP * LD + 64 > G * (DP * (DP + 1) / 2) + 64) ? DP * LD + 64 : G * (DP * (DP + 1) / 2) + 64;
+    static constexpr int GAT_D = (8192 + (NSTAGE >= 2 ? NSTAGE * STAGE_B : STAGE_B + TMAX * 4)) / 8;
     static constexpr int WAVE_LDS = FIN_D > GAT_D ? FIN_D : GAT_D;
 };
 
@@ -195,14 +211,39 @@ __device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int l
     }
 }
 
-// ---- accumulate one item, LDS-DMA path (even D, shared baseline), in passes of at most TMAX observations -----------
-// The item's other-mode ids and values are staged in LDS by DMA once; then a ring of RING_SLOTS k-step slots is kept
-// full by global_load_lds gathers (per-lane source address = chunk (l % LPR) of factor row ids[l / LPR], lane-linear LDS
-// destination), P = slots/NO - 1 k-steps ahead of the MFMAs.  Nothing but DMAs uses the vector-memory counter inside
-// the loop, so the waits are exact: `s_waitcnt vmcnt((P-1) * NO * IPK)` retires precisely the oldest k-step.
+// ---- accumulate one item, LDS-DMA path (even D, shared baseline) --------------------------------------------------------
+// The item's other-mode ids and values are staged in LDS by DMA (stage_item, up to TMAX observations per pass); then a
+// ring of k-step slots is kept full by global_load_lds gathers (per-lane source address = chunk (l % LPR) of factor row
+// ids[l / LPR], lane-linear LDS destination), P = R - 1 k-steps ahead of the MFMAs.  Nothing but DMAs uses the
+// vector-memory counter inside the loop, so the waits are exact: `s_waitcnt vmcnt((P-1) * NO * IPK)` retires precisely
+// the oldest k-step.
 template <int DP, int NO>
-__device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int lane, double *wl, d4 (&acc)[Geo<DP>::NB],
-                                      double (&bred)[Geo<DP>::DB])
+__device__ inline void stage_item(const TermDev &T, int64_t qb, int n, int lane, char *stage)
+{
+    constexpr int TMAX = Geo<DP>::TMAX;
+    int32_t *svals = (int32_t *)stage;                    // TMAX doubles as dwords
+    int32_t *sidx = (int32_t *)(stage + TMAX * 8);        // [NO][TMAX]
+    const int last = n - 1;
+#pragma unroll
+    for (int m = 0; m < NO; m++)
+#pragma unroll
+        for (int part = 0; part < (TMAX + 63) / 64; part++) {
+            const int o = part * 64 + lane;
+            const int32_t *src = T.colidx + (int64_t)m * T.nnz + qb + (o < n ? o : last);
+            if (part * 64 < TMAX && (part + 1) * 64 <= TMAX + 63)
+                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sidx + m * TMAX + part * 64), 4, 0, 0);
+        }
+#pragma unroll
+    for (int part = 0; part < (2 * TMAX + 63) / 64; part++) {
+        const int w = part * 64 + lane;                   // dword index into the values
+        const int32_t *src = (const int32_t *)(T.vals + qb) + (w < 2 * n ? w : 2 * last + (w & 1));
+        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(svals + part * 64), 4, 0, 0);
+    }
+}
+
+template <int DP, int NO>
+__device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel,
+                                      bool prestaged, d4 (&acc)[Geo<DP>::NB], double (&bred)[Geo<DP>::DB])
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, NB = GG::NB, LPR = GG::LPR, ROWB = GG::ROWB, IPK = GG::IPK, SLOTB = GG::SLOTB;
@@ -214,8 +255,9 @@ __device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int l
     const int D = a.D;
     const int j = lane & 15, h = lane >> 4;
     char *ring = (char *)wl;
-    int32_t *sidx = (int32_t *)(ring + 8192);             // [NO][TMAX]
-    double *svals = (double *)(ring + 8192 + 2 * TMAX * 4);
+    char *stage = ring + 8192 + stage_sel * GG::STAGE_B;
+    const double *svals = (const double *)stage;
+    const int32_t *sidx = (const int32_t *)(stage + TMAX * 8);
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
     double bpart[DB];
@@ -231,78 +273,74 @@ __device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int l
     const int rowbytes = D * 8;
     const int chunk = lane % LPR;
     const int coff = (chunk * 16 < rowbytes) ? chunk * 16 : rowbytes - 16;   // lanes past the row re-read its last chunk
+    const int lrow = lane / LPR;
     for (int pass0 = 0; pass0 < it.count; pass0 += TMAX) {
-    const int n = (it.count - pass0 < TMAX) ? it.count - pass0 : TMAX;       // observations of this pass
-    const int64_t qb = it.q_begin + pass0;
-    // ---- stage ids (4 bytes per lane) and values (as dwords) of the pass
-    {
-        const int last = n - 1;
-#pragma unroll
-        for (int m = 0; m < NO; m++)
-#pragma unroll
-            for (int part = 0; part < TMAX / 64; part++) {
-                const int o = part * 64 + lane;
-                const int32_t *src = T.colidx + (int64_t)m * T.nnz + qb + (o < n ? o : last);
-                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sidx + m * TMAX + part * 64), 4, 0, 0);
-            }
-#pragma unroll
-        for (int part = 0; part < 2 * TMAX / 64; part++) {
-            const int w = part * 64 + lane;               // dword index into the values
-            const int32_t *src = (const int32_t *)(T.vals + qb) + (w < 2 * n ? w : 2 * last + (w & 1));
-            __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)((int32_t *)svals + part * 64), 4, 0, 0);
-        }
+        const int n = (it.count - pass0 < TMAX) ? it.count - pass0 : TMAX;   // observations of this pass
+        if (!(prestaged && pass0 == 0)) stage_item<DP, NO>(T, it.q_begin + pass0, n, lane, stage);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const int nks = (n + 3) >> 2;
+        const int nks = (n + 3) >> 2;
 
-    auto issue = [&](int ks) {
-        // gather the 4 factor rows of k-step ks (clamped into the pass) of every other mode into slot ks % R
-        char *slot = ring + (ks % R) * (NO * SLOTB);
+        // gather the 4 factor rows of a k-step into slot ks % R; rix[m][q] = row index read from the stage
+        auto gather = [&](int ks, const int32_t (&rix)[NO][IPK]) {
+            char *slot = ring + (ks % R) * (NO * SLOTB);
 #pragma unroll
-        for (int m = 0; m < NO; m++)
+            for (int m = 0; m < NO; m++)
 #pragma unroll
-            for (int q = 0; q < IPK; q++) {
-                int o = 4 * ks + q * (64 / LPR) + lane / LPR;
-                o = o < n ? o : n - 1;
-                const char *src = (const char *)(T.fac[m] + (int64_t)sidx[m * TMAX + o] * D) + coff;
-                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot + m * SLOTB + q * 1024), 16, 0, 0);
-            }
-    };
+                for (int q = 0; q < IPK; q++) {
+                    const char *src = (const char *)(T.fac[m] + (int64_t)rix[m][q] * D) + coff;
+                    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot + m * SLOTB + q * 1024), 16, 0, 0);
+                }
+        };
+        auto read_idx = [&](int ks, int32_t (&rix)[NO][IPK]) {
 #pragma unroll
-    for (int s = 0; s < P; s++) issue(s);
-    for (int ks = 0; ks < nks; ks++) {
-        // exactly P k-steps are outstanding here: ks .. ks+P-1; retire the oldest
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NO * IPK) : "memory");
-        const char *slot = ring + (ks % R) * (NO * SLOTB) + h * ROWB;
-        double w[DB];
+            for (int m = 0; m < NO; m++)
 #pragma unroll
-        for (int I = 0; I < DB; I++) {
-            double v = *(const double *)(slot + eoff[I]);
+                for (int q = 0; q < IPK; q++) {
+                    int o = 4 * ks + q * (64 / LPR) + lrow;
+                    o = o < n ? o : n - 1;                   // past the end: any row of the pass (operands are zeroed)
+                    rix[m][q] = sidx[m * TMAX + o];
+                }
+        };
 #pragma unroll
-            for (int m = 1; m < NO; m++) v *= *(const double *)(slot + m * SLOTB + eoff[I]);    // Hadamard product
-            w[I] = v;
+        for (int s = 0; s < P; s++) {
+            int32_t rix[NO][IPK];
+            read_idx(s, rix);
+            gather(s, rix);
         }
-        const int o = 4 * ks + h;
-        const bool valid = o < n;
-        const double rr = valid ? svals[valid ? o : 0] - T.mean : 0.0;
+        for (int ks = 0; ks < nks; ks++) {
+            // exactly P k-steps are outstanding here: ks .. ks+P-1; retire the oldest
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NO * IPK) : "memory");
+            const char *slot = ring + (ks % R) * (NO * SLOTB) + h * ROWB;
+            double w[DB];
 #pragma unroll
-        for (int I = 0; I < DB; I++) w[I] = (valid && eok[I]) ? w[I] : 0.0;
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // operands are in registers before their slot is reused
-        issue(ks + P);
-        int b = 0;
+            for (int I = 0; I < DB; I++) {
+                double v = *(const double *)(slot + eoff[I]);
 #pragma unroll
-        for (int I = 0; I < DB; I++) {
-#pragma unroll
-            for (int J = 0; J <= I; J++) {
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[I], w[J], acc[b], 0, 0, 0);
-                b++;
+                for (int m = 1; m < NO; m++) v *= *(const double *)(slot + m * SLOTB + eoff[I]);    // Hadamard product
+                w[I] = v;
             }
-            bpart[I] = fma(w[I], rr, bpart[I]);
+            const int o = 4 * ks + h;
+            const bool valid = o < n;
+            const double rr = valid ? svals[valid ? o : 0] - T.mean : 0.0;
+            int32_t rix[NO][IPK];
+            read_idx(ks + P, rix);                           // same LDS round trip as the operands
+#pragma unroll
+            for (int I = 0; I < DB; I++) w[I] = (valid && eok[I]) ? w[I] : 0.0;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers before their slot is reused
+            gather(ks + P, rix);
+            int b = 0;
+#pragma unroll
+            for (int I = 0; I < DB; I++) {
+#pragma unroll
+                for (int J = 0; J <= I; J++) {
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[I], w[J], acc[b], 0, 0, 0);
+                    b++;
+                }
+                bpart[I] = fma(w[I], rr, bpart[I]);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead gathers before the stage is rewritten
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the run-ahead gathers before the stage is rewritten
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // drain the run-ahead gathers before the LDS is reused
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
 #pragma unroll
@@ -314,18 +352,37 @@ __device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int l
     }
 }
 
+template <int DP>
+__device__ inline bool item_uses_dma(const SampleArgs &a, const Item &it)
+{
+    const TermDev &T = a.t[it.term];
+    return (a.D % 2 == 0) && T.linear == nullptr && T.n_other <= 2;
+}
+
+// issue the staging DMAs of an item ahead of its accumulation (returns false if the item takes the register path)
+template <int DP>
+__device__ inline bool prestage(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel)
+{
+    if (it.row < 0 || it.count <= 0 || !item_uses_dma<DP>(a, it)) return false;
+    const TermDev &T = a.t[it.term];
+    if (T.n_other != 1 && stage_sel != 0) return false;       // a two-mode stage spills into the next one
+    char *stage = (char *)wl + 8192 + stage_sel * Geo<DP>::STAGE_B;
+    const int n = it.count < Geo<DP>::TMAX ? it.count : Geo<DP>::TMAX;
+    if (T.n_other == 1) stage_item<DP, 1>(T, it.q_begin, n, lane, stage);
+    else stage_item<DP, 2>(T, it.q_begin, n, lane, stage);
+    return true;
+}
+
 // path and other-mode count are wave-uniform
 template <int DP>
-__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, double *wl, d4 (&acc)[Geo<DP>::NB],
-                                      double (&bred)[Geo<DP>::DB])
+__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel,
+                                      bool prestaged, d4 (&acc)[Geo<DP>::NB], double (&bred)[Geo<DP>::DB])
 {
     const TermDev &T = a.t[it.term];
     const int no = T.n_other;
-    const bool dma = (a.D % 2 == 0) && T.linear == nullptr;
-    if (dma && no == 1) {
-        accumulate_dma<DP, 1>(a, it, lane, wl, acc, bred);
-    } else if (dma && no == 2) {
-        accumulate_dma<DP, 2>(a, it, lane, wl, acc, bred);
+    if (item_uses_dma<DP>(a, it)) {
+        if (no == 1) accumulate_dma<DP, 1>(a, it, lane, wl, stage_sel, prestaged, acc, bred);
+        else accumulate_dma<DP, 2>(a, it, lane, wl, stage_sel, prestaged, acc, bred);   // 3 other modes: register path
     } else {
         if (no == 1) accumulate_reg<DP, 1>(a, it, lane, acc, bred);
         else if (no == 2) accumulate_reg<DP, 2>(a, it, lane, acc, bred);
@@ -357,15 +414,14 @@ __device__ inline void acc_to_image(const d4 (&acc)[Geo<DP>::NB], double *img, i
 
 // ---- finish G rows at once: lane group grp = lane / DP owns row myrow; col[] = column c of P~ (prior included) --------
 template <int DP, bool DUMP>
-__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double *wl, int lane)
+__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double *wl, int lane,
+                                   int64_t wid)
 {
     constexpr int LD = Geo<DP>::LD;
     const int D = a.D;
     const int c = lane % DP;
     const int ec = D - 1 - c;
-    double *img = wl;                       // DP x LD image (conversion / transposition buffer)
-    double *fb = wl + DP * LD;              // [64] broadcast row
-    double *piv = fb + 64;                  // [64] 1 / pivot
+    double *tri = wl;                       // packed factor (aliases the conversion image, which has been consumed)
 
     if (DUMP) {
         if (myrow >= 0 && ec >= 0) {
@@ -378,48 +434,104 @@ __device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&
         }
         return;
     }
-    double p_own;
-    if (wl_factor<DP>(col, p_own, fb, piv, lane) && myrow >= 0) atomicOr(a.flag, 1);
+    double p_own, rp_own;
+    STAMP(4);
+    if (wl_factor<DP>(col, p_own, rp_own, tri, lane) && myrow >= 0) atomicOr(a.flag, 1);
+    STAMP(5);
     const double sq_own = p_own * fast_rsqrt(p_own);                 // L[c][c] = sqrt(p_c)
     // L w = b, y = w + z, carried as yh = y sqrt(p) = b' + z sqrt(p)   (z reversed: column c takes normal number D-1-c)
-    const double bp = wl_forward<DP>(col, bj, piv, lane);
+    const double bp = wl_forward<DP>(col, bj, rp_own, lane);
     double yh = 0.0;
     if (myrow >= 0 && ec >= 0)
         yh = fma(bdf_normal(a.seed, *a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec), sq_own, bp);
-    wl_transpose<DP>(col, img, lane);
-    const double x = wl_backward<DP>(col, yh, piv, lane);            // L' x = y
+    STAMP(6);
+    STAMP(7);
+    const double x = wl_backward<DP>(tri, yh, rp_own, lane);         // L' x = y
     if (myrow >= 0 && ec >= 0) a.out[myrow * D + ec] = x;
+    STAMP(8);
 }
 
-// column c of the prior in reversed coordinates: Lambda~[i][c] (identity padding) and (Lambda mu_i)~[c]
+// ---- prior: Lambda~ in the accumulator (C) layout, identity on the padding; loaded once per wave, added to every row's
+// accumulator before the layout change.  The prior part of b, Lambda mu_i, comes from a small pre-launch (k_prior_b).
 template <int DP>
-__device__ inline void add_prior(const SampleArgs &a, int64_t myrow, int c, double (&col)[DP], double &bj)
+__device__ inline void load_prior_c(const SampleArgs &a, int lane, d4 (&lamc)[Geo<DP>::NB])
 {
+    constexpr int DB = Geo<DP>::DB;
     const int D = a.D;
-    const int ec = D - 1 - c;
-    if (ec >= 0 && myrow >= 0) {
-        const double *mu_i = a.mu_is_matrix ? a.mu + myrow * D : a.mu;
-        double s = 0.0;
+    const int j = lane & 15, h = lane >> 4;
+    int b = 0;
 #pragma unroll
-        for (int i = 0; i < DP; i++) {
-            const int ei = D - 1 - i;
-            if (ei >= 0) {
-                const double lam = a.Lambda[ei + (int64_t)ec * D];
-                col[i] += lam;
-                s = fma(lam, mu_i[ei], s);        // (Lambda mu)[ec] = sum_ei Lambda[ec][ei] mu[ei] (Lambda symmetric)
+    for (int I = 0; I < DB; I++)
+#pragma unroll
+        for (int J = 0; J <= I; J++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * I + h + 4 * r, colm = 16 * J + j;
+                const int er = D - 1 - row, ecm = D - 1 - colm;
+                double v = (row == colm) ? 1.0 : 0.0;
+                if (er >= 0 && ecm >= 0) v = a.Lambda[er + (int64_t)ecm * D];
+                else if (er >= 0 || ecm >= 0) v = 0.0;
+                lamc[b][r] = v;
+            }
+            b++;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_prior_b(int D, int64_t nrows, const double *Lambda, const double *mu,
+                                                 int mu_is_matrix, double *out)
+{
+    // out[row*D + e] = sum_i Lambda[e][i] mu_row[i]   (nrows = 1 for a shared prior mean)
+    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= nrows * D) return;
+    const int64_t row = idx / D;
+    const int e = (int)(idx % D);
+    const double *m = mu_is_matrix ? mu + row * D : mu;
+    double s = 0.0;
+    for (int i = 0; i < D; i++) s = fma(Lambda[e + (int64_t)i * D], m[i], s);
+    out[idx] = s;
+}
+
+// ---- sum the partials of a split row in slot order (fixed order: the result does not depend on which wave does it) ---
+template <int DP>
+__device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int lane, d4 (&acc)[Geo<DP>::NB],
+                                    double (&bred)[Geo<DP>::DB])
+{
+    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, PSZ = Geo<DP>::PSZ;
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < DB; I++) bred[I] = 0.0;
+    // four slots are loaded per trip so that their latencies overlap
+    for (int s0 = 0; s0 < sr.n_slots; s0 += 4) {
+        double v[4][NB * 4 + DB];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int s = (s0 + u < sr.n_slots) ? s0 + u : sr.n_slots - 1;
+            const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
+#pragma unroll
+            for (int e = 0; e < NB * 4; e++) v[u][e] = src[e * 64 + lane];
+#pragma unroll
+            for (int I = 0; I < DB; I++) v[u][NB * 4 + I] = src[NB * 4 * 64 + I * 16 + (lane & 15)];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            if (s0 + u < sr.n_slots) {
+#pragma unroll
+                for (int b = 0; b < NB; b++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) acc[b][r] += v[u][b * 4 + r];
+#pragma unroll
+                for (int I = 0; I < DB; I++) bred[I] += v[u][NB * 4 + I];
             }
         }
-        bj += s;
-    } else {
-#pragma unroll
-        for (int i = 0; i < DP; i++) col[i] = (i == c) ? 1.0 : 0.0;
-        bj = 0.0;
     }
 }
 
-// ---- launch 1: accumulate every item; finish the direct rows -------------------------------------------------------
+// ---- the launch: wave w < n_split accumulates split item w and publishes its partial; the wave whose publication
+// completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
+// independent: cdna_hip_programming.md Guideline 16).  The remaining waves take G direct rows each. -----------------------
 template <int DP, bool DUMP>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows_accum(SampleArgs a, PlanDev p)
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows(SampleArgs a, PlanDev p)
 {
     constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
     constexpr int WPB = Geo<DP>::WPB;
@@ -427,162 +539,137 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double *wl = lds + wave * Geo<DP>::WAVE_LDS;
     const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
+    const int grp = lane / DP, c = lane % DP;
+    double col[DP];
+    double bj = 0.0;
+    int64_t myrow = -1;
+    STAMP(0);
 
-    const int64_t n_dwaves = p.n_direct / G;
-    if (wid >= n_dwaves) {
-        // a split item (launched after the direct rows, so that the short items fill the tail of the launch):
-        // partial to the slab, slot layout [block*4 + r][lane] then b[I][j]
-        if (wid - n_dwaves >= p.n_split) return;
+    if (wid < p.n_split) {
         d4 acc[NB];
         double bred[DB];
-        const Item it = p.split[wid - n_dwaves];
-        accumulate_any<DP>(a, it, lane, wl, acc, bred);
-        double *dst = p.partials + (int64_t)it.slot * PSZ;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
-        if (lane < 16) {
-#pragma unroll
-            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bred[I];
-        }
-        return;
-    }
-    const int64_t first = wid * G;
-    const int grp = lane / DP, c = lane % DP;
-    // accumulate the G rows of this wave one after the other; their accumulators stay in registers (NB*4 doubles
-    // each) until all are done, so that the column array of the finishing phase is not live during the gathers
-    d4 accg[G][NB];
-    double bredg[G][DB];
-    int64_t rows[G];
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        const Item it = p.direct[first + g];
-        rows[g] = it.row;
-#pragma unroll
-        for (int b = 0; b < NB; b++) accg[g][b] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int I = 0; I < DB; I++) bredg[g][I] = 0.0;
-        if (it.row >= 0 && it.count > 0) accumulate_any<DP>(a, it, lane, wl, accg[g], bredg[g]);    // wave-uniform branch
-    }
-    double col[DP];
-    double bj = 0.0;
-    int64_t myrow = -1;
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        if (rows[g] >= 0) {
-            wave_sync();
-            acc_to_image<DP>(accg[g], wl, lane);
-            if (lane < 16) {
-#pragma unroll
-                for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bredg[g][I];
-            }
-            wave_sync();
-            if (grp == g) {
-#pragma unroll
-                for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
-                bj = wl[DP * LD + c];
-                myrow = rows[g];
-            }
-        }
-    }
-    wave_sync();
-    add_prior<DP>(a, myrow, c, col, bj);
-    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane);
-}
-
-// ---- items-only launch (every row split): accumulate items to the slab, nothing else -------------------------------------
-template <int DP>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB) void k_rows_items(SampleArgs a, PlanDev p)
-{
-    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, PSZ = Geo<DP>::PSZ, WPB = Geo<DP>::WPB;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::GAT_D];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *wl = lds + wave * Geo<DP>::GAT_D;
-    const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
-    if (wid >= p.n_split) return;
-    d4 acc[NB];
-    double bred[DB];
-    const Item it = p.split[wid];
-    accumulate_any<DP>(a, it, lane, wl, acc, bred);
-    double *dst = p.partials + (int64_t)it.slot * PSZ;
-#pragma unroll
-    for (int b = 0; b < NB; b++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
-    if (lane < 16) {
-#pragma unroll
-        for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bred[I];
-    }
-}
-
-// ---- launch 2: add the partials of the split rows in slot order and finish them --------------------------------------
-template <int DP, bool DUMP>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows_finish(SampleArgs a, PlanDev p)
-{
-    constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
-    constexpr int WPB = Geo<DP>::WPB;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *wl = lds + wave * Geo<DP>::WAVE_LDS;
-    const int64_t first = ((int64_t)blockIdx.x * WPB + wave) * G;
-    if (first >= p.n_split_rows) return;
-    const int grp = lane / DP, c = lane % DP;
-    double col[DP];
-    double bj = 0.0;
-    int64_t myrow = -1;
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        const SplitRow sr = p.rows[first + g];
-        if (sr.row >= 0) {
-            d4 acc[NB];
-            double bred[DB];
+        const Item it = p.split[wid];
+        if (it.count > 0) accumulate_any<DP>(a, it, lane, wl, 0, false, acc, bred);
+        else {
 #pragma unroll
             for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int I = 0; I < DB; I++) bred[I] = 0.0;
-            // slot order is fixed; four slots are loaded per trip so that their latencies overlap
-            for (int s0 = 0; s0 < sr.n_slots; s0 += 4) {
-                double v[4][NB * 4 + DB];
+        }
+        // slot layout [block*4 + r][lane] then b[I][j]; write-through (sc1) stores: the slab needs no L2 write-back
+        double *dst = p.partials + (int64_t)it.slot * PSZ;
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const int s = (s0 + u < sr.n_slots) ? s0 + u : sr.n_slots - 1;
-                    const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
+        for (int b = 0; b < NB; b++)
 #pragma unroll
-                    for (int e = 0; e < NB * 4; e++) v[u][e] = src[e * 64 + lane];
+            for (int r = 0; r < 4; r++)
+                __hip_atomic_store(dst + (b * 4 + r) * 64 + lane, acc[b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane < 16) {
 #pragma unroll
-                    for (int I = 0; I < DB; I++) v[u][NB * 4 + I] = src[NB * 4 * 64 + I * 16 + (lane & 15)];
+            for (int I = 0; I < DB; I++)
+                __hip_atomic_store(dst + NB * 4 * 64 + I * 16 + lane, bred[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        // publish: every lane's write-through stores have completed, then one arrival
+        const SplitRow sr = p.rows[it.srow];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        int old = 0;
+        if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        old = __builtin_amdgcn_readfirstlane(old);
+        STAMP(1);
+        if (old != sr.n_slots - 1) return;                      // not the last item of the row
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
+        sum_partials<DP>(p, sr, lane, acc, bred);
+        STAMP(2);
+        {
+            d4 lamc[NB];
+            load_prior_c<DP>(a, lane, lamc);
+#pragma unroll
+            for (int b = 0; b < NB; b++) acc[b] += lamc[b];
+        }
+        wave_sync();
+        acc_to_image<DP>(acc, wl, lane);
+        if (lane < 16) {
+#pragma unroll
+            for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bred[I];
+        }
+        wave_sync();
+        if (grp == 0) {
+#pragma unroll
+            for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
+            bj = wl[DP * LD + c];
+            myrow = sr.row;
+        }
+    } else {
+        const int64_t first = (wid - p.n_split) * G;
+        if (first >= p.n_direct) return;
+        // accumulate the G rows of this wave one after the other; their accumulators stay in registers (NB*4 doubles
+        // each) until all are done, so that the column array of the finishing phase is not live during the gathers
+        d4 accg[G][NB];
+        double bredg[G][DB];
+        int64_t rows[G];
+        bool staged[G];
+        // the first NSTAGE items are staged together (one exposed latency) when they are matrix-relation items
+        bool all_matrix = true;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const Item it = p.direct[first + g];
+            if (it.row >= 0 && a.t[it.term].n_other != 1) all_matrix = false;
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++)
+            staged[g] = (g < Geo<DP>::NSTAGE && (all_matrix || g == 0)) ? prestage<DP>(a, p.direct[first + g], lane, wl, g) : false;
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const Item it = p.direct[first + g];
+            rows[g] = it.row;
+#pragma unroll
+            for (int b = 0; b < NB; b++) accg[g][b] = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int I = 0; I < DB; I++) bredg[g][I] = 0.0;
+            if (it.row >= 0 && it.count > 0)                                                            // wave-uniform
+                accumulate_any<DP>(a, it, lane, wl, staged[g] ? g : 0, staged[g], accg[g], bredg[g]);
+            STAMP(1 + g);
+        }
+        {
+            d4 lamc[NB];                                  // loaded after the gathers so that it is not live during them
+            load_prior_c<DP>(a, lane, lamc);
+#pragma unroll
+            for (int g = 0; g < G; g++)
+#pragma unroll
+                for (int b = 0; b < NB; b++) accg[g][b] += lamc[b];
+        }
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            if (rows[g] >= 0) {
+                wave_sync();
+                acc_to_image<DP>(accg[g], wl, lane);
+                if (lane < 16) {
+#pragma unroll
+                    for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bredg[g][I];
                 }
+                wave_sync();
+                if (grp == g) {
 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (s0 + u < sr.n_slots) {
-#pragma unroll
-                        for (int b = 0; b < NB; b++)
-#pragma unroll
-                            for (int r = 0; r < 4; r++) acc[b][r] += v[u][b * 4 + r];
-#pragma unroll
-                        for (int I = 0; I < DB; I++) bred[I] += v[u][NB * 4 + I];
-                    }
+                    for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
+                    bj = wl[DP * LD + c];
+                    myrow = rows[g];
                 }
-            }
-            wave_sync();
-            acc_to_image<DP>(acc, wl, lane);
-            if (lane < 16) {
-#pragma unroll
-                for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bred[I];
-            }
-            wave_sync();
-            if (grp == g) {
-#pragma unroll
-                for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
-                bj = wl[DP * LD + c];
-                myrow = sr.row;
             }
         }
     }
     wave_sync();
-    add_prior<DP>(a, myrow, c, col, bj);
-    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane);
+    STAMP(3);
+    {
+        const int ec = a.D - 1 - c;
+        if (myrow >= 0 && ec >= 0) bj += a.prior_b[(a.mu_is_matrix ? myrow * a.D : 0) + ec];
+        else if (myrow < 0) {       // only the split-row finisher has unused lane groups
+#pragma unroll
+            for (int i = 0; i < DP; i++) col[i] = (i == c) ? 1.0 : 0.0;
+            bj = 0.0;
+        }
+    }
+    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane, wid);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -599,6 +686,7 @@ struct Plan {
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
     double *partials_dev = nullptr;
+    int32_t *arrived_dev = nullptr;
 };
 
 struct PlanCache {
@@ -629,9 +717,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
             n_items += (int)((n + T - 1) / T);
         }
-        static const bool all_split = getenv("BDF_ALL_SPLIT") != nullptr;
-        if (n_items <= 1 && !all_split) {
-            Item it{row, 0, 0, 0, -1};
+        if (n_items <= 1) {
+            Item it{row, 0, 0, 0, -1, -1, 0};
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
                 const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
@@ -640,7 +727,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             direct.push_back(it);
         } else {
             if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
-                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size()});
+                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), 0});
                 srows.push_back(SplitRow{row, (int32_t)split.size() - 1, 1, 0});
                 continue;
             }
@@ -652,23 +739,26 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
                 for (int s = 0; s < pieces; s++) {
                     // equal pieces rather than T, T, ..., remainder
                     const int64_t b0 = beg + n * s / pieces, b1 = beg + n * (s + 1) / pieces;
-                    split.push_back(Item{row, r, b0, (int32_t)(b1 - b0), (int32_t)split.size()});
+                    split.push_back(Item{row, r, b0, (int32_t)(b1 - b0), (int32_t)split.size(), (int32_t)srows.size(), 0});
                 }
             }
             srows.push_back(sr);
         }
     }
-    while (direct.size() % (size_t)G) direct.push_back(Item{-1, 0, 0, 0, -1});
-    while (srows.size() % (size_t)G) srows.push_back(SplitRow{-1, 0, 0, 0});
+    // a wave finishes G rows at once: fill the last wave by repeating its last row (same result written twice)
+    while (!direct.empty() && direct.size() % (size_t)G) direct.push_back(direct.back());
     int rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
         (rc = to_device(srows, &plan.rows_dev)))
         return rc;
     BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
+    BDF_HIP(hipMalloc((void **)&plan.arrived_dev, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
+    BDF_HIP(hipMemset(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
     plan.dev.direct = plan.direct_dev; plan.dev.n_direct = (int32_t)direct.size();
     plan.dev.split = plan.split_dev;   plan.dev.n_split = (int32_t)split.size();
     plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
     plan.dev.partials = plan.partials_dev;
+    plan.dev.arrived = plan.arrived_dev;
     return BDF_OK;
 }
 
@@ -676,22 +766,11 @@ template <int DP>
 int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
     constexpr int G = Geo<DP>::G, WPB = Geo<DP>::WPB;
-    const int64_t waves1 = (int64_t)p.n_split + p.n_direct / G;
-    if (p.n_direct == 0 && p.n_split > 0) {
-        dim3 grid((unsigned)((p.n_split + WPB - 1) / WPB)), block(64 * WPB);
-        hipLaunchKernelGGL((k_rows_items<DP>), grid, block, 0, ctx->stream, a, p);
-        BDF_HIP(hipGetLastError());
-    } else if (waves1 > 0) {
-        dim3 grid((unsigned)((waves1 + WPB - 1) / WPB)), block(64 * WPB);
-        if (dump) hipLaunchKernelGGL((k_rows_accum<DP, true>), grid, block, 0, ctx->stream, a, p);
-        else      hipLaunchKernelGGL((k_rows_accum<DP, false>), grid, block, 0, ctx->stream, a, p);
-        BDF_HIP(hipGetLastError());
-    }
-    const int64_t waves2 = p.n_split_rows / G;
-    if (waves2 > 0) {
-        dim3 grid((unsigned)((waves2 + WPB - 1) / WPB)), block(64 * WPB);
-        if (dump) hipLaunchKernelGGL((k_rows_finish<DP, true>), grid, block, 0, ctx->stream, a, p);
-        else      hipLaunchKernelGGL((k_rows_finish<DP, false>), grid, block, 0, ctx->stream, a, p);
+    const int64_t waves = (int64_t)p.n_split + p.n_direct / G;
+    if (waves > 0) {
+        dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
+        if (dump) hipLaunchKernelGGL((k_rows<DP, true>), grid, block, 0, ctx->stream, a, p);
+        else      hipLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, a, p);
         BDF_HIP(hipGetLastError());
     }
     return BDF_OK;
@@ -710,7 +789,7 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
         for (int r = 0; r < kv->first.n_terms; r++) hit = hit || kv->first.rel[r] == rel_serial;
         if (hit) {
             hipFree(kv->second.direct_dev); hipFree(kv->second.split_dev); hipFree(kv->second.rows_dev);
-            hipFree(kv->second.partials_dev);
+            hipFree(kv->second.partials_dev); hipFree(kv->second.arrived_dev);
             kv = plans.erase(kv);
         } else {
             ++kv;
@@ -719,9 +798,24 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
     if (rel_serial == 0) g_caches.erase(it);
 }
 
-int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
+int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump)
 {
+    SampleArgs a = a_in;
+    {
+        // prior part of b: Lambda mu (one vector) or Lambda mu_i for every row (per-row prior means, macau.jl:104)
+        const int64_t N = rels[0]->dims[modes[0]];
+        const int64_t nr = a.mu_is_matrix ? N : 1;
+        void *pb;
+        int rc = bdf_scratch(ctx, (size_t)nr * a.D * sizeof(double), &pb);
+        if (rc) return rc;
+        if (nr * a.D > 0) {
+            hipLaunchKernelGGL(k_prior_b, dim3((unsigned)((nr * a.D + 255) / 256)), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda,
+                               a.mu, a.mu_is_matrix, (double *)pb);
+            BDF_HIP(hipGetLastError());
+        }
+        a.prior_b = (const double *)pb;
+    }
     const int DP = a.D <= 16 ? 16 : (a.D <= 32 ? 32 : 64);
     const int G = 64 / DP;
     const int DB = DP / 16, NB = DB * (DB + 1) / 2;

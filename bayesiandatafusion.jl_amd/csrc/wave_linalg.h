@@ -10,9 +10,13 @@
 //     L' x = y  <=>  Ah' x = yh,  yh = y * sqrt(p)
 // and run on MASKED columns (strict lower part, zeros elsewhere) so that their inner step is one unconditional fma.
 //
-// LDS needs per wave (doubles): fb[64] broadcast row, piv[64] pivots then 1/pivots, img[DP * (DP + 1)] transposition.
+// LDS needs per wave: WL<DP>::tri_doubles(share) doubles for the packed factor.
 #pragma once
 #include "bdf_common.h"
+
+#ifndef WL_CH
+#define WL_CH 8
+#endif
 
 __device__ inline void wave_sync()
 {
@@ -42,28 +46,61 @@ __device__ inline double fast_rsqrt(double x)
 }
 
 // In : col[i] = A[i][c] (symmetric, all rows).
-// Out: col[k] = Ah[c][k] for k < c, 0 for k >= c (strict lower part of row c, masked); p_own = pivot p_c;
-//      piv[lane] = 1 / p_c (for the solves).  Returns true (in every lane of the group) if a pivot was not positive.
+// Out: col[k] = Ah[c][k] for k < c, 0 for k >= c (strict lower part of row c, masked); p_own = pivot p_c,
+//      rp_own = 1 / p_c; tri = the factor by columns in packed form: column k (entries Ah[i][k], i >= k, Ah[k][k] = p_k)
+//      at tri[grp * TRI + off(k) + (i - k)], off(k) = k DP - k (k-1) / 2, TRI = DP (DP+1) / 2.  Step k's broadcast row IS
+//      column k of the factor, so storing it costs nothing and the backward solve needs no transposition.
+//      tri needs G * TRI + 64 doubles (SHARE: every group holds the same matrix and they share one copy: TRI + 64).
+// Returns true (in every lane of the group) if a pivot was not positive.
 template <int DP>
-__device__ inline bool wl_factor(double (&col)[DP], double &p_own, double *fb, double *piv, int lane)
+struct WL {
+    static constexpr int G = 64 / DP;
+    static constexpr int TRI = DP * (DP + 1) / 2;
+    __host__ __device__ static constexpr int off(int k) { return k * DP - k * (k - 1) / 2; }
+    static constexpr int tri_doubles(bool share) { return (share ? 1 : G) * TRI + 64; }
+};
+
+template <int DP, bool SHARE = false>
+__device__ inline bool wl_factor(double (&col)[DP], double &p_own, double &rp_own, double *tri, int lane)
 {
+    using W = WL<DP>;
     const int grp = lane / DP, c = lane % DP;
-    double *row = fb + grp * DP;
+    double *tg = tri + (SHARE ? 0 : grp * W::TRI);
+    double *dummy = tri + (SHARE ? 1 : W::G) * W::TRI + lane;
     bool notpd = false;
     p_own = 1.0;
 #pragma unroll
     for (int k = 0; k < DP; k++) {
-        row[c] = col[k];                                  // A[k][c] = A[c][k]
+        double *rk = tg + W::off(k) - k;                  // rk[i] = entry i of column k (i >= k)
+        double *dst = (c >= k) ? rk + c : dummy;          // lanes c < k are done: they park their store
+        *dst = col[k];                                    // A[k][c] = A[c][k]
         wave_sync();
-        const double pk = row[k];
+        const double pk = rk[k];
         if (!(pk > 0.0)) notpd = true;
         const double g = col[k] * fast_rcp(pk);           // A[c][k] / A[k][k]
+        // trailing rows in chunks of WL_CH: a compiler-only memory barrier after each chunk's reads keeps at most two
+        // chunks of broadcast values live (otherwise every read of the step is hoisted: +2 (DP-k) registers)
+        {
+            constexpr int CH = WL_CH;
+            double cur[CH], nxt[CH];
 #pragma unroll
-        for (int i = k + 1; i < DP; i++) col[i] = fma(-row[i], g, col[i]);
+            for (int u = 0; u < CH; u++) cur[u] = (k + 1 + u < DP) ? rk[k + 1 + u] : 0.0;
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int i0 = k + 1; i0 < DP; i0 += CH) {
+#pragma unroll
+                for (int u = 0; u < CH; u++) nxt[u] = (i0 + CH + u < DP) ? rk[i0 + CH + u] : 0.0;
+                asm volatile("" ::: "memory");
+#pragma unroll
+                for (int u = 0; u < CH; u++)
+                    if (i0 + u < DP) col[i0 + u] = fma(-cur[u], g, col[i0 + u]);
+#pragma unroll
+                for (int u = 0; u < CH; u++) cur[u] = nxt[u];
+            }
+        }
         p_own = (c == k) ? pk : p_own;
-        wave_sync();                                      // row[] is rewritten by the next step (compiler barrier only)
     }
-    piv[lane] = fast_rcp(p_own);
+    rp_own = fast_rcp(p_own);
 #pragma unroll
     for (int k = 0; k < DP; k++) col[k] = (k < c) ? col[k] : 0.0;
     wave_sync();
@@ -75,51 +112,35 @@ __device__ inline double wl_bcast(double v, int src_lane)
     return __shfl(v, src_lane);
 }
 
-// forward solve Ah wh = b on masked rows (lane c holds row c).  Returns b'_c = wh_c * p_c (the reduced right-hand side).
+// forward solve Ah wh = b on masked rows (lane c holds row c; rp_own = 1 / p_c).
+// Returns b'_c = wh_c * p_c (the reduced right-hand side).
 template <int DP>
-__device__ inline double wl_forward(const double (&rowm)[DP], double b, const double *piv, int lane)
+__device__ inline double wl_forward(const double (&rowm)[DP], double b, double rp_own, int lane)
 {
     const int base = (lane / DP) * DP;
 #pragma unroll
     for (int k = 0; k < DP; k++) {
-        const double wk = wl_bcast(b, base + k) * piv[base + k];
+        const double wk = wl_bcast(b * rp_own, base + k);     // lane k's b is final at step k
         b = fma(-rowm[k], wk, b);
     }
     return b;
 }
 
-// masked rows -> masked columns through the image (img: DP * (DP+1) doubles), one group at a time.
-// in: rowm[k] = Ah[c][k] (k < c, else 0).  out: colm[i] = Ah[i][c] (i > c, else 0).
-template <int DP>
-__device__ inline void wl_transpose(double (&col)[DP], double *img, int lane)
+// backward solve Ah' x = yh reading the factor's columns from tri (lane c uses column c).  Returns x_c.
+template <int DP, bool SHARE = false>
+__device__ inline double wl_backward(const double *tri, double yh, double rp_own, int lane)
 {
-    constexpr int G = 64 / DP, LD = DP + 1;
-    const int grp = lane / DP, c = lane % DP;
-#pragma unroll
-    for (int g = 0; g < G; g++) {
-        wave_sync();
-        if (grp == g) {
-#pragma unroll
-            for (int k = 0; k < DP; k++) img[c * LD + k] = col[k];
-        }
-        wave_sync();
-        if (grp == g) {
-#pragma unroll
-            for (int i = 0; i < DP; i++) col[i] = img[i * LD + c];
-        }
-    }
+    using W = WL<DP>;
+    const int grp = lane / DP, c = lane % DP, base = grp * DP;
+    const double *colc = tri + (SHARE ? 0 : grp * W::TRI) + (c * DP - c * (c - 1) / 2) - c;   // colc[i] = Ah[i][c], i >= c
+    const double *zero = tri + (SHARE ? 1 : W::G) * W::TRI + lane;
+    *(double *)zero = 0.0;          // wl_factor parked arbitrary values in these slots
     wave_sync();
-}
-
-// backward solve Ah' x = yh on masked columns (lane c holds column c).  Returns x_c.
-template <int DP>
-__device__ inline double wl_backward(const double (&colm)[DP], double yh, const double *piv, int lane)
-{
-    const int base = (lane / DP) * DP;
 #pragma unroll
     for (int i = DP - 1; i >= 0; i--) {
-        const double xi = wl_bcast(yh, base + i) * piv[base + i];
-        yh = fma(-colm[i], xi, yh);
+        const double xi = wl_bcast(yh * rp_own, base + i);    // lane i's yh is final at step i
+        const double *src = (i > c) ? colc + i : zero;
+        yh = fma(-(*src), xi, yh);
     }
-    return yh * piv[lane];
+    return yh * rp_own;
 }

@@ -25,12 +25,12 @@ def _ptr(t):
 class Context:
     """bdf_ctx bound to a torch device and torch's current stream."""
 
-    def __init__(self, device=None, seed=0):
+    def __init__(self, device=None, seed=0, stream=None):
         if not torch.cuda.is_available():
             raise _lib.NoGpuError("no GPU visible: bayesiandatafusion.jl_amd has no CPU path (the reference is the CPU path)")
         self.device = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
         torch.cuda.set_device(self.device)
-        self.stream = torch.cuda.current_stream(self.device)
+        self.stream = stream if stream is not None else torch.cuda.current_stream(self.device)
         self.handle = C.c_void_p()
         check(lib().bdf_ctx_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.c_uint64(int(seed) & (2 ** 64 - 1)),
                                    C.byref(self.handle)))
@@ -270,6 +270,12 @@ class GibbsEngine:
         self.ctx = Context(device, seed)
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
+        # second HIP stream: the hyperprior of entity j (reductions + Normal-Wishart draw) runs beside the row sampling
+        # of entity j+1, which does not depend on it (macau.jl:96-134 draws them in this order; the values are the same)
+        self.ctx_h = self.ctx
+        if not os.environ.get("BDF_NO_OVERLAP"):
+            self.ctx_h = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+        self._ev_rows, self._ev_hyper = {}, {}
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
@@ -383,15 +389,15 @@ class GibbsEngine:
     def update_prior(self, j):
         en, st = self.data.entities[j], self.ent[j]
         L = lib()
-        check(L.bdf_hyper_sums(self.ctx.handle, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
+        h = self.ctx_h.handle
+        check(L.bdf_hyper_sums(h, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
                                _ptr(st.sumU), _ptr(st.UUt)))
         nu, Tinv = st.nu0, st.WI
         if st.F is not None and self.full_lambda_u:
             nu += st.numF
-            check(L.bdf_hyper_feature_terms(self.ctx.handle, self.D, st.numF, _ptr(st.beta), _ptr(st.WI), _ptr(st.lambda_beta),
-                                            _ptr(st.Tinv)))
+            check(L.bdf_hyper_feature_terms(h, self.D, st.numF, _ptr(st.beta), _ptr(st.WI), _ptr(st.lambda_beta), _ptr(st.Tinv)))
             Tinv = st.Tinv
-        check(L.bdf_hyper_sample(self.ctx.handle, self.D, st.N, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
+        check(L.bdf_hyper_sample(h, self.D, st.N, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
                                  nu, st.tag, _ptr(st.mu), _ptr(st.Lambda), _ptr(st.params)))
 
     # ---- macau.jl:138-140: beta of entity j ----------------------------------------------------------------
@@ -410,12 +416,37 @@ class GibbsEngine:
 
     # ---- one Gibbs iteration without reporting (the timed unit of bench.py) ---------------------------------------
     def sweep(self, i):
+        main, side = self.ctx.stream, self.ctx_h.stream
+        two = self.ctx_h is not self.ctx
         self.ctx.set_sweep(i)
+        if two:
+            self.ctx_h.set_sweep(i)
         for j in range(len(self.ent)):
+            if two and j in self._ev_hyper:
+                main.wait_event(self._ev_hyper[j])       # (mu, Lambda) of entity j from the previous iteration
             self.sample_entity(j)
+            if two:
+                ev = self._ev_rows.setdefault(j, torch.cuda.Event())
+                ev.record(main)
+                side.wait_event(ev)
             self.update_prior(j)
+            if two:
+                ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
+                ev.record(side)
         for j in range(len(self.ent)):
-            self.update_beta(j)
+            if self.ent[j].F is not None:
+                if two:
+                    main.wait_event(self._ev_hyper[j])
+                self.update_beta(j)
+                if two:                                  # the next hyperprior of j reads beta / lambda_beta
+                    ev = self._ev_rows[j]
+                    ev.record(main)
+                    side.wait_event(ev)
+
+    def sync(self):
+        if self.ctx_h is not self.ctx:
+            self.ctx_h.sync()
+        self.ctx.sync()
 
     # ---- predictions ------------------------------------------------------------------------------------------
     def factors_of(self, r):
@@ -442,4 +473,6 @@ class GibbsEngine:
                 st.F.close()
         for dr in self.rel:
             dr.close()
+        if self.ctx_h is not self.ctx:
+            self.ctx_h.close()
         self.ctx.close()

@@ -120,11 +120,11 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
             if i == burnin + 1 and verbose:
                 print("--------- Burn-in complete, averaging posterior samples ----------")
             if callable(f):
-                eng.ctx.sync()
+                eng.sync()
                 f_output.append(f(data))
 
         if verbose or i == burnin + psamples:
-            eng.ctx.sync()
+            eng.sync()
             eng.sync_host_scalars()
             if haveTest:
                 s = stats.cpu().numpy()
@@ -138,7 +138,7 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
                 rstr = " ".join(toStr(r) for r in data.relations)
                 print(f"{i:3d}: ROC={roc_avg:6.4f} RMSE={rmse_avg:6.4f} | {estr} | {rstr} [{time.time() - time0:1.1f}s]")
 
-    eng.ctx.sync()
+    eng.sync()
     eng.sync_host_scalars()
     result = {
         "num_latent": num_latent,

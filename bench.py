@@ -115,7 +115,7 @@ def main():
 
     for i in range(1, args.warmup + 1):
         step(i, 0)
-    eng.ctx.sync()
+    eng.sync()
     fence()
     eng.k1_events = []
     t0 = time.perf_counter()
@@ -123,7 +123,7 @@ def main():
         step(args.warmup + 1 + k, 1 if k == 0 else 2)
     fence()
     elapsed = time.perf_counter() - t0
-    eng.ctx.sync()
+    eng.sync()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void k_finish(double *out, int n
     const int64_t wid = (int64_t)blockIdx.x * 4 + wave;
     if (wid >= nwaves) return;
     double *wl = lds + wave * (DP * LD + 128);
-    double *img = wl, *fb = wl + DP * LD, *piv = fb + 64;
+    double *tri = wl;
     const int c = lane % DP;
     double col[DP];
 #pragma unroll
@@ -26,13 +26,12 @@ __global__ __launch_bounds__(256, WAVES_PER_EU) void k_finish(double *out, int n
         col[i] = (i == c ? 40.0 : 0.0) + 1.0 / (1.0 + lo + 2 * hi + (wid & 7));      // symmetric, diagonally dominant
     }
     double bj = 1.0 + c;
-    double p_own;
-    bool bad = wl_factor<DP>(col, p_own, fb, piv, lane);
+    double p_own, rp_own;
+    bool bad = wl_factor<DP>(col, p_own, rp_own, tri, lane);
     const double sq = p_own * fast_rsqrt(p_own);
-    const double bp = wl_forward<DP>(col, bj, piv, lane);
+    const double bp = wl_forward<DP>(col, bj, rp_own, lane);
     const double yh = fma(bdf_normal(1234, *sweep, 1, 1, (uint64_t)wid, c), sq, bp);
-    wl_transpose<DP>(col, img, lane);
-    const double x = wl_backward<DP>(col, yh, piv, lane);
+    const double x = wl_backward<DP>(tri, yh, rp_own, lane);
     out[wid * 64 + lane] = bad ? -1.0 : x;
 }
 
