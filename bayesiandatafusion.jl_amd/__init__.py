@@ -24,9 +24,9 @@ def __getattr__(name):
     # the engine and driver import torch; load them on first use so that the host-only data model (and the
     # CPU test suite) does not pay for it
     if name in ("macau", "pred", "pred_all", "AUC_ROC", "write_binary_matrix", "read_binary_float32", "makeClamped"):
-        from . import macau as _m
-        return getattr(_m, name)
+        import importlib
+        return getattr(importlib.import_module(__name__ + ".driver"), name)
     if name in ("GibbsEngine", "Context", "DeviceRelation", "DevicePairs", "FeatOperator"):
-        from . import engine as _e
-        return getattr(_e, name)
+        import importlib
+        return getattr(importlib.import_module(__name__ + ".engine"), name)
     raise AttributeError(name)

@@ -9,6 +9,7 @@ Layout: an entity's sample is the reference's D x N column-major matrix == a con
 """
 import ctypes as C
 import os
+import weakref
 
 import numpy as np
 import torch
@@ -35,6 +36,12 @@ class Context:
         check(lib().bdf_ctx_create(self.device.index, C.c_void_p(self.stream.cuda_stream), C.c_uint64(int(seed) & (2 ** 64 - 1)),
                                    C.byref(self.handle)))
         self.seed = int(seed)
+        # device objects created on this context; they are destroyed before it whatever order the garbage collector
+        # finalises things in (a relation / feature handle points back into the context)
+        self._children = weakref.WeakSet()
+
+    def adopt(self, child):
+        self._children.add(child)
 
     def set_item_size(self, observations):
         check(lib().bdf_ctx_set_item_size(self.handle, int(observations)))
@@ -56,6 +63,8 @@ class Context:
 
     def close(self):
         if self.handle:
+            for ch in list(self._children):
+                ch.close()
             lib().bdf_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
 
@@ -80,6 +89,7 @@ class DeviceRelation:
                                         C.byref(self.handle)))
         self.dims = list(idf.dims)
         self.nnz = idf.nnz()
+        ctx.adopt(self)
 
     def index(self, mode0):
         rp, ri = _lib.c_i64p(), _lib.c_i64p()
@@ -99,7 +109,8 @@ class DeviceRelation:
 
     def close(self):
         if self.handle:
-            lib().bdf_relation_destroy(self.handle)
+            if self.ctx.handle:                 # a closed context has already destroyed its objects
+                lib().bdf_relation_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -121,6 +132,7 @@ class DevicePairs:
         check(lib().bdf_pairs_create(ctx.handle, self.n_modes, self.n, ids.ctypes.data_as(C.c_void_p), 8,
                                      values.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
         self.stats = ctx.zeros(4)
+        ctx.adopt(self)
 
     def _facs(self, factors):
         return (C.c_void_p * len(factors))(*[f.data_ptr() for f in factors])
@@ -148,7 +160,8 @@ class DevicePairs:
 
     def close(self):
         if self.handle:
-            lib().bdf_pairs_destroy(self.handle)
+            if self.ctx.handle:                 # a closed context has already destroyed its objects
+                lib().bdf_pairs_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -192,6 +205,8 @@ class FeatOperator:
             check(L.bdf_feat_create_dense(ctx.handle, A.shape[0], A.shape[1], A.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
             self.m, self.n = int(A.shape[0]), int(A.shape[1])
 
+        ctx.adopt(self)
+
     # B, out: torch tensors holding column-major matrices, i.e. shape (ncol, rows)
     def mul(self, B, transpose=False):
         ncol = B.shape[0]
@@ -206,7 +221,8 @@ class FeatOperator:
 
     def close(self):
         if self.handle:
-            lib().bdf_feat_destroy(self.handle)
+            if self.ctx.handle:                 # a closed context has already destroyed its objects
+                lib().bdf_feat_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):

@@ -1,0 +1,190 @@
+"""GPU parity of the side-information path (K2-K5): Entity.F operators, AtA_mul_B!, cg_AtA / solve_cg2, solve_full,
+sample_beta, sample_lambda_beta -- against the CPU oracle and against the dense algebra the reference's own tests use
+(test/solver.jl, test/sparse_csr.jl, test/sparsebin_csr.jl, test/parallel_matrix.jl:41-109, test/heavy_copyto.jl:28-69).
+Tolerances: products 1e-12 relative; CG solutions 1e-9 relative (the solver stops at eps*numF like the reference);
+sampled beta 1e-7 relative for the same normals.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+SEED = 1234
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _colmajor(ctx, A):
+    """numpy (rows, cols) -> torch tensor holding the column-major matrix (shape (cols, rows))"""
+    return ctx.tensor(np.ascontiguousarray(np.asarray(A, dtype=np.float64).T))
+
+
+def _from_colmajor(t):
+    return t.cpu().numpy().T
+
+
+def _reference_pattern():
+    """rows = [1:200; 151:350], cols = [151:350; 1:2:399] -- test/sparsebin_csr.jl:4-5, test/parallel_matrix.jl:41-42"""
+    rows = np.concatenate([np.arange(1, 201), np.arange(151, 351)]).astype(np.int32)
+    cols = np.concatenate([np.arange(151, 351), np.arange(1, 400, 2)]).astype(np.int32)
+    A = np.zeros((350, 399))
+    np.add.at(A, (rows - 1, cols - 1), 1.0)
+    return rows, cols, A
+
+
+def _operators(B, ctx, rng):
+    import scipy.sparse as sp
+    rows, cols, Abin = _reference_pattern()
+    Fd = rng.standard_normal((120, 37))
+    S = sp.random(90, 64, density=0.15, random_state=3, format="coo")
+    return {
+        "dense": (B.FeatOperator(ctx, Fd), Fd),
+        "csr": (B.FeatOperator(ctx, S), S.toarray()),
+        "bincoo": (B.FeatOperator(ctx, B.SparseBinMatrix(rows, cols)), Abin),
+        "bincsr": (B.FeatOperator(ctx, B.SparseBinMatrixCSR(rows, cols)), Abin),
+    }
+
+
+def test_feature_products_all_kinds(B, ctx):
+    rng = np.random.default_rng(0)
+    for name, (op, A) in _operators(B, ctx, rng).items():
+        m, n = A.shape
+        assert (op.m, op.n) == (m, n)
+        X = rng.standard_normal((n, 5))
+        Y = rng.standard_normal((m, 3))
+        np.testing.assert_allclose(_from_colmajor(op.mul(_colmajor(ctx, X))), A @ X, rtol=1e-12, atol=1e-12, err_msg=name)
+        np.testing.assert_allclose(_from_colmajor(op.mul(_colmajor(ctx, Y), transpose=True)), A.T @ Y, rtol=1e-12, atol=1e-12,
+                                   err_msg=name)
+        # AtA_mul_B! (parallel_cg.jl:7-14), lambda = 0.1 as in test/parallel_matrix.jl:72-92
+        got = _from_colmajor(op.AtA_mul(_colmajor(ctx, X), 0.1))
+        np.testing.assert_allclose(got, A.T @ (A @ X) + 0.1 * X, rtol=1e-12, atol=1e-11, err_msg=name)
+        op.close()
+
+
+def test_sparse_csr_literal(B, ctx):
+    """test/sparse_csr.jl:28-34"""
+    F = B.sparse_csr([1, 2, 2, 4], [2, 1, 3, 3], [0.1, 0.2, 0.15, 0.3])
+    op = B.FeatOperator(ctx, F)
+    z = np.array([0.3, -1.2, 0.7])
+    dense = np.zeros((4, 3))
+    dense[[0, 1, 1, 3], [1, 0, 2, 2]] = [0.1, 0.2, 0.15, 0.3]
+    np.testing.assert_allclose(_from_colmajor(op.mul(_colmajor(ctx, z[:, None])))[:, 0], dense @ z, rtol=1e-14)
+    op.close()
+
+
+def _sample_beta(B, ctx, op, D, sample, mu, Lam, lb, use_ff, tol, sample_lambda=False, nu=1e-3, mu_h=1.0, tag=3, maxiter=0):
+    from bdf_amd._lib import check, lib
+    import torch
+    S_t, mu_t, Lam_t = ctx.tensor(sample), ctx.tensor(mu), ctx.tensor(Lam)
+    lb_t = ctx.tensor([lb])
+    beta_t, rhs_t = ctx.zeros(D, op.n), ctx.zeros(D, op.n)
+    it_t = torch.zeros(D, dtype=torch.int32, device=ctx.device)
+    check(lib().bdf_sample_beta(ctx.handle, op.handle, D, _p(S_t), _p(mu_t), _p(Lam_t), _p(lb_t), int(use_ff),
+                                float("nan") if tol is None else tol, maxiter, int(sample_lambda), nu, mu_h, tag,
+                                _p(beta_t), _p(rhs_t), _p(it_t)))
+    ctx.sync()
+    return _from_colmajor(beta_t), _from_colmajor(rhs_t), it_t.cpu().numpy(), float(lb_t.item())
+
+
+@pytest.mark.parametrize("kind,D", [("dense", 8), ("csr", 5), ("bincoo", 3), ("dense", 32)])
+def test_sample_beta_cg_and_direct_match_oracle(B, O, ctx, kind, D):
+    rng = np.random.default_rng(11)
+    op, A = _operators(B, ctx, rng)[kind]
+    N, numF = A.shape
+    sample = rng.standard_normal((N, D))
+    mu = rng.standard_normal(D) * 0.1
+    M = rng.standard_normal((D, D))
+    Lam = M @ M.T / D + np.eye(D)
+    lb = 0.75
+    ctx.set_sweep(6)
+    if kind == "dense":
+        ofeat = O.Feat.from_dense(A)
+    else:
+        r, c = np.nonzero(A)
+        ofeat = O.Feat.from_csr(r, c, A[r, c], N, numF)
+    beta_e, rhs_e, it_e = O.sample_beta(ofeat, sample, mu, Lam, lb, False, None, SEED, 6, 3)
+    beta, rhs, iters, _ = _sample_beta(B, ctx, op, D, sample, mu, Lam, lb, False, None)
+    np.testing.assert_allclose(rhs, rhs_e, rtol=1e-9, atol=1e-9)
+    scale = np.abs(beta_e).max()
+    np.testing.assert_allclose(beta, beta_e, rtol=1e-7, atol=1e-9 * scale)
+    # both solve (F'F + lb I) beta = rhs to the reference's tolerance: compare with the direct solve as test/heavy_copyto.jl does
+    direct = np.linalg.solve(A.T @ A + lb * np.eye(numF), rhs_e)
+    np.testing.assert_allclose(beta, direct, rtol=1e-7, atol=1e-9 * scale)
+    assert np.all(np.abs(iters - it_e) <= 2), (iters, it_e)
+    # FF path (solve_full): same system, direct
+    beta_ff, _, _, _ = _sample_beta(B, ctx, op, D, sample, mu, Lam, lb, True, None)
+    np.testing.assert_allclose(beta_ff, direct, rtol=1e-7, atol=1e-9 * scale)
+    op.close()
+
+
+def test_cg_reference_cases(B, O, ctx):
+    """cg_AtA against the direct solve: lambda 0.5 (test/parallel_matrix.jl:107-109), 0.75 with tol 1e-6 and several
+    right-hand sides (test/heavy_copyto.jl:28-50), driven through sample_beta with the noise switched off by a huge Lambda"""
+    rows, cols, A = _reference_pattern()
+    op = B.FeatOperator(ctx, B.SparseBinMatrix(rows, cols))
+    rng = np.random.default_rng(2)
+    D = 3
+    N, numF = A.shape
+    target = rng.random((N, D))
+    Lam = np.eye(D) * 1e30                    # noise ~ 1e-15: rhs == F' target
+    for lb, tol in ((0.5, None), (0.75, 1e-6)):
+        beta, rhs, iters, _ = _sample_beta(B, ctx, op, D, target, np.zeros(D), Lam, lb, False, tol)
+        np.testing.assert_allclose(rhs, A.T @ target, rtol=1e-9, atol=1e-9)
+        exact = np.linalg.solve(A.T @ A + lb * np.eye(numF), rhs)
+        np.testing.assert_allclose(beta, exact, rtol=1e-5 if tol else 1e-8, atol=1e-6 if tol else 1e-9)
+        assert np.all(iters > 0) and np.all(iters <= numF)
+    op.close()
+
+
+def test_solve_full_literal_shape(B, ctx):
+    """test/solver.jl:4-12: X 1000 x 50, y 50 x 3, lambda 0.75 -- through the FF path of sample_beta"""
+    rng = np.random.default_rng(5)
+    X = rng.random((1000, 50))
+    op = B.FeatOperator(ctx, X)
+    D = 3
+    target = rng.random((1000, D))
+    beta, rhs, _, _ = _sample_beta(B, ctx, op, D, target, np.zeros(D), np.eye(D) * 1e30, 0.75, True, None)
+    exact = np.linalg.solve(X.T @ X + 0.75 * np.eye(50), X.T @ target)
+    np.testing.assert_allclose(beta, exact, rtol=1e-8, atol=1e-10)
+    op.close()
+
+
+def test_lambda_beta_draw_matches_oracle(B, O, ctx):
+    rng = np.random.default_rng(9)
+    D, N, numF = 6, 80, 12
+    F = rng.standard_normal((N, numF))
+    op = B.FeatOperator(ctx, F)
+    sample = rng.standard_normal((N, D))
+    mu = np.zeros(D)
+    M = rng.standard_normal((D, D))
+    Lam = M @ M.T / D + np.eye(D)
+    ctx.set_sweep(4)
+    beta, _, _, lb_new = _sample_beta(B, ctx, op, D, sample, mu, Lam, 1.5, True, None, sample_lambda=True, nu=1e-3, mu_h=1.0, tag=7)
+    exp = O.sample_lambda_beta(beta, Lam, 1e-3, 1.0, SEED, 4, 7)
+    assert lb_new > 0
+    np.testing.assert_allclose(lb_new, exp, rtol=1e-8)
+    op.close()
+
+
+def test_uhat_and_feature_hyper_terms(B, ctx):
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(13)
+    D, N, numF = 10, 55, 7
+    F = rng.standard_normal((N, numF))
+    op = B.FeatOperator(ctx, F)
+    beta = rng.standard_normal((numF, D))
+    mu = rng.standard_normal(D)
+    beta_t, mu_t = _colmajor(ctx, beta), ctx.tensor(mu)
+    uhat_t, mm_t = ctx.zeros(N, D), ctx.zeros(N, D)
+    check(lib().bdf_uhat(ctx.handle, op.handle, D, _p(beta_t), _p(mu_t), _p(uhat_t), _p(mm_t)))
+    WI = np.eye(D) * 2.0
+    WI_t, lb_t, T_t = ctx.tensor(WI), ctx.tensor([0.6]), ctx.zeros(D, D)
+    check(lib().bdf_hyper_feature_terms(ctx.handle, D, numF, _p(beta_t), _p(WI_t), _p(lb_t), _p(T_t)))
+    ctx.sync()
+    np.testing.assert_allclose(uhat_t.cpu().numpy(), F @ beta, rtol=1e-12, atol=1e-12)        # (F beta)' as D x N
+    np.testing.assert_allclose(mm_t.cpu().numpy(), F @ beta + mu, rtol=1e-12, atol=1e-12)      # mu .+ uhat
+    np.testing.assert_allclose(T_t.cpu().numpy(), WI + beta.T @ beta * 0.6, rtol=1e-12)
+    op.close()
