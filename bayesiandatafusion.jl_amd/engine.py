@@ -23,6 +23,28 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
+def shard_rows(order, world):
+    """rows of each rank: positions rank, rank + world, ... of the degree-descending launch order -- the reference deals
+    rows i:P:N to its P workers for the same balance (sampling.jl:154); bdf_sample_rows(shard, n_shards) samples exactly these"""
+    return [np.ascontiguousarray(order[p::world]) for p in range(world)]
+
+
+def allgather_rows(sample, lists, rank, world):
+    """all-gather of the rows each rank sampled into every rank's replica of the factor (N x D tensor); shards are padded to
+    equal length for all_gather_into_tensor.  torch.distributed: RCCL over xGMI on the GPUs, gloo in the CPU tests."""
+    import torch.distributed as dist
+    counts = [len(l) for l in lists]
+    nmax = max(counts)
+    D = sample.shape[1]
+    send = torch.zeros(nmax, D, dtype=sample.dtype, device=sample.device)
+    send[:counts[rank]] = sample.index_select(0, lists[rank])
+    recv = torch.empty(world * nmax, D, dtype=sample.dtype, device=sample.device)
+    dist.all_gather_into_tensor(recv, send)
+    for p in range(world):
+        if p != rank:
+            sample.index_copy_(0, lists[p], recv[p * nmax:p * nmax + counts[p]])
+
+
 class Context:
     """bdf_ctx bound to a torch device and torch's current stream."""
 
@@ -353,17 +375,13 @@ class GibbsEngine:
         return terms
 
     def _rowlist(self, j):
-        """rows of entity j owned by each rank: positions rank, rank+world, ... of the degree-descending order
-        (the reference partitions rows i:P:N for balance, sampling.jl:154); needed to pack the all-gather"""
         if j not in self._rowlists:
             en = self.data.entities[j]
             r0 = en.relations[0]
             ri = [x is r0 for x in self.data.relations].index(True)
             order = self.rel[ri].order(en.modes[0] - 1)
-            parts = [order[p::self.world] for p in range(self.world)]
-            self._rowlists[j] = ([self.ctx.tensor(p, dtype=torch.int32) for p in parts], [len(p) for p in parts])
-        lists, counts = self._rowlists[j]
-        return lists[self.rank], counts[self.rank]
+            self._rowlists[j] = [self.ctx.tensor(p, dtype=torch.int64) for p in shard_rows(order, self.world)]
+        return self._rowlists[j]
 
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
     def sample_entity(self, j):
@@ -387,19 +405,8 @@ class GibbsEngine:
             self._allgather(j)
 
     def _allgather(self, j):
-        """RCCL all-gather of the rows each rank sampled (C1). Shards are padded to equal length."""
-        import torch.distributed as dist
-        st = self.ent[j]
-        self._rowlist(j)
-        lists, counts = self._rowlists[j]
-        nmax = max(counts)
-        send = torch.zeros(nmax, self.D, dtype=torch.float64, device=self.ctx.device)
-        send[:counts[self.rank]] = st.sample.index_select(0, lists[self.rank].long())
-        recv = torch.empty(self.world * nmax, self.D, dtype=torch.float64, device=self.ctx.device)
-        dist.all_gather_into_tensor(recv, send)
-        for p in range(self.world):
-            if p != self.rank:
-                st.sample.index_copy_(0, lists[p].long(), recv[p * nmax:p * nmax + counts[p]])
+        """RCCL all-gather of the rows each rank sampled (C1)"""
+        allgather_rows(self.ent[j].sample, self._rowlist(j), self.rank, self.world)
 
     # ---- macau.jl:119-134: hyperprior of entity j ----------------------------------------------------------------
     def update_prior(self, j):

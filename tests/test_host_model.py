@@ -1,0 +1,230 @@
+"""Host-side data model (IndexedDF / FastIDF / Entity / Relation / RelationData) against the reference's own test literals,
+the C-ABI library's symbol table, and the sharded all-gather logic on CPU (gloo, world size 2).  No GPU needed: the only
+calls into libbdf_hip.so are host-side (bdf_index_build, bdf_last_error).
+"""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol(B):
+    header = open(os.path.join(ROOT, "include", "bdf.h")).read()
+    declared = set(re.findall(r"\b(bdf_[a-z0-9_A-Z]+)\s*\(", header))
+    declared -= {"bdf_ctx", "bdf_rel", "bdf_pairs", "bdf_feat", "bdf_term"}
+    assert len(declared) >= 35
+    lib = B.lib()                                   # resolves every symbol of the ctypes table or raises
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} is declared in include/bdf.h but not exported by libbdf_hip.so"
+    assert set(B.declared_symbols()) == declared, set(B.declared_symbols()) ^ declared
+    out = subprocess.run(["nm", "-D", "--defined-only", B.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r"\bT (bdf_[a-zA-Z0-9_]+)", out))
+    assert declared <= exported
+    assert lib.bdf_version() >= 100
+
+
+def test_no_gpu_fails_loudly(B):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    import ctypes as C
+    h = C.c_void_p()
+    rc = B.lib().bdf_ctx_create(0, None, C.c_uint64(1), C.byref(h))
+    assert rc == -5 and b"no CPU path" in B.lib().bdf_last_error()
+    with pytest.raises(B.NoGpuError):
+        B.Context()
+
+
+def test_indexeddf_reference_literals(B):
+    """test/basic.jl:7-19"""
+    X = B.IndexedDF({"A": [2, 2, 3], "B": [1, 3, 4], "C": [0.0, -1.0, 0.5]}, [4, 4])
+    assert B.nnz(X) == 3
+    assert B.getData(X, 1, 1)[0].shape == (0, 2) and B.getData(X, 1, 4)[0].shape == (0, 2)
+    ids, vals = B.getData(X, 1, 2)
+    assert ids.shape == (2, 2) and ids[:, 0].tolist() == [2, 2] and ids[:, 1].tolist() == [1, 3] and vals.tolist() == [0.0, -1.0]
+    assert B.getData(X, 2, 2)[0].shape == (0, 2)
+    assert [i.tolist() for i in X.index[0]] == [[], [1, 2], [3], []]
+    assert [i.tolist() for i in X.index[1]] == [[1], [], [2], [3]]
+    assert B.rep_int([2, 4, 1, 10], [3, 2, 1, 0]).tolist() == [2, 2, 2, 4, 4, 1]
+
+
+def test_fastidf_and_types(B):
+    """test/basic.jl:23-33"""
+    X = B.IndexedDF({"A": [2, 2, 3], "B": [1, 3, 4], "C": [0.0, -1.0, 0.5]}, [4, 4])
+    Xf = B.FastIDF(X)
+    assert Xf.nnz() == 3
+    assert Xf.getData(1, 1)[0].shape == (0, 2) and Xf.getData(1, 1)[1].shape == (0,)
+    i, v = Xf.getData(1, 2)
+    assert i[:, 0].tolist() == [2, 2] and i[:, 1].tolist() == [1, 3] and v.tolist() == [0.0, -1.0]
+    X32 = B.FastIDF(B.IndexedDF((np.array([[1, 1], [2, 2], [3, 3]], dtype=np.int32), np.array([0.5, -0.1, 0.0], dtype=np.float32))))
+    assert X32.Ti == np.int32 and X32.Tv == np.float32
+
+
+def test_indexeddf_dims_and_remove(B):
+    """test/basic.jl:36-49"""
+    X2 = B.IndexedDF({"A": [2, 2, 3], "B": [1, 3, 4], "C": [0.0, -1.0, 0.5]}, (4, 4))
+    assert X2.size() == (4, 4)
+    X2a = B.IndexedDF({"A": [2, 2, 3], "B": [1, 1, 4], "C": [0.4, -1, -9]})
+    assert X2a.size() == (3, 4)
+    X3 = B.removeSamples(X2, [2])
+    assert B.nnz(X3) == 2 and X3.size() == (4, 4)
+    ids, _ = B.getData(X3, 1, 2)
+    assert ids.shape == (1, 2) and B.getCount(X3, 1, 2) == 1
+    with pytest.raises(B.BoundsError):
+        B.IndexedDF({"A": [5], "B": [1], "C": [0.1]}, [4, 4])
+
+
+def test_index_matches_oracle_bit_for_bit(B, O):
+    rng = np.random.default_rng(0)
+    for dims, nnz, dt in (([50, 40], 2000, np.int64), ([9, 7, 5], 300, np.int32), ([3, 3], 0, np.int64)):
+        ids = np.stack([rng.integers(1, d + 1, nnz) for d in dims], axis=1).astype(dt).reshape(nnz, len(dims))
+        idf = B.IndexedDF((ids, rng.standard_normal(nnz)), dims)
+        ref = O.index_build(ids.astype(np.int64), dims) if nnz else None
+        for m in range(len(dims)):
+            if nnz:
+                assert np.array_equal(idf._rowptr[m], ref[m][0]) and np.array_equal(idf._rowids[m], ref[m][1])
+            else:
+                assert idf._rowptr[m].tolist() == [0] * (dims[m] + 1)
+
+
+def test_relation_entity_api(B):
+    """test/basic.jl:52-101"""
+    import scipy.sparse as sp
+    a = {"A": [1, 2, 2, 3, 2], "B": [1, 3, 1, 4, 4], "v": [0.4, 1.0, -1.9, 1.4, 0.85]}
+    r = B.Relation(a, "a")
+    assert r.size() == (3, 4)
+    r.F = np.array([[1.0, 2.5], [-1, -2], [0, 1], [3, -3]])
+    B.assignToTest(r, [1, 4])
+    assert np.array_equal(r.F, [[-1.0, -2], [0, 1]]) and np.array_equal(r.test_F, [[1.0, 2.5], [3, -3]])
+    assert B.numTest(r) == 2 and B.numData(r) == 3
+    e1, e2, e3 = B.Entity("e1"), B.Entity("e2"), B.Entity("e3")
+    r2 = B.Relation(a, "r2", [e1, e2])
+    assert e1.count == r2.size(1) and e2.count == r2.size(2) and r2.size() == (3, 4)
+    B.setTest(r2, {"A": [1, 2], "B": [3, 4], "v": [0.1, -0.2]})
+    assert r2.test_vec.shape == (2, 3) and B.numData(r2) == 5
+    B.setTest(r2, sp.csc_matrix(([-0.4, 0.6, 0.7], ([2, 1, 1], [0, 1, 0])), shape=(3, 4)))
+    assert B.numTest(r2) == 3 and B.numData(r2) == 5
+    B.setPrecision(r2, 1.75)
+    assert r2.model.alpha == 1.75
+    r3 = B.Relation({"B": [1], "C": [5], "v": [0.1]}, "r3", [e2, e3])
+    assert e3.count == 5 and r3.size() == (4, 5)
+    with pytest.raises(B.ArgumentError):
+        B.Relation({"A": [5], "C": [4], "v": [0.1]}, "r4", [e1, e3])
+
+
+def test_relationdata_constructors(B):
+    """test/basic.jl:97-101, test/custom_rd.jl:33-42, test/tensor.jl:16-23, docs multi-relation (note N1)"""
+    import scipy.sparse as sp
+    Y = sp.random(15, 10, 0.3, random_state=1, format="csc")
+    rd = B.RelationData(Y, class_cut=0.5)
+    assert [e.count for e in rd.entities] == [15, 10] and rd.relations[0].model.alpha == 5.0
+    # findnz order of a SparseMatrixCSC is column-major (RelationData.jl:299-305)
+    ids = rd.relations[0].data.ids
+    assert np.all(np.diff(ids[:, 1]) >= 0)
+    B.assignToTest(rd.relations[0], 2, rng=np.random.default_rng(0))
+    assert B.numTest(rd.relations[0]) == 2 and len(rd.relations[0].test_label) == 2
+    r2 = B.Relation(sp.random(100, 50, 0.01, random_state=2), "HPO2", [B.Entity("genes2"), B.Entity("pheno2")])
+    assert r2.size() == (100, 50) and len(r2.entities) == 2
+    rd2 = B.RelationData(r2)
+    assert len(rd2.relations) == 1 and len(rd2.entities) == 2
+    with pytest.raises(B.ArgumentError):
+        B.RelationData(Y, feat1=np.zeros((14, 3)))
+    # an entity shared by two relations is registered on both (the evident intent of addRelation!, note N1)
+    a, b, c = B.Entity("a"), B.Entity("b"), B.Entity("c")
+    rab = B.Relation({"a": [1, 2], "b": [1, 3], "v": [0.1, 0.2]}, "ab", [a, b])
+    rac = B.Relation({"a": [2, 1], "c": [2, 2], "v": [0.3, 0.4]}, "ac", [a, c])
+    rd3 = B.RelationData()
+    B.addRelation(rd3, rab)
+    B.addRelation(rd3, rac)
+    assert len(a.relations) == 2 and len(rd3.entities) == 3 and len(rd3.relations) == 2
+    bad = B.Relation({"a": [1], "b": [1], "v": [0.1]}, "bad", [a, b])
+    bad.entities = [a]
+    with pytest.raises(B.ArgumentError):
+        B.addRelation(rd3, bad)
+
+
+def test_sparse_bin_matrix_subsetting(B):
+    """test/sbm.jl:6-32"""
+    rows = np.concatenate([np.arange(1, 4), np.arange(2, 5), np.arange(1, 5)])
+    cols = np.array([1, 1, 1, 2, 2, 2, 3, 3, 3, 3])
+    m = B.SparseBinMatrix(rows, cols)
+    assert m.size() == (4, 3)
+    m2 = m[np.array([True, False, True, False]), :]
+    assert m2.size() == (2, 3) and len(m2.rows) == 5
+    assert m2.rows.tolist() == [1, 2, 2, 1, 2] and m2.cols.tolist() == [1, 1, 2, 3, 3]
+    rng = np.random.default_rng(1)
+    A = (rng.random((100, 50)) < 0.2).astype(float)
+    I, J = np.nonzero(A)
+    sbm = B.SparseBinMatrix(100, 50, I + 1, J + 1)
+    z = np.zeros(100, dtype=bool)
+    z[:20] = True; z[39] = True; z[59:80] = True
+    assert np.array_equal(sbm[z, :].toarray(), A[z, :])
+    with pytest.raises(B.DimensionMismatch):
+        B.SparseBinMatrix(np.append(rows, 1), cols)
+    csr = B.SparseBinMatrixCSR(rows, cols)
+    assert csr.row_ptr.tolist() == [1, 3, 6, 9, 11] and csr.col_ind.tolist() == [1, 3, 1, 2, 3, 1, 2, 3, 2, 3]
+
+
+def test_split_and_dataset_helpers(B):
+    from bdf_amd import datasets
+    ids = datasets.split_test_ids(1000, 400, seed=1)
+    assert len(ids) == 400 and len(set(ids.tolist())) == 400 and ids.min() >= 1 and ids.max() <= 1000
+    assert np.array_equal(ids, datasets.split_test_ids(1000, 400, seed=1))
+    assert not np.array_equal(ids, datasets.split_test_ids(1000, 400, seed=2))
+    # splitmix64 known values (reference implementation by Vigna: first outputs for state 0 and 1)
+    assert int(datasets.splitmix64(np.array([0], dtype=np.uint64))[0]) == 0xE220A8397B1DCDAF
+    if os.path.exists(datasets.MOVIELENS_PATH):
+        d = datasets.load_movielens()
+        assert d["X"].shape == (6040, 3952) and d["X"].nnz == 1000209
+        assert d["Fu"].shape == (6040, 29) and d["Fv"].shape == (3952, 18)
+
+
+_GLOO_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+rank, world = int(sys.argv[2]), 2
+os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+dist.init_process_group("gloo", rank=rank, world_size=world)
+import bdf_amd as B
+from bdf_amd.engine import shard_rows, allgather_rows
+# a relation whose launch order the two ranks derive independently
+rng = np.random.default_rng(0)
+N, D = 37, 4
+ids = np.stack([rng.integers(1, N + 1, 300), rng.integers(1, 11, 300)], axis=1)
+idf = B.IndexedDF((ids, rng.standard_normal(300)), [N, 10])
+counts = np.diff(idf._rowptr[0])
+order = np.argsort(-counts, kind="stable").astype(np.int32)
+lists = shard_rows(order, world)
+assert sorted(np.concatenate(lists).tolist()) == list(range(N))
+# every rank "samples" its own rows (value = row id + 0.5 * column), then the all-gather must give everyone everything
+sample = torch.full((N, D), -1.0, dtype=torch.float64)
+mine = torch.as_tensor(lists[rank].astype(np.int64))
+sample[mine] = mine[:, None].double() + 0.5 * torch.arange(D, dtype=torch.float64)[None, :]
+allgather_rows(sample, [torch.as_tensor(l.astype(np.int64)) for l in lists], rank, world)
+expect = torch.arange(N, dtype=torch.float64)[:, None] + 0.5 * torch.arange(D, dtype=torch.float64)[None, :]
+assert torch.equal(sample, expect), (rank, sample)
+# nnz balance of the strided deal
+load = [int(counts[l].sum()) for l in lists]
+assert max(load) - min(load) <= counts.max()
+dist.destroy_process_group()
+print("ok", rank)
+'''
+
+
+def test_sharded_allgather_gloo_world2(tmp_path):
+    """the N>1 path: rows dealt rank::world over the degree order, all-gather of the sampled rows (torch.distributed,
+    gloo on CPU here, RCCL on the GPUs)"""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    port = str(29500 + os.getpid() % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = [p.communicate(timeout=240)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and f"ok {r}" in o, o

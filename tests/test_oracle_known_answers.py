@@ -1,0 +1,203 @@
+"""The CPU oracle (oracle/bdf_oracle.c) pinned on every known-answer the reference's own tests hold for this path, on the
+Random123 Philox vectors, and on independent numpy fp64 algebra.  (The reference stores no seeded sampled values, so the
+random STREAM is unpinned -- see the oracle header; the maps from normals to samples are checked here deterministically.)
+"""
+import numpy as np
+import pytest
+
+
+def test_indexeddf_literals(O):
+    """test/basic.jl:7-19: A=[2,2,3], B=[1,3,4], dims [4,4]"""
+    ids = np.array([[2, 1], [2, 3], [3, 4]])
+    (rp1, ri1), (rp2, ri2) = O.index_build(ids, [4, 4])
+    assert rp1.tolist() == [0, 0, 2, 3, 3] and ri1.tolist() == [1, 2, 3]      # entity 2 of mode 1 -> rows 1,2 ; entity 3 -> row 3
+    assert rp2.tolist() == [0, 1, 1, 2, 3] and ri2.tolist() == [1, 2, 3]
+    with pytest.raises(IndexError):
+        O.index_build(np.array([[5, 1]]), [4, 4])
+
+
+def test_index_is_stable_in_table_order(O):
+    rng = np.random.default_rng(0)
+    dims = [9, 7, 4]
+    ids = np.stack([rng.integers(1, d + 1, 500) for d in dims], axis=1)
+    for m, (rp, ri) in enumerate(O.index_build(ids, dims)):
+        for j in range(dims[m]):
+            expect = np.nonzero(ids[:, m] == j + 1)[0] + 1          # push!(index[mode][j], i) in row order
+            assert np.array_equal(ri[rp[j]:rp[j + 1]], expect)
+
+
+def test_rep_int_literal(O):
+    """test/basic.jl:20"""
+    assert O.rep_int([2, 4, 1, 10], [3, 2, 1, 0]).tolist() == [2, 2, 2, 4, 4, 1]
+
+
+def test_philox_random123_vectors(O):
+    """Random123 kat_vectors, philox4x32-10"""
+    assert [hex(x) for x in O.philox4x32_10([0, 0, 0, 0], [0, 0])] == ["0x6627e8d5", "0xe169c58d", "0xbc57ac4c", "0x9b00dbd8"]
+    assert [hex(x) for x in O.philox4x32_10([0xffffffff] * 4, [0xffffffff] * 2)] == ["0x408f276d", "0x41c83b0e", "0xa20bc7c6", "0x6d5451fd"]
+    assert [hex(x) for x in O.philox4x32_10([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0])] == \
+        ["0xd16cfe09", "0x94fdcceb", "0x5001e420", "0x24126ea1"]
+
+
+def test_normals_and_gamma_moments(O):
+    z = np.concatenate([O.normals(7, 3, 1, 2, r, 32) for r in range(3000)])
+    assert abs(z.mean()) < 0.02 and abs(z.std() - 1) < 0.02 and abs((z ** 4).mean() - 3) < 0.15
+    for a in (0.5, 3.5, 40.0):
+        g = np.array([O.gamma(5, 1, 0, i, a) for i in range(20000)])
+        assert abs(g.mean() - a) < 0.05 * max(a, 1) and abs(g.var() - a) < 0.1 * max(a, 1)
+
+
+def test_row_sample_is_the_reference_map(O):
+    """sample_user_basic (sampling.jl:200-212): covar = inv(Lambda + alpha MM MM'); mu = covar (alpha MM rr + Lambda mu_u);
+    x = chol(covar)' z + mu -- against numpy; the tensor form (:215-234) and the sum over relations (:266-289) too"""
+    rng = np.random.default_rng(1)
+    D = 7
+    dimsA, dimsB = [11, 8, 5], [11, 9]
+    idsA = np.stack([rng.integers(1, d + 1, 200) for d in dimsA], axis=1)
+    idsB = np.stack([rng.integers(1, d + 1, 80) for d in dimsB], axis=1)
+    vA, vB = rng.standard_normal(200), rng.standard_normal(80)
+    F = [rng.standard_normal((d, D)) for d in dimsA]
+    FB = rng.standard_normal((9, D))
+    linB = rng.standard_normal(80)
+    M = rng.standard_normal((D, D))
+    Lam = M @ M.T + np.eye(D)
+    mu = rng.standard_normal(D)
+    tA = O.Term(idsA, vA, dimsA, 0, 1.5, 0.2, [None, F[1], F[2]])
+    tB = O.Term(idsB, vB, dimsB, 0, 0.5, -0.1, [None, FB], linear_values=linB)
+    for row in range(11):
+        z = rng.standard_normal(D)
+        P = Lam.copy()
+        b = Lam @ mu
+        sel = idsA[:, 0] == row + 1
+        MM = (F[1][idsA[sel, 1] - 1] * F[2][idsA[sel, 2] - 1]).T
+        P += 1.5 * MM @ MM.T
+        b += 1.5 * MM @ (vA[sel] - 0.2)
+        sel = idsB[:, 0] == row + 1
+        MM = FB[idsB[sel, 1] - 1].T
+        P += 0.5 * MM @ MM.T
+        b += 0.5 * MM @ (vB[sel] - linB[sel])
+        cov = np.linalg.inv(P)
+        expect = np.linalg.cholesky(cov) @ z + cov @ b
+        x, m = O.sample_row(D, [tA, tB], row, mu, Lam, z)
+        np.testing.assert_allclose(x, expect, rtol=1e-10, atol=1e-12)
+        np.testing.assert_allclose(m, cov @ b, rtol=1e-10, atol=1e-12)
+        P2, b2 = O.row_system(D, [tA, tB], row, mu, Lam)
+        np.testing.assert_allclose(P2, P, rtol=1e-12)
+        np.testing.assert_allclose(b2, b, rtol=1e-12, atol=1e-12)
+
+
+def test_conditional_normal_wishart_parameters_and_draw(O):
+    """ConditionalNormalWishart (sampling.jl:116-127) against numpy; rand(::NormalWishart) (normal_wishart.jl:38-42):
+    Lambda = (L_T A)(L_T A)' with the Bartlett A built from the oracle's own streams, mu = mu_N + chol(inv(Lam)/kappa)' z"""
+    rng = np.random.default_rng(2)
+    D, N = 5, 40
+    U = rng.standard_normal((N, D)) + 0.3
+    mu0 = rng.standard_normal(D) * 0.1
+    M = rng.standard_normal((D, D))
+    Tinv = M @ M.T + np.eye(D)
+    b0, nu = 2.0, 7.0
+    mu_N, beta_N, T_N, nu_N = O.hyper_params(U, mu0, b0, Tinv, nu)
+    NU, NS = U.sum(0), U.T @ U
+    assert nu_N == nu + N and beta_N == b0 + N
+    mu_e = (b0 * mu0 + NU) / (b0 + N)
+    np.testing.assert_allclose(mu_N, mu_e, rtol=1e-13)
+    T_e = np.linalg.inv(Tinv + NS + b0 * np.outer(mu0, mu0) - beta_N * np.outer(mu_e, mu_e))
+    np.testing.assert_allclose(T_N, T_e, rtol=1e-10, atol=1e-14)
+    mu, Lam = O.hyper_draw(mu_N, beta_N, T_N, nu_N, 99, 4, 2)
+    A = np.zeros((D, D))
+    for i in range(D):
+        A[i, :i] = O.normals(99, 4, O.P_NW_NORMAL, 2, i, D)[:i]
+        A[i, i] = np.sqrt(2.0 * O.gamma(99, 4, 2, i, 0.5 * (nu_N - i)))
+    Z = np.linalg.cholesky((T_N + T_N.T) / 2) @ A
+    np.testing.assert_allclose(Lam, Z @ Z.T, rtol=1e-9, atol=1e-12)
+    z = O.normals(99, 4, O.P_NW_MEAN, 2, 0, D)
+    np.testing.assert_allclose(mu, mu_N + np.linalg.cholesky(np.linalg.inv(Lam) / beta_N) @ z, rtol=1e-9, atol=1e-12)
+
+
+def _reference_pattern():
+    rows = np.concatenate([np.arange(1, 201), np.arange(151, 351)])
+    cols = np.concatenate([np.arange(151, 351), np.arange(1, 400, 2)])
+    A = np.zeros((350, 399))
+    np.add.at(A, (rows - 1, cols - 1), 1.0)
+    return rows, cols, A
+
+
+def test_binary_operators_reference_pattern(O):
+    """test/sparsebin_csr.jl:4-23, test/parallel_matrix.jl:41-92: A_mul_B!, At_mul_B, AtA_mul_B! (lambda 0.1) vs sparse(rows,cols,1.0)"""
+    rows, cols, A = _reference_pattern()
+    rng = np.random.default_rng(3)
+    x, y = rng.random(399), rng.random(350)
+    for f in (O.Feat.from_bincsr(rows - 1, cols - 1, 350, 399), O.Feat.from_bincoo(rows - 1, cols - 1, 350, 399)):
+        np.testing.assert_allclose(f.mul(x), A @ x, rtol=1e-13)
+        np.testing.assert_allclose(f.tmul(y), A.T @ y, rtol=1e-13)
+        np.testing.assert_allclose(f.AtA_mul_B(x, 0.1), A.T @ (A @ x) + 0.1 * x, rtol=1e-12)
+
+
+def test_sparse_csr_literal_and_random(O):
+    """test/sparse_csr.jl:4-34"""
+    f = O.Feat.from_csr(np.array([1, 2, 2, 4]) - 1, np.array([2, 1, 3, 3]) - 1, [0.1, 0.2, 0.15, 0.3], 4, 3)
+    z = np.array([0.4, 0.9, -0.3])
+    dense = np.zeros((4, 3))
+    dense[[0, 1, 1, 3], [1, 0, 2, 2]] = [0.1, 0.2, 0.15, 0.3]
+    np.testing.assert_allclose(f.mul(z), dense @ z, rtol=1e-14)
+    import scipy.sparse as sp
+    X = sp.random(50, 100, 0.1, random_state=1, format="coo")
+    f = O.Feat.from_csr(X.row, X.col, X.data, 50, 100)
+    rng = np.random.default_rng(4)
+    y1, y2 = rng.random(100), rng.random(50)
+    np.testing.assert_allclose(f.mul(y1), X @ y1, rtol=1e-13)
+    np.testing.assert_allclose(f.tmul(y2), X.T @ y2, rtol=1e-13)
+
+
+def test_cg_and_solve_full_against_direct(O):
+    """test/parallel_matrix.jl:107-109 (lambda 0.5), test/heavy_copyto.jl:28-50 (0.75, tol 1e-6), test/solver.jl:4-20"""
+    rows, cols, A = _reference_pattern()
+    f = O.Feat.from_bincoo(rows - 1, cols - 1, 350, 399)
+    rng = np.random.default_rng(5)
+    x = rng.random(399)
+    AA = A.T @ A
+    beta, it = f.cg_AtA(x, 0.5)
+    np.testing.assert_allclose(beta, np.linalg.solve(AA + 0.5 * np.eye(399), x), rtol=1e-9, atol=1e-11)
+    assert 0 < it <= 399
+    beta2, _ = f.cg_AtA(x, 0.75, tol=1e-6)
+    np.testing.assert_allclose(beta2, np.linalg.solve(AA + 0.75 * np.eye(399), x), rtol=1e-4, atol=1e-6)
+    Xd = rng.random((1000, 50))
+    y = rng.random((50, 3))
+    np.testing.assert_allclose(O.solve_full(Xd.T @ Xd, y, 0.75), np.linalg.solve(Xd.T @ Xd + 0.75 * np.eye(50), y), rtol=1e-9)
+    Ad = rng.random((500, 20))
+    xd = rng.random(20)
+    np.testing.assert_allclose(O.Feat.from_dense(Ad).AtA_mul_B(xd, 0.5), (Ad.T @ Ad + 0.5 * np.eye(20)) @ xd, rtol=1e-12)
+
+
+def test_sample_beta_structure(O):
+    """sample_beta (sampling.jl:291-312): rhs = F'((U - mu)' + E1) + sqrt(lb) E2 with E rows = chol(inv(Lambda))' z;
+    CG (per column, tol eps*numF) and solve_full agree with the direct solve"""
+    rng = np.random.default_rng(6)
+    N, numF, D = 70, 9, 4
+    F = rng.standard_normal((N, numF))
+    S = rng.standard_normal((N, D))
+    mu = rng.standard_normal(D) * 0.1
+    M = rng.standard_normal((D, D))
+    Lam = M @ M.T + np.eye(D)
+    Lc = np.linalg.cholesky(np.linalg.inv(Lam))
+    E1 = np.stack([Lc @ O.normals(3, 2, O.P_BETA_E1, 5, i, D) for i in range(N)])
+    E2 = np.stack([Lc @ O.normals(3, 2, O.P_BETA_E2, 5, i, D) for i in range(numF)])
+    rhs_e = F.T @ (S - mu + E1) + np.sqrt(0.8) * E2
+    beta_cg, rhs, iters = O.sample_beta(O.Feat.from_dense(F), S, mu, Lam, 0.8, False, None, 3, 2, 5)
+    np.testing.assert_allclose(rhs, rhs_e, rtol=1e-9, atol=1e-10)
+    direct = np.linalg.solve(F.T @ F + 0.8 * np.eye(numF), rhs_e)
+    np.testing.assert_allclose(beta_cg, direct, rtol=1e-8, atol=1e-10)
+    assert np.all(iters <= numF)
+    beta_ff, _, _ = O.sample_beta(O.Feat.from_dense(F), S, mu, Lam, 0.8, True, None, 3, 2, 5)
+    np.testing.assert_allclose(beta_ff, direct, rtol=1e-9, atol=1e-11)
+
+
+def test_predict_identity(O):
+    """pred = sum_k prod_modes sample + mean (sampling.jl:9-45; test/basic.jl:112, test/tensor.jl:26-31)"""
+    rng = np.random.default_rng(7)
+    dims, D = [6, 5, 3], 4
+    facs = [rng.standard_normal((d, D)) for d in dims]
+    ids = np.array([[4, 2, 1], [1, 5, 3]])
+    p = O.predict(ids, facs, 0.7)
+    for q, (i, j, k) in enumerate(ids):
+        assert np.isclose(p[q], np.sum(facs[0][i - 1] * facs[1][j - 1] * facs[2][k - 1]) + 0.7)
