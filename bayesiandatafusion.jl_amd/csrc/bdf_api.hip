@@ -47,7 +47,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
-    c->item_size = 512;
+    c->item_size = 192;
     *out = c;
     return BDF_OK;
 }
@@ -87,17 +87,13 @@ __global__ void k_inc_u32(uint32_t *p) { *p = *p + 1; }
 extern "C" int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_set_sweep: ctx is NULL");
-    hipLaunchKernelGGL(k_set_u32, dim3(1), dim3(1), 0, ctx->stream, ctx->sweep_dev, sweep);
-    BDF_HIP(hipGetLastError());
-    ctx->sweep_host = sweep;
+    ctx->sweep_host = sweep;          // passed to every launch by value (no launch, no device round trip)
     return BDF_OK;
 }
 
 extern "C" int bdf_ctx_advance_sweep(bdf_ctx *ctx)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_advance_sweep: ctx is NULL");
-    hipLaunchKernelGGL(k_inc_u32, dim3(1), dim3(1), 0, ctx->stream, ctx->sweep_dev);
-    BDF_HIP(hipGetLastError());
     ctx->sweep_host++;
     return BDF_OK;
 }
@@ -352,7 +348,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
     a.mu = mu;
     a.mu_is_matrix = mu_is_matrix;
     a.Lambda = Lambda;
-    a.sweep = ctx->sweep_dev;
+    a.sweep = ctx->sweep_host;
     a.seed = ctx->seed;
     a.flag = ctx->flag_dev;
     return BDF_OK;
@@ -415,14 +411,14 @@ extern "C" int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const
     return bdf_launch_sample_rows(ctx, a, rels, modes, 0, 1, true);
 }
 
-__global__ void k_normals(uint64_t seed, const uint32_t *sweep, uint32_t purpose, uint32_t entity,
+__global__ void k_normals(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                           int64_t row_begin, int64_t n_rows, int n, double *out)
 {
     int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n_rows * n) return;
     int64_t r = idx / n;
     int e = (int)(idx % n);
-    out[idx] = bdf_normal(seed, *sweep, purpose, entity, (uint64_t)(row_begin + r), e);
+    out[idx] = bdf_normal(seed, sweep, purpose, entity, (uint64_t)(row_begin + r), e);
 }
 
 extern "C" int bdf_normals(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, int64_t row_begin,
@@ -432,15 +428,15 @@ extern "C" int bdf_normals(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, 
     int64_t total = n_rows * n;
     if (total == 0) return BDF_OK;
     hipLaunchKernelGGL(k_normals, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, ctx->seed,
-                       ctx->sweep_dev, purpose, entity_tag, row_begin, n_rows, n, out);
+                       ctx->sweep_host, purpose, entity_tag, row_begin, n_rows, n, out);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
 
-__global__ void k_philox(uint64_t seed, const uint32_t *sweep, uint32_t purpose, uint32_t entity, uint64_t row,
+__global__ void k_philox(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity, uint64_t row,
                          uint32_t pair, uint32_t *out)
 {
-    u32x4 o = bdf_draw(seed, *sweep, purpose, entity, row, pair);
+    u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, pair);
     out[0] = o.x; out[1] = o.y; out[2] = o.z; out[3] = o.w;
 }
 
@@ -451,7 +447,7 @@ extern "C" int bdf_philox(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, u
     void *s;
     int rc = bdf_scratch(ctx, 256, &s);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_philox, dim3(1), dim3(1), 0, ctx->stream, ctx->seed, ctx->sweep_dev, purpose, entity_tag, row,
+    hipLaunchKernelGGL(k_philox, dim3(1), dim3(1), 0, ctx->stream, ctx->seed, ctx->sweep_host, purpose, entity_tag, row,
                        pair, (uint32_t *)s);
     BDF_HIP(hipGetLastError());
     return bdf_d2h(ctx, out_host, s, 4 * sizeof(uint32_t));

@@ -191,7 +191,7 @@ struct SampleArgs {
     const double *mu;
     int32_t mu_is_matrix, _pad;
     const double *Lambda;
-    const uint32_t *sweep;
+    uint32_t sweep, _pad3;
     uint64_t seed;
     uint32_t entity_tag, _pad2;
     double *out;

@@ -177,14 +177,13 @@ __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, 
 template <int DP>
 __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const double *Lr, const double *sample,
                                                      const double *mu, const double *scale_sq, uint64_t seed,
-                                                     const uint32_t *sweep_p, uint32_t purpose, uint32_t entity, double *T)
+                                                     uint32_t sweep, uint32_t purpose, uint32_t entity, double *T)
 {
     __shared__ double sL[DP * DP + 2 * DP];
     for (int e = threadIdx.x; e < DP * DP + 2 * DP; e += blockDim.x) sL[e] = Lr[e];
     __syncthreads();
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    const uint32_t sweep = *sweep_p;
     double e[DP];
 #pragma unroll
     for (int j = DP - 1; j >= 0; j--) {
@@ -215,7 +214,7 @@ int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr,
     }
     if (n > 0) {
         hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, D, n, Lr,
-                           sample, mu, scale_sq, ctx->seed, ctx->sweep_dev, purpose, entity, T);
+                           sample, mu, scale_sq, ctx->seed, ctx->sweep_host, purpose, entity, T);
         BDF_HIP(hipGetLastError());
     }
     return BDF_OK;
@@ -337,7 +336,7 @@ __global__ void k_tinv_feat(int D, const double *G, const double *WI, const doub
 }
 
 __global__ __launch_bounds__(64) void k_lambda_beta(int D, int64_t numF, const double *G, const double *Lambda, double nu,
-                                                    double mu, uint64_t seed, const uint32_t *sweep, uint32_t entity,
+                                                    double mu, uint64_t seed, uint32_t sweep, uint32_t entity,
                                                     double *lambda_beta)
 {
     // trace((beta'beta) Lambda) = sum_ij G[i][j] Lambda[j][i]
@@ -351,7 +350,7 @@ __global__ __launch_bounds__(64) void k_lambda_beta(int D, int64_t numF, const d
     if (threadIdx.x == 0) {
         const double nux = nu + (double)numF * (double)D;
         const double mux = mu * nux / (nu + mu * tr);
-        *lambda_beta = bdf_gamma(seed, *sweep, entity, (uint64_t)D, 0.5 * nux) * (2.0 * mux / nux);
+        *lambda_beta = bdf_gamma(seed, sweep, entity, (uint64_t)D, 0.5 * nux) * (2.0 * mux / nux);
     }
 }
 
@@ -641,7 +640,7 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
     if (sample_lambda) {
         hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, (const double *)beta_out, G);
         hipLaunchKernelGGL(k_lambda_beta, dim3(1), dim3(64), 0, ctx->stream, D, numF, (const double *)G, Lambda, lb_nu, lb_mu,
-                           ctx->seed, ctx->sweep_dev, entity_tag, lambda_beta_dev);
+                           ctx->seed, ctx->sweep_host, entity_tag, lambda_beta_dev);
         BDF_HIP(hipGetLastError());
     }
     return BDF_OK;

@@ -68,22 +68,22 @@ __global__ __launch_bounds__(HS_THREADS) void k_hyper_partial(int D, int64_t N, 
 }
 
 // ---- stage 2: fixed-order sum of the partials -----------------------------------------------------------------
-// one wave per 16 output elements: lane (b4, e) sums partials b4, b4+4, ... of element e, then the four partial sums
-// are combined in lane order -- a fixed order, so the result does not depend on scheduling
-__global__ __launch_bounds__(64) void k_hyper_final(int D, int nblocks, const double *__restrict__ partial,
-                                                    double *__restrict__ sumU, double *__restrict__ UUt)
+// 16 lanes per output element: lane q sums partials q, q+16, ... and the 16 sums are combined by a butterfly -- a fixed
+// order, so the result does not depend on scheduling
+__global__ __launch_bounds__(256) void k_hyper_final(int D, int nblocks, const double *__restrict__ partial,
+                                                     double *__restrict__ sumU, double *__restrict__ UUt)
 {
     const int DD = D * D;
-    const int e = blockIdx.x * 16 + (threadIdx.x & 15);
-    const int b4 = threadIdx.x >> 4;
+    const int q = threadIdx.x & 15;
+    const int e = (blockIdx.x * 256 + threadIdx.x) >> 4;
     double s = 0.0;
     if (e < DD + D)
-        for (int b = b4; b < nblocks; b += 4) s += partial[(int64_t)b * (DD + D) + e];
-    const double s1 = __shfl_down(s, 16), s2 = __shfl_down(s, 32), s3 = __shfl_down(s, 48);
-    if (b4 == 0 && e < DD + D) {
-        const double t = ((s + s1) + s2) + s3;
-        if (e < DD) UUt[e] = t;
-        else sumU[e - DD] = t;
+        for (int b = q; b < nblocks; b += 16) s += partial[(int64_t)b * (DD + D) + e];
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (q == 0 && e < DD + D) {
+        if (e < DD) UUt[e] = s;
+        else sumU[e - DD] = s;
     }
 }
 
@@ -94,7 +94,7 @@ struct NWArgs {
     const double *sumU, *UUt, *mu0, *Tinv;
     double b0, nu;
     uint64_t seed;
-    const uint32_t *sweep;
+    uint32_t sweep;
     uint32_t entity_tag;
     double *mu_out, *Lambda_out, *params_out;
     int *flag;
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
     __shared__ int s_bad;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int D = a.D;
-    const uint32_t sweep = *a.sweep;
+    const uint32_t sweep = a.sweep;
     const double beta_N = a.b0 + a.N;
     const double nu_N = a.nu + a.N;
     if (tid == 0) s_bad = 0;
@@ -238,7 +238,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
                        (double *)scratch);
     BDF_HIP(hipGetLastError());
     int tot = D * D + D;
-    hipLaunchKernelGGL(k_hyper_final, dim3((tot + 15) / 16), dim3(64), 0, ctx->stream, D, nblocks,
+    hipLaunchKernelGGL(k_hyper_final, dim3((tot + 15) / 16), dim3(256), 0, ctx->stream, D, nblocks,
                        (const double *)scratch, sumU, UUt);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
@@ -252,7 +252,7 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sample: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     NWArgs a;
     a.D = D; a.N = (double)N; a.sumU = sumU; a.UUt = UUt; a.mu0 = mu0; a.Tinv = Tinv; a.b0 = b0; a.nu = nu;
-    a.seed = ctx->seed; a.sweep = ctx->sweep_dev; a.entity_tag = entity_tag;
+    a.seed = ctx->seed; a.sweep = ctx->sweep_host; a.entity_tag = entity_tag;
     a.mu_out = mu_out; a.Lambda_out = Lambda_out; a.params_out = params_out; a.flag = ctx->flag_dev;
     if (D <= 16) hipLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, a);
     else if (D <= 32) hipLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, a);

@@ -131,7 +131,7 @@ int launch_predict(bdf_ctx *ctx, PredArgs &a)
 {
     if (a.n == 0) return BDF_OK;
     const int64_t need = (a.n * LPP + 255) / 256;
-    const int nblocks = (int)std::min<int64_t>((need + 1) / 2, 8192);
+    const int nblocks = (int)std::min<int64_t>((need + 1) / 2, 4096);
     if (a.phase >= 0) {
         void *sc;
         int rc = bdf_scratch(ctx, (size_t)nblocks * 4 * sizeof(double), &sc);

@@ -443,7 +443,7 @@ __device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&
     const double bp = wl_forward<DP>(col, bj, rp_own, lane);
     double yh = 0.0;
     if (myrow >= 0 && ec >= 0)
-        yh = fma(bdf_normal(a.seed, *a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec), sq_own, bp);
+        yh = fma(bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec), sq_own, bp);
     STAMP(6);
     STAMP(7);
     const double x = wl_backward<DP>(tri, yh, rp_own, lane);         // L' x = y
@@ -480,15 +480,17 @@ __device__ inline void load_prior_c(const SampleArgs &a, int lane, d4 (&lamc)[Ge
 __global__ __launch_bounds__(256) void k_prior_b(int D, int64_t nrows, const double *Lambda, const double *mu,
                                                  int mu_is_matrix, double *out)
 {
-    // out[row*D + e] = sum_i Lambda[e][i] mu_row[i]   (nrows = 1 for a shared prior mean)
-    const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // out[row*D + e] = sum_i Lambda[e][i] mu_row[i]   (nrows = 1 for a shared prior mean); one wave per output
+    const int lane = threadIdx.x & 63;
+    const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     if (idx >= nrows * D) return;
     const int64_t row = idx / D;
     const int e = (int)(idx % D);
     const double *m = mu_is_matrix ? mu + row * D : mu;
-    double s = 0.0;
-    for (int i = 0; i < D; i++) s = fma(Lambda[e + (int64_t)i * D], m[i], s);
-    out[idx] = s;
+    double s = (lane < D) ? Lambda[e + (int64_t)lane * D] * m[lane] : 0.0;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) out[idx] = s;
 }
 
 // ---- sum the partials of a split row in slot order (fixed order: the result does not depend on which wave does it) ---
@@ -810,7 +812,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         int rc = bdf_scratch(ctx, (size_t)nr * a.D * sizeof(double), &pb);
         if (rc) return rc;
         if (nr * a.D > 0) {
-            hipLaunchKernelGGL(k_prior_b, dim3((unsigned)((nr * a.D + 255) / 256)), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda,
+            hipLaunchKernelGGL(k_prior_b, dim3((unsigned)((nr * a.D + 3) / 4)), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda,
                                a.mu, a.mu_is_matrix, (double *)pb);
             BDF_HIP(hipGetLastError());
         }

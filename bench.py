@@ -136,6 +136,16 @@ def main():
     achieved = (k1_bytes / 1e9) / (k1_ms / 1e3) if k1_ms > 0 else 0.0
     eng.k1_events = None
 
+    # HBM traffic of one K1 launch from the PMC passes of the same workload (tools/profile_round.sh: FETCH_SIZE and
+    # WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), if recorded
+    traffic = None
+    tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
+    if os.path.exists(tj) and world == 1:
+        try:
+            traffic = json.load(open(tj))["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"]
+        except (KeyError, ValueError):
+            traffic = None
+
     stats = test.stats.cpu().numpy() if not args.no_predict else None
     rmse = float(np.sqrt(stats[0] / len(rel.test_vec))) if stats is not None else None
 
@@ -159,7 +169,7 @@ def main():
                        "parallelism": f"rows sharded over {world} GPU(s), all-gather per half-sweep" if world > 1 else "1 GPU"},
             "test_rmse": None if rmse is None else round(rmse, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "k_sample_rows", "launches_timed": n_launch,
                          "avg_launch_us": round(1e3 * k1_ms / n_launch, 2),
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch)},

@@ -63,12 +63,12 @@ int bdf_version(void);
  * default stream.  seed keys every random draw of the context. */
 int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx **out);
 int bdf_ctx_destroy(bdf_ctx *ctx);
-/* Gibbs iteration number (macau.jl:80 loop variable); lives in device memory so that a
- * captured hipGraph of one sweep can be replayed: bdf_ctx_advance_sweep enqueues ++sweep. */
+/* Gibbs iteration number (macau.jl:80 loop variable): part of every random-stream address; handed to
+ * the launches that follow by value. */
 int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
 int bdf_ctx_advance_sweep(bdf_ctx *ctx);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
-/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 512 */
+/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 192 */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 /* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
 int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);

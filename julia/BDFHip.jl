@@ -1,0 +1,114 @@
+# BDFHip.jl -- Julia-side binding of libbdf_hip.so (include/bdf.h) for BayesianDataFusion.jl.
+#
+# UNTESTED IN THIS REPOSITORY: neither the build image nor the GPU box has Julia, and the reference itself is Julia 0.4
+# syntax.  This file is written for Julia >= 1.6 and shows the binding a maintainer would add; the same entry points are
+# exercised from Python (ctypes) by tests/.  Device buffers are owned through bdf_dev_alloc / bdf_h2d / bdf_d2h.
+module BDFHip
+
+const lib = get(ENV, "BDF_HIP_LIB", "libbdf_hip.so")
+
+struct BDFError <: Exception
+    code::Cint
+    msg::String
+end
+
+function check(rc::Cint)
+    rc == 0 && return nothing
+    msg = unsafe_string(ccall((:bdf_last_error, lib), Cstring, ()))
+    rc == -1 && throw(ArgumentError(msg))
+    rc == -2 && throw(BoundsError(msg))
+    throw(BDFError(rc, msg))
+end
+
+mutable struct Context
+    h::Ptr{Cvoid}
+    function Context(device::Integer=0; seed::Integer=0)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bdf_ctx_create, lib), Cint, (Cint, Ptr{Cvoid}, UInt64, Ref{Ptr{Cvoid}}), device, C_NULL, seed % UInt64, out))
+        c = new(out[])
+        finalizer(x -> ccall((:bdf_ctx_destroy, lib), Cint, (Ptr{Cvoid},), x.h), c)
+        c
+    end
+end
+
+set_sweep!(c::Context, i) = check(ccall((:bdf_ctx_set_sweep, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, i))
+sync(c::Context) = check(ccall((:bdf_ctx_sync, lib), Cint, (Ptr{Cvoid},), c.h))
+
+"device copy of a Julia array (column-major as is)"
+mutable struct DevArray{T}
+    ctx::Context
+    p::Ptr{Cvoid}
+    dims::Tuple
+end
+function DevArray(c::Context, a::Array{T}) where T
+    p = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bdf_dev_alloc, lib), Cint, (Ptr{Cvoid}, Csize_t, Ref{Ptr{Cvoid}}), c.h, sizeof(a), p))
+    check(ccall((:bdf_h2d, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, p[], a, sizeof(a)))
+    d = DevArray{T}(c, p[], size(a))
+    finalizer(x -> ccall((:bdf_dev_free, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), x.ctx.h, x.p), d)
+    d
+end
+function Base.Array(d::DevArray{T}) where T
+    a = Array{T}(undef, d.dims...)
+    check(ccall((:bdf_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), d.ctx.h, a, d.p, sizeof(a)))
+    a
+end
+
+"Relation.data (IndexedDF / FastIDF) on the device: replaces FastIDF(rel.data) + @spawnat (src/macau.jl:50-52)"
+mutable struct DevRelation
+    h::Ptr{Cvoid}
+    function DevRelation(c::Context, ids::Matrix{Int64}, values::Vector{Float64}, dims::Vector{Int64})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bdf_relation_create, lib), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Int64}, Int64, Ptr{Cvoid}, Cint, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                    c.h, size(ids, 2), dims, size(ids, 1), ids, 8, values, out))
+        r = new(out[])
+        finalizer(x -> ccall((:bdf_relation_destroy, lib), Cint, (Ptr{Cvoid},), x.h), r)
+        r
+    end
+end
+
+# struct bdf_term of include/bdf.h (BDF_MAX_MODES = 4)
+struct Term
+    rel::Ptr{Cvoid}
+    mode::Int32
+    _pad::Int32
+    alpha::Float64
+    mean_value::Float64
+    linear_values::Ptr{Cvoid}
+    factors::NTuple{4,Ptr{Cvoid}}
+end
+
+"""
+    sample_rows!(ctx, D, N, terms, mu, Lambda, entity_tag, out; shard=0, n_shards=1)
+
+Replaces `sample_latent_all2!` (src/sampling.jl:149-172) and `sample_user2_all!` (:251-264): every row of the entity
+(or the rows of one shard) is drawn into the device sample matrix `out` (D x N).
+"""
+function sample_rows!(c::Context, D, N, terms::Vector{Term}, mu::DevArray{Float64}, Lambda::DevArray{Float64}, entity_tag,
+                      out::DevArray{Float64}; shard=0, n_shards=1)
+    check(ccall((:bdf_sample_rows, lib), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Term}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, UInt32, Cint, Cint, Ptr{Cvoid}),
+                c.h, D, N, length(terms), terms, mu.p, length(mu.dims) == 2 ? 1 : 0, Lambda.p, entity_tag, shard, n_shards, out.p))
+end
+
+"ConditionalNormalWishart + rand (src/sampling.jl:116-127, src/normal_wishart.jl:38-42; call site src/macau.jl:120-134)"
+function update_prior!(c::Context, D, N, sample, uhat, sumU, UUt, mu0, b0, Tinv, nu, entity_tag, mu, Lambda)
+    check(ccall((:bdf_hyper_sums, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, D, N, sample.p, uhat === nothing ? C_NULL : uhat.p, sumU.p, UUt.p))
+    check(ccall((:bdf_hyper_sample, lib), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, D, N, sumU.p, UUt.p, mu0.p, b0, Tinv.p, nu, entity_tag, mu.p, Lambda.p, C_NULL))
+end
+
+"update_beta! (src/sampling.jl:361-370): feat is a bdf_feat handle from bdf_feat_create_{dense,csr,bin}"
+function update_beta!(c::Context, feat::Ptr{Cvoid}, D, sample, mu, Lambda, lambda_beta_dev, use_ff::Bool, tol, sample_lambda::Bool,
+                      nu, mu_h, entity_tag, beta)
+    check(ccall((:bdf_sample_beta, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Float64, Float64,
+                 UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, feat, D, sample.p, mu.p, Lambda.p, lambda_beta_dev.p, use_ff, tol, 0, sample_lambda, nu, mu_h, entity_tag,
+                beta.p, C_NULL, C_NULL))
+end
+
+end # module
