@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libbdf_hip.so")
+# BDF_LIB_PATH selects another build of the same library (kernel tuning variants, tools/ab_k1.sh)
+LIB_PATH = os.environ.get("BDF_LIB_PATH") or os.path.join(_HERE, "csrc", "libbdf_hip.so")
 
 BDF_MAX_MODES = 4
 BDF_MAX_TERMS = 4

@@ -5,10 +5,10 @@
 // 32 bytes each, so that a gathered factor row is read as whole 128-byte segments.
 #include "bdf_common.h"
 #include <algorithm>
+#include <cstdlib>
 
 namespace {
 
-constexpr int LPP = 8;     // lanes per pair
 
 struct PredArgs {
     int D, n_modes;
@@ -32,10 +32,20 @@ __device__ inline double clampv(double x, double lo, double hi)
 }
 
 // one test pair per group of LPP lanes; a group handles two pairs per trip so that their gathers overlap
+template <int LPP>
 __device__ inline double pair_dot(const PredArgs &a, int64_t pair, int sub)
 {
     double s = 0.0;
-    if ((a.D & 3) == 0) {
+    if (LPP == 16 && (a.D & 1) == 0) {
+        for (int e = sub * 2; e < a.D; e += LPP * 2) {
+            double2 p = *(const double2 *)(a.fac[0] + (int64_t)a.ids[pair] * a.D + e);
+            for (int k = 1; k < a.n_modes; k++) {
+                const double2 q = *(const double2 *)(a.fac[k] + (int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e);
+                p.x *= q.x; p.y *= q.y;
+            }
+            s += p.x + p.y;
+        }
+    } else if ((a.D & 3) == 0) {
         for (int e = sub * 4; e < a.D; e += LPP * 4) {
             double4 p = *(const double4 *)(a.fac[0] + (int64_t)a.ids[pair] * a.D + e);
             for (int k = 1; k < a.n_modes; k++) {
@@ -75,6 +85,7 @@ __device__ inline void pair_update(const PredArgs &a, int64_t pair, double s, do
     }
 }
 
+template <int LPP, int PPT>
 __global__ __launch_bounds__(256) void k_predict(PredArgs a)
 {
     const int tid = threadIdx.x;
@@ -82,15 +93,20 @@ __global__ __launch_bounds__(256) void k_predict(PredArgs a)
     double st[4] = {0.0, 0.0, 0.0, 0.0};
     const int64_t ngroups = (int64_t)gridDim.x * (256 / LPP);
     // the lanes of a group share their pairs, so a group enters and leaves the loop together (the shuffles only cross
-    // lanes of one group)
-    for (int64_t p0 = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; p0 < a.n; p0 += 2 * ngroups) {
-        const int64_t p1 = p0 + ngroups;
-        const bool has1 = p1 < a.n;
-        const double s0 = pair_dot(a, p0, sub);
-        const double s1 = pair_dot(a, has1 ? p1 : p0, sub);
+    // lanes of one group); a group handles PPT pairs per trip so that their gathers overlap
+    for (int64_t p0 = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; p0 < a.n; p0 += PPT * ngroups) {
+        double s[PPT];
+#pragma unroll
+        for (int u = 0; u < PPT; u++) {
+            const int64_t pu = p0 + u * ngroups;
+            s[u] = pair_dot<LPP>(a, pu < a.n ? pu : p0, sub);
+        }
         if (sub == 0) {
-            pair_update(a, p0, s0, st);
-            if (has1) pair_update(a, p1, s1, st);
+#pragma unroll
+            for (int u = 0; u < PPT; u++) {
+                const int64_t pu = p0 + u * ngroups;
+                if (pu < a.n) pair_update(a, pu, s[u], st);
+            }
         }
     }
     if (a.phase >= 0) {
@@ -130,15 +146,20 @@ __global__ __launch_bounds__(256) void k_predict_final(int nblocks, const double
 int launch_predict(bdf_ctx *ctx, PredArgs &a)
 {
     if (a.n == 0) return BDF_OK;
+    static const int variant = getenv("BDF_PREDICT_VARIANT") ? atoi(getenv("BDF_PREDICT_VARIANT")) : 0;
+    const int LPP = (variant == 1 || variant == 3) ? 16 : 8, PPT = (variant >= 2) ? 4 : 2;
     const int64_t need = (a.n * LPP + 255) / 256;
-    const int nblocks = (int)std::min<int64_t>((need + 1) / 2, 4096);
+    const int nblocks = (int)std::min<int64_t>((need + PPT - 1) / PPT, 4096);
     if (a.phase >= 0) {
         void *sc;
         int rc = bdf_scratch(ctx, (size_t)nblocks * 4 * sizeof(double), &sc);
         if (rc) return rc;
         a.partial = (double *)sc;
     }
-    hipLaunchKernelGGL(k_predict, dim3(nblocks), dim3(256), 0, ctx->stream, a);
+    if (variant == 0) hipLaunchKernelGGL((k_predict<8, 2>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
+    else if (variant == 1) hipLaunchKernelGGL((k_predict<16, 2>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
+    else if (variant == 2) hipLaunchKernelGGL((k_predict<8, 4>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
+    else hipLaunchKernelGGL((k_predict<16, 4>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
     if (a.phase >= 0) hipLaunchKernelGGL(k_predict_final, dim3(1), dim3(256), 0, ctx->stream, nblocks, (const double *)a.partial, a.stats);
     BDF_HIP(hipGetLastError());
     return BDF_OK;

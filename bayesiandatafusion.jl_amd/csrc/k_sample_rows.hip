@@ -47,6 +47,12 @@
 #ifndef BDF_K1_WAVES
 #define BDF_K1_WAVES 3
 #endif
+#ifndef BDF_K1_RING_B
+#define BDF_K1_RING_B 8192        // bytes of the gather ring per wave (D <= 32)
+#endif
+#ifndef BDF_K1_TMAX
+#define BDF_K1_TMAX 192           // observations staged per pass
+#endif
 
 #ifdef BDF_K1_STAMPS
 #define STAMP(slot) do { if (lane == 0 && a.b_dump) ((unsigned long long *)a.b_dump)[wid * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
@@ -97,15 +103,16 @@ struct Geo {
     static constexpr int ROWB = LPR * 16;              // bytes between rows in a slot
     static constexpr int IPK = 4 * LPR / 64;           // DMA instructions per k-step and other mode
     static constexpr int SLOTB = 4 * ROWB;             // bytes per slot
-    static constexpr int RING_SLOTS = 8192 / SLOTB;    // 8 (DP <= 32) or 4 (DP = 64) slots, shared by the other modes
-    static constexpr int TMAX = 192;                   // observations staged per pass on the DMA path
+    static constexpr int RING_B = (DP == 64) ? 8192 : BDF_K1_RING_B;
+    static constexpr int RING_SLOTS = RING_B / SLOTB;  // 8 (DP <= 32) or 4 (DP = 64) slots, shared by the other modes
+    static constexpr int TMAX = BDF_K1_TMAX;                   // observations staged per pass on the DMA path
     // stage of one item: [values TMAX x 8][ids of other mode 0, TMAX x 4][ids of other mode 1, TMAX x 4]; consecutive
     // stages are STAGE_B apart, so an item with two other modes needs the room of the following stage as well
     static constexpr int STAGE_B = TMAX * 12;
     static constexpr int NSTAGE = (G >= 2) ? 2 : 1;    // items of a wave staged ahead (matrix relations only)
     // per-wave LDS (doubles): the finishing area [img | fb | piv] aliases the gather area [ring | stage]
     static constexpr int FIN_D = (DP * LD + 64 > G * (DP * (DP + 1) / 2) + 64) ? DP * LD + 64 : G * (DP * (DP + 1) / 2) + 64;
-    static constexpr int GAT_D = (8192 + (NSTAGE >= 2 ? NSTAGE * STAGE_B : STAGE_B + TMAX * 4)) / 8;
+    static constexpr int GAT_D = (RING_B + (NSTAGE >= 2 ? NSTAGE * STAGE_B : STAGE_B + TMAX * 4)) / 8;
     static constexpr int WAVE_LDS = FIN_D > GAT_D ? FIN_D : GAT_D;
 };
 
@@ -255,7 +262,7 @@ __device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int l
     const int D = a.D;
     const int j = lane & 15, h = lane >> 4;
     char *ring = (char *)wl;
-    char *stage = ring + 8192 + stage_sel * GG::STAGE_B;
+    char *stage = ring + GG::RING_B + stage_sel * GG::STAGE_B;
     const double *svals = (const double *)stage;
     const int32_t *sidx = (const int32_t *)(stage + TMAX * 8);
 #pragma unroll
@@ -366,7 +373,7 @@ __device__ inline bool prestage(const SampleArgs &a, const Item &it, int lane, d
     if (it.row < 0 || it.count <= 0 || !item_uses_dma<DP>(a, it)) return false;
     const TermDev &T = a.t[it.term];
     if (T.n_other != 1 && stage_sel != 0) return false;       // a two-mode stage spills into the next one
-    char *stage = (char *)wl + 8192 + stage_sel * Geo<DP>::STAGE_B;
+    char *stage = (char *)wl + Geo<DP>::RING_B + stage_sel * Geo<DP>::STAGE_B;
     const int n = it.count < Geo<DP>::TMAX ? it.count : Geo<DP>::TMAX;
     if (T.n_other == 1) stage_item<DP, 1>(T, it.q_begin, n, lane, stage);
     else stage_item<DP, 2>(T, it.q_begin, n, lane, stage);
@@ -414,8 +421,8 @@ __device__ inline void acc_to_image(const d4 (&acc)[Geo<DP>::NB], double *img, i
 
 // ---- finish G rows at once: lane group grp = lane / DP owns row myrow; col[] = column c of P~ (prior included) --------
 template <int DP, bool DUMP>
-__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double *wl, int lane,
-                                   int64_t wid)
+__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double znorm,
+                                   double *wl, int lane, int64_t wid)
 {
     constexpr int LD = Geo<DP>::LD;
     const int D = a.D;
@@ -441,9 +448,7 @@ __device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&
     const double sq_own = p_own * fast_rsqrt(p_own);                 // L[c][c] = sqrt(p_c)
     // L w = b, y = w + z, carried as yh = y sqrt(p) = b' + z sqrt(p)   (z reversed: column c takes normal number D-1-c)
     const double bp = wl_forward<DP>(col, bj, rp_own, lane);
-    double yh = 0.0;
-    if (myrow >= 0 && ec >= 0)
-        yh = fma(bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)myrow, ec), sq_own, bp);
+    const double yh = (myrow >= 0 && ec >= 0) ? fma(znorm, sq_own, bp) : 0.0;
     STAMP(6);
     STAMP(7);
     const double x = wl_backward<DP>(tri, yh, rp_own, lane);         // L' x = y
@@ -543,7 +548,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
     const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
     const int grp = lane / DP, c = lane % DP;
     double col[DP];
-    double bj = 0.0;
+    double bj = 0.0, znorm = 0.0;
     int64_t myrow = -1;
     STAMP(0);
 
@@ -581,6 +586,9 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
+        // the row's normal (column c takes number D-1-c of the row's stream), drawn while few registers are live
+        if (grp == 0 && a.D - 1 - c >= 0 && !DUMP)
+            znorm = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)sr.row, a.D - 1 - c);
         sum_partials<DP>(p, sr, lane, acc, bred);
         STAMP(2);
         {
@@ -634,6 +642,13 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
             STAMP(1 + g);
         }
         {
+            int64_t r = -1;
+#pragma unroll
+            for (int g = 0; g < G; g++) r = (grp == g) ? rows[g] : r;
+            if (r >= 0 && a.D - 1 - c >= 0 && !DUMP)
+                znorm = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)r, a.D - 1 - c);
+        }
+        {
             d4 lamc[NB];                                  // loaded after the gathers so that it is not live during them
             load_prior_c<DP>(a, lane, lamc);
 #pragma unroll
@@ -651,12 +666,16 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
                     for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bredg[g][I];
                 }
                 wave_sync();
-                if (grp == g) {
+                // select form (not a divergent block): the column array is updated in place, no second copy of it
+                const bool mine = (grp == g);
 #pragma unroll
-                    for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
-                    bj = wl[DP * LD + c];
-                    myrow = rows[g];
+                for (int i = 0; i < DP; i++) {
+                    const double v = wl[i * LD + c];
+                    col[i] = (g == 0 || mine) ? v : col[i];
                 }
+                const double vb = wl[DP * LD + c];
+                bj = mine ? vb : bj;
+                myrow = mine ? rows[g] : myrow;
             }
         }
     }
@@ -671,7 +690,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
             bj = 0.0;
         }
     }
-    finish_rows<DP, DUMP>(a, myrow, col, bj, wl, lane, wid);
+    finish_rows<DP, DUMP>(a, myrow, col, bj, znorm, wl, lane, wid);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -790,8 +809,8 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
         bool hit = rel_serial == 0;
         for (int r = 0; r < kv->first.n_terms; r++) hit = hit || kv->first.rel[r] == rel_serial;
         if (hit) {
-            hipFree(kv->second.direct_dev); hipFree(kv->second.split_dev); hipFree(kv->second.rows_dev);
-            hipFree(kv->second.partials_dev); hipFree(kv->second.arrived_dev);
+            (void)hipFree(kv->second.direct_dev); (void)hipFree(kv->second.split_dev); (void)hipFree(kv->second.rows_dev);
+            (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev);
             kv = plans.erase(kv);
         } else {
             ++kv;
