@@ -335,11 +335,14 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         T.nnz = t.rel->nnz;
         T.n_other = t.rel->n_modes - 1;
         int plane = 0;
+        bool lean = t.linear_values == nullptr && T.n_other <= 2;
         for (int k = 0; k < t.rel->n_modes; k++) {
             if (k == t.mode) continue;
             BDF_REQUIRE(t.factors[k] != nullptr, BDF_ERR_ARG, "%s: terms[%d].factors[%d] is NULL", who, r, k);
             T.fac[plane++] = t.factors[k];
+            lean = lean && t.rel->dims[k] < (1 << 24) && t.rel->dims[k] * (int64_t)D * 8 < ((int64_t)1 << 32);
         }
+        T.lean = lean ? 1 : 0;
         T.alpha = t.alpha;
         T.mean = t.mean_value;
     }

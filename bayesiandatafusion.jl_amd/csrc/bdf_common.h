@@ -181,7 +181,7 @@ struct TermDev {
     const double *fac[BDF_MAX_MODES - 1];
     int64_t nnz;
     int32_t n_other;
-    int32_t _pad;
+    int32_t lean;              // K1: shared baseline, <= 2 other modes, factor matrices < 4 GiB with < 2^24 rows
     double alpha, mean;
 };
 
@@ -196,6 +196,7 @@ struct SampleArgs {
     uint32_t entity_tag, _pad2;
     double *out;
     const double *prior_b;     // Lambda mu (D) or Lambda mu_i (D x N), filled by the launch front-end
+    const double *prior_c;     // index-reversed Lambda in the accumulator layout, filled by the launch front-end
     double *P_dump, *b_dump;
     int *flag;
 };

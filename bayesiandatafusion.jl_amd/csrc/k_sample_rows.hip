@@ -18,7 +18,7 @@
 // Cholesky L L' and the two solves become forward then backward substitution.
 //
 // Work decomposition (ragged rows: MovieLens rows have 0..1668 observations):
-//   * a row's observations are cut into ITEMS of at most T observations; one wavefront accumulates one item.
+//   * a row's observations are cut into ITEMS of at most T observations; ONE WAVEFRONT PER ITEM.
 //   * a row with a single item is DIRECT: the wave that accumulated it also factors, solves and draws.
 //   * a row with several items (long rows, or several relations) is SPLIT: its items write partial (S, b) to a
 //     scratch slab and count themselves in; the wave whose arrival completes the row adds the row's partials in slot
@@ -31,27 +31,31 @@
 // global memory to the matrix pipe with no LDS staging and no cross-lane traffic (measured on MI355X: 64 cycles
 // per MFMA, 77 TFLOP/s chip-wide against 64 TFLOP/s for v_fma_f64 which would also need every operand broadcast).
 //
-// Finishing: G = 64/DP rows at a time per wave (lane group = row, lane in group = column of P~ held in registers).
-// Cholesky keeps the matrix fully symmetric so row k of a lane's column doubles as A[c][k]; step k broadcasts row k
-// through LDS once (ds_write_b64 + broadcast ds_reads) and updates the trailing rows with one fma per element.
+// Finishing happens IN THE ACCUMULATOR LAYOUT, with the matrix never leaving the registers the MFMAs left it in:
+// lane (j = l & 15, h = l >> 4), register r of block (I, J) holds element (16 I + h + 4 r, 16 J + j) -- a lane owns
+// DB columns (j, 16 + j, ...) and of each the rows of its class h (mod 4): 12 doubles for D <= 32.  Step k of the
+// right-looking factorisation needs, in lane (j, h), the entries of column k in the lane's rows -- they sit in lane
+// (k % 16, h), same row of 16 lanes, same registers: a DPP row broadcast folded into the fma (v_fmac_f64_dpp
+// row_newbcast) -- and the multipliers of the lane's columns, read from the copy of column k that its four owner
+// lanes put in LDS (the packed factor that the backward solve reads anyway).  b rides along as one more matrix row,
+// which makes the forward solve part of the factorisation.  The low register count (about a third of a
+// column-per-lane layout) is what lets 5-6 waves share a SIMD and hide each other's dependent-step latencies.
 #include "bdf_common.h"
 #include "wave_linalg.h"
 #include <algorithm>
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <utility>
 
 #ifndef BDF_K1_WPB
 #define BDF_K1_WPB 4
 #endif
-#ifndef BDF_K1_WAVES
-#define BDF_K1_WAVES 3
+#ifndef BDF_K1_WAVES32
+#define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
 #endif
-#ifndef BDF_K1_RING_B
-#define BDF_K1_RING_B 8192        // bytes of the gather ring per wave (D <= 32)
-#endif
-#ifndef BDF_K1_TMAX
-#define BDF_K1_TMAX 192           // observations staged per pass
+#ifndef BDF_K1_KS
+#define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
 #endif
 
 #ifdef BDF_K1_STAMPS
@@ -63,11 +67,10 @@
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) void lds_void;
-typedef const __attribute__((address_space(1))) void gbl_void;
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 struct Item {             // one wave's accumulation work
-    int32_t row;          // entity row (-1: padding)
+    int32_t row;          // entity row
     int32_t term;
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
@@ -83,39 +86,37 @@ struct SplitRow {
 };
 
 struct PlanDev {
-    const Item *direct;   int32_t n_direct;      // padded to a multiple of G
+    const Item *direct;   int32_t n_direct;
     const Item *split;    int32_t n_split;
     const SplitRow *rows; int32_t n_split_rows;
     double *partials;                            // n_split * PSZ doubles
     int32_t *arrived;                            // per split row: items that have published their partial (self-resetting)
+    const int32_t *order;                        // launch order: wave w takes item order[w] of [split | direct]
 };
 
 template <int DP>
 struct Geo {
-    static constexpr int G = 64 / DP;                  // rows finished together by one wave
     static constexpr int DB = DP / 16;                 // 16-wide blocks per dimension
     static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
-    static constexpr int LD = DP + 1;                  // padded leading dimension of the LDS images
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
-    static constexpr int WPB = (DP == 64) ? 1 : BDF_K1_WPB;   // waves per workgroup (static LDS must stay under 64 KB)
-    // LDS-DMA gather ring: a slot holds the 4 gathered factor rows of one MFMA k-step
-    static constexpr int LPR = (DP == 64) ? 32 : 16;   // lanes (16 bytes each) per gathered row
-    static constexpr int ROWB = LPR * 16;              // bytes between rows in a slot
-    static constexpr int IPK = 4 * LPR / 64;           // DMA instructions per k-step and other mode
-    static constexpr int SLOTB = 4 * ROWB;             // bytes per slot
-    static constexpr int RING_B = (DP == 64) ? 8192 : BDF_K1_RING_B;
-    static constexpr int RING_SLOTS = RING_B / SLOTB;  // 8 (DP <= 32) or 4 (DP = 64) slots, shared by the other modes
-    static constexpr int TMAX = BDF_K1_TMAX;                   // observations staged per pass on the DMA path
-    // stage of one item: [values TMAX x 8][ids of other mode 0, TMAX x 4][ids of other mode 1, TMAX x 4]; consecutive
-    // stages are STAGE_B apart, so an item with two other modes needs the room of the following stage as well
-    static constexpr int STAGE_B = TMAX * 12;
-    static constexpr int NSTAGE = (G >= 2) ? 2 : 1;    // items of a wave staged ahead (matrix relations only)
-    // per-wave LDS (doubles): the finishing area [img | fb | piv] aliases the gather area [ring | stage]
-    static constexpr int FIN_D = (DP * LD + 64 > G * (DP * (DP + 1) / 2) + 64) ? DP * LD + 64 : G * (DP * (DP + 1) / 2) + 64;
-    static constexpr int GAT_D = (RING_B + (NSTAGE >= 2 ? NSTAGE * STAGE_B : STAGE_B + TMAX * 4)) / 8;
-    static constexpr int WAVE_LDS = FIN_D > GAT_D ? FIN_D : GAT_D;
+    static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
+    static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
+    __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
+    // packed factor in LDS: column k (block column K = k / 16) keeps rows 16 K .. DP-1, by row class:
+    // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - 16 K) / 4.  Columns are one double further apart than
+    // they are long: an odd stride, so that the backward solve's per-lane reads (lane = column, same row) fall in
+    // different LDS banks
+    __host__ __device__ static constexpr int col_rows(int k) { return DP - 16 * (k / 16); }
+    __host__ __device__ static constexpr int col_stride(int k) { return col_rows(k) + 1; }
+    __host__ __device__ static constexpr int col_base(int k)
+    {
+        int s = 0;
+        for (int q = 0; q < k / 16; q++) s += 16 * col_stride(16 * q);
+        return s + (k % 16) * col_stride(k);
+    }
+    static constexpr int TRI_D = (col_base(DP - 1) + col_stride(DP - 1) + 1) / 2 * 2;   // 272, 800, 2624 doubles
+    static constexpr int WAVE_LDS = TRI_D;
 };
-
 
 // ---- accumulate one item, register path (any D, per-observation baselines): acc (MFMA C layout, lower block-triangle)
 // and bred (the item's part of b) ------------------------------------------------------------------------------------
@@ -127,7 +128,7 @@ __device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int l
                                   double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
-    constexpr int KS = (NO == 1) ? 4 : 2;                 // k-steps (of 4 observations) per trip
+    constexpr int KS = (NO == 1) ? BDF_K1_KS : (NO == 2 ? 2 : 1);   // k-steps (of 4 observations) per trip
     const TermDev &T = a.t[it.term];
     const int D = a.D;
     const int j = lane & 15, h = lane >> 4;
@@ -218,136 +219,104 @@ __device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int l
     }
 }
 
-// ---- accumulate one item, LDS-DMA path (even D, shared baseline) --------------------------------------------------------
-// The item's other-mode ids and values are staged in LDS by DMA (stage_item, up to TMAX observations per pass); then a
-// ring of k-step slots is kept full by global_load_lds gathers (per-lane source address = chunk (l % LPR) of factor row
-// ids[l / LPR], lane-linear LDS destination), P = R - 1 k-steps ahead of the MFMAs.  Nothing but DMAs uses the
-// vector-memory counter inside the loop, so the waits are exact: `s_waitcnt vmcnt((P-1) * NO * IPK)` retires precisely
-// the oldest k-step.
-template <int DP, int NO>
-__device__ inline void stage_item(const TermDev &T, int64_t qb, int n, int lane, char *stage)
+// ---- accumulate one item, lean register path: shared baseline (no per-observation linear_values), at most two other
+// modes, factor matrices below 4 GiB with fewer than 2^24 rows (TermDev::lean, checked by the host) -----------------------
+// Same pipeline as accumulate_reg, with what the general path pays per load taken out: wave-uniform (SGPR) bases with
+// 32-bit byte offsets, row offsets by one 24-bit mad, no predicated loads (indices are clamped to the item instead, and
+// only the item's last trip masks its operands).
+template <int DP, int NO, bool FULL>
+__device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                       double (&bred)[Geo<DP>::DB])
 {
-    constexpr int TMAX = Geo<DP>::TMAX;
-    int32_t *svals = (int32_t *)stage;                    // TMAX doubles as dwords
-    int32_t *sidx = (int32_t *)(stage + TMAX * 8);        // [NO][TMAX]
-    const int last = n - 1;
-#pragma unroll
-    for (int m = 0; m < NO; m++)
-#pragma unroll
-        for (int part = 0; part < (TMAX + 63) / 64; part++) {
-            const int o = part * 64 + lane;
-            const int32_t *src = T.colidx + (int64_t)m * T.nnz + qb + (o < n ? o : last);
-            if (part * 64 < TMAX && (part + 1) * 64 <= TMAX + 63)
-                __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(sidx + m * TMAX + part * 64), 4, 0, 0);
-        }
-#pragma unroll
-    for (int part = 0; part < (2 * TMAX + 63) / 64; part++) {
-        const int w = part * 64 + lane;                   // dword index into the values
-        const int32_t *src = (const int32_t *)(T.vals + qb) + (w < 2 * n ? w : 2 * last + (w & 1));
-        __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(svals + part * 64), 4, 0, 0);
-    }
-}
-
-template <int DP, int NO>
-__device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel,
-                                      bool prestaged, d4 (&acc)[Geo<DP>::NB], double (&bred)[Geo<DP>::DB])
-{
-    using GG = Geo<DP>;
-    constexpr int DB = GG::DB, NB = GG::NB, LPR = GG::LPR, ROWB = GG::ROWB, IPK = GG::IPK, SLOTB = GG::SLOTB;
-    constexpr int R = GG::RING_SLOTS / NO;                // ring depth in k-steps
-    constexpr int P = R - 1;                              // k-steps in flight
-    static_assert(R >= 2, "ring too small");
-    constexpr int TMAX = GG::TMAX;
+    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
+    constexpr int KS = (NO == 1) ? BDF_K1_KS : 1;
     const TermDev &T = a.t[it.term];
-    const int D = a.D;
+    const int D = FULL ? DP : a.D;
     const int j = lane & 15, h = lane >> 4;
-    char *ring = (char *)wl;
-    char *stage = ring + GG::RING_B + stage_sel * GG::STAGE_B;
-    const double *svals = (const double *)stage;
-    const int32_t *sidx = (const int32_t *)(stage + TMAX * 8);
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
     double bpart[DB];
-    int eoff[DB];                                         // byte offset in a gathered row of reversed element 16 I + j
+    uint32_t eoff[DB];                        // byte offset in a factor row of reversed element 16 I + j
     bool eok[DB];
 #pragma unroll
     for (int I = 0; I < DB; I++) {
         bpart[I] = 0.0;
         const int ec = D - 1 - (16 * I + j);
-        eok[I] = ec >= 0;
-        eoff[I] = (ec >= 0 ? ec : 0) * 8;
+        eok[I] = FULL || ec >= 0;
+        eoff[I] = (uint32_t)(ec >= 0 ? ec : 0) * 8u;
     }
-    const int rowbytes = D * 8;
-    const int chunk = lane % LPR;
-    const int coff = (chunk * 16 < rowbytes) ? chunk * 16 : rowbytes - 16;   // lanes past the row re-read its last chunk
-    const int lrow = lane / LPR;
-    for (int pass0 = 0; pass0 < it.count; pass0 += TMAX) {
-        const int n = (it.count - pass0 < TMAX) ? it.count - pass0 : TMAX;   // observations of this pass
-        if (!(prestaged && pass0 == 0)) stage_item<DP, NO>(T, it.q_begin + pass0, n, lane, stage);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const int nks = (n + 3) >> 2;
+    const uint32_t n = (uint32_t)it.count, rowb = (uint32_t)D * 8u;
+    const uint32_t ntrips = (n + 4 * KS - 1) / (4 * KS);
+    const char *ids[NO], *fac[NO];
+#pragma unroll
+    for (int m = 0; m < NO; m++) {
+        ids[m] = (const char *)(T.colidx + (int64_t)m * T.nnz + it.q_begin);
+        fac[m] = (const char *)T.fac[m];
+    }
+    const char *vals = (const char *)(T.vals + it.q_begin);
+    const double mean = T.mean;
 
-        // gather the 4 factor rows of a k-step into slot ks % R; rix[m][q] = row index read from the stage
-        auto gather = [&](int ks, const int32_t (&rix)[NO][IPK]) {
-            char *slot = ring + (ks % R) * (NO * SLOTB);
-#pragma unroll
-            for (int m = 0; m < NO; m++)
-#pragma unroll
-                for (int q = 0; q < IPK; q++) {
-                    const char *src = (const char *)(T.fac[m] + (int64_t)rix[m][q] * D) + coff;
-                    __builtin_amdgcn_global_load_lds((gbl_void *)src, (lds_void *)(slot + m * SLOTB + q * 1024), 16, 0, 0);
-                }
-        };
-        auto read_idx = [&](int ks, int32_t (&rix)[NO][IPK]) {
-#pragma unroll
-            for (int m = 0; m < NO; m++)
-#pragma unroll
-                for (int q = 0; q < IPK; q++) {
-                    int o = 4 * ks + q * (64 / LPR) + lrow;
-                    o = o < n ? o : n - 1;                   // past the end: any row of the pass (operands are zeroed)
-                    rix[m][q] = sidx[m * TMAX + o];
-                }
-        };
-#pragma unroll
-        for (int s = 0; s < P; s++) {
-            int32_t rix[NO][IPK];
-            read_idx(s, rix);
-            gather(s, rix);
-        }
-        for (int ks = 0; ks < nks; ks++) {
-            // exactly P k-steps are outstanding here: ks .. ks+P-1; retire the oldest
-            asm volatile("s_waitcnt vmcnt(%0)" ::"n"((P - 1) * NO * IPK) : "memory");
-            const char *slot = ring + (ks % R) * (NO * SLOTB) + h * ROWB;
-            double w[DB];
-#pragma unroll
-            for (int I = 0; I < DB; I++) {
-                double v = *(const double *)(slot + eoff[I]);
-#pragma unroll
-                for (int m = 1; m < NO; m++) v *= *(const double *)(slot + m * SLOTB + eoff[I]);    // Hadamard product
-                w[I] = v;
-            }
-            const int o = 4 * ks + h;
-            const bool valid = o < n;
-            const double rr = valid ? svals[valid ? o : 0] - T.mean : 0.0;
-            int32_t rix[NO][IPK];
-            read_idx(ks + P, rix);                           // same LDS round trip as the operands
-#pragma unroll
-            for (int I = 0; I < DB; I++) w[I] = (valid && eok[I]) ? w[I] : 0.0;
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // operands are in registers before their slot is reused
-            gather(ks + P, rix);
-            int b = 0;
-#pragma unroll
-            for (int I = 0; I < DB; I++) {
-#pragma unroll
-                for (int J = 0; J <= I; J++) {
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[I], w[J], acc[b], 0, 0, 0);
-                    b++;
-                }
-                bpart[I] = fma(w[I], rr, bpart[I]);
-            }
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // drain the run-ahead gathers before the stage is rewritten
+    // two register sets, used alternately by even and odd trips (no rotation copies: a copy would have to wait for
+    // the load it moves).  Trip t multiplies set t%2; the gathers of trip t+1 fill the other set; the ids and values of
+    // trip t+2 are loaded into set t%2 once trip t has used it.
+    uint32_t ix[2][KS][NO];
+    double rr[2][KS];
+    double w[2][KS][NO][DB];
+#define LOAD_IDX(t, S)                                                                          \
+    _Pragma("unroll") for (int k = 0; k < KS; k++) {                                            \
+        uint32_t o = (t) * (4 * KS) + 4 * k + h;                                                \
+        o = (o < n ? o : n - 1) * 4u;                                                           \
+        _Pragma("unroll") for (int m = 0; m < NO; m++) ix[S][k][m] = *(const uint32_t *)(ids[m] + o); \
+        rr[S][k] = *(const double *)(vals + 2u * o);                                            \
     }
+#define LOAD_DATA(S)                                                                            \
+    _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
+        _Pragma("unroll") for (int m = 0; m < NO; m++)                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
+                w[S][k][m][I] = *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I]));
+#define TRIP(t, C, X)                                                                           \
+    {                                                                                           \
+        LOAD_DATA(X)  /* unconditional (ids are clamped to the item): a branch here would cost exact waitcnts */ \
+        double w_c[KS][DB];                                                                     \
+        _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
+                double v = w[C][k][0][I];                                                       \
+                _Pragma("unroll") for (int m = 1; m < NO; m++) v *= w[C][k][m][I];              \
+                w_c[k][I] = v;                                                                  \
+            }                                                                                   \
+        if ((t) + 1 >= ntrips || !FULL) {     /* ragged last trip; padded elements when D < DP */ \
+            _Pragma("unroll") for (int k = 0; k < KS; k++) {                                    \
+                const bool valid = (t) * (4 * KS) + 4 * k + h < n;                              \
+                _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = (valid && eok[I]) ? w_c[k][I] : 0.0; \
+            }                                                                                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KS; k++) {                                        \
+            const double r = rr[C][k] - mean;                                                   \
+            int b = 0;                                                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
+                _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
+                    b++;                                                                        \
+                }                                                                               \
+                bpart[I] = fma(w_c[k][I], r, bpart[I]);                                         \
+            }                                                                                   \
+        }                                                                                       \
+        LOAD_IDX((t) + 2, C)                                                                    \
+    }
+
+    LOAD_IDX(0u, 0)
+    LOAD_IDX(1u, 1)
+    LOAD_DATA(0)
+    // trips go in pairs in one straight-line block (a branch between them lets the compiler sink the run-ahead loads to
+    // their use); for an odd count the last one is empty: its operands are masked to zero
+    for (uint32_t t = 0; t < ntrips; t += 2) {
+        TRIP(t, 0, 1)
+        TRIP(t + 1, 1, 0)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the run-ahead loads of the last trips
+#undef LOAD_IDX
+#undef LOAD_DATA
+#undef TRIP
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
 #pragma unroll
@@ -359,143 +328,208 @@ __device__ inline void accumulate_dma(const SampleArgs &a, const Item &it, int l
     }
 }
 
-template <int DP>
-__device__ inline bool item_uses_dma(const SampleArgs &a, const Item &it)
-{
-    const TermDev &T = a.t[it.term];
-    return (a.D % 2 == 0) && T.linear == nullptr && T.n_other <= 2;
-}
-
-// issue the staging DMAs of an item ahead of its accumulation (returns false if the item takes the register path)
-template <int DP>
-__device__ inline bool prestage(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel)
-{
-    if (it.row < 0 || it.count <= 0 || !item_uses_dma<DP>(a, it)) return false;
-    const TermDev &T = a.t[it.term];
-    if (T.n_other != 1 && stage_sel != 0) return false;       // a two-mode stage spills into the next one
-    char *stage = (char *)wl + Geo<DP>::RING_B + stage_sel * Geo<DP>::STAGE_B;
-    const int n = it.count < Geo<DP>::TMAX ? it.count : Geo<DP>::TMAX;
-    if (T.n_other == 1) stage_item<DP, 1>(T, it.q_begin, n, lane, stage);
-    else stage_item<DP, 2>(T, it.q_begin, n, lane, stage);
-    return true;
-}
-
 // path and other-mode count are wave-uniform
 template <int DP>
-__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, double *wl, int stage_sel,
-                                      bool prestaged, d4 (&acc)[Geo<DP>::NB], double (&bred)[Geo<DP>::DB])
+__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                      double (&bred)[Geo<DP>::DB])
 {
-    const TermDev &T = a.t[it.term];
-    const int no = T.n_other;
-    if (item_uses_dma<DP>(a, it)) {
-        if (no == 1) accumulate_dma<DP, 1>(a, it, lane, wl, stage_sel, prestaged, acc, bred);
-        else accumulate_dma<DP, 2>(a, it, lane, wl, stage_sel, prestaged, acc, bred);   // 3 other modes: register path
-    } else {
-        if (no == 1) accumulate_reg<DP, 1>(a, it, lane, acc, bred);
-        else if (no == 2) accumulate_reg<DP, 2>(a, it, lane, acc, bred);
-        else accumulate_reg<DP, 3>(a, it, lane, acc, bred);
-    }
-}
-
-// ---- spread an accumulator (C layout) as a full symmetric image P~[i][c] at img[i*LD + c] ----------------------------
-// C layout of block (I,J): lane l, register r holds element (row 16I + (l>>4) + 4r, column 16J + (l&15)).
-template <int DP>
-__device__ inline void acc_to_image(const d4 (&acc)[Geo<DP>::NB], double *img, int lane)
-{
-    constexpr int DB = Geo<DP>::DB, LD = Geo<DP>::LD;
-    const int j = lane & 15, h = lane >> 4;
-    int b = 0;
-#pragma unroll
-    for (int I = 0; I < DB; I++)
-#pragma unroll
-        for (int J = 0; J <= I; J++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * I + h + 4 * r, colm = 16 * J + j;
-                img[row * LD + colm] = acc[b][r];
-                if (I != J) img[colm * LD + row] = acc[b][r];
-            }
-            b++;
-        }
-}
-
-// ---- finish G rows at once: lane group grp = lane / DP owns row myrow; col[] = column c of P~ (prior included) --------
-template <int DP, bool DUMP>
-__device__ inline void finish_rows(const SampleArgs &a, int64_t myrow, double (&col)[DP], double bj, double znorm,
-                                   double *wl, int lane, int64_t wid)
-{
-    constexpr int LD = Geo<DP>::LD;
-    const int D = a.D;
-    const int c = lane % DP;
-    const int ec = D - 1 - c;
-    double *tri = wl;                       // packed factor (aliases the conversion image, which has been consumed)
-
-    if (DUMP) {
-        if (myrow >= 0 && ec >= 0) {
-#pragma unroll
-            for (int i = 0; i < DP; i++) {
-                const int ei = D - 1 - i;
-                if (ei >= 0) a.P_dump[(myrow * D + ec) * D + ei] = col[i];
-            }
-            a.b_dump[myrow * D + ec] = bj;
+    const int no = a.t[it.term].n_other;
+    if (a.t[it.term].lean) {
+        if (a.D == DP) {
+            if (no == 1) accumulate_lean<DP, 1, true>(a, it, lane, acc, bred);
+            else accumulate_lean<DP, 2, true>(a, it, lane, acc, bred);
+        } else {
+            if (no == 1) accumulate_lean<DP, 1, false>(a, it, lane, acc, bred);
+            else accumulate_lean<DP, 2, false>(a, it, lane, acc, bred);
         }
         return;
     }
-    double p_own, rp_own;
-    STAMP(4);
-    if (wl_factor<DP>(col, p_own, rp_own, tri, lane) && myrow >= 0) atomicOr(a.flag, 1);
-    STAMP(5);
-    const double sq_own = p_own * fast_rsqrt(p_own);                 // L[c][c] = sqrt(p_c)
-    // L w = b, y = w + z, carried as yh = y sqrt(p) = b' + z sqrt(p)   (z reversed: column c takes normal number D-1-c)
-    const double bp = wl_forward<DP>(col, bj, rp_own, lane);
-    const double yh = (myrow >= 0 && ec >= 0) ? fma(znorm, sq_own, bp) : 0.0;
-    STAMP(6);
-    STAMP(7);
-    const double x = wl_backward<DP>(tri, yh, rp_own, lane);         // L' x = y
-    if (myrow >= 0 && ec >= 0) a.out[myrow * D + ec] = x;
-    STAMP(8);
+    if (no == 1) accumulate_reg<DP, 1>(a, it, lane, acc, bred);
+    else if (no == 2) accumulate_reg<DP, 2>(a, it, lane, acc, bred);
+    else accumulate_reg<DP, 3>(a, it, lane, acc, bred);
 }
 
-// ---- prior: Lambda~ in the accumulator (C) layout, identity on the padding; loaded once per wave, added to every row's
-// accumulator before the layout change.  The prior part of b, Lambda mu_i, comes from a small pre-launch (k_prior_b).
-template <int DP>
-__device__ inline void load_prior_c(const SampleArgs &a, int lane, d4 (&lamc)[Geo<DP>::NB])
+// ---- DPP row-broadcast fma: d += (s of lane KJ of this lane's row of 16) * m.  Inline asm is opaque to the compiler's
+// hazard recogniser (a VALU write of a DPP source needs 2 wait states before the DPP read), hence the leading s_nop. ----
+template <int KJ>
+__device__ inline void fm4(double &d0, double &d1, double &d2, double &d3, double s0, double s1, double s2, double s3,
+                           double m)
 {
-    constexpr int DB = Geo<DP>::DB;
-    const int D = a.D;
-    const int j = lane & 15, h = lane >> 4;
-    int b = 0;
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm4_self(double &d0, double &d1, double &d2, double &d3, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm1(double &d, double s, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d) : "v"(s), "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm1_self(double &d, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d) : "v"(m), "n"(KJ));
+}
+
+// ---- the factorisation (unscaled: the stored column k is Lt[i][k] = L[i][k] sqrt(d_k), Lt[k][k] = d_k) ------------------
+// A[blk(I,J)*4 + r] = element (16 I + h + 4 r, 16 J + j); bv[J] = entry 16 J + j of the extra row b (same in every h).
+// Software-pipelined: step k first updates the block column that holds column k+1, then -- while the rest of step k's
+// updates issue -- column k+1's pivot is broadcast, its four owner lanes store it to the packed factor in LDS, and every
+// lane reads back the entries of its own columns' rows (the multipliers of step k+1), so that neither the reciprocal
+// nor the LDS round trip sits between two steps.
+struct FactorLanes {            // per-lane LDS offsets (doubles), one per block column: kept opaque so that they stay in
+    int wr[4];                  // registers instead of being recomputed at every step
+    int rd[4];
+};
+
+// preparation of step k: pivot (wave-uniform), column k to LDS by its four owner lanes, the lane's multipliers
+// nm[J] = -(Lt[16 J + j][k] / d_k).  (The LDS stores are asm so that the register-resident matrix is stored from where
+// it is; the compiler's own ds_write2 wanted copies.  LDS operations of a wave execute in order, and the compiler's wait
+// before it uses its reads covers them.)
+template <int DP, int k>
+__device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], double *tri, const FactorLanes &fl, int j,
+                            double (&nm)[Geo<DP>::DB])
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB, K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
+    const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
+    if (j == kj) {
+        const unsigned waddr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + fl.wr[K] + cb);
 #pragma unroll
-    for (int I = 0; I < DB; I++)
+        for (int I = K; I < DB; I++)
 #pragma unroll
-        for (int J = 0; J <= I; J++) {
+            for (int r = 0; r < 4; r++)
+                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(waddr), "v"(A[GG::blk(I, K) * 4 + r]),
+                             "n"((4 * (I - K) + r) * 8) : "memory");
+    }
+    wave_sync();
+    double raw[DB];
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int row = 16 * I + h + 4 * r, colm = 16 * J + j;
-                const int er = D - 1 - row, ecm = D - 1 - colm;
-                double v = (row == colm) ? 1.0 : 0.0;
-                if (er >= 0 && ecm >= 0) v = a.Lambda[er + (int64_t)ecm * D];
-                else if (er >= 0 || ecm >= 0) v = 0.0;
-                lamc[b][r] = v;
-            }
-            b++;
+    for (int J = K; J < DB; J++) raw[J] = tri[fl.rd[K] + cb + 4 * (J - K)];
+    const double rd = fast_rcp(d);
+#pragma unroll
+    for (int J = K; J < DB; J++) nm[J] = -(raw[J] * rd);
+}
+
+// step k: the updates of columns > k.  Block columns J > K first: they read column k (block column K) through the DPP
+// broadcast, and the update of block column K rewrites it.  No masking of finished columns (<= k) in block column K:
+// their registers are dead (a column is read for the last time at its own step).
+template <int DP, int k>
+__device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                   double *tri, const FactorLanes &fl, int j, double (&nm)[Geo<DP>::DB])
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB;
+    constexpr int K = k / 16, kj = k % 16;
+    ts[K] = (j == kj) ? bv[K] : ts[K];            // entry k of the extra row is final (t_k): keep it, the updates below
+                                                  // run unmasked over the finished columns
+#pragma unroll
+    for (int J = DB - 1; J > K; J--) {
+#pragma unroll
+        for (int I = J; I < DB; I++) {
+            double *t = &A[GG::blk(I, J) * 4];
+            const double *s = &A[GG::blk(I, K) * 4];
+            fm4<kj>(t[0], t[1], t[2], t[3], s[0], s[1], s[2], s[3], nm[J]);
         }
+        fm1<kj>(bv[J], bv[K], nm[J]);
+    }
+    if constexpr (kj < 15) {                      // block column K still has unfinished columns
+#pragma unroll
+        for (int I = K; I < DB; I++) {
+            double *t = &A[GG::blk(I, K) * 4];
+            fm4_self<kj>(t[0], t[1], t[2], t[3], nm[K]);
+        }
+        fm1_self<kj>(bv[K], nm[K]);
+    }
+    prep<DP, k + 1>(A, tri, fl, j, nm);
 }
 
-__global__ __launch_bounds__(256) void k_prior_b(int D, int64_t nrows, const double *Lambda, const double *mu,
-                                                 int mu_is_matrix, double *out)
+template <int DP, int... Ks>
+__device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                  double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
 {
-    // out[row*D + e] = sum_i Lambda[e][i] mu_row[i]   (nrows = 1 for a shared prior mean); one wave per output
+    using GG = Geo<DP>;
+    FactorLanes fl;
+#pragma unroll
+    for (int K = 0; K < GG::DB; K++) {
+        const int nr4 = (DP - 16 * K) / 4;
+        fl.wr[K] = h * nr4;
+        fl.rd[K] = (j & 3) * nr4 + (j >> 2);
+        asm volatile("" : "+v"(fl.wr[K]), "+v"(fl.rd[K]));
+    }
+    double nm[GG::DB];
+    prep<DP, 0>(A, tri, fl, j, nm);
+    // steps 0 .. D-2 (the last column has nothing to update; padded columns are skipped).  One wave-uniform exit per
+    // step out of straight-line code (a skip-and-rejoin per step would make every step a merge point of the whole
+    // register-resident matrix)
+    (void)(... && ((Ks + 1 < D) && (factor_step<DP, Ks>(A, bv, ts, tri, fl, j, nm), true)));
+}
+
+// ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----
+template <int DP, int i>
+__device__ inline void backward_step(double &yh, double rdv, const double *const (&colq)[4], int lane)
+{
+    const double xi = readlane_f64(yh * rdv, i);
+    if (lane < i) yh = fma(-colq[i & 3][i >> 2], xi, yh);
+}
+
+template <int DP, int... Is>
+__device__ inline void backward_all(double &yh, double rdv, const double *const (&colq)[4], int lane, int D,
+                                    std::integer_sequence<int, Is...>)
+{
+    (((DP - 1 - Is) < D ? backward_step<DP, DP - 1 - Is>(yh, rdv, colq, lane) : (void)0), ...);
+}
+
+// ---- prior: a small pre-launch writes Lambda mu_i (the prior part of b) and the image of the index-reversed Lambda in
+// the accumulator layout ([block * 4 + r][lane], identity on the padding), which every wave adds with coalesced loads. ----
+__global__ __launch_bounds__(256) void k_prior(int D, int DP, int64_t nrows, const double *Lambda, const double *mu,
+                                               int mu_is_matrix, double *out_b, double *out_c)
+{
+    // waves 0 .. nrows*D-1: out_b[row*D + e] = sum_i Lambda[e][i] mu_row[i]  (nrows = 1 for a shared prior mean)
+    // then NB*4 waves, one per (block, register) of the image
     const int lane = threadIdx.x & 63;
     const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (idx >= nrows * D) return;
-    const int64_t row = idx / D;
-    const int e = (int)(idx % D);
-    const double *m = mu_is_matrix ? mu + row * D : mu;
-    double s = (lane < D) ? Lambda[e + (int64_t)lane * D] * m[lane] : 0.0;
+    const int DB = DP / 16;
+    if (idx < nrows * D) {
+        const int64_t row = idx / D;
+        const int e = (int)(idx % D);
+        const double *m = mu_is_matrix ? mu + row * D : mu;
+        double s = (lane < D) ? Lambda[e + (int64_t)lane * D] * m[lane] : 0.0;
 #pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    if (lane == 0) out[idx] = s;
+        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
+        if (lane == 0) out_b[idx] = s;
+        return;
+    }
+    const int e = (int)(idx - nrows * D);
+    if (e >= DB * (DB + 1) / 2 * 4) return;
+    const int b = e >> 2, r = e & 3;
+    int I = 0;
+    while ((I + 1) * (I + 2) / 2 <= b) I++;
+    const int J = b - I * (I + 1) / 2;
+    const int row = 16 * I + (lane >> 4) + 4 * r, colm = 16 * J + (lane & 15);
+    const int er = D - 1 - row, ecm = D - 1 - colm;
+    double v = (row == colm) ? 1.0 : 0.0;
+    if (er >= 0 && ecm >= 0) v = Lambda[er + (int64_t)ecm * D];
+    else if (er >= 0 || ecm >= 0) v = 0.0;
+    out_c[e * 64 + lane] = v;
 }
 
 // ---- sum the partials of a split row in slot order (fixed order: the result does not depend on which wave does it) ---
@@ -504,15 +538,15 @@ __device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int la
                                     double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, PSZ = Geo<DP>::PSZ;
+    constexpr int U = 1;                              // slots loaded per trip
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < DB; I++) bred[I] = 0.0;
-    // four slots are loaded per trip so that their latencies overlap
-    for (int s0 = 0; s0 < sr.n_slots; s0 += 4) {
-        double v[4][NB * 4 + DB];
+    for (int s0 = 0; s0 < sr.n_slots; s0 += U) {
+        double v[U][NB * 4 + DB];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             const int s = (s0 + u < sr.n_slots) ? s0 + u : sr.n_slots - 1;
             const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
 #pragma unroll
@@ -521,7 +555,7 @@ __device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int la
             for (int I = 0; I < DB; I++) v[u][NB * 4 + I] = src[NB * 4 * 64 + I * 16 + (lane & 15)];
         }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < U; u++) {
             if (s0 + u < sr.n_slots) {
 #pragma unroll
                 for (int b = 0; b < NB; b++)
@@ -536,33 +570,39 @@ __device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int la
 
 // ---- the launch: wave w < n_split accumulates split item w and publishes its partial; the wave whose publication
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
-// independent: cdna_hip_programming.md Guideline 16).  The remaining waves take G direct rows each. -----------------------
+// independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
+// One work item (index wi in [split items | direct items]) on one wave.
 template <int DP, bool DUMP>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) void k_rows(SampleArgs a, PlanDev p)
+__device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
-    constexpr int G = Geo<DP>::G, DB = Geo<DP>::DB, NB = Geo<DP>::NB, LD = Geo<DP>::LD, PSZ = Geo<DP>::PSZ;
-    constexpr int WPB = Geo<DP>::WPB;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * Geo<DP>::WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double *wl = lds + wave * Geo<DP>::WAVE_LDS;
-    const int64_t wid = (int64_t)blockIdx.x * WPB + wave;
-    const int grp = lane / DP, c = lane % DP;
-    double col[DP];
-    double bj = 0.0, znorm = 0.0;
-    int64_t myrow = -1;
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB, NB = GG::NB, PSZ = GG::PSZ;
+    const int j = lane & 15, h = lane >> 4;
+    const int D = a.D;
+    d4 acc[NB];
+    double bv[DB];
+    int64_t row;
     STAMP(0);
+#ifdef BDF_K1_STAMPS
+    if (lane == 0 && a.b_dump) {           // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID
+        ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) );
+        ((unsigned long long *)a.b_dump)[wid * 16 + 10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    }
+#endif
 
-    if (wid < p.n_split) {
-        d4 acc[NB];
-        double bred[DB];
-        const Item it = p.split[wid];
-        if (it.count > 0) accumulate_any<DP>(a, it, lane, wl, 0, false, acc, bred);
-        else {
+    const bool is_split = wid < p.n_split;                      // wave-uniform
+    const Item it = is_split ? p.split[wid] : p.direct[wid - p.n_split];
+    row = it.row;
+    if (it.count > 0) accumulate_any<DP>(a, it, lane, acc, bv);
+    else {
 #pragma unroll
-            for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+        for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int I = 0; I < DB; I++) bred[I] = 0.0;
-        }
+        for (int I = 0; I < DB; I++) bv[I] = 0.0;
+    }
+    STAMP(1);
+    if (is_split) {
         // slot layout [block*4 + r][lane] then b[I][j]; write-through (sc1) stores: the slab needs no L2 write-back
         double *dst = p.partials + (int64_t)it.slot * PSZ;
 #pragma unroll
@@ -573,7 +613,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
         if (lane < 16) {
 #pragma unroll
             for (int I = 0; I < DB; I++)
-                __hip_atomic_store(dst + NB * 4 * 64 + I * 16 + lane, bred[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(dst + NB * 4 * 64 + I * 16 + lane, bv[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         // publish: every lane's write-through stores have completed, then one arrival
         const SplitRow sr = p.rows[it.srow];
@@ -581,116 +621,107 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, (DP == 64) ? 1 : BDF_K1_WAVES) v
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
-        STAMP(1);
         if (old != sr.n_slots - 1) return;                      // not the last item of the row
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
-        // the row's normal (column c takes number D-1-c of the row's stream), drawn while few registers are live
-        if (grp == 0 && a.D - 1 - c >= 0 && !DUMP)
-            znorm = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)sr.row, a.D - 1 - c);
-        sum_partials<DP>(p, sr, lane, acc, bred);
+        sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
-        {
-            d4 lamc[NB];
-            load_prior_c<DP>(a, lane, lamc);
+    }
 #pragma unroll
-            for (int b = 0; b < NB; b++) acc[b] += lamc[b];
-        }
-        wave_sync();
-        acc_to_image<DP>(acc, wl, lane);
-        if (lane < 16) {
+    for (int b = 0; b < NB; b++)
 #pragma unroll
-            for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bred[I];
-        }
-        wave_sync();
-        if (grp == 0) {
+        for (int r = 0; r < 4; r++) acc[b][r] += a.prior_c[(b * 4 + r) * 64 + lane];
 #pragma unroll
-            for (int i = 0; i < DP; i++) col[i] = wl[i * LD + c];
-            bj = wl[DP * LD + c];
-            myrow = sr.row;
-        }
-    } else {
-        const int64_t first = (wid - p.n_split) * G;
-        if (first >= p.n_direct) return;
-        // accumulate the G rows of this wave one after the other; their accumulators stay in registers (NB*4 doubles
-        // each) until all are done, so that the column array of the finishing phase is not live during the gathers
-        d4 accg[G][NB];
-        double bredg[G][DB];
-        int64_t rows[G];
-        bool staged[G];
-        // the first NSTAGE items are staged together (one exposed latency) when they are matrix-relation items
-        bool all_matrix = true;
+    for (int J = 0; J < DB; J++) {
+        const int ec = D - 1 - (16 * J + j);
+        if (ec >= 0) bv[J] += a.prior_b[(a.mu_is_matrix ? row * D : 0) + ec];
+    }
+    STAMP(3);
+
+    if (DUMP) {
+        // P~ and b of the row (bdf_row_system): element (i, c) of the reversed system is entry (D-1-i, D-1-c) of P
+        int b = 0;
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const Item it = p.direct[first + g];
-            if (it.row >= 0 && a.t[it.term].n_other != 1) all_matrix = false;
-        }
+        for (int I = 0; I < DB; I++)
 #pragma unroll
-        for (int g = 0; g < G; g++)
-            staged[g] = (g < Geo<DP>::NSTAGE && (all_matrix || g == 0)) ? prestage<DP>(a, p.direct[first + g], lane, wl, g) : false;
+            for (int J = 0; J <= I; J++) {
 #pragma unroll
-        for (int g = 0; g < G; g++) {
-            const Item it = p.direct[first + g];
-            rows[g] = it.row;
-#pragma unroll
-            for (int b = 0; b < NB; b++) accg[g][b] = d4{0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-            for (int I = 0; I < DB; I++) bredg[g][I] = 0.0;
-            if (it.row >= 0 && it.count > 0)                                                            // wave-uniform
-                accumulate_any<DP>(a, it, lane, wl, staged[g] ? g : 0, staged[g], accg[g], bredg[g]);
-            STAMP(1 + g);
-        }
-        {
-            int64_t r = -1;
-#pragma unroll
-            for (int g = 0; g < G; g++) r = (grp == g) ? rows[g] : r;
-            if (r >= 0 && a.D - 1 - c >= 0 && !DUMP)
-                znorm = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)r, a.D - 1 - c);
-        }
-        {
-            d4 lamc[NB];                                  // loaded after the gathers so that it is not live during them
-            load_prior_c<DP>(a, lane, lamc);
-#pragma unroll
-            for (int g = 0; g < G; g++)
-#pragma unroll
-                for (int b = 0; b < NB; b++) accg[g][b] += lamc[b];
-        }
-#pragma unroll
-        for (int g = 0; g < G; g++) {
-            if (rows[g] >= 0) {
-                wave_sync();
-                acc_to_image<DP>(accg[g], wl, lane);
-                if (lane < 16) {
-#pragma unroll
-                    for (int I = 0; I < DB; I++) wl[DP * LD + I * 16 + lane] = bredg[g][I];
+                for (int r = 0; r < 4; r++) {
+                    const int ei = D - 1 - (16 * I + h + 4 * r), ec = D - 1 - (16 * J + j);
+                    if (ei >= 0 && ec >= 0) {
+                        a.P_dump[(row * D + ec) * D + ei] = acc[b][r];
+                        if (I != J) a.P_dump[(row * D + ei) * D + ec] = acc[b][r];
+                    }
                 }
-                wave_sync();
-                // select form (not a divergent block): the column array is updated in place, no second copy of it
-                const bool mine = (grp == g);
+                b++;
+            }
+        if (h == 0) {
 #pragma unroll
-                for (int i = 0; i < DP; i++) {
-                    const double v = wl[i * LD + c];
-                    col[i] = (g == 0 || mine) ? v : col[i];
-                }
-                const double vb = wl[DP * LD + c];
-                bj = mine ? vb : bj;
-                myrow = mine ? rows[g] : myrow;
+            for (int J = 0; J < DB; J++) {
+                const int ec = D - 1 - (16 * J + j);
+                if (ec >= 0) a.b_dump[row * D + ec] = bv[J];
             }
         }
+        return;
     }
-    wave_sync();
-    STAMP(3);
-    {
-        const int ec = a.D - 1 - c;
-        if (myrow >= 0 && ec >= 0) bj += a.prior_b[(a.mu_is_matrix ? myrow * a.D : 0) + ec];
-        else if (myrow < 0) {       // only the split-row finisher has unused lane groups
+
+    // the row's normals: lane c < D (lane = column from here on) draws number D-1-c of the row's stream
+    const double z = (lane < D) ? bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane) : 0.0;
+    STAMP(4);
+
+    double A[NB * 4];
 #pragma unroll
-            for (int i = 0; i < DP; i++) col[i] = (i == c) ? 1.0 : 0.0;
-            bj = 0.0;
-        }
+    for (int b = 0; b < NB; b++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) A[b * 4 + r] = acc[b][r];
+    double ts[DB];                                // ts[J] in lane j: t_(16 J + j) once its step has passed; the last column's
+#pragma unroll                                    // (and any column's before its step) is still in bv
+    for (int J = 0; J < DB; J++) ts[J] = 0.0;
+    factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
+    STAMP(5);
+
+    // lane c = column c: pivot d_c from the packed factor, t_c (the forward solve, unscaled) from the extra row
+    const int cK = (lane < DP) ? (lane >> 4) : 0, cj = lane & 15;
+    const int nr4 = (DP - 16 * cK) / 4;
+    const int cbase = 16 * (cK * DP - 8 * cK * (cK - 1) + cK) + cj * (DP - 16 * cK + 1);
+    wave_sync();
+    double dv = 1.0, tv = 0.0;
+    if (lane < D) dv = tri[cbase + (cj & 3) * nr4 + (cj >> 2)];
+    if (!(dv > 0.0)) atomicOr(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
+#pragma unroll
+    for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? (lane == D - 1 ? bv[J] : ts[J]) : tv;
+    const double rdv = fast_rcp(dv);
+    // L w = b, y = w + z carried as yh = y sqrt(d) = t + z sqrt(d);  then Lt' x = yh
+    double yh = fma(z, dv * fast_rsqrt(dv), tv);
+    const double *colq[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) colq[q] = tri + cbase + q * nr4 - 4 * cK;
+    backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
+    if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
+    STAMP(8);
+}
+
+template <int DP, bool DUMP>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, Geo<DP>::WAVES) void k_rows(SampleArgs a, PlanDev p)
+{
+    using GG = Geo<DP>;
+    constexpr int WPB = GG::WPB;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t w = (int64_t)blockIdx.x * WPB + wave;
+#ifdef BDF_K1_PRIO
+    // unequal issue priorities among the waves that share a SIMD (they come from different workgroups): the matrix pipe
+    // then serves them more nearly one after the other than all at once, and they reach the VALU-bound factorisation at
+    // different times
+    switch ((blockIdx.x / BDF_K1_PRIO) & 3) {
+    case 0: __builtin_amdgcn_s_setprio(0); break;
+    case 1: __builtin_amdgcn_s_setprio(1); break;
+    case 2: __builtin_amdgcn_s_setprio(2); break;
+    default: __builtin_amdgcn_s_setprio(3); break;
     }
-    finish_rows<DP, DUMP>(a, myrow, col, bj, znorm, wl, lane, wid);
+#endif
+    if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -706,6 +737,7 @@ struct Plan {
     PlanDev dev;
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
+    int32_t *order_dev = nullptr;
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
 };
@@ -725,8 +757,8 @@ int to_device(const std::vector<T> &v, T **out)
     return BDF_OK;
 }
 
-int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, const std::vector<int32_t> &rows, int G,
-               int psz, Plan &plan)
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, const std::vector<int32_t> &rows, int psz,
+               Plan &plan)
 {
     const int T = key.T;
     std::vector<Item> direct, split;
@@ -766,11 +798,26 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             srows.push_back(sr);
         }
     }
-    // a wave finishes G rows at once: fill the last wave by repeating its last row (same result written twice)
-    while (!direct.empty() && direct.size() % (size_t)G) direct.push_back(direct.back());
+    // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
+    // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
+    // so neighbours in launch order should differ in length: a fixed stride permutation of the sorted list.
+    const int64_t total = (int64_t)split.size() + (int64_t)direct.size();
+    std::vector<int32_t> order((size_t)total);
+    {
+        static const int mode = getenv("BDF_K1_ORDER") ? atoi(getenv("BDF_K1_ORDER")) : 1;
+        int64_t stride = 1;
+        if (mode == 1 && total > 2) {
+            stride = (int64_t)(0.6180339887 * (double)total) | 1;
+            auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+            while (gcd(stride, total) != 1) stride += 2;
+        }
+        for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i * stride) % total);
+        if (mode == 2)
+            for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i & 1) ? total - 1 - i / 2 : i / 2);
+    }
     int rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
-        (rc = to_device(srows, &plan.rows_dev)))
+        (rc = to_device(srows, &plan.rows_dev)) || (rc = to_device(order, &plan.order_dev)))
         return rc;
     BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
     BDF_HIP(hipMalloc((void **)&plan.arrived_dev, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
@@ -780,14 +827,15 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
     plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
     plan.dev.partials = plan.partials_dev;
     plan.dev.arrived = plan.arrived_dev;
+    plan.dev.order = plan.order_dev;
     return BDF_OK;
 }
 
 template <int DP>
 int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
-    constexpr int G = Geo<DP>::G, WPB = Geo<DP>::WPB;
-    const int64_t waves = (int64_t)p.n_split + p.n_direct / G;
+    constexpr int WPB = Geo<DP>::WPB;
+    const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
         dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
         if (dump) hipLaunchKernelGGL((k_rows<DP, true>), grid, block, 0, ctx->stream, a, p);
@@ -810,7 +858,7 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
         for (int r = 0; r < kv->first.n_terms; r++) hit = hit || kv->first.rel[r] == rel_serial;
         if (hit) {
             (void)hipFree(kv->second.direct_dev); (void)hipFree(kv->second.split_dev); (void)hipFree(kv->second.rows_dev);
-            (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev);
+            (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
             kv = plans.erase(kv);
         } else {
             ++kv;
@@ -827,18 +875,19 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         // prior part of b: Lambda mu (one vector) or Lambda mu_i for every row (per-row prior means, macau.jl:104)
         const int64_t N = rels[0]->dims[modes[0]];
         const int64_t nr = a.mu_is_matrix ? N : 1;
+        const int DPp = a.D <= 16 ? 16 : (a.D <= 32 ? 32 : 64);
+        const int nimg = (DPp / 16) * (DPp / 16 + 1) / 2 * 4;          // (block, register) pairs of the image
         void *pb;
-        int rc = bdf_scratch(ctx, (size_t)nr * a.D * sizeof(double), &pb);
+        int rc = bdf_scratch(ctx, ((size_t)nr * a.D + (size_t)nimg * 64) * sizeof(double), &pb);
         if (rc) return rc;
-        if (nr * a.D > 0) {
-            hipLaunchKernelGGL(k_prior_b, dim3((unsigned)((nr * a.D + 3) / 4)), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda,
-                               a.mu, a.mu_is_matrix, (double *)pb);
-            BDF_HIP(hipGetLastError());
-        }
+        const int64_t waves = nr * a.D + nimg;
+        hipLaunchKernelGGL(k_prior, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a.D, DPp, nr, a.Lambda, a.mu,
+                           a.mu_is_matrix, (double *)pb, (double *)pb + nr * a.D);
+        BDF_HIP(hipGetLastError());
         a.prior_b = (const double *)pb;
+        a.prior_c = (const double *)pb + nr * a.D;
     }
     const int DP = a.D <= 16 ? 16 : (a.D <= 32 ? 32 : 64);
-    const int G = 64 / DP;
     const int DB = DP / 16, NB = DB * (DB + 1) / 2;
     const int psz = NB * 4 * 64 + DB * 16;
     PlanKey key;
@@ -858,7 +907,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             std::vector<int32_t> rows;
             for (size_t pos = (size_t)shard; pos < order.size(); pos += (size_t)n_shards) rows.push_back(order[pos]);
             Plan np;
-            int rc = build_plan(ctx, key, rels, rows, G, psz, np);
+            int rc = build_plan(ctx, key, rels, rows, psz, np);
             if (rc) return rc;
             it = cache.plans.emplace(key, np).first;
         }

@@ -11,8 +11,12 @@ if [ "$1" = build ]; then
   tmp=$(mktemp -d)
   for f in $src/*.hip; do
     o=$tmp/$(basename ${f%.hip}).o
-    if [ $(basename $f) = k_sample_rows.hip ]; then extra="$flags"; else extra=""; fi
-    if [ $(basename $f) != k_sample_rows.hip ] && [ -f ${f%.hip}.o ]; then cp ${f%.hip}.o $o; continue; fi
+    extra=""
+    case "$(basename $f)" in
+      k_sample_rows.hip) extra="$flags" ;;
+      bdf_api.hip) case "$flags" in *BDF_K1_STAMPS*) extra="-DBDF_K1_STAMPS" ;; esac ;;
+    esac
+    if [ -z "$extra" ] && [ -f ${f%.hip}.o ]; then cp ${f%.hip}.o $o; continue; fi
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 $extra -c $f -o $o
   done
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $var/libbdf_$name.so $tmp/*.o
