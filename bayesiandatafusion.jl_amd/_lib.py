@@ -75,14 +75,16 @@ _SIGS = {
     "bdf_relation_value_mean": (C.c_int, [C.c_void_p, c_dp]),
     "bdf_relation_order": (C.c_int, [C.c_void_p, C.c_int, c_i32p]),
     "bdf_sample_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
-                                  C.c_uint32, C.c_int, C.c_int, C.c_void_p]),
+                                  C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "bdf_prior_pack_doubles": (C.c_int, [C.c_int]),
     "bdf_row_system": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "bdf_normals": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "bdf_philox": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bdf_hyper_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_hyper_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
-                                   C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                   C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_hyper_draws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint32, C.c_void_p]),
     "bdf_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
     "bdf_pairs_destroy": (C.c_int, [C.c_void_p]),
     "bdf_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),

@@ -41,9 +41,9 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->own_stream = false;
     c->stream = (hipStream_t)stream;          // NULL is the device's default stream
     BDF_HIP(hipMalloc((void **)&c->sweep_dev, sizeof(uint32_t)));
-    BDF_HIP(hipMalloc((void **)&c->flag_dev, sizeof(int)));
+    BDF_HIP(hipMalloc((void **)&c->flag_dev, 16 * sizeof(int)));      // [0] error flag, [1..] self-resetting arrival counters
     BDF_HIP(hipMemsetAsync(c->sweep_dev, 0, sizeof(uint32_t), c->stream));
-    BDF_HIP(hipMemsetAsync(c->flag_dev, 0, sizeof(int), c->stream));
+    BDF_HIP(hipMemsetAsync(c->flag_dev, 0, 16 * sizeof(int), c->stream));
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch_bytes = 0;
@@ -359,7 +359,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
 
 extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                                const double *mu, int mu_is_matrix, const double *Lambda,
-                               uint32_t entity_tag, int shard, int n_shards, double *out)
+                               uint32_t entity_tag, int shard, int n_shards, double *out, const double *prior_pack)
 {
     SampleArgs a;
     int rc = fill_args(ctx, "bdf_sample_rows", D, N, n_terms, terms, mu, mu_is_matrix, Lambda, a);
@@ -377,6 +377,7 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     }
     a.entity_tag = entity_tag;
     a.out = out;
+    if (prior_pack && !mu_is_matrix) { a.prior_b = prior_pack; a.prior_c = prior_pack + D; }
 #ifdef BDF_K1_STAMPS
     {   // diagnostic build only: per-wave phase stamps (16 x u64 per wave) readable through bdf_debug_stamps
         extern void *g_bdf_stamp_buf;

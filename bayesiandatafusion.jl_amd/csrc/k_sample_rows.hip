@@ -396,30 +396,65 @@ __device__ inline void fm1_self(double &d, double m)
 // lane reads back the entries of its own columns' rows (the multipliers of step k+1), so that neither the reciprocal
 // nor the LDS round trip sits between two steps.
 struct FactorLanes {            // per-lane LDS offsets (doubles), one per block column: kept opaque so that they stay in
-    int wr[4];                  // registers instead of being recomputed at every step
+    int wr[4];                  // registers instead of being recomputed at every step (wr: LDS byte address)
     int rd[4];
 };
 
 // preparation of step k: pivot (wave-uniform), column k to LDS by its four owner lanes, the lane's multipliers
-// nm[J] = -(Lt[16 J + j][k] / d_k).  (The LDS stores are asm so that the register-resident matrix is stored from where
-// it is; the compiler's own ds_write2 wanted copies.  LDS operations of a wave execute in order, and the compiler's wait
-// before it uses its reads covers them.)
+// nm[J] = -(Lt[16 J + j][k] / d_k); and the owner lanes keep entry k of the extra row (t_k, final now) in ts.
+// The owner lanes (j == k % 16) are a compile-time lane pattern, so their part runs under a constant EXEC mask set by
+// scalar moves: no vector compares, no copies (the compiler's own ds_write2 wanted the register-resident matrix copied).
+// LDS operations of a wave execute in order, and the compiler's wait before it uses its own reads covers these writes.
+template <int NV>
+struct OwnerStore;
+template <>
+struct OwnerStore<4> {
+    template <int MASK, int OFF>
+    __device__ static inline void run(unsigned addr, double v0, double v1, double v2, double v3)
+    {
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b32 exec_lo, %6\n\t"
+                     "s_mov_b32 exec_hi, %6\n\t"
+                     "ds_write_b64 %1, %2 offset:%7\n\t"
+                     "ds_write_b64 %1, %3 offset:%7+8\n\t"
+                     "ds_write_b64 %1, %4 offset:%7+16\n\t"
+                     "ds_write_b64 %1, %5 offset:%7+24\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(save) : "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(MASK), "n"(OFF) : "memory");
+    }
+};
+template <int MASK>
+__device__ inline void owner_keep(double &dst, double src)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %3\n\t"
+                 "s_mov_b32 exec_hi, %3\n\t"
+                 "v_mov_b64 %0, %2\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(save) : "v"(src), "n"(MASK));
+}
+
+template <int DP, int k, int... Is>
+__device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
+{
+    using GG = Geo<DP>;
+    constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16);
+    (OwnerStore<4>::run<MASK, (cb + 4 * Is) * 8>(addr, A[GG::blk(K + Is, K) * 4], A[GG::blk(K + Is, K) * 4 + 1],
+                                                 A[GG::blk(K + Is, K) * 4 + 2], A[GG::blk(K + Is, K) * 4 + 3]), ...);
+}
+
 template <int DP, int k>
-__device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], double *tri, const FactorLanes &fl, int j,
-                            double (&nm)[Geo<DP>::DB])
+__device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                            double *tri, const FactorLanes &fl, double (&nm)[Geo<DP>::DB])
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
+    constexpr int MASK = 0x00010001 << kj;                     // lanes with (lane & 15) == kj, per 32-lane half
     const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
-    if (j == kj) {
-        const unsigned waddr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + fl.wr[K] + cb);
-#pragma unroll
-        for (int I = K; I < DB; I++)
-#pragma unroll
-            for (int r = 0; r < 4; r++)
-                asm volatile("ds_write_b64 %0, %1 offset:%2" :: "v"(waddr), "v"(A[GG::blk(I, K) * 4 + r]),
-                             "n"((4 * (I - K) + r) * 8) : "memory");
-    }
+    owner_store_all<DP, k>(A, (unsigned)fl.wr[K], std::make_integer_sequence<int, DB - K>{});
+    owner_keep<MASK>(ts[K], bv[K]);
     wave_sync();
     double raw[DB];
 #pragma unroll
@@ -439,8 +474,6 @@ __device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Ge
     using GG = Geo<DP>;
     constexpr int DB = GG::DB;
     constexpr int K = k / 16, kj = k % 16;
-    ts[K] = (j == kj) ? bv[K] : ts[K];            // entry k of the extra row is final (t_k): keep it, the updates below
-                                                  // run unmasked over the finished columns
 #pragma unroll
     for (int J = DB - 1; J > K; J--) {
 #pragma unroll
@@ -459,7 +492,7 @@ __device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Ge
         }
         fm1_self<kj>(bv[K], nm[K]);
     }
-    prep<DP, k + 1>(A, tri, fl, j, nm);
+    prep<DP, k + 1>(A, bv, ts, tri, fl, nm);
 }
 
 template <int DP, int... Ks>
@@ -471,12 +504,12 @@ __device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo
 #pragma unroll
     for (int K = 0; K < GG::DB; K++) {
         const int nr4 = (DP - 16 * K) / 4;
-        fl.wr[K] = h * nr4;
+        fl.wr[K] = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * nr4);   // LDS byte address
         fl.rd[K] = (j & 3) * nr4 + (j >> 2);
         asm volatile("" : "+v"(fl.wr[K]), "+v"(fl.rd[K]));
     }
     double nm[GG::DB];
-    prep<DP, 0>(A, tri, fl, j, nm);
+    prep<DP, 0>(A, bv, ts, tri, fl, nm);
     // steps 0 .. D-2 (the last column has nothing to update; padded columns are skipped).  One wave-uniform exit per
     // step out of straight-line code (a skip-and-rejoin per step would make every step a merge point of the whole
     // register-resident matrix)
@@ -503,21 +536,30 @@ __device__ inline void backward_all(double &yh, double rdv, const double *const 
 __global__ __launch_bounds__(256) void k_prior(int D, int DP, int64_t nrows, const double *Lambda, const double *mu,
                                                int mu_is_matrix, double *out_b, double *out_c)
 {
-    // waves 0 .. nrows*D-1: out_b[row*D + e] = sum_i Lambda[e][i] mu_row[i]  (nrows = 1 for a shared prior mean)
-    // then NB*4 waves, one per (block, register) of the image
+    // groups of eight lanes 0 .. nrows*D-1: out_b[row*D + e] = sum_i Lambda[e][i] mu_row[i]  (nrows = 1 for a shared prior
+    // mean); lane part p adds i = p, p+8, ... in order, then a three-step butterfly (the order k_hyper_sample uses too).
+    // Then NB*4 waves, one per (block, register) of the image.
     const int lane = threadIdx.x & 63;
-    const int64_t idx = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const int DB = DP / 16;
-    if (idx < nrows * D) {
-        const int64_t row = idx / D;
-        const int e = (int)(idx % D);
-        const double *m = mu_is_matrix ? mu + row * D : mu;
-        double s = (lane < D) ? Lambda[e + (int64_t)lane * D] * m[lane] : 0.0;
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-        if (lane == 0) out_b[idx] = s;
+    const int64_t nb8 = (nrows * D + 7) / 8;                  // waves used by the first part
+    if ((t >> 6) < nb8) {
+        const int64_t o = t >> 3;
+        const int part = (int)(t & 7);
+        double v = 0.0;
+        if (o < nrows * D) {
+            const int64_t row = o / D;
+            const int e = (int)(o % D);
+            const double *m = mu_is_matrix ? mu + row * D : mu;
+            for (int i = part; i < D; i += 8) v = fma(Lambda[e + (int64_t)i * D], m[i], v);
+        }
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (part == 0 && o < nrows * D) out_b[o] = v;
         return;
     }
+    const int64_t idx = (t >> 6) - nb8 + nrows * D;
     const int e = (int)(idx - nrows * D);
     if (e >= DB * (DB + 1) / 2 * 4) return;
     const int b = e >> 2, r = e & 3;
@@ -690,7 +732,7 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     if (lane < D) dv = tri[cbase + (cj & 3) * nr4 + (cj >> 2)];
     if (!(dv > 0.0)) atomicOr(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
 #pragma unroll
-    for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? (lane == D - 1 ? bv[J] : ts[J]) : tv;
+    for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? ts[J] : tv;
     const double rdv = fast_rcp(dv);
     // L w = b, y = w + z carried as yh = y sqrt(d) = t + z sqrt(d);  then Lt' x = yh
     double yh = fma(z, dv * fast_rsqrt(dv), tv);
@@ -871,7 +913,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
                            int n_shards, bool dump)
 {
     SampleArgs a = a_in;
-    {
+    if (a.prior_b == nullptr) {         // no prior pack from bdf_hyper_sample: derive Lambda mu and the image here
         // prior part of b: Lambda mu (one vector) or Lambda mu_i for every row (per-row prior means, macau.jl:104)
         const int64_t N = rels[0]->dims[modes[0]];
         const int64_t nr = a.mu_is_matrix ? N : 1;
@@ -880,7 +922,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         void *pb;
         int rc = bdf_scratch(ctx, ((size_t)nr * a.D + (size_t)nimg * 64) * sizeof(double), &pb);
         if (rc) return rc;
-        const int64_t waves = nr * a.D + nimg;
+        const int64_t waves = (nr * a.D + 7) / 8 + nimg;
         hipLaunchKernelGGL(k_prior, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a.D, DPp, nr, a.Lambda, a.mu,
                            a.mu_is_matrix, (double *)pb, (double *)pb + nr * a.D);
         BDF_HIP(hipGetLastError());

@@ -269,6 +269,12 @@ class EntityState:
         self.sumU = ctx.zeros(D)
         self.UUt = ctx.zeros(D, D)
         self.params = ctx.zeros(D + D * D)
+        # what K1 needs of (mu, Lambda), written by the hyperprior draw (bdf_hyper_sample) so that K1 needs no pre-launch
+        self.prior_pack = ctx.zeros(lib().bdf_prior_pack_doubles(D))
+        self.prior_pack_valid = False
+        # the random part of the hyperprior draw (Bartlett matrix + mean normals), drawn ahead of the rows (bdf_hyper_draws)
+        self.draws = ctx.zeros(D * D + D)
+        self.draws_sweep = None
         self.F = None
         self.numF = 0
         self.beta = ctx.zeros(D, 0)
@@ -346,6 +352,8 @@ class GibbsEngine:
         self._test_pairs = None
         self._train_pairs = None
         self.k1_events = None     # bench.py: list of (entity, start, end) HIP events around each K1 launch
+        self.k1_event_every = 1   # ... of every n-th sweep (an event pair costs the stream several microseconds)
+        self._k1_sweep = 0
 
     def k1_algorithmic_bytes(self, j):
         """bytes one K1 launch over all rows of entity j must move, summed over its relations:
@@ -393,12 +401,14 @@ class GibbsEngine:
         if st.F is not None:
             check(lib().bdf_uhat(self.ctx.handle, st.F.handle, self.D, _ptr(st.beta), _ptr(st.mu), _ptr(st.uhat), _ptr(st.mu_matrix)))
             mu, is_matrix = st.mu_matrix, 1
-        if self.k1_events is not None:
+        timed = self.k1_events is not None and self._k1_sweep % self.k1_event_every == 0
+        if timed:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(self.ctx.stream)
+        pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
         check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
-                                    st.tag, self.rank, self.world, _ptr(st.sample)))
-        if self.k1_events is not None:
+                                    st.tag, self.rank, self.world, _ptr(st.sample), _ptr(pack) if pack is not None else None))
+        if timed:
             e1.record(self.ctx.stream)
             self.k1_events.append((j, e0, e1))
         if self.world > 1:
@@ -409,10 +419,21 @@ class GibbsEngine:
         allgather_rows(self.ent[j].sample, self._rowlist(j), self.rank, self.world)
 
     # ---- macau.jl:119-134: hyperprior of entity j ----------------------------------------------------------------
-    def update_prior(self, j):
+    def _hyper_nu(self, j):
+        st = self.ent[j]
+        return st.nu0 + (st.numF if (st.F is not None and self.full_lambda_u) else 0)
+
+    def prepare_prior(self, j, sweep):
+        """the data-independent part of update_prior(j) of this sweep; may be issued before the rows of j are sampled"""
+        st = self.ent[j]
+        check(lib().bdf_hyper_draws(self.ctx_h.handle, self.D, st.N, self._hyper_nu(j), st.tag, _ptr(st.draws)))
+        st.draws_sweep = sweep
+
+    def update_prior(self, j, sweep=None):
         en, st = self.data.entities[j], self.ent[j]
         L = lib()
         h = self.ctx_h.handle
+        draws = st.draws if (sweep is not None and st.draws_sweep == sweep) else None
         check(L.bdf_hyper_sums(h, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
                                _ptr(st.sumU), _ptr(st.UUt)))
         nu, Tinv = st.nu0, st.WI
@@ -421,7 +442,9 @@ class GibbsEngine:
             check(L.bdf_hyper_feature_terms(h, self.D, st.numF, _ptr(st.beta), _ptr(st.WI), _ptr(st.lambda_beta), _ptr(st.Tinv)))
             Tinv = st.Tinv
         check(L.bdf_hyper_sample(h, self.D, st.N, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
-                                 nu, st.tag, _ptr(st.mu), _ptr(st.Lambda), _ptr(st.params)))
+                                 nu, st.tag, _ptr(st.mu), _ptr(st.Lambda), _ptr(st.params), _ptr(st.prior_pack),
+                                 _ptr(draws) if draws is not None else None))
+        st.prior_pack_valid = True
 
     # ---- macau.jl:138-140: beta of entity j ----------------------------------------------------------------
     def update_beta(self, j):
@@ -441,18 +464,21 @@ class GibbsEngine:
     def sweep(self, i):
         main, side = self.ctx.stream, self.ctx_h.stream
         two = self.ctx_h is not self.ctx
+        self._k1_sweep = i
         self.ctx.set_sweep(i)
         if two:
             self.ctx_h.set_sweep(i)
         for j in range(len(self.ent)):
             if two and j in self._ev_hyper:
                 main.wait_event(self._ev_hyper[j])       # (mu, Lambda) of entity j from the previous iteration
+            if two:
+                self.prepare_prior(j, i)                 # side stream, beside the row sampling
             self.sample_entity(j)
             if two:
                 ev = self._ev_rows.setdefault(j, torch.cuda.Event())
                 ev.record(main)
                 side.wait_event(ev)
-            self.update_prior(j)
+            self.update_prior(j, i)
             if two:
                 ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
                 ev.record(side)

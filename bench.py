@@ -74,6 +74,8 @@ def main():
     ap.add_argument("--num-latent", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--k1-event-every", type=int, default=8,
+                    help="HIP-event pairs around the K1 launches of every n-th step (each pair costs the stream microseconds)")
     ap.add_argument("--no-predict", action="store_true", help="leave the test-set prediction update out of the step")
     args = ap.parse_args()
 
@@ -118,6 +120,7 @@ def main():
     eng.sync()
     fence()
     eng.k1_events = []
+    eng.k1_event_every = args.k1_event_every
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + 1 + k, 1 if k == 0 else 2)

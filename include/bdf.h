@@ -118,10 +118,14 @@ typedef struct {
  * macau.jl:103-105).  (shard, n_shards): the rows sampled are positions shard, shard + n_shards, ... of
  * bdf_relation_order(terms[0].rel, terms[0].mode) -- the reference deals rows i:P:N to its P workers
  * (sampling.jl:154); (0, 1) = every row.  out: dev D x N; only this shard's rows are written; must not
- * alias any terms[].factors[k] with k != mode. */
+ * alias any terms[].factors[k] with k != mode.
+ * prior_pack (dev, nullable): the pack bdf_hyper_sample wrote for exactly this (mu, Lambda) -- Lambda mu and Lambda
+ * laid out for the row kernel; saves the small pre-launch that otherwise derives them.  Ignored with mu_is_matrix. */
 int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                     const double *mu, int mu_is_matrix, const double *Lambda,
-                    uint32_t entity_tag, int shard, int n_shards, double *out);
+                    uint32_t entity_tag, int shard, int n_shards, double *out, const double *prior_pack);
+/* doubles in a prior pack for num_latent = D */
+int bdf_prior_pack_doubles(int D);
 /* parity hook: the deterministic part only.  P_out: dev D x D x N, b_out: dev D x N */
 int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                    const double *mu, int mu_is_matrix, const double *Lambda,
@@ -141,10 +145,16 @@ int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *sample, const d
 /* ConditionalNormalWishart + rand(::NormalWishart): draws (mu, Lambda) on the device from the sums.
  * mu0 (dev D), Tinv (dev D x D), b0, nu: the hyper-prior AFTER the feature terms of macau.jl:124-129.
  * params_out (dev, nullable): mu_N (D) followed by inv(T_N) (D x D, the matrix sampling.jl:124 inverts)
- * for parity checks. */
+ * for parity checks.  prior_pack_out (dev, nullable, bdf_prior_pack_doubles(D) doubles): what bdf_sample_rows needs of
+ * the drawn (mu, Lambda), see there.  draws (dev, nullable): output of bdf_hyper_draws for the same arguments. */
 int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *sumU, const double *UUt,
                      const double *mu0, double b0, const double *Tinv, double nu,
-                     uint32_t entity_tag, double *mu_out, double *Lambda_out, double *params_out);
+                     uint32_t entity_tag, double *mu_out, double *Lambda_out, double *params_out, double *prior_pack_out,
+                     const double *draws);
+/* The random part of bdf_hyper_sample (Bartlett matrix D x D row-major, then the D normals of the mean: D*D + D doubles),
+ * which does not depend on the rows: call it for the same (sweep, N, nu, entity_tag) before the rows are done and pass the
+ * buffer as `draws` to take the gamma rejection loops off the critical path.  Same streams, same values. */
+int bdf_hyper_draws(bdf_ctx *ctx, int D, int64_t N, double nu, uint32_t entity_tag, double *draws_out);
 
 /* ---- f2: test-set prediction (src/sampling.jl:9-45, macau.jl:142-203, 231-241) -------- */
 /* ids: n x n_modes column-major 1-based (test_vec[:,1:end-1]); values: n (test_vec[:,end]) */

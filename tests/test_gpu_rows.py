@@ -46,10 +46,10 @@ def _p(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
-def _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, tag, out_t, shard=0, n_shards=1):
+def _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, tag, out_t, shard=0, n_shards=1, pack_t=None):
     from bdf_amd._lib import check, lib
     check(lib().bdf_sample_rows(ctx.handle, D, N, len(terms), terms, _p(mu_t), int(mu_t.dim() == 2), _p(Lam_t), tag,
-                                shard, n_shards, _p(out_t)))
+                                shard, n_shards, _p(out_t), _p(pack_t)))
     ctx.sync()
 
 
@@ -217,7 +217,7 @@ def test_row_moments(B, O, ctx):
     from bdf_amd._lib import check, lib
     for s in range(n):
         ctx.set_sweep(s + 1)
-        check(lib().bdf_sample_rows(ctx.handle, D, 4, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, 0, 1, _p(out_t)))
+        check(lib().bdf_sample_rows(ctx.handle, D, 4, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, 0, 1, _p(out_t), None))
         draws[s] = out_t[1].cpu().numpy()
     P, b = O.row_system(D, [O.Term(ids, vals, dims, 0, 2.0, 0.1, [None, facs[1]])], 1, mu, Lam)
     cov = np.linalg.inv(P)
@@ -240,7 +240,7 @@ def test_not_positive_definite_is_reported(B, ctx):
     bad_t, mu_t = ctx.tensor(-np.eye(D) * 1e6), ctx.tensor(mu)
     out_t = ctx.zeros(5, D)
     from bdf_amd._lib import check, lib
-    check(lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu_t), 0, _p(bad_t), 1, 0, 1, _p(out_t)))
+    check(lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu_t), 0, _p(bad_t), 1, 0, 1, _p(out_t), None))
     with pytest.raises(B.NotPositiveDefinite):
         ctx.sync()
     ctx.sync()      # flag is cleared
@@ -257,13 +257,13 @@ def test_argument_errors(B, ctx):
     terms = _dev_terms(B, ctx, [(dr, 0, 1.0, 0.0, [None, f2], None)])
     mu, Lam = ctx.zeros(D), ctx.tensor(np.eye(D))
     # entity count disagrees with the relation (ArgumentError, RelationData.jl:399)
-    assert lib().bdf_sample_rows(ctx.handle, D, 7, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, D, 7, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1), None) == -1
     # num_latent out of range
-    assert lib().bdf_sample_rows(ctx.handle, 65, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, 65, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f1), None) == -1
     # output aliasing a gathered factor
-    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f2)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 0, 1, _p(f2), None) == -1
     # shard outside 0..n_shards-1
-    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 2, 2, _p(f1)) == -1
+    assert lib().bdf_sample_rows(ctx.handle, D, 5, 1, terms, _p(mu), 0, _p(Lam), 1, 2, 2, _p(f1), None) == -1
     with pytest.raises(B.BoundsError):
         B.DeviceRelation(ctx, type("X", (), {"dims": [2, 2], "values": np.ones(1), "ids": np.asfortranarray(np.array([[3, 1]])),
                                              "nnz": lambda self: 1})())
@@ -307,7 +307,7 @@ def test_hyper_sums_and_normal_wishart(B, O, ctx, D, N, with_uhat):
     mu_t, Lam_t, par_t = ctx.zeros(D), ctx.zeros(D, D), ctx.zeros(D + D * D)
     mu0_t, Tinv_t = ctx.tensor(mu0), ctx.tensor(Tinv)      # keep alive until the kernel has run
     check(lib().bdf_hyper_sample(ctx.handle, D, N, _p(sumU), _p(UUt), _p(mu0_t), b0, _p(Tinv_t), nu, 5,
-                                 _p(mu_t), _p(Lam_t), _p(par_t)))
+                                 _p(mu_t), _p(Lam_t), _p(par_t), None, None))
     ctx.sync()
     mu_N, beta_N, T_N, nu_N = O.hyper_params(U, mu0, b0, Tinv, nu)
     par = par_t.cpu().numpy()
@@ -317,6 +317,46 @@ def test_hyper_sums_and_normal_wishart(B, O, ctx, D, N, with_uhat):
     mu_e, Lam_e = O.hyper_draw(mu_N, beta_N, T_N, nu_N, SEED, 12, 5)
     np.testing.assert_allclose(Lam_t.cpu().numpy(), Lam_e, rtol=1e-7, atol=1e-9)
     np.testing.assert_allclose(mu_t.cpu().numpy(), mu_e, rtol=1e-7, atol=1e-9)
+    # the random part drawn ahead of time (bdf_hyper_draws) gives the same bits
+    draws_t, mu2_t, Lam2_t = ctx.zeros(D * D + D), ctx.zeros(D), ctx.zeros(D, D)
+    check(lib().bdf_hyper_draws(ctx.handle, D, N, nu, 5, _p(draws_t)))
+    check(lib().bdf_hyper_sample(ctx.handle, D, N, _p(sumU), _p(UUt), _p(mu0_t), b0, _p(Tinv_t), nu, 5,
+                                 _p(mu2_t), _p(Lam2_t), None, None, _p(draws_t)))
+    ctx.sync()
+    assert np.array_equal(mu2_t.cpu().numpy(), mu_t.cpu().numpy())
+    assert np.array_equal(Lam2_t.cpu().numpy(), Lam_t.cpu().numpy())
+
+
+@pytest.mark.parametrize("D", [5, 16, 32, 40])
+def test_prior_pack_equals_prelaunch(B, O, ctx, D):
+    """bdf_hyper_sample's prior pack (Lambda mu and the accumulator-layout image of Lambda) gives bdf_sample_rows bit for bit
+    what its own pre-launch derives from (mu, Lambda)"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(100 + D)
+    N = 300
+    S_t = ctx.tensor(rng.standard_normal((N, D)))
+    sumU, UUt = ctx.zeros(D), ctx.zeros(D, D)
+    check(lib().bdf_hyper_sums(ctx.handle, D, N, _p(S_t), None, _p(sumU), _p(UUt)))
+    mu0_t, Tinv_t = ctx.zeros(D), ctx.tensor(np.eye(D))
+    mu_t, Lam_t = ctx.zeros(D), ctx.zeros(D, D)
+    pack_t = ctx.zeros(lib().bdf_prior_pack_doubles(D))
+    ctx.set_sweep(3)
+    check(lib().bdf_hyper_sample(ctx.handle, D, N, _p(sumU), _p(UUt), _p(mu0_t), 2.0, _p(Tinv_t), float(D), 9,
+                                 _p(mu_t), _p(Lam_t), None, _p(pack_t), None))
+    ctx.sync()
+    Lam, mu = Lam_t.cpu().numpy(), mu_t.cpu().numpy()
+    np.testing.assert_allclose(pack_t.cpu().numpy()[:D], Lam @ mu, rtol=1e-12, atol=1e-12)
+    dims = [40, 30]
+    ids, vals, facs, _, _ = _problem(rng, dims, 700, D)
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    ft = [ctx.tensor(f) for f in facs]
+    terms = _dev_terms(B, ctx, [(dr, 0, 1.7, float(vals.mean()), [None, ft[1]], None)])
+    out_a, out_b = ctx.zeros(dims[0], D), ctx.zeros(dims[0], D)
+    ctx.set_sweep(4)
+    _run_rows(B, ctx, D, dims[0], terms, mu_t, Lam_t, 2, out_a)
+    _run_rows(B, ctx, D, dims[0], terms, mu_t, Lam_t, 2, out_b, pack_t=pack_t)
+    assert np.array_equal(out_a.cpu().numpy(), out_b.cpu().numpy())
+    dr.close()
 
 
 def test_predict_and_running_mean(B, O, ctx):

@@ -15,6 +15,7 @@ if [ "$1" = build ]; then
     case "$(basename $f)" in
       k_sample_rows.hip) extra="$flags" ;;
       bdf_api.hip) case "$flags" in *BDF_K1_STAMPS*) extra="-DBDF_K1_STAMPS" ;; esac ;;
+      k_hyper.hip) case "$flags" in *BDF_HYPER_STAMPS*) extra="-DBDF_HYPER_STAMPS" ;; esac ;;
     esac
     if [ -z "$extra" ] && [ -f ${f%.hip}.o ]; then cp ${f%.hip}.o $o; continue; fi
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 $extra -c $f -o $o

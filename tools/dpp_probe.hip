@@ -51,8 +51,30 @@ __global__ void k_spin(unsigned long long ticks, unsigned long long *o)
     o[1] = __builtin_amdgcn_s_memrealtime() - r0;
 }
 
+__global__ void k_rcp(double *o)
+{
+    // accuracy of v_rcp_f64 / v_rsq_f64 alone and after one Newton step
+    const double x = 0.37 + threadIdx.x * 1.618033988749;
+    double y = __builtin_amdgcn_rcp(x);
+    o[threadIdx.x * 4 + 0] = fabs(y * x - 1.0);
+    double e = fma(-x, y, 1.0); y = fma(y, e, y);
+    o[threadIdx.x * 4 + 1] = fabs(fma(y, x, -1.0));
+    double r = __builtin_amdgcn_rsq(x);
+    o[threadIdx.x * 4 + 2] = fabs(r * r * x - 1.0);
+    double e2 = fma(-x * r, r, 1.0); r = fma(r * 0.5, e2, r);
+    o[threadIdx.x * 4 + 3] = fabs(fma(r * r, x, -1.0));
+}
+
 int main()
 {
+    {
+        double *o; hipMalloc(&o, 256 * 4 * 8);
+        k_rcp<<<1, 256>>>(o);
+        std::vector<double> h(1024); hipMemcpy(h.data(), o, 8192, hipMemcpyDeviceToHost);
+        double m[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 256; i++) for (int q = 0; q < 4; q++) m[q] = h[i * 4 + q] > m[q] ? h[i * 4 + q] : m[q];
+        printf("max relative error: v_rcp_f64 %.3g, +1 Newton %.3g; v_rsq_f64 %.3g, +1 Newton %.3g\n", m[0], m[1], m[2], m[3]);
+    }
     {   // what does s_memtime count?  spin for 2^28 ticks and compare with the wall clock and s_memrealtime (100 MHz)
         unsigned long long *o; hipMalloc(&o, 16);
         hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
