@@ -14,7 +14,7 @@ BDF_MAX_MODES = 4
 BDF_MAX_TERMS = 4
 BDF_MAX_D = 64
 
-P_ROW, P_BETA_E1, P_BETA_E2, P_NW_NORMAL, P_GAMMA_N, P_GAMMA_U, P_NW_MEAN = 1, 2, 3, 4, 5, 6, 7
+P_ROW, P_BETA_E1, P_BETA_E2, P_NW_NORMAL, P_GAMMA_N, P_GAMMA_U, P_NW_MEAN, P_BETA_REL1, P_BETA_REL2 = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 class ArgumentError(ValueError):
@@ -85,6 +85,12 @@ _SIGS = {
     "bdf_hyper_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                    C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_hyper_draws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint32, C.c_void_p]),
+    "bdf_pairs_set_baseline": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_feat_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
+    "bdf_predict_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p, C.c_void_p]),
+    "bdf_sample_alpha": (C.c_int, [C.c_void_p, C.c_double, C.c_double, C.c_int64, C.c_void_p, C.c_uint32, C.c_void_p]),
+    "bdf_sample_beta_rel": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_double,
+                                      C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
     "bdf_pairs_destroy": (C.c_int, [C.c_void_p]),
     "bdf_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),

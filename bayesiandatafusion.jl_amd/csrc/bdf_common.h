@@ -69,6 +69,7 @@ struct bdf_pairs {
     double *values_dev;   // n
     double *avg_dev, *sq_dev;
     double count;         // counter_prob (macau.jl:171-183)
+    const double *baseline_dev;   // nullable, borrowed: per-pair baseline replacing mean_value (relation features)
 };
 
 struct bdf_feat {
@@ -203,4 +204,5 @@ struct SampleArgs {
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump);
-void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);   // rel_serial 0: every plan of the context
+void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
+int bdf_predict_plain(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value, double *out);   // rel_serial 0: every plan of the context

@@ -559,6 +559,44 @@ extern "C" int bdf_hyper_feature_terms(bdf_ctx *ctx, int D, int64_t numF, const 
     return BDF_OK;
 }
 
+// D simultaneous cg_AtA solves of (F'F + lambda I) X = rhs (solve_cg2, parallel_matrix.jl:488-507); with use_ff the operator
+// is the precomputed F'F.  R, P, Z: numF x D; Tm: N x D; scal: 3 D doubles; ints: 2 D + 1 ints.
+static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double *lambda_beta_dev, const double *rhs,
+                    double *beta_out, double tol, int maxiter, double *R, double *P, double *Z, double *Tm, double *scal,
+                    int *ints, int **iters_dev)
+{
+    const int64_t N = f->m, numF = f->n;
+    int rc;
+    CgState s;
+    s.n = numF; s.D = D; s.X = beta_out; s.R = R; s.P = P; s.Z = Z;
+    s.bknum = scal; s.bkden = scal + D; s.tolb = scal + 2 * D;
+    s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
+    hipLaunchKernelGGL(k_cg_init, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)rhs, tol);
+    BDF_HIP(hipGetLastError());
+    for (int iter = 1; iter <= maxiter; iter++) {
+        hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, iter);
+        if (use_ff) {
+            GemmArgs g;
+            g.M = numF; g.N = D; g.K = numF; g.A = f->FF_dev; g.ars = 1; g.acs = numF;
+            g.B = P; g.brs = 1; g.bcs = numF; g.C = Z; g.crs = 1; g.ccs = numF; g.bias = nullptr; g.C2 = nullptr;
+            if ((rc = gemm(ctx, g))) return rc;
+        } else {
+            if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, 1, N))) return rc;
+            if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
+        }
+        hipLaunchKernelGGL(k_cg_post, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter);
+        BDF_HIP(hipGetLastError());
+        if (iter % 8 == 0 || iter == maxiter) {
+            int nact = 0;
+            BDF_HIP(hipMemcpyAsync(&nact, s.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+            BDF_HIP(hipStreamSynchronize(ctx->stream));
+            if (nact == 0) break;
+        }
+    }
+    *iters_dev = s.iters;
+    return BDF_OK;
+}
+
 extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const double *sample, const double *mu,
                                const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
                                int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
@@ -609,38 +647,125 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
         if (iters_out) BDF_HIP(hipMemsetAsync(iters_out, 0, D * sizeof(int32_t), ctx->stream));
     } else {
         // D simultaneous cg_AtA solves; with use_ff the operator is the precomputed F'F (same system, numF > 64)
-        CgState s;
-        s.n = numF; s.D = D; s.X = beta_out; s.R = R; s.P = P; s.Z = Z;
-        s.bknum = scal; s.bkden = scal + D; s.tolb = scal + 2 * D;
-        s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
-        hipLaunchKernelGGL(k_cg_init, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)rhs, tol);
-        BDF_HIP(hipGetLastError());
-        for (int iter = 1; iter <= maxiter; iter++) {
-            hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, iter);
-            if (use_ff) {
-                GemmArgs g;
-                g.M = numF; g.N = D; g.K = numF; g.A = f->FF_dev; g.ars = 1; g.acs = numF;
-                g.B = P; g.brs = 1; g.bcs = numF; g.C = Z; g.crs = 1; g.ccs = numF; g.bias = nullptr; g.C2 = nullptr;
-                if ((rc = gemm(ctx, g))) return rc;
-            } else {
-                if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, 1, N))) return rc;
-                if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
-            }
-            hipLaunchKernelGGL(k_cg_post, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter);
-            BDF_HIP(hipGetLastError());
-            if (iter % 8 == 0 || iter == maxiter) {
-                int nact = 0;
-                BDF_HIP(hipMemcpyAsync(&nact, s.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-                BDF_HIP(hipStreamSynchronize(ctx->stream));
-                if (nact == 0) break;
-            }
-        }
-        if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, s.iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        int *cg_iters = nullptr;
+        if ((rc = cg_solve(ctx, f, use_ff != 0, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+        if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (sample_lambda) {
         hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, (const double *)beta_out, G);
         hipLaunchKernelGGL(k_lambda_beta, dim3(1), dim3(64), 0, ctx->stream, D, numF, (const double *)G, Lambda, lb_nu, lb_mu,
                            ctx->seed, ctx->sweep_host, entity_tag, lambda_beta_dev);
+        BDF_HIP(hipGetLastError());
+    }
+    return BDF_OK;
+}
+
+// ---- relation-level side information (sample_beta_rel, src/sampling.jl:322-337) and alpha (sample_alpha, :129-134) -----
+__global__ void k_rel_target(int64_t N, const double *values, const double *pred, double inv_sqrt_alpha, uint64_t seed,
+                             uint32_t sweep, uint32_t tag, double *v)
+{
+    // v = (values - udot - mean) + alpha^-1/2 z,  pred = udot + mean
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < N) v[i] = (values[i] - pred[i]) + inv_sqrt_alpha * bdf_normal(seed, sweep, BDF_P_BETA_REL1, tag, (uint64_t)i, 0);
+}
+
+__global__ void k_rel_rhs(int64_t numF, double alpha, double lambda, uint64_t seed, uint32_t sweep, uint32_t tag,
+                          double *rhs, double *rhs_scaled, double *lam_scaled)
+{
+    // aFt_y = alpha F'v + sqrt(lambda) z;  the solve runs on (FF + (lambda / alpha) I) beta = aFt_y / alpha
+    const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (f < numF) {
+        const double r = alpha * rhs[f] + sqrt(lambda) * bdf_normal(seed, sweep, BDF_P_BETA_REL2, tag, (uint64_t)f, 0);
+        rhs[f] = r;
+        rhs_scaled[f] = r / alpha;
+    }
+    if (f == 0) *lam_scaled = lambda / alpha;
+}
+
+__global__ void k_add_scalar(int64_t n, double a, double *x)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) x[i] += a;
+}
+
+__global__ void k_sample_alpha(double lambda0, double nu0, double n, const double *sumsq, uint64_t seed, uint32_t sweep,
+                               uint32_t tag, double *alpha_out)
+{
+    // Wishart(nu0 + n, SW) in one dimension: SW * chi2(nu0 + n) = SW * 2 Gamma((nu0 + n) / 2)
+    const double SW = 1.0 / (1.0 / lambda0 + *sumsq);
+    *alpha_out = SW * 2.0 * bdf_gamma(seed, sweep, tag, 0, 0.5 * (nu0 + n));
+}
+
+extern "C" int bdf_feat_linear(bdf_ctx *ctx, const bdf_feat *f, const double *beta, double mean_value, double *out)
+{
+    // out = mean_value + F beta (one column): linear_values of macau.jl:91, and the test rows' baseline of pred(r, probe, F)
+    BDF_REQUIRE(ctx && f && beta && out, BDF_ERR_ARG, "bdf_feat_linear: NULL argument");
+    int rc = feat_apply(ctx, f, false, beta, 1, f->n, 1, out, 1, f->m);
+    if (rc) return rc;
+    if (f->m > 0) {
+        hipLaunchKernelGGL(k_add_scalar, dim3((unsigned)((f->m + 255) / 256)), dim3(256), 0, ctx->stream, f->m, mean_value, out);
+        BDF_HIP(hipGetLastError());
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_sample_alpha(bdf_ctx *ctx, double alpha_lambda0, double alpha_nu0, int64_t n, const double *sumsq_err,
+                                uint32_t rel_tag, double *alpha_out)
+{
+    BDF_REQUIRE(ctx && sumsq_err && alpha_out, BDF_ERR_ARG, "bdf_sample_alpha: NULL argument");
+    hipLaunchKernelGGL(k_sample_alpha, dim3(1), dim3(1), 0, ctx->stream, alpha_lambda0, alpha_nu0, (double)n, sumsq_err,
+                       ctx->seed, ctx->sweep_host, 0x800000u | rel_tag, alpha_out);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *fc, const bdf_pairs *train, int D,
+                                   const double *const *factors, double mean_value, double alpha, double lambda_beta,
+                                   uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out)
+{
+    BDF_REQUIRE(ctx && fc && train && factors && beta_out && linear_out, BDF_ERR_ARG, "bdf_sample_beta_rel: NULL argument");
+    BDF_REQUIRE(alpha > 0.0 && lambda_beta >= 0.0, BDF_ERR_ARG, "bdf_sample_beta_rel: alpha must be positive, lambda_beta >= 0");
+    bdf_feat *f = const_cast<bdf_feat *>(fc);
+    const int64_t N = f->m, numF = f->n;
+    BDF_REQUIRE(train->n == N, BDF_ERR_ARG,
+                "bdf_sample_beta_rel: the relation has %lld observations but its feature matrix has %lld rows (DimensionMismatch)",
+                (long long)train->n, (long long)N);
+    const uint32_t tag = 0x800000u | rel_tag;
+    // scratch (doubles): pred N | v N | t numF | rs numF | R P Z (numF each) | Tm N | scal 4 | lam 1, then ints
+    const size_t total = 3 * (size_t)N + 5 * (size_t)numF + 16;
+    void *sv;
+    int rc = bdf_scratch(ctx, total * sizeof(double) + 16 * sizeof(int), &sv);
+    if (rc) return rc;
+    double *pred = (double *)sv, *v = pred + N, *t = v + N, *rs = t + numF, *R = rs + numF, *P = R + numF, *Z = P + numF,
+           *Tm = Z + numF, *scal = Tm + N, *lam = scal + 8;
+    int *ints = (int *)(lam + 8);
+    if ((rc = bdf_predict_plain(ctx, train, D, factors, mean_value, pred))) return rc;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_rel_target, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N,
+                           (const double *)train->values_dev, (const double *)pred, 1.0 / sqrt(alpha), ctx->seed,
+                           ctx->sweep_host, tag, v);
+        BDF_HIP(hipGetLastError());
+    }
+    if ((rc = feat_apply(ctx, f, true, v, 1, N, 1, t, 1, numF))) return rc;
+    hipLaunchKernelGGL(k_rel_rhs, dim3((unsigned)((numF + 255) / 256)), dim3(256), 0, ctx->stream, numF, alpha, lambda_beta,
+                       ctx->seed, ctx->sweep_host, tag, t, rs, lam);
+    BDF_HIP(hipGetLastError());
+    if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, t, numF * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = ensure_FF(f))) return rc;
+    if (numF <= 64) {
+        if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+        else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+        else hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+        BDF_HIP(hipGetLastError());
+    } else {
+        int *it = nullptr;
+        if ((rc = cg_solve(ctx, f, true, 1, lam, rs, beta_out, 2.220446049250313e-16 * (double)numF, (int)numF, R, P, Z, Tm, scal, ints, &it)))
+            return rc;
+    }
+    // linear_values = mean_value + F beta (macau.jl:91)
+    if ((rc = feat_apply(ctx, f, false, beta_out, 1, numF, 1, linear_out, 1, N))) return rc;
+    if (N > 0) {
+        hipLaunchKernelGGL(k_add_scalar, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N, mean_value, linear_out);
         BDF_HIP(hipGetLastError());
     }
     return BDF_OK;

@@ -16,6 +16,7 @@ struct PredArgs {
     const int32_t *ids;            // n_modes planes of n, 0-based
     const double *fac[BDF_MAX_MODES];
     double mean;
+    const double *linear;          // nullable: per-pair baseline instead of mean (relation features: linear_values)
     const double *values;
     double *out;                   // nullable: raw predictions
     double *avg, *sq;              // running state (update mode)
@@ -68,14 +69,14 @@ __device__ inline double pair_dot(const PredArgs &a, int64_t pair, int sub)
 
 __device__ inline void pair_update(const PredArgs &a, int64_t pair, double s, double (&st)[4])
 {
-    const double p = s + a.mean;
+    const double p = s + (a.linear ? a.linear[pair] : a.mean);
     if (a.out) a.out[pair] = p;
     if (a.phase >= 0) {
         double avg;
-        if (a.phase == 0) { avg = p; }
+        if (a.phase == 0 || a.phase == 3) { avg = p; }
         else if (a.phase == 1) { avg = p; a.sq[pair] = p * p; }
         else { avg = (a.count * a.avg[pair] + p) / (a.count + 1.0); a.sq[pair] += p * p; }
-        a.avg[pair] = avg;
+        if (a.phase != 3) a.avg[pair] = avg;           // phase 3: statistics of this sample only, no running state
         const double y = a.values[pair];
         const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
         const bool label = y < a.cut;
@@ -176,6 +177,7 @@ int fill(const char *who, bdf_ctx *ctx, const bdf_pairs *p, int D, const double 
         a.fac[k] = factors[k];
     }
     a.phase = -1;
+    a.linear = p->baseline_dev;
     return BDF_OK;
 }
 
@@ -196,7 +198,7 @@ extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void
         h[q] = (int32_t)(v - 1);
     }
     bdf_pairs *p = new bdf_pairs();
-    p->ctx = ctx; p->n_modes = n_modes; p->n = n; p->count = 0.0;
+    p->ctx = ctx; p->n_modes = n_modes; p->n = n; p->count = 0.0; p->baseline_dev = nullptr;
     size_t nb = std::max<size_t>((size_t)n * sizeof(double), 8);
     BDF_HIP(hipMalloc((void **)&p->ids_dev, std::max<size_t>(h.size() * sizeof(int32_t), 8)));
     BDF_HIP(hipMalloc((void **)&p->values_dev, nb));
@@ -233,6 +235,16 @@ extern "C" int bdf_predict(bdf_ctx *ctx, const bdf_pairs *p, int D, const double
     return launch_predict(ctx, a);
 }
 
+// udot + mean_value, whatever baseline the pairs carry (sample_beta_rel needs the residual against the plain mean)
+int bdf_predict_plain(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value, double *out)
+{
+    PredArgs a;
+    int rc = fill("bdf_predict", ctx, p, D, factors, a);
+    if (rc) return rc;
+    a.mean = mean_value; a.linear = nullptr; a.out = out;
+    return launch_predict(ctx, a);
+}
+
 extern "C" int bdf_predict_update(bdf_ctx *ctx, bdf_pairs *p, int D, const double *const *factors,
                                   double mean_value, int phase, double clamp_lo, double clamp_hi,
                                   double class_cut, double *stats_out)
@@ -248,6 +260,27 @@ extern "C" int bdf_predict_update(bdf_ctx *ctx, bdf_pairs *p, int D, const doubl
     if (rc) return rc;
     if (phase == 1) p->count = 1.0;
     else if (phase == 2) p->count += 1.0;
+    return BDF_OK;
+}
+
+extern "C" int bdf_predict_sse(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value,
+                               const double *linear_values, double *stats_out)
+{
+    // sum over the pairs of (value - pred)^2 with pred = udot + (linear_values[pair] | mean_value): the err' err of
+    // sample_alpha (macau.jl:86-87); stats_out as bdf_predict_update's, [1] is the sum of squares
+    PredArgs a;
+    int rc = fill("bdf_predict_sse", ctx, p, D, factors, a);
+    if (rc) return rc;
+    BDF_REQUIRE(stats_out != nullptr, BDF_ERR_ARG, "bdf_predict_sse: stats_out is NULL");
+    a.mean = mean_value; if (linear_values) a.linear = linear_values; a.phase = 3; a.count = 0.0;
+    a.clamp_lo = 1.0; a.clamp_hi = 0.0; a.cut = 0.0; a.stats = stats_out;
+    return launch_predict(ctx, a);
+}
+
+extern "C" int bdf_pairs_set_baseline(bdf_pairs *p, const double *baseline)
+{
+    BDF_REQUIRE(p != nullptr, BDF_ERR_ARG, "bdf_pairs_set_baseline: NULL argument");
+    p->baseline_dev = baseline;
     return BDF_OK;
 }
 

@@ -60,8 +60,6 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
     if output_type not in ("csv", "binary"):
         raise ArgumentError("output_type must be either \"csv\" or \"binary\".")
     clamp = [float(c) for c in clamp]
-    if full_prediction:
-        raise NotImplementedError("full_prediction (pred_all, sampling.jl:91-97) is not on the GPU path yet")
 
     verbose and print("Model setup")
     eng = engine
@@ -83,22 +81,27 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
     test = eng.test_pairs() if haveTest else None
     train = eng.train_pairs() if rmse_train else None
     f_output = []
+    yhat_full = None
+    if full_prediction:
+        if hasFeatures(rel):
+            raise ArgumentError("Prediction of all elements is not possible when Relation has features.")   # sampling.jl:92-94
+        import torch
+        yhat_full = torch.zeros(tuple(rel.data.dims), dtype=torch.float64, device=eng.ctx.device)
     rmse_avg = roc_avg = err_avg = float("nan")
     probe_avg = None
 
     verbose and print("Sampling")
     for i in range(1, burnin + psamples + 1):
         time0 = time.time()
-        for r in data.relations:
-            if r.model.alpha_sample:
-                raise NotImplementedError("alpha sampling (sample_alpha, sampling.jl:129-134) is not on the GPU path yet")
-        eng.sweep(i)
+        eng.sweep(i)        # relation models (alpha, relation beta) first, then rows, hyperpriors, beta: macau.jl:83-140
 
         phase = 0 if i <= burnin else (1 if i == burnin + 1 else 2)
         facs = eng.factors_of(rel)
         stats = None
         if haveTest:
             stats = test.update(D, facs, rel.model.mean_value, phase, clamp, rel.class_cut)
+        if full_prediction and i > burnin:
+            yhat_full += eng.pred_all(rel)                    # macau.jl:145-147: a plain dense product, on the device
         if i > burnin:
             if output:
                 ndigits = int(math.floor(math.log10(psamples))) + 1
@@ -149,6 +152,8 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
         "accuracy": err_avg,
         "ROC": roc_avg,
     }
+    if full_prediction:
+        result["predictions_full"] = (yhat_full / psamples).cpu().numpy()        # macau.jl:228-230
     if rmse_train:
         tavg, _ = train.state()
         result["RMSE_train"] = float(np.sqrt(np.mean((rel.data.getValues() - makeClamped(tavg, clamp)) ** 2)))

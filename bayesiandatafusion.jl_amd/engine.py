@@ -164,6 +164,12 @@ class DevicePairs:
         check(lib().bdf_predict(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, _ptr(out)))
         return out
 
+    def sse(self, D, factors, mean_value, linear=None):
+        """device scalar (stats[1]): sum of (value - pred)^2, pred = udot + (linear | mean_value)"""
+        check(lib().bdf_predict_sse(self.ctx.handle, self.handle, D, self._facs(factors), mean_value,
+                                    _ptr(linear) if linear is not None else None, _ptr(self.stats)))
+        return self.stats
+
     def update(self, D, factors, mean_value, phase, clamp, class_cut):
         lo, hi = (clamp[0], clamp[1]) if len(clamp) else (1.0, -1.0)
         check(lib().bdf_predict_update(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, phase, lo, hi,
@@ -347,8 +353,22 @@ class GibbsEngine:
             r.model.mean_value = dr.value_mean()
             r._dev = dr
             self.rel.append(dr)
+            # relation-level side information (RelationData.jl:348-353): FF path only, as in the reference
+            dr.F = dr.beta = dr.linear = dr.train = None
             if not feat.isempty(r.F):
-                raise NotImplementedError("relation-level side information (sample_beta_rel, sampling.jl:322-337) is not on the GPU path yet")
+                dr.F = FeatOperator(self.ctx, r.F)
+                if dr.F.m != r.data.nnz():
+                    raise ArgumentError(f"Relation {r.name} has {r.data.nnz()} observations but its feature matrix has {dr.F.m} rows")
+                if dr.F.n > compute_ff_size:
+                    raise ArgumentError("conjugate gradient unimplemented for sampling relation beta")      # sampling.jl:335
+                dr.beta = self.ctx.zeros(dr.F.n)
+                dr.linear = self.ctx.tensor(np.full(r.data.nnz(), r.model.mean_value))
+                r.model.beta = np.zeros(dr.F.n)
+            if dr.F is not None or r.model.alpha_sample:
+                dr.train = DevicePairs(self.ctx, r.data.ids, r.data.values)
+                if dr.F is not None:         # pred(r) = udot + linear_values on the training table (sampling.jl:16-18)
+                    check(lib().bdf_pairs_set_baseline(dr.train.handle, _ptr(dr.linear)))
+            dr.alpha_dev = self.ctx.zeros(1)
         self._test_pairs = None
         self._train_pairs = None
         self.k1_events = None     # bench.py: list of (entity, start, end) HIP events around each K1 launch
@@ -377,7 +397,7 @@ class GibbsEngine:
             terms[t].mode = en.modes[t] - 1
             terms[t].alpha = r.model.alpha
             terms[t].mean_value = r.model.mean_value
-            terms[t].linear_values = None
+            terms[t].linear_values = self.rel[ri].linear.data_ptr() if self.rel[ri].linear is not None else None
             for k, e2 in enumerate(r.entities):
                 terms[t].factors[k] = self.ent[self._entity_index(e2)].sample.data_ptr()
         return terms
@@ -390,6 +410,28 @@ class GibbsEngine:
             order = self.rel[ri].order(en.modes[0] - 1)
             self._rowlists[j] = [self.ctx.tensor(p, dtype=torch.int64) for p in shard_rows(order, self.world)]
         return self._rowlists[j]
+
+    # ---- macau.jl:83-92: relation models (alpha, relation-level beta) -----------------------------------------------
+    def update_relations(self):
+        """alpha ~ sample_alpha(err) and beta = sample_beta_rel(r), linear_values = mean + F beta, for the relations that
+        ask for them; runs on the main stream before the latent rows of the sweep (alpha is a host scalar of the row
+        kernel's arguments: sampling it costs one device-to-host read per sweep, as the reference's host loop does)"""
+        for ri, r in enumerate(self.data.relations):
+            dr = self.rel[ri]
+            if not (r.model.alpha_sample or dr.F is not None):
+                continue
+            facs = self.factors_of(r)
+            if r.model.alpha_sample:
+                sse = dr.train.sse(self.D, facs, r.model.mean_value)          # the pairs carry linear_values as baseline
+                check(lib().bdf_sample_alpha(self.ctx.handle, r.model.alpha_lambda0, r.model.alpha_nu0, r.data.nnz(),
+                                             C.c_void_p(sse.data_ptr() + 8), ri + 1, _ptr(dr.alpha_dev)))
+                self.ctx.sync()
+                r.model.alpha = float(dr.alpha_dev.item())
+            if dr.F is not None:
+                fp = (C.c_void_p * len(facs))(*[f.data_ptr() for f in facs])
+                check(lib().bdf_sample_beta_rel(self.ctx.handle, dr.F.handle, dr.train.handle, self.D, fp, r.model.mean_value,
+                                                r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
+        self.refresh_baselines()
 
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
     def sample_entity(self, j):
@@ -459,6 +501,9 @@ class GibbsEngine:
         for en, st in zip(self.data.entities, self.ent):
             if st.lambda_beta is not None:
                 en.lambda_beta = float(st.lambda_beta.item())
+        for r, dr in zip(self.data.relations, self.rel):
+            if dr.F is not None:
+                r.model.beta = dr.beta.cpu().numpy().copy()
 
     # ---- one Gibbs iteration without reporting (the timed unit of bench.py) ---------------------------------------
     def sweep(self, i):
@@ -468,6 +513,7 @@ class GibbsEngine:
         self.ctx.set_sweep(i)
         if two:
             self.ctx_h.set_sweep(i)
+        self.update_relations()
         for j in range(len(self.ent)):
             if two and j in self._ev_hyper:
                 main.wait_event(self._ev_hyper[j])       # (mu, Lambda) of entity j from the previous iteration
@@ -501,14 +547,40 @@ class GibbsEngine:
     def factors_of(self, r):
         return [self.ent[self._entity_index(e)].sample for e in r.entities]
 
+    def pred_all(self, r):
+        """pred_all(r) (sampling.jl:91-97): udot over every cell + mean_value, as one library GEMM / einsum on the device"""
+        S = self.factors_of(r)                                  # each (N_k, D)
+        with torch.cuda.stream(self.ctx.stream):
+            if len(S) == 2:
+                return torch.mm(S[0], S[1].T) + r.model.mean_value
+            letters = "abcdefg"[:len(S)]
+            expr = ",".join(f"{c}z" for c in letters) + "->" + letters
+            return torch.einsum(expr, *S) + r.model.mean_value
+
     def test_pairs(self):
         r = self.data.relations[0]
         if self._test_pairs is None:
             self._test_pairs = DevicePairs(self.ctx, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
+            dr = self.rel[0]
+            if dr.F is not None:             # pred(r, probe_vec, F) = udot + F_test beta + mean_value (sampling.jl:9-14)
+                if feat.isempty(r.test_F):
+                    raise ArgumentError(f"Relation {r.name} has features but its test set has no feature rows (test_F)")
+                dr.F_test = FeatOperator(self.ctx, r.test_F)
+                dr.test_baseline = self.ctx.zeros(self._test_pairs.n)
+                check(lib().bdf_pairs_set_baseline(self._test_pairs.handle, _ptr(dr.test_baseline)))
         return self._test_pairs
+
+    def refresh_baselines(self):
+        """after the relation beta of this sweep: the test pairs' baseline mean_value + F_test beta (first relation)"""
+        dr = self.rel[0]
+        if dr.F is not None and self._test_pairs is not None:
+            r = self.data.relations[0]
+            check(lib().bdf_feat_linear(self.ctx.handle, dr.F_test.handle, _ptr(dr.beta), r.model.mean_value, _ptr(dr.test_baseline)))
 
     def train_pairs(self):
         r = self.data.relations[0]
+        if self._train_pairs is None and self.rel[0].train is not None:
+            self._train_pairs = self.rel[0].train
         if self._train_pairs is None:
             self._train_pairs = DevicePairs(self.ctx, r.data.ids, r.data.values)
         return self._train_pairs

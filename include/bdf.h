@@ -49,6 +49,8 @@ extern "C" {
 #define BDF_P_GAMMA_N   5
 #define BDF_P_GAMMA_U   6
 #define BDF_P_NW_MEAN   7
+#define BDF_P_BETA_REL1 8   /* sample_beta_rel: noise per observation (row = observation)  */
+#define BDF_P_BETA_REL2 9   /* sample_beta_rel: noise per feature    (row = feature)        */
 
 typedef struct bdf_ctx   bdf_ctx;    /* device, stream, seed, sweep counter, scratch        */
 typedef struct bdf_rel   bdf_rel;    /* Relation.data :: IndexedDF / FastIDF on the device  */
@@ -155,6 +157,33 @@ int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *sumU, const d
  * which does not depend on the rows: call it for the same (sweep, N, nu, entity_tag) before the rows are done and pass the
  * buffer as `draws` to take the gamma rejection loops off the critical path.  Same streams, same values. */
 int bdf_hyper_draws(bdf_ctx *ctx, int D, int64_t N, double nu, uint32_t entity_tag, double *draws_out);
+
+/* per-pair baseline (dev, n doubles, borrowed; NULL to clear) that replaces mean_value in bdf_predict / bdf_predict_update for
+ * these pairs: mean_value + F_test beta of pred(r, probe_vec, F) (src/sampling.jl:9-14) for a relation with features */
+int bdf_pairs_set_baseline(bdf_pairs *pairs, const double *baseline);
+/* out (dev, rows of F) = mean_value + F beta, beta dev numF: linear_values (macau.jl:91) / the baseline above */
+int bdf_feat_linear(bdf_ctx *ctx, const bdf_feat *F, const double *beta, double mean_value, double *out);
+/* sum over the pairs of (value - pred)^2, pred = udot + (linear_values[pair] if non-NULL else mean_value): err' err of
+ * sample_alpha (macau.jl:86-87).  stats_out (dev, 4 doubles) as bdf_predict_update's; [1] is the sum.  No running state. */
+int bdf_predict_sse(bdf_ctx *ctx, const bdf_pairs *pairs, int D, const double *const *factors, double mean_value,
+                    const double *linear_values, double *stats_out);
+
+/* ---- f1/f4: relation model (src/macau.jl:83-92) ---------------------------------------------- */
+/* sample_alpha (src/sampling.jl:129-134): alpha ~ Wishart(alpha_nu0 + n, 1 / (1/alpha_lambda0 + sum err^2)) in one dimension.
+ * sumsq_err (dev, 1 double): sum over the relation's n observations of (pred - value)^2; alpha_out (dev, 1 double).
+ * Gamma stream (BDF_P_GAMMA_N/U, entity 0x800000 | rel_tag, row 0). */
+int bdf_sample_alpha(bdf_ctx *ctx, double alpha_lambda0, double alpha_nu0, int64_t n, const double *sumsq_err,
+                     uint32_t rel_tag, double *alpha_out);
+/* sample_beta_rel (src/sampling.jl:322-337) + linear_values (macau.jl:91): relation-level side information F (one row per
+ * observation, COO order), FF path (the reference has no other):
+ *   beta = (alpha F'F + lambda_beta I) \ (alpha F'(values - udot - mean_value + alpha^-1/2 z1) + sqrt(lambda_beta) z2)
+ *   linear_out = mean_value + F beta
+ * train: the relation's observations as pairs (bdf_pairs_create on the COO ids and values); factors as for bdf_predict.
+ * beta_out dev numF, linear_out dev nnz, rhs_out dev numF nullable (the right-hand side, for parity checks).
+ * z1: stream (BDF_P_BETA_REL1, 0x800000 | rel_tag, row = observation), z2: (BDF_P_BETA_REL2, ..., row = feature). */
+int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *F, const bdf_pairs *train, int D, const double *const *factors,
+                        double mean_value, double alpha, double lambda_beta, uint32_t rel_tag,
+                        double *beta_out, double *linear_out, double *rhs_out);
 
 /* ---- f2: test-set prediction (src/sampling.jl:9-45, macau.jl:142-203, 231-241) -------- */
 /* ids: n x n_modes column-major 1-based (test_vec[:,1:end-1]); values: n (test_vec[:,end]) */

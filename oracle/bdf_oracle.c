@@ -146,7 +146,7 @@ void orc_normals(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entit
 }
 
 enum { P_ROW = 1, P_BETA_E1 = 2, P_BETA_E2 = 3, P_NW_NORMAL = 4, P_GAMMA_N = 5, P_GAMMA_U = 6,
-       P_NW_MEAN = 7 };
+       P_NW_MEAN = 7, P_BETA_REL1 = 8, P_BETA_REL2 = 9 };
 
 /* Gamma(shape a, scale 1) -- Marsaglia & Tsang (2000); stands in for Distributions.jl's
  * Gamma/Chisq samplers used by Wishart (src/normal_wishart.jl:39) and sample_lambda_beta
@@ -635,6 +635,40 @@ int orc_sample_beta(const orc_feat *F, int D, const double *sample, const double
         }
     }
     free(E1);
+    return rc;
+}
+
+/* sample_beta_rel (src/sampling.jl:322-337): relation-level side information, one feature row per observation.
+ *   res   = values - udot - mean_value                       (caller)
+ *   aFt_y = alpha F'(res + alpha^-1/2 randn(N)) + sqrt(lambda) randn(numF)
+ *   beta  = (alpha FF + lambda I) \ aFt_y                     (FF path only: the reference errors out otherwise)
+ * Normals: stream (P_BETA_REL1, 0x800000 | rel_tag, row = observation, 0) and (P_BETA_REL2, ..., row = feature, 0). */
+int orc_sample_beta_rel(const orc_feat *F, const double *res, double alpha, double lambda_beta,
+                        uint64_t seed, uint32_t sweep, uint32_t rel_tag, double *beta_out, double *rhs_out)
+{
+    int64_t N = F->m, numF = F->n;
+    uint32_t tag = 0x800000u | rel_tag;
+    double *v = (double *)malloc(sizeof(double) * (size_t)N);
+    double sa = 1.0 / sqrt(alpha), sl = sqrt(lambda_beta);
+    for (int64_t i = 0; i < N; i++) {
+        double z;
+        orc_normals(seed, sweep, P_BETA_REL1, tag, (uint64_t)i, 1, &z);
+        v[i] = res[i] + sa * z;
+    }
+    orc_feat_tmul(F, v, rhs_out);
+    for (int64_t f = 0; f < numF; f++) {
+        double z;
+        orc_normals(seed, sweep, P_BETA_REL2, tag, (uint64_t)f, 1, &z);
+        rhs_out[f] = alpha * rhs_out[f] + sl * z;
+    }
+    double *K = (double *)malloc(sizeof(double) * (size_t)numF * numF);
+    double *e = (double *)calloc((size_t)numF, sizeof(double)), *fe = (double *)malloc(sizeof(double) * (size_t)N);
+    for (int64_t j = 0; j < numF; j++) {               /* FF = full(F'F), RelationData.jl:351 */
+        e[j] = 1.0; orc_feat_mul(F, e, fe); orc_feat_tmul(F, fe, K + (size_t)j * numF); e[j] = 0.0;
+    }
+    for (size_t q = 0; q < (size_t)numF * numF; q++) K[q] *= alpha;
+    int rc = orc_solve_full(numF, K, rhs_out, 1, lambda_beta, beta_out);      /* (alpha FF + lambda I) \ aFt_y */
+    free(K); free(e); free(fe); free(v);
     return rc;
 }
 

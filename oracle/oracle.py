@@ -20,7 +20,7 @@ c_i64p = C.POINTER(C.c_int64)
 c_i32p = C.POINTER(C.c_int32)
 c_u32p = C.POINTER(C.c_uint32)
 
-P_ROW, P_BETA_E1, P_BETA_E2, P_NW_NORMAL, P_GAMMA_N, P_GAMMA_U, P_NW_MEAN = 1, 2, 3, 4, 5, 6, 7
+P_ROW, P_BETA_E1, P_BETA_E2, P_NW_NORMAL, P_GAMMA_N, P_GAMMA_U, P_NW_MEAN, P_BETA_REL1, P_BETA_REL2 = 1, 2, 3, 4, 5, 6, 7, 8, 9
 
 
 def build():
@@ -322,6 +322,18 @@ def sample_beta(feat, sample, mu, Lambda, lambda_beta, use_ff, tol, seed, sweep,
     if rc:
         raise np.linalg.LinAlgError("sample_beta failed")
     return beta, rhs, iters
+
+
+def sample_beta_rel(feat, res, alpha, lambda_beta, seed, sweep, rel_tag):
+    """sample_beta_rel (sampling.jl:322-337), FF path. res: values - udot - mean_value per observation. Returns beta, rhs"""
+    res = _f64(res)
+    beta, rhs = np.zeros(feat.n), np.zeros(feat.n)
+    s = feat.struct()
+    rc = lib().orc_sample_beta_rel(C.byref(s), _dp(res), C.c_double(alpha), C.c_double(lambda_beta), C.c_uint64(seed),
+                                   C.c_uint32(sweep), C.c_uint32(rel_tag), beta.ctypes.data_as(c_dp), rhs.ctypes.data_as(c_dp))
+    if rc:
+        raise np.linalg.LinAlgError("sample_beta_rel failed")
+    return beta, rhs
 
 
 def noise_rows(D, n, Lambda, seed, sweep, purpose, entity_tag):

@@ -188,3 +188,61 @@ def test_uhat_and_feature_hyper_terms(B, ctx):
     np.testing.assert_allclose(mm_t.cpu().numpy(), F @ beta + mu, rtol=1e-12, atol=1e-12)      # mu .+ uhat
     np.testing.assert_allclose(T_t.cpu().numpy(), WI + beta.T @ beta * 0.6, rtol=1e-12)
     op.close()
+
+
+def test_sample_alpha_and_sse_match_oracle(B, O, ctx):
+    """sample_alpha (sampling.jl:129-134) on the device: err' err over the training table, then the Wishart(1-d) draw"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(21)
+    D, dims, n = 6, [30, 20], 400
+    ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
+    y = rng.standard_normal(n)
+    facs = [rng.standard_normal((d, D)) * 0.4 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    pairs = B.DevicePairs(ctx, ids, y)
+    mean = 0.3
+    stats = pairs.sse(D, ft, mean)
+    ctx.sync()
+    pred = O.predict(ids, facs, mean)
+    sse = float(np.sum((pred - y) ** 2))
+    np.testing.assert_allclose(stats.cpu().numpy()[1], sse, rtol=1e-12)
+    lin = rng.standard_normal(n)
+    lin_t = ctx.tensor(lin)
+    stats = pairs.sse(D, ft, mean, lin_t)
+    ctx.sync()
+    np.testing.assert_allclose(stats.cpu().numpy()[1], np.sum((pred - mean + lin - y) ** 2), rtol=1e-12)
+    ctx.set_sweep(9)
+    alpha_t = ctx.zeros(1)
+    stats = pairs.sse(D, ft, mean)
+    check(lib().bdf_sample_alpha(ctx.handle, 1.0, 2.0, n, C.c_void_p(stats.data_ptr() + 8), 1, _p(alpha_t)))
+    ctx.sync()
+    np.testing.assert_allclose(alpha_t.item(), O.sample_alpha(1.0, 2.0, n, sse, SEED, 9, 1), rtol=1e-9)
+    pairs.close()
+
+
+@pytest.mark.parametrize("numF", [2, 40, 90])
+def test_sample_beta_rel_matches_oracle(B, O, ctx, numF):
+    """sample_beta_rel (sampling.jl:322-337) + linear_values (macau.jl:91)"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(31 + numF)
+    D, dims, n = 5, [25, 18], 500
+    ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
+    y = rng.standard_normal(n) * 2
+    facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    Fm = rng.standard_normal((n, numF))
+    op = B.FeatOperator(ctx, Fm)
+    pairs = B.DevicePairs(ctx, ids, y)
+    mean, alpha, lam = 0.2, 1.7, 0.8
+    beta_t, lin_t, rhs_t = ctx.zeros(numF), ctx.zeros(n), ctx.zeros(numF)
+    fp = (C.c_void_p * 2)(*[f.data_ptr() for f in ft])
+    ctx.set_sweep(4)
+    check(lib().bdf_sample_beta_rel(ctx.handle, op.handle, pairs.handle, D, fp, mean, alpha, lam, 2, _p(beta_t), _p(lin_t), _p(rhs_t)))
+    ctx.sync()
+    res = y - O.predict(ids, facs, mean)
+    beta_e, rhs_e = O.sample_beta_rel(O.Feat.from_dense(Fm), res, alpha, lam, SEED, 4, 2)
+    np.testing.assert_allclose(rhs_t.cpu().numpy(), rhs_e, rtol=1e-9, atol=1e-9)
+    np.testing.assert_allclose(beta_t.cpu().numpy(), beta_e, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(lin_t.cpu().numpy(), mean + Fm @ beta_t.cpu().numpy(), rtol=1e-11, atol=1e-11)
+    op.close()
+    pairs.close()

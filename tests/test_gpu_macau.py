@@ -245,3 +245,51 @@ def test_movielens_macau_published_figure(B):
     assert abs(res["accuracy"] - 0.8704) < 0.004, res["accuracy"]
     assert abs(res["ROC"] - 0.8485) < 0.006, res["ROC"]
     assert res["lambda_beta"] > 0
+
+
+def test_alpha_sampling(B):
+    """test/alpha_sampling.jl:6-11"""
+    Y = _sprand(15, 10, 0.3, 5)
+    rd = B.RelationData(Y, class_cut=0.5, alpha_sample=True)
+    B.assignToTest(rd.relations[0], 2, rng=np.random.default_rng(0))
+    B.macau(rd, burnin=5, psamples=6, verbose=False)
+    assert rd.relations[0].model.alpha > 0 and rd.relations[0].model.alpha != 1.0
+
+
+def test_relation_features(B):
+    """test/rel_feat.jl:6-28: fully observed 30 x 40 rank-2 relation plus two observation-level features, alpha sampled"""
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    A, Bm = rng.standard_normal((30, 2)), rng.standard_normal((40, 2))
+    X = A @ Bm.T
+    ii, jj = np.meshgrid(np.arange(1, 31), np.arange(1, 41), indexing="ij")
+    df = pd.DataFrame({"A": ii.ravel(), "B": jj.ravel(), "v": X.ravel()})
+    feat = rng.standard_normal((len(df), 2))
+    beta = np.array([1.0, -1.0])
+    df["v"] = df["v"] + feat @ beta
+    rd = B.RelationData(df)
+    rd.relations[0].model.alpha_sample = True
+    rd.relations[0].F = feat
+    B.assignToTest(rd.relations[0], 10, rng=np.random.default_rng(1))
+    assert rd.relations[0].test_F.shape == (10, 2)
+    result = B.macau(rd, burnin=50, psamples=10, num_latent=2, verbose=False)
+    # the model is exact (rank 2 + linear features): the relation beta is recovered and the held-out cells are predicted
+    np.testing.assert_allclose(rd.relations[0].model.beta, beta, atol=0.1)
+    assert result["RMSE"] < 0.3
+    assert rd.relations[0].model.alpha > 1.0
+    with pytest.raises(B.ArgumentError):
+        B.macau(rd, burnin=1, psamples=1, num_latent=2, verbose=False, full_prediction=True)
+
+
+def test_full_prediction(B):
+    """macau.jl:37-39, 145-147, 228-230: predictions_full is the posterior mean of pred_all; on the test cells it equals
+    the unclamped running mean of the test predictions"""
+    Y = _sprand(20, 12, 0.4, 7)
+    rd = B.RelationData(Y, class_cut=0.5)
+    B.assignToTest(rd.relations[0], 15, rng=np.random.default_rng(2))
+    res = B.macau(rd, burnin=3, psamples=5, num_latent=4, verbose=False, full_prediction=True, clamp=[])
+    full = res["predictions_full"]
+    assert full.shape == (20, 12)
+    p = res["predictions"]
+    ids = rd.relations[0].test_vec.ids
+    np.testing.assert_allclose(full[ids[:, 0] - 1, ids[:, 1] - 1], np.asarray(p["pred"]), rtol=1e-10, atol=1e-12)

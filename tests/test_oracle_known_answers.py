@@ -201,3 +201,20 @@ def test_predict_identity(O):
     p = O.predict(ids, facs, 0.7)
     for q, (i, j, k) in enumerate(ids):
         assert np.isclose(p[q], np.sum(facs[0][i - 1] * facs[1][j - 1] * facs[2][k - 1]) + 0.7)
+
+
+def test_oracle_sample_beta_rel_is_the_reference_formula():
+    """sample_beta_rel (src/sampling.jl:322-337) restated with the oracle's own normals: the C routine equals
+    (alpha F'F + lambda I) \\ (alpha F'(res + alpha^-1/2 z1) + sqrt(lambda) z2) in numpy"""
+    from oracle import oracle as O
+    rng = np.random.default_rng(8)
+    n, numF = 120, 7
+    Fm = rng.standard_normal((n, numF))
+    res = rng.standard_normal(n)
+    alpha, lam, seed, sweep, tag = 2.5, 0.6, 99, 3, 4
+    beta, rhs = O.sample_beta_rel(O.Feat.from_dense(Fm), res, alpha, lam, seed, sweep, tag)
+    z1 = np.array([O.normals(seed, sweep, O.P_BETA_REL1, 0x800000 | tag, i, 1)[0] for i in range(n)])
+    z2 = np.array([O.normals(seed, sweep, O.P_BETA_REL2, 0x800000 | tag, f, 1)[0] for f in range(numF)])
+    rhs_np = alpha * Fm.T @ (res + z1 / np.sqrt(alpha)) + np.sqrt(lam) * z2
+    np.testing.assert_allclose(rhs, rhs_np, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(beta, np.linalg.solve(alpha * Fm.T @ Fm + lam * np.eye(numF), rhs_np), rtol=1e-10)
