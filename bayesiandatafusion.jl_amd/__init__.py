@@ -12,6 +12,10 @@ from .indexed_df import (IndexedDF, FastIDF, nnz, getData, getCount, getI, getVa
 from .features import SparseBinMatrix, SparseBinMatrixCSR, SparseMatrixCSR, sparse_csr
 from .relation_data import (Entity, EntityModel, Relation, RelationModel, RelationData, addRelation, assignToTest, setTest,
                             setPrecision, numData, numTest, hasFeatures, toStr, normalizeFeatures, normalizeRows)
+from .data_reading import (read_ecfp, read_sparse, read_rowcol, read_binary_int32, filter_rare, write_binary_int32,
+                           write_binary_matrix, read_binary_float32, read_sparse_float32, write_sparse_float32,
+                           read_sparse_float64, write_sparse_float64, read_sparse_binary_matrix, write_sparse_binary_matrix,
+                           read_matrix_market, write_matrix_market)
 
 
 def rep_int(x, times):
@@ -23,7 +27,7 @@ def rep_int(x, times):
 def __getattr__(name):
     # the engine and driver import torch; load them on first use so that the host-only data model (and the
     # CPU test suite) does not pay for it
-    if name in ("macau", "pred", "pred_all", "AUC_ROC", "write_binary_matrix", "read_binary_float32", "makeClamped"):
+    if name in ("macau", "pred", "pred_all", "AUC_ROC", "makeClamped"):
         import importlib
         return getattr(importlib.import_module(__name__ + ".driver"), name)
     if name in ("GibbsEngine", "Context", "DeviceRelation", "DevicePairs", "FeatOperator"):

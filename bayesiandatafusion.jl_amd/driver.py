@@ -35,19 +35,7 @@ def makeClamped(x, clamp):
     return np.clip(x, clamp[0], clamp[1])
 
 
-def write_binary_matrix(filename, X):
-    """src/data_reading.jl:93-99: Int64 nrow, Int64 ncol, column-major payload"""
-    X = np.asarray(X)
-    with open(filename, "wb") as f:
-        f.write(struct.pack("<qq", X.shape[0], X.shape[1]))
-        f.write(np.asfortranarray(X).tobytes(order="F"))
-
-
-def read_binary_float32(filename):
-    """src/data_reading.jl:61-67"""
-    with open(filename, "rb") as f:
-        nrows, ncols = struct.unpack("<qq", f.read(16))
-        return np.frombuffer(f.read(), dtype=np.float32).reshape((nrows, ncols), order="F")
+from .data_reading import read_binary_float32, write_binary_matrix  # noqa: E402,F401  (src/data_reading.jl:61-67, 93-99)
 
 
 def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=200, verbose=True, full_lambda_u=True,

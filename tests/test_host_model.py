@@ -228,3 +228,47 @@ def test_sharded_allgather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_data_reading_formats(tmp_path):
+    """src/data_reading.jl: byte layouts (Int64 headers, column-major payloads) and round trips; test/basic.jl:126-161 and
+    test/beta_saving.jl:21-35 read posterior dumps back through read_binary_float32"""
+    import struct
+    import scipy.sparse as sp
+    import bdf_amd as B
+    rng = np.random.default_rng(0)
+    X = rng.standard_normal((3, 5)).astype(np.float32)
+    f = str(tmp_path / "m.binary")
+    B.write_binary_matrix(f, X)
+    raw = open(f, "rb").read()
+    assert struct.unpack("<qq", raw[:16]) == (3, 5)
+    assert np.array_equal(np.frombuffer(raw[16:], dtype="<f4"), X.T.ravel())          # column-major payload
+    assert np.array_equal(B.read_binary_float32(f), X)
+    Xi = rng.integers(-5, 5, (4, 2)).astype(np.int32)
+    B.write_binary_int32(f, Xi)
+    assert np.array_equal(B.read_binary_int32(f), Xi)
+    S = sp.random(7, 6, density=0.4, random_state=1, format="csc")
+    B.write_sparse_float64(f, S)
+    assert (B.read_sparse_float64(f) != S).nnz == 0
+    B.write_sparse_float32(f, S)
+    r, c, v = B.read_sparse_float32(f)
+    S32 = sp.csc_matrix((v, (r - 1, c - 1)), shape=S.shape)
+    np.testing.assert_allclose(S32.toarray(), S.toarray(), rtol=1e-6)
+    assert struct.unpack("<q", open(f, "rb").read(8))[0] == S.nnz
+    B.write_sparse_binary_matrix(f, S)
+    Sb = B.read_sparse_binary_matrix(f)
+    assert np.array_equal(Sb.toarray() != 0, S.toarray() != 0) and Sb.shape == S.shape
+    # text formats
+    g = str(tmp_path / "rc.csv")
+    open(g, "w").write("1,2\n3,1\n3,1\n")
+    r, c = B.read_rowcol(g)
+    assert r.tolist() == [1, 3, 3] and c.tolist() == [2, 1, 1] and r.dtype == np.int32
+    assert B.read_sparse(g).toarray().tolist() == [[0, 1], [0, 0], [2, 0]]
+    open(g, "w").write("mol1,77,5\nmol2,5,900\n")
+    rows, cols, fp = B.read_ecfp(g)
+    assert rows.tolist() == [1, 1, 2, 2] and cols.tolist() == [1, 2, 2, 3] and fp == {77: 1, 5: 2, 900: 3}
+    assert B.filter_rare(sp.csc_matrix(np.array([[1, 0, 1], [1, 0, 0]])), 1).shape == (2, 2)
+    m = str(tmp_path / "a.mtx")
+    B.write_matrix_market(m, np.array([[1, 2, 0.5], [3, 1, -2.0]]))
+    A = B.read_matrix_market(m)
+    assert A.shape == (3, 2) and A[0, 1] == 0.5 and A[2, 0] == -2.0
