@@ -86,19 +86,23 @@ Replaces `sample_latent_all2!` (src/sampling.jl:149-172) and `sample_user2_all!`
 (or the rows of one shard) is drawn into the device sample matrix `out` (D x N).
 """
 function sample_rows!(c::Context, D, N, terms::Vector{Term}, mu::DevArray{Float64}, Lambda::DevArray{Float64}, entity_tag,
-                      out::DevArray{Float64}; shard=0, n_shards=1)
+                      out::DevArray{Float64}; shard=0, n_shards=1, prior_pack=nothing)
     check(ccall((:bdf_sample_rows, lib), Cint,
-                (Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Term}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, UInt32, Cint, Cint, Ptr{Cvoid}),
-                c.h, D, N, length(terms), terms, mu.p, length(mu.dims) == 2 ? 1 : 0, Lambda.p, entity_tag, shard, n_shards, out.p))
+                (Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Term}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, UInt32, Cint, Cint, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, D, N, length(terms), terms, mu.p, length(mu.dims) == 2 ? 1 : 0, Lambda.p, entity_tag, shard, n_shards, out.p,
+                prior_pack === nothing ? C_NULL : prior_pack.p))
 end
 
 "ConditionalNormalWishart + rand (src/sampling.jl:116-127, src/normal_wishart.jl:38-42; call site src/macau.jl:120-134)"
-function update_prior!(c::Context, D, N, sample, uhat, sumU, UUt, mu0, b0, Tinv, nu, entity_tag, mu, Lambda)
+function update_prior!(c::Context, D, N, sample, uhat, sumU, UUt, mu0, b0, Tinv, nu, entity_tag, mu, Lambda;
+                       prior_pack=nothing, draws=nothing)   # prior_pack: bdf_prior_pack_doubles(D) doubles; draws: bdf_hyper_draws
     check(ccall((:bdf_hyper_sums, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                 c.h, D, N, sample.p, uhat === nothing ? C_NULL : uhat.p, sumU.p, UUt.p))
     check(ccall((:bdf_hyper_sample, lib), Cint,
-                (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
-                c.h, D, N, sumU.p, UUt.p, mu0.p, b0, Tinv.p, nu, entity_tag, mu.p, Lambda.p, C_NULL))
+                (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid},
+                 Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, D, N, sumU.p, UUt.p, mu0.p, b0, Tinv.p, nu, entity_tag, mu.p, Lambda.p, C_NULL,
+                prior_pack === nothing ? C_NULL : prior_pack.p, draws === nothing ? C_NULL : draws.p))
 end
 
 "update_beta! (src/sampling.jl:361-370): feat is a bdf_feat handle from bdf_feat_create_{dense,csr,bin}"
