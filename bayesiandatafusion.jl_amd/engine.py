@@ -266,6 +266,7 @@ class EntityState:
     def __init__(self, ctx, en, D, tag):
         self.ctx, self.D, self.N, self.tag = ctx, D, en.count, tag
         self.sample = ctx.zeros(en.count, D)
+        self.sample_alt = ctx.zeros(en.count, D)     # the rows of the next sweep are written here, then the two swap
         self.mu = ctx.zeros(D)
         self.Lambda = (5.0 * torch.eye(D, dtype=torch.float64)).to(ctx.device)
         self.mu0 = ctx.zeros(D)
@@ -325,6 +326,12 @@ class GibbsEngine:
         self.ctx_h = self.ctx
         if not os.environ.get("BDF_NO_OVERLAP"):
             self.ctx_h = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+        # third stream for the prediction updates (test set, training set): they only read the sampled rows, and every
+        # entity's rows alternate between two buffers, so the update of sweep t runs beside the rows of sweep t+1
+        self.ctx_p = self.ctx
+        if not os.environ.get("BDF_NO_OVERLAP") and all(feat.isempty(r.F) for r in data.relations):
+            self.ctx_p = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+        self._ev_pred = None
         self._ev_rows, self._ev_hyper = {}, {}
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
@@ -448,8 +455,11 @@ class GibbsEngine:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record(self.ctx.stream)
         pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
+        # written into the entity's other buffer (nothing this launch reads), which then becomes the current one: readers
+        # of the previous sweep's rows on other streams (prediction updates) are never overwritten under their feet
         check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
-                                    st.tag, self.rank, self.world, _ptr(st.sample), _ptr(pack) if pack is not None else None))
+                                    st.tag, self.rank, self.world, _ptr(st.sample_alt), _ptr(pack) if pack is not None else None))
+        st.sample, st.sample_alt = st.sample_alt, st.sample
         if timed:
             e1.record(self.ctx.stream)
             self.k1_events.append((j, e0, e1))
@@ -513,6 +523,14 @@ class GibbsEngine:
         self.ctx.set_sweep(i)
         if two:
             self.ctx_h.set_sweep(i)
+        three = self.ctx_p is not self.ctx
+        if three:
+            # this sweep overwrites the buffers that held the rows of sweep i-2: the prediction updates that read them
+            # were all enqueued before the previous sweep began (a wait on a finished event is nearly free)
+            if self._ev_pred is not None:
+                main.wait_event(self._ev_pred)
+            self._ev_pred = torch.cuda.Event()
+            self._ev_pred.record(self.ctx_p.stream)
         self.update_relations()
         for j in range(len(self.ent)):
             if two and j in self._ev_hyper:
@@ -528,6 +546,8 @@ class GibbsEngine:
             if two:
                 ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
                 ev.record(side)
+        if three:
+            self.ctx_p.stream.wait_event(self._ev_rows[len(self.ent) - 1])    # prediction updates read this sweep's rows
         for j in range(len(self.ent)):
             if self.ent[j].F is not None:
                 if two:
@@ -539,6 +559,8 @@ class GibbsEngine:
                     side.wait_event(ev)
 
     def sync(self):
+        if self.ctx_p is not self.ctx:
+            self.ctx_p.sync()
         if self.ctx_h is not self.ctx:
             self.ctx_h.sync()
         self.ctx.sync()
@@ -560,7 +582,7 @@ class GibbsEngine:
     def test_pairs(self):
         r = self.data.relations[0]
         if self._test_pairs is None:
-            self._test_pairs = DevicePairs(self.ctx, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
+            self._test_pairs = DevicePairs(self.ctx_p, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
             dr = self.rel[0]
             if dr.F is not None:             # pred(r, probe_vec, F) = udot + F_test beta + mean_value (sampling.jl:9-14)
                 if feat.isempty(r.test_F):
@@ -582,7 +604,7 @@ class GibbsEngine:
         if self._train_pairs is None and self.rel[0].train is not None:
             self._train_pairs = self.rel[0].train
         if self._train_pairs is None:
-            self._train_pairs = DevicePairs(self.ctx, r.data.ids, r.data.values)
+            self._train_pairs = DevicePairs(self.ctx_p, r.data.ids, r.data.values)
         return self._train_pairs
 
     def close(self):
@@ -594,6 +616,8 @@ class GibbsEngine:
                 st.F.close()
         for dr in self.rel:
             dr.close()
+        if self.ctx_p is not self.ctx:
+            self.ctx_p.close()
         if self.ctx_h is not self.ctx:
             self.ctx_h.close()
         self.ctx.close()
