@@ -1,0 +1,229 @@
+// c_layout_chol.h -- factorisation and triangular solves of a D x D (D <= 64) symmetric positive-definite matrix held
+// in the MFMA accumulator (C) layout of one wavefront, shared by K1 (k_sample_rows.hip) and K6 (k_hyper.hip).
+// Lane (j = l & 15, h = l >> 4), register r of block (I, J) holds element (16 I + h + 4 r, 16 J + j).  See the header of
+// k_sample_rows.hip for the scheme (DPP row broadcasts folded into the fmas, owner lanes store each finished column to the
+// packed factor in LDS under a compile-time EXEC mask, the forward solve rides along as one more matrix row).
+#pragma once
+#include "bdf_common.h"
+#include "wave_linalg.h"
+#include <utility>
+
+#ifndef BDF_K1_WPB
+#define BDF_K1_WPB 4
+#endif
+#ifndef BDF_K1_WAVES32
+#define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
+#endif
+
+namespace {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int DP>
+struct Geo {
+    static constexpr int DB = DP / 16;                 // 16-wide blocks per dimension
+    static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
+    static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
+    static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
+    static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
+    __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
+    // packed factor in LDS: column k (block column K = k / 16) keeps rows 16 K .. DP-1, by row class:
+    // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - 16 K) / 4.  Columns are one double further apart than
+    // they are long: an odd stride, so that the backward solve's per-lane reads (lane = column, same row) fall in
+    // different LDS banks
+    __host__ __device__ static constexpr int col_rows(int k) { return DP - 16 * (k / 16); }
+    __host__ __device__ static constexpr int col_stride(int k) { return col_rows(k) + 1; }
+    __host__ __device__ static constexpr int col_base(int k)
+    {
+        int s = 0;
+        for (int q = 0; q < k / 16; q++) s += 16 * col_stride(16 * q);
+        return s + (k % 16) * col_stride(k);
+    }
+    static constexpr int TRI_D = (col_base(DP - 1) + col_stride(DP - 1) + 1) / 2 * 2;   // 272, 800, 2624 doubles
+    static constexpr int WAVE_LDS = TRI_D;
+};
+
+// ---- DPP row-broadcast fma: d += (s of lane KJ of this lane's row of 16) * m.  Inline asm is opaque to the compiler's
+// hazard recogniser (a VALU write of a DPP source needs 2 wait states before the DPP read), hence the leading s_nop. ----
+template <int KJ>
+__device__ inline void fm4(double &d0, double &d1, double &d2, double &d3, double s0, double s1, double s2, double s3,
+                           double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %4, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %5, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %6, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %7, %8 row_newbcast:%9 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm4_self(double &d0, double &d1, double &d2, double &d3, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
+                 : "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm1(double &d, double s, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d) : "v"(s), "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ inline void fm1_self(double &d, double m)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                 : "+v"(d) : "v"(m), "n"(KJ));
+}
+
+// ---- the factorisation (unscaled: the stored column k is Lt[i][k] = L[i][k] sqrt(d_k), Lt[k][k] = d_k) ------------------
+// A[blk(I,J)*4 + r] = element (16 I + h + 4 r, 16 J + j); bv[J] = entry 16 J + j of the extra row b (same in every h).
+// Software-pipelined: step k first updates the block column that holds column k+1, then -- while the rest of step k's
+// updates issue -- column k+1's pivot is broadcast, its four owner lanes store it to the packed factor in LDS, and every
+// lane reads back the entries of its own columns' rows (the multipliers of step k+1), so that neither the reciprocal
+// nor the LDS round trip sits between two steps.
+struct FactorLanes {            // per-lane LDS offsets (doubles), one per block column: kept opaque so that they stay in
+    int wr[4];                  // registers instead of being recomputed at every step (wr: LDS byte address)
+    int rd[4];
+};
+
+// preparation of step k: pivot (wave-uniform), column k to LDS by its four owner lanes, the lane's multipliers
+// nm[J] = -(Lt[16 J + j][k] / d_k); and the owner lanes keep entry k of the extra row (t_k, final now) in ts.
+// The owner lanes (j == k % 16) are a compile-time lane pattern, so their part runs under a constant EXEC mask set by
+// scalar moves: no vector compares, no copies (the compiler's own ds_write2 wanted the register-resident matrix copied).
+// LDS operations of a wave execute in order, and the compiler's wait before it uses its own reads covers these writes.
+template <int NV>
+struct OwnerStore;
+template <>
+struct OwnerStore<4> {
+    template <int MASK, int OFF>
+    __device__ static inline void run(unsigned addr, double v0, double v1, double v2, double v3)
+    {
+        unsigned long long save;
+        asm volatile("s_mov_b64 %0, exec\n\t"
+                     "s_mov_b32 exec_lo, %6\n\t"
+                     "s_mov_b32 exec_hi, %6\n\t"
+                     "ds_write_b64 %1, %2 offset:%7\n\t"
+                     "ds_write_b64 %1, %3 offset:%7+8\n\t"
+                     "ds_write_b64 %1, %4 offset:%7+16\n\t"
+                     "ds_write_b64 %1, %5 offset:%7+24\n\t"
+                     "s_mov_b64 exec, %0"
+                     : "=&s"(save) : "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(MASK), "n"(OFF) : "memory");
+    }
+};
+template <int MASK>
+__device__ inline void owner_keep(double &dst, double src)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %3\n\t"
+                 "s_mov_b32 exec_hi, %3\n\t"
+                 "v_mov_b64 %0, %2\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(dst), "=&s"(save) : "v"(src), "n"(MASK));
+}
+
+template <int DP, int k, int... Is>
+__device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
+{
+    using GG = Geo<DP>;
+    constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16);
+    (OwnerStore<4>::run<MASK, (cb + 4 * Is) * 8>(addr, A[GG::blk(K + Is, K) * 4], A[GG::blk(K + Is, K) * 4 + 1],
+                                                 A[GG::blk(K + Is, K) * 4 + 2], A[GG::blk(K + Is, K) * 4 + 3]), ...);
+}
+
+template <int DP, int k>
+__device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                            double *tri, const FactorLanes &fl, double (&nm)[Geo<DP>::DB])
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB, K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
+    constexpr int MASK = 0x00010001 << kj;                     // lanes with (lane & 15) == kj, per 32-lane half
+    const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
+    owner_store_all<DP, k>(A, (unsigned)fl.wr[K], std::make_integer_sequence<int, DB - K>{});
+    owner_keep<MASK>(ts[K], bv[K]);
+    wave_sync();
+    double raw[DB];
+#pragma unroll
+    for (int J = K; J < DB; J++) raw[J] = tri[fl.rd[K] + cb + 4 * (J - K)];
+    const double rd = fast_rcp(d);
+#pragma unroll
+    for (int J = K; J < DB; J++) nm[J] = -(raw[J] * rd);
+}
+
+// step k: the updates of columns > k.  Block columns J > K first: they read column k (block column K) through the DPP
+// broadcast, and the update of block column K rewrites it.  No masking of finished columns (<= k) in block column K:
+// their registers are dead (a column is read for the last time at its own step).
+template <int DP, int k>
+__device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                   double *tri, const FactorLanes &fl, int j, double (&nm)[Geo<DP>::DB])
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB;
+    constexpr int K = k / 16, kj = k % 16;
+#pragma unroll
+    for (int J = DB - 1; J > K; J--) {
+#pragma unroll
+        for (int I = J; I < DB; I++) {
+            double *t = &A[GG::blk(I, J) * 4];
+            const double *s = &A[GG::blk(I, K) * 4];
+            fm4<kj>(t[0], t[1], t[2], t[3], s[0], s[1], s[2], s[3], nm[J]);
+        }
+        fm1<kj>(bv[J], bv[K], nm[J]);
+    }
+    if constexpr (kj < 15) {                      // block column K still has unfinished columns
+#pragma unroll
+        for (int I = K; I < DB; I++) {
+            double *t = &A[GG::blk(I, K) * 4];
+            fm4_self<kj>(t[0], t[1], t[2], t[3], nm[K]);
+        }
+        fm1_self<kj>(bv[K], nm[K]);
+    }
+    prep<DP, k + 1>(A, bv, ts, tri, fl, nm);
+}
+
+template <int DP, int... Ks>
+__device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                  double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
+{
+    using GG = Geo<DP>;
+    FactorLanes fl;
+#pragma unroll
+    for (int K = 0; K < GG::DB; K++) {
+        const int nr4 = (DP - 16 * K) / 4;
+        fl.wr[K] = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * nr4);   // LDS byte address
+        fl.rd[K] = (j & 3) * nr4 + (j >> 2);
+        asm volatile("" : "+v"(fl.wr[K]), "+v"(fl.rd[K]));
+    }
+    double nm[GG::DB];
+    prep<DP, 0>(A, bv, ts, tri, fl, nm);
+    // steps 0 .. D-2 (the last column has nothing to update; padded columns are skipped).  One wave-uniform exit per
+    // step out of straight-line code (a skip-and-rejoin per step would make every step a merge point of the whole
+    // register-resident matrix)
+    (void)(... && ((Ks + 1 < D) && (factor_step<DP, Ks>(A, bv, ts, tri, fl, j, nm), true)));
+}
+
+// ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----
+template <int DP, int i>
+__device__ inline void backward_step(double &yh, double rdv, const double *const (&colq)[4], int lane)
+{
+    const double xi = readlane_f64(yh * rdv, i);
+    if (lane < i) yh = fma(-colq[i & 3][i >> 2], xi, yh);
+}
+
+template <int DP, int... Is>
+__device__ inline void backward_all(double &yh, double rdv, const double *const (&colq)[4], int lane, int D,
+                                    std::integer_sequence<int, Is...>)
+{
+    (((DP - 1 - Is) < D ? backward_step<DP, DP - 1 - Is>(yh, rdv, colq, lane) : (void)0), ...);
+}
+
+}  // namespace

@@ -1,0 +1,307 @@
+// hyper_job.h -- device code of the hyperprior update (K6), shared by the stand-alone kernels of k_hyper.hip and by the row
+// sampler's launch (k_sample_rows.hip), which can carry the previous entity's hyperprior update in a few extra workgroups.
+//
+//   hyper_partial<DP> : per-workgroup partial of sum_i u_i and U U' over 128 rows -- the same rank-4 MFMA update as K1's
+//   hyper_reduce<DP>  : fixed-order sum of the partials (the order of k_hyper_final: 16 interleaved chains, then a butterfly)
+//   nw_draw<DP>       : ConditionalNormalWishart (src/sampling.jl:116-127) + rand(::NormalWishart)
+//                       (src/normal_wishart.jl:38-42) in one workgroup, random part supplied (k_hyper_draws)
+#pragma once
+#include "c_layout_chol.h"
+
+namespace {
+
+typedef double hd4 __attribute__((ext_vector_type(4)));
+constexpr int HS_THREADS = 256;
+constexpr int HS_ROWS = 128;         // rows per workgroup: 8 steps of 4 rows per wave at 4 waves
+
+template <int DP>
+struct HGeo {
+    static constexpr int DB = DP / 16, NB = DB * (DB + 1) / 2;
+    static constexpr int PSZ = NB * 4 * 64 + DB * 16;      // doubles per partial: C-layout blocks, then the column sums
+    static constexpr int LD = DP + 1;
+    // LDS of nw_draw (doubles): sL | sA | tri | s_muN s_mu s_rd s_sq
+    static constexpr int NW_LDS = 2 * DP * LD + Geo<DP>::TRI_D + 4 * 64;
+};
+
+struct NWArgs {
+    int D;
+    double N;
+    const double *sumU, *UUt, *mu0, *Tinv;
+    double b0, nu;
+    double *mu_out, *Lambda_out, *params_out;
+    const double *draws;       // Bartlett matrix (D x D row-major) + D mean normals, from k_hyper_draws
+    double *pack_out;          // nullable: Lambda mu (D) then the accumulator-layout image of the reversed Lambda (K1)
+    int *flag;
+};
+
+// ---- stage 1: partial sums of rows [r0, r0 + HS_ROWS) by NW waves; red: (NW-1) * PSZ doubles of LDS -----------------------
+// U U' = sum over rows of u u' is the same rank-4 MFMA update as K1's: lane (j = l & 15, h = l >> 4) supplies element
+// 16 I + j of row 4 s + h, straight from global memory (a coalesced 128-byte read per 16 lanes), and the lower
+// block-triangle accumulates in the MFMA C layout.  The waves take every NW-th 4-row step, all of a wave's loads are
+// issued before its first MFMA, and the waves' results are added in wave order.
+template <int DP, int NW>
+__device__ inline void hyper_partial(int D, int64_t N, const double *__restrict__ sample, const double *__restrict__ uhat,
+                                     int64_t r0, double *__restrict__ p, double *red, int tid)
+{
+    constexpr int DB = HGeo<DP>::DB, NB = HGeo<DP>::NB, PSZ = HGeo<DP>::PSZ;
+    constexpr int KS = HS_ROWS / (4 * NW);              // steps per wave
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, h = lane >> 4;
+    double u[KS][DB];
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        const int64_t row = r0 + 4 * (wave + NW * k) + h;
+#pragma unroll
+        for (int I = 0; I < DB; I++) {
+            const int e = 16 * I + j;
+            const bool ok = row < N && e < D;
+            const int64_t off = (ok ? row : 0) * D + (ok ? e : 0);
+            const double v = sample[off] - (uhat ? uhat[off] : 0.0);
+            u[k][I] = ok ? v : 0.0;
+        }
+    }
+    hd4 acc[NB];
+    double cs[DB];
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = hd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int I = 0; I < DB; I++) cs[I] = 0.0;
+#pragma unroll
+    for (int k = 0; k < KS; k++) {
+        int b = 0;
+#pragma unroll
+        for (int I = 0; I < DB; I++) {
+#pragma unroll
+            for (int J = 0; J <= I; J++) {
+                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k][I], u[k][J], acc[b], 0, 0, 0);
+                b++;
+            }
+            cs[I] += u[k][I];
+        }
+    }
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        cs[I] += __shfl_xor(cs[I], 16);
+        cs[I] += __shfl_xor(cs[I], 32);
+    }
+    if (wave > 0) {
+        double *dst = red + (wave - 1) * PSZ;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
+        if (lane < 16)
+#pragma unroll
+            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = cs[I];
+    }
+    __syncthreads();
+    if (wave == 0) {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = acc[b][r];
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++) v += red[w * PSZ + (b * 4 + r) * 64 + lane];
+                __hip_atomic_store(p + (b * 4 + r) * 64 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        if (lane < 16)
+#pragma unroll
+            for (int I = 0; I < DB; I++) {
+                double v = cs[I];
+#pragma unroll
+                for (int w = 0; w < NW - 1; w++) v += red[w * PSZ + NB * 4 * 64 + I * 16 + lane];
+                __hip_atomic_store(p + NB * 4 * 64 + I * 16 + lane, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+    }
+}
+
+// element e of the summed partials, in the order k_hyper_final adds them: chain q takes blocks q, q+16, ..., then the
+// butterfly (8, 4, 2, 1) as lane 0 of 16 sees it
+__device__ inline double hyper_sum_element(const double *partial, int psz, int nblocks, int e)
+{
+    double c[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) c[q] = 0.0;
+    for (int b0 = 0; b0 < nblocks; b0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 16; q++)
+            if (b0 + q < nblocks) c[q] += partial[(int64_t)(b0 + q) * psz + e];
+    }
+#pragma unroll
+    for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+        for (int q = 0; q < off; q++) c[q] += c[q + off];
+    return c[0];
+}
+
+// scatter of a summed C-layout element to U U' (and its mirror image) / the column sums
+template <int DP>
+__device__ inline void hyper_scatter(int D, int e, double s, double *sumU, double *UUt)
+{
+    constexpr int NB = HGeo<DP>::NB;
+    if (e < NB * 4 * 64) {
+        const int b = e >> 8, r = (e >> 6) & 3, l = e & 63;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= b) I++;
+        const int J = b - I * (I + 1) / 2;
+        const int row = 16 * I + (l >> 4) + 4 * r, col = 16 * J + (l & 15);
+        if (row < D && col < D) {
+            UUt[row + (int64_t)col * D] = s;
+            if (I != J) UUt[col + (int64_t)row * D] = s;
+        }
+    } else {
+        const int el = e - NB * 4 * 64;                   // 16 I + j
+        if (el < D) sumU[el] = s;
+    }
+}
+
+// ---- the Normal-Wishart draw on one workgroup (nthreads = 256 or 128); lds: HGeo<DP>::NW_LDS doubles ------------------
+// In the reference's terms:
+//     W    = Tinv + UU' + b0 mu0 mu0' - beta_N mu_N mu_N'         (= inv(T_N))
+//     Lam  = (L_T A)(L_T A)',  L_T = chol(T_N)' lower,  A = Bartlett matrix
+//     mu   = mu_N + chol(inv(Lam) / beta_N)' z
+// Both "Cholesky factor of an inverse" steps come without forming the inverse (see k_hyper.hip): in index-reversed
+// coordinates (~)  W~ = L~ L~',  Z~ = L~^-T (J A),  Lam~ = Z~ Z~',  Lam~ = L2~ L2~',  mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N).
+// The two factorisations run on wave 0 in the accumulator layout (c_layout_chol.h), the rest on all threads.
+template <int DP>
+__device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthreads)
+{
+    using GG = Geo<DP>;
+    constexpr int LD = HGeo<DP>::LD, DB = GG::DB, NB = GG::NB;
+    double *sL = lds, *sA = sL + DP * LD, *tri = sA + DP * LD, *s_muN = tri + GG::TRI_D, *s_mu = s_muN + 64,
+           *s_rd = s_mu + 64, *s_sq = s_rd + 64;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, h = lane >> 4;
+    const int D = a.D;
+    const double beta_N = a.b0 + a.N;
+    if (tid < 64) {
+        const int e = D - 1 - tid;
+        s_muN[tid] = (e >= 0) ? (a.b0 * a.mu0[e] + a.sumU[e]) / beta_N : 0.0;      // reversed: s_muN[c] = mu_N[D-1-c]
+    }
+    __syncthreads();
+    // ---- W~ (Symmetric(): upper triangle) into sL, the reversed-row Bartlett matrix A~ = J A into sA: all threads
+    for (int e = tid; e < DP * DP; e += nthreads) {
+        const int i = e / DP, c = e % DP;
+        const int ei = D - 1 - i, ej = D - 1 - c;
+        double w = (i == c) ? 1.0 : 0.0;
+        if (ei >= 0 && ej >= 0) {
+            const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;
+            w = a.Tinv[lo + (int64_t)hi * D] + a.UUt[lo + (int64_t)hi * D] + a.b0 * a.mu0[lo] * a.mu0[hi] -
+                beta_N * s_muN[D - 1 - lo] * s_muN[D - 1 - hi];
+            if (a.params_out) a.params_out[D + ei + (int64_t)ej * D] = w;
+        }
+        sL[i * LD + c] = w;
+        sA[i * LD + c] = (ei >= 0 && c < D) ? a.draws[ei * D + c] : 0.0;          // sA[i][c] = A[D-1-i][c]
+    }
+    if (a.params_out && tid < DP && D - 1 - tid >= 0) a.params_out[D - 1 - tid] = s_muN[tid];
+    __syncthreads();
+
+    // the factorisation of the matrix in sL on wave 0; pivots' reciprocals and square roots to s_rd / s_sq
+    auto factor_sL = [&](double &dv_out) {
+        double A[NB * 4], bv[DB], ts[DB];
+#pragma unroll
+        for (int I = 0; I < DB; I++)
+#pragma unroll
+            for (int J = 0; J <= I; J++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) A[GG::blk(I, J) * 4 + r] = sL[(16 * I + h + 4 * r) * LD + 16 * J + j];
+#pragma unroll
+        for (int J = 0; J < DB; J++) { bv[J] = 0.0; ts[J] = 0.0; }
+        wave_sync();
+        factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
+        wave_sync();
+        const int cK = (lane < DP) ? (lane >> 4) : 0, cj = lane & 15;
+        const int nr4 = (DP - 16 * cK) / 4;
+        const int cbase = 16 * (cK * DP - 8 * cK * (cK - 1) + cK) + cj * (DP - 16 * cK + 1);
+        double dv = 1.0;
+        if (lane < D) dv = tri[cbase + (cj & 3) * nr4 + (cj >> 2)];
+        if (!(dv > 0.0)) atomicOr(a.flag, 2);
+        dv_out = dv;
+        return cbase;
+    };
+
+    if (wave == 0) {
+        double dv;
+        factor_sL(dv);
+        s_rd[lane] = fast_rcp(dv);
+        s_sq[lane] = dv * fast_rsqrt(dv);
+    }
+    __syncthreads();
+
+    // ---- Z~ = L~^-T A~  <=>  Lt' Z~ = diag(sqrt(d)) A~ : one thread per column, backward substitution over the packed factor
+    if (tid < DP) {
+        double z[DP];
+#pragma unroll
+        for (int i = DP - 1; i >= 0; i--) {
+            if (i >= D) { z[i] = 0.0; continue; }            // padding: identity
+            constexpr int dummy = 0; (void)dummy;
+            // four interleaved partial sums (fixed assignment m % 4): four short dependency chains instead of one long one
+            double s4[4] = {s_sq[i] * sA[i * LD + tid], 0.0, 0.0, 0.0};
+            const int cb = GG::col_base(i), nr4 = GG::col_rows(i) / 4, r16 = 16 * (i / 16);
+#pragma unroll
+            for (int m = i + 1; m < DP; m++) s4[m & 3] = fma(-tri[cb + (m & 3) * nr4 + (m - r16) / 4], z[m], s4[m & 3]);
+            z[i] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * s_rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DP; i++) sA[i * LD + tid] = z[i];
+    }
+    __syncthreads();
+
+    // ---- Lam~ = Z~ Z~' (identity on the padding), stored reversed in sL and natural in Lambda_out
+    for (int e = tid; e < DP * DP; e += nthreads) {
+        const int i = e / DP, c2 = e % DP;
+        const int ei = D - 1 - i, ej = D - 1 - c2;
+        double s = 0.0;
+        if (ei >= 0 && ej >= 0) {
+            // fixed summation order in c; (i,j) and (j,i) multiply the same pairs: the result is exactly symmetric
+            for (int c = 0; c < DP; c++) s = fma(sA[i * LD + c], sA[c2 * LD + c], s);
+            a.Lambda_out[ei + (int64_t)ej * D] = s;
+        } else {
+            s = (i == c2) ? 1.0 : 0.0;
+        }
+        sL[i * LD + c2] = s;
+    }
+    __syncthreads();
+
+    // ---- mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
+    if (wave == 0) {
+        double dv;
+        const int cbase = factor_sL(dv);
+        const int cK = (lane < DP) ? (lane >> 4) : 0;
+        const int nr4 = (DP - 16 * cK) / 4;
+        const int ej = D - 1 - lane;
+        const double rdv = fast_rcp(dv);
+        double yh = (lane < D) ? a.draws[D * D + ej] * (dv * fast_rsqrt(dv)) : 0.0;
+        const double *colq[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) colq[q] = tri + cbase + q * nr4 - 4 * cK;
+        backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
+        const double mu_c = s_muN[lane] + (yh * rdv) / sqrt(beta_N);
+        if (lane < D) a.mu_out[ej] = mu_c;
+        s_mu[lane] = (lane < D) ? mu_c : 0.0;                      // reversed: s_mu[c] = mu[D-1-c]
+    }
+    if (a.pack_out == nullptr) return;
+    __syncthreads();
+    // ---- what the row sampler needs of (mu, Lambda), written here so that it needs no pre-launch of its own:
+    // Lambda mu (same products in the same order as k_prior of k_sample_rows.hip: bit-identical), and Lam~ in
+    // the MFMA accumulator layout [block * 4 + r][lane] (identity on the padding -- exactly what sL holds)
+    for (int e = tid >> 3; e < D; e += nthreads / 8) {            // eight lanes per entry: lane part p adds i = p, p+8, ...
+        const int part = tid & 7;
+        double v = 0.0;
+        for (int i = part; i < D; i += 8) v = fma(sL[(D - 1 - e) * LD + (D - 1 - i)], s_mu[D - 1 - i], v);
+        v += __shfl_xor(v, 4);
+        v += __shfl_xor(v, 2);
+        v += __shfl_xor(v, 1);
+        if (part == 0) a.pack_out[e] = v;
+    }
+    for (int e = wave; e < NB * 4; e += nthreads / 64) {
+        const int b = e >> 2, r = e & 3;
+        int I = 0;
+        while ((I + 1) * (I + 2) / 2 <= b) I++;
+        const int J = b - I * (I + 1) / 2;
+        a.pack_out[D + e * 64 + lane] = sL[(16 * I + (lane >> 4) + 4 * r) * LD + 16 * J + (lane & 15)];
+    }
+}
+
+}  // namespace
