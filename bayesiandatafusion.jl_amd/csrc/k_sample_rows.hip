@@ -508,6 +508,9 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     double ts[DB];                                // ts[J] in lane j: t_(16 J + j) once its step has passed; the last column's
 #pragma unroll                                    // (and any column's before its step) is still in bv
     for (int J = 0; J < DB; J++) ts[J] = 0.0;
+#ifdef BDF_K1_FACTOR_PRIO
+    __builtin_amdgcn_s_setprio(BDF_K1_FACTOR_PRIO);      // the factorisation is a chain of dependent steps: let it issue when ready
+#endif
     factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
     STAMP(5);
 
