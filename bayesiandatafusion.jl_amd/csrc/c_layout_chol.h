@@ -28,19 +28,31 @@ struct Geo {
     static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
     static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
     __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
-    // packed factor in LDS: column k (block column K = k / 16) keeps rows 16 K .. DP-1, by row class:
-    // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - 16 K) / 4.  Columns are one double further apart than
-    // they are long: an odd stride, so that the backward solve's per-lane reads (lane = column, same row) fall in
-    // different LDS banks
-    __host__ __device__ static constexpr int col_rows(int k) { return DP - 16 * (k / 16); }
+    // packed factor in LDS: column k keeps rows col_first(k) = RG * (k / RG) .. DP-1, by row class:
+    // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - col_first(k)) / 4.  Columns are one double further apart
+    // than they are long: an odd stride, so that the backward solve's per-lane reads (lane = column, same row) fall in
+    // different LDS banks.  608 doubles at DP = 32 (4.9 KB per wave: seven waves per SIMD fit the 160 KB of a CU).
+    static constexpr int RG = 4;
+    __host__ __device__ static constexpr int col_first(int k) { return RG * (k / RG); }
+    __host__ __device__ static constexpr int col_rows(int k) { return DP - col_first(k); }
     __host__ __device__ static constexpr int col_stride(int k) { return col_rows(k) + 1; }
     __host__ __device__ static constexpr int col_base(int k)
     {
         int s = 0;
-        for (int q = 0; q < k / 16; q++) s += 16 * col_stride(16 * q);
-        return s + (k % 16) * col_stride(k);
+        for (int q = 0; q < k / RG; q++) s += RG * col_stride(RG * q);
+        return s + (k % RG) * col_stride(k);
     }
-    static constexpr int TRI_D = (col_base(DP - 1) + col_stride(DP - 1) + 1) / 2 * 2;   // 272, 800, 2624 doubles
+    static constexpr int TRI_D = (col_base(DP - 1) + col_stride(DP - 1) + 1) / 2 * 2;   // 176, 608, 2240 doubles
+    // the same for a column known at run time (lane = column): base, rows per class, first row / 4
+    struct ColRT { int cbase, nr4, q; };
+    __device__ static inline ColRT col_rt(int c)
+    {
+        ColRT r;
+        r.q = c / RG;
+        r.nr4 = (DP - RG * r.q) / 4;
+        r.cbase = RG * (r.q * (DP + 1) - RG * r.q * (r.q - 1) / 2) + (c % RG) * (DP - RG * r.q + 1);
+        return r;
+    }
     static constexpr int WAVE_LDS = TRI_D;
 };
 
@@ -90,9 +102,9 @@ __device__ inline void fm1_self(double &d, double m)
 // updates issue -- column k+1's pivot is broadcast, its four owner lanes store it to the packed factor in LDS, and every
 // lane reads back the entries of its own columns' rows (the multipliers of step k+1), so that neither the reciprocal
 // nor the LDS round trip sits between two steps.
-struct FactorLanes {            // per-lane LDS offsets (doubles), one per block column: kept opaque so that they stay in
-    int wr[4];                  // registers instead of being recomputed at every step (wr: LDS byte address)
-    int rd[4];
+struct FactorLanes {            // per-lane LDS addressing, kept opaque so that it stays in registers
+    int wr0, h8;                // owner lanes: byte address of class h at q = 0, and 8 h (one double less per class per q)
+    int rd0, j3;                // multiplier reads: (j & 3) * DP / 4 + (j >> 2), and j & 3
 };
 
 // preparation of step k: pivot (wave-uniform), column k to LDS by its four owner lanes, the lane's multipliers
@@ -102,23 +114,25 @@ struct FactorLanes {            // per-lane LDS offsets (doubles), one per block
 // LDS operations of a wave execute in order, and the compiler's wait before it uses its own reads covers these writes.
 template <int NV>
 struct OwnerStore;
-template <>
-struct OwnerStore<4> {
-    template <int MASK, int OFF>
-    __device__ static inline void run(unsigned addr, double v0, double v1, double v2, double v3)
-    {
-        unsigned long long save;
-        asm volatile("s_mov_b64 %0, exec\n\t"
-                     "s_mov_b32 exec_lo, %6\n\t"
-                     "s_mov_b32 exec_hi, %6\n\t"
-                     "ds_write_b64 %1, %2 offset:%7\n\t"
-                     "ds_write_b64 %1, %3 offset:%7+8\n\t"
-                     "ds_write_b64 %1, %4 offset:%7+16\n\t"
-                     "ds_write_b64 %1, %5 offset:%7+24\n\t"
-                     "s_mov_b64 exec, %0"
-                     : "=&s"(save) : "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(MASK), "n"(OFF) : "memory");
-    }
-};
+#define BDF_OWNER_STORE(NV, STORES, OPS, NARGS)                                                                        \
+    template <>                                                                                                       \
+    struct OwnerStore<NV> {                                                                                           \
+        template <int MASK, int OFF>                                                                                  \
+        __device__ static inline void run(unsigned addr, double v0, double v1, double v2, double v3)                  \
+        {                                                                                                             \
+            unsigned long long save;                                                                                  \
+            asm volatile("s_mov_b64 %0, exec\n\t"                                                                     \
+                         "s_mov_b32 exec_lo, %6\n\t"                                                                  \
+                         "s_mov_b32 exec_hi, %6\n\t" STORES "s_mov_b64 exec, %0"                                      \
+                         : "=&s"(save) : "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(MASK), "n"(OFF) : "memory"); \
+        }                                                                                                             \
+    };
+// the last NV of the four registers of a block (rows below the column's first stored row are left out)
+BDF_OWNER_STORE(4, "ds_write_b64 %1, %2 offset:%7\n\tds_write_b64 %1, %3 offset:%7+8\n\tds_write_b64 %1, %4 offset:%7+16\n\tds_write_b64 %1, %5 offset:%7+24\n\t", , )
+BDF_OWNER_STORE(3, "ds_write_b64 %1, %3 offset:%7\n\tds_write_b64 %1, %4 offset:%7+8\n\tds_write_b64 %1, %5 offset:%7+16\n\t", , )
+BDF_OWNER_STORE(2, "ds_write_b64 %1, %4 offset:%7\n\tds_write_b64 %1, %5 offset:%7+8\n\t", , )
+BDF_OWNER_STORE(1, "ds_write_b64 %1, %5 offset:%7\n\t", , )
+#undef BDF_OWNER_STORE
 template <int MASK>
 __device__ inline void owner_keep(double &dst, double src)
 {
@@ -135,9 +149,12 @@ template <int DP, int k, int... Is>
 __device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
 {
     using GG = Geo<DP>;
-    constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16);
-    (OwnerStore<4>::run<MASK, (cb + 4 * Is) * 8>(addr, A[GG::blk(K + Is, K) * 4], A[GG::blk(K + Is, K) * 4 + 1],
-                                                 A[GG::blk(K + Is, K) * 4 + 2], A[GG::blk(K + Is, K) * 4 + 3]), ...);
+    constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16), q = GG::col_first(k) / 4;
+    constexpr int r0 = q - 4 * K;                       // first stored register of block (K, K): rows >= col_first(k)
+    // block (K + Is, K), registers r >= (Is == 0 ? r0 : 0), to class-local positions 4 (K + Is) + r - q
+    (OwnerStore<(Is == 0 ? 4 - r0 : 4)>::template run<MASK, (cb + 4 * (K + Is) + (Is == 0 ? r0 : 0) - q) * 8>(
+         addr, A[GG::blk(K + Is, K) * 4], A[GG::blk(K + Is, K) * 4 + 1], A[GG::blk(K + Is, K) * 4 + 2],
+         A[GG::blk(K + Is, K) * 4 + 3]), ...);
 }
 
 template <int DP, int k>
@@ -148,12 +165,14 @@ __device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&b
     constexpr int DB = GG::DB, K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
     constexpr int MASK = 0x00010001 << kj;                     // lanes with (lane & 15) == kj, per 32-lane half
     const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
-    owner_store_all<DP, k>(A, (unsigned)fl.wr[K], std::make_integer_sequence<int, DB - K>{});
+    constexpr int q = GG::col_first(k) / 4;                   // rows per class: DP / 4 - q
+    owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8), std::make_integer_sequence<int, DB - K>{});
     owner_keep<MASK>(ts[K], bv[K]);
     wave_sync();
     double raw[DB];
+    const int ri = fl.rd0 - q * fl.j3 + (cb - q);             // row 16 J + j of column k is at ri + 4 J
 #pragma unroll
-    for (int J = K; J < DB; J++) raw[J] = tri[fl.rd[K] + cb + 4 * (J - K)];
+    for (int J = K; J < DB; J++) raw[J] = tri[ri + 4 * J];
     const double rd = fast_rcp(d);
 #pragma unroll
     for (int J = K; J < DB; J++) nm[J] = -(raw[J] * rd);
@@ -196,13 +215,11 @@ __device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo
 {
     using GG = Geo<DP>;
     FactorLanes fl;
-#pragma unroll
-    for (int K = 0; K < GG::DB; K++) {
-        const int nr4 = (DP - 16 * K) / 4;
-        fl.wr[K] = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * nr4);   // LDS byte address
-        fl.rd[K] = (j & 3) * nr4 + (j >> 2);
-        asm volatile("" : "+v"(fl.wr[K]), "+v"(fl.rd[K]));
-    }
+    fl.wr0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * (DP / 4));   // LDS byte address
+    fl.h8 = 8 * h;
+    fl.rd0 = (j & 3) * (DP / 4) + (j >> 2);
+    fl.j3 = j & 3;
+    asm volatile("" : "+v"(fl.wr0), "+v"(fl.h8), "+v"(fl.rd0), "+v"(fl.j3));
     double nm[GG::DB];
     prep<DP, 0>(A, bv, ts, tri, fl, nm);
     // steps 0 .. D-2 (the last column has nothing to update; padded columns are skipped).  One wave-uniform exit per

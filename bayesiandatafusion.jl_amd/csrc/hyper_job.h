@@ -211,14 +211,12 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
         wave_sync();
         factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
         wave_sync();
-        const int cK = (lane < DP) ? (lane >> 4) : 0, cj = lane & 15;
-        const int nr4 = (DP - 16 * cK) / 4;
-        const int cbase = 16 * (cK * DP - 8 * cK * (cK - 1) + cK) + cj * (DP - 16 * cK + 1);
+        const typename GG::ColRT cr = GG::col_rt(lane < DP ? lane : 0);
         double dv = 1.0;
-        if (lane < D) dv = tri[cbase + (cj & 3) * nr4 + (cj >> 2)];
+        if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];
         if (!(dv > 0.0)) atomicOr(a.flag, 2);
         dv_out = dv;
-        return cbase;
+        return cr;
     };
 
     if (wave == 0) {
@@ -238,7 +236,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
             constexpr int dummy = 0; (void)dummy;
             // four interleaved partial sums (fixed assignment m % 4): four short dependency chains instead of one long one
             double s4[4] = {s_sq[i] * sA[i * LD + tid], 0.0, 0.0, 0.0};
-            const int cb = GG::col_base(i), nr4 = GG::col_rows(i) / 4, r16 = 16 * (i / 16);
+            const int cb = GG::col_base(i), nr4 = GG::col_rows(i) / 4, r16 = GG::col_first(i);
 #pragma unroll
             for (int m = i + 1; m < DP; m++) s4[m & 3] = fma(-tri[cb + (m & 3) * nr4 + (m - r16) / 4], z[m], s4[m & 3]);
             z[i] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * s_rd[i];
@@ -267,15 +265,13 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
     // ---- mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
     if (wave == 0) {
         double dv;
-        const int cbase = factor_sL(dv);
-        const int cK = (lane < DP) ? (lane >> 4) : 0;
-        const int nr4 = (DP - 16 * cK) / 4;
+        const typename GG::ColRT cr = factor_sL(dv);
         const int ej = D - 1 - lane;
         const double rdv = fast_rcp(dv);
         double yh = (lane < D) ? a.draws[D * D + ej] * (dv * fast_rsqrt(dv)) : 0.0;
         const double *colq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) colq[q] = tri + cbase + q * nr4 - 4 * cK;
+        for (int q = 0; q < 4; q++) colq[q] = tri + cr.cbase + q * cr.nr4 - cr.q;
         backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
         const double mu_c = s_muN[lane] + (yh * rdv) / sqrt(beta_N);
         if (lane < D) a.mu_out[ej] = mu_c;

@@ -515,12 +515,11 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     STAMP(5);
 
     // lane c = column c: pivot d_c from the packed factor, t_c (the forward solve, unscaled) from the extra row
-    const int cK = (lane < DP) ? (lane >> 4) : 0, cj = lane & 15;
-    const int nr4 = (DP - 16 * cK) / 4;
-    const int cbase = 16 * (cK * DP - 8 * cK * (cK - 1) + cK) + cj * (DP - 16 * cK + 1);
+    const int cK = (lane < DP) ? (lane >> 4) : 0;
+    const typename GG::ColRT cr = GG::col_rt(lane < DP ? lane : 0);       // this lane's column of the packed factor
     wave_sync();
     double dv = 1.0, tv = 0.0;
-    if (lane < D) dv = tri[cbase + (cj & 3) * nr4 + (cj >> 2)];
+    if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];      // the diagonal entry is the first of its row class
     if (!(dv > 0.0)) atomicOr(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
 #pragma unroll
     for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? ts[J] : tv;
@@ -529,7 +528,7 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     double yh = fma(z, dv * fast_rsqrt(dv), tv);
     const double *colq[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) colq[q] = tri + cbase + q * nr4 - 4 * cK;
+    for (int q = 0; q < 4; q++) colq[q] = tri + cr.cbase + q * cr.nr4 - cr.q;     // row i at colq[i & 3][i >> 2]
     backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
     if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
     STAMP(8);

@@ -85,7 +85,7 @@ int main()
         printf("s_memtime: %llu ticks in %.3f ms -> %.1f MHz; s_memrealtime %llu ticks -> %.1f MHz\n", h[0], ms, h[0] / ms / 1e3, h[1], h[1] / ms / 1e3);
     }
     double *out; unsigned long long *cyc;
-    hipMalloc(&out, 1 << 20); hipMalloc(&cyc, 1 << 16);
+    hipMalloc(&out, 1 << 24); hipMalloc(&cyc, 1 << 16);
     k_sem<<<1, 64>>>(out);
     std::vector<double> h(64);
     hipMemcpy(h.data(), out, 64 * 8, hipMemcpyDeviceToHost);
@@ -101,6 +101,17 @@ int main()
             printf("%s, %d wave(s)/SIMD: %.2f cycles per instruction per wave\n", dpp ? "v_fmac_f64_dpp" : "v_fmac_f64    ", waves,
                    (double)c / (rounds * 8.0));
         }
+    }
+    // chip-wide fp64 FMA rate: 256 CUs x {1,2,4,8} workgroups of 256 threads (= waves per SIMD), 8 independent chains each
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+        const int blocks = 256 * wps, rounds2 = 1 << 16;
+        k_rate<false><<<blocks, 256>>>(out, cyc, 1024);
+        hipDeviceSynchronize();
+        hipEventRecord(e0); k_rate<false><<<blocks, 256>>>(out, cyc, rounds2); hipEventRecord(e1); hipEventSynchronize(e1);
+        float ms; hipEventElapsedTime(&ms, e0, e1);
+        const double flops = 2.0 * 64 * 8.0 * rounds2 * 4.0 * blocks;
+        printf("%d wave(s)/SIMD on every CU: %.1f TFLOP/s fp64 FMA (%.3f ms)\n", wps, flops / ms / 1e9, ms);
     }
     return bad;
 }
