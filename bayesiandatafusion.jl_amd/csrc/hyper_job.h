@@ -41,42 +41,44 @@ struct NWArgs {
 // issued before its first MFMA, and the waves' results are added in wave order.
 template <int DP, int NW>
 __device__ inline void hyper_partial(int D, int64_t N, const double *__restrict__ sample, const double *__restrict__ uhat,
-                                     int64_t r0, double *__restrict__ p, double *red, int tid)
+                                     int64_t r0, int64_t r1, double *__restrict__ p, double *red, int tid)
 {
     constexpr int DB = HGeo<DP>::DB, NB = HGeo<DP>::NB, PSZ = HGeo<DP>::PSZ;
-    constexpr int KS = HS_ROWS / (4 * NW);              // steps per wave
+    constexpr int KS = HS_ROWS / (4 * NW);              // steps per wave and chunk of HS_ROWS rows
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, h = lane >> 4;
-    double u[KS][DB];
-#pragma unroll
-    for (int k = 0; k < KS; k++) {
-        const int64_t row = r0 + 4 * (wave + NW * k) + h;
-#pragma unroll
-        for (int I = 0; I < DB; I++) {
-            const int e = 16 * I + j;
-            const bool ok = row < N && e < D;
-            const int64_t off = (ok ? row : 0) * D + (ok ? e : 0);
-            const double v = sample[off] - (uhat ? uhat[off] : 0.0);
-            u[k][I] = ok ? v : 0.0;
-        }
-    }
     hd4 acc[NB];
     double cs[DB];
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] = hd4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < DB; I++) cs[I] = 0.0;
+    for (int64_t c0 = r0; c0 < r1; c0 += HS_ROWS) {      // one chunk unless the entity is very large (workgroup count capped)
+        double u[KS][DB];
 #pragma unroll
-    for (int k = 0; k < KS; k++) {
-        int b = 0;
+        for (int k = 0; k < KS; k++) {
+            const int64_t row = c0 + 4 * (wave + NW * k) + h;
 #pragma unroll
-        for (int I = 0; I < DB; I++) {
-#pragma unroll
-            for (int J = 0; J <= I; J++) {
-                acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k][I], u[k][J], acc[b], 0, 0, 0);
-                b++;
+            for (int I = 0; I < DB; I++) {
+                const int e = 16 * I + j;
+                const bool ok = row < r1 && row < N && e < D;
+                const int64_t off = (ok ? row : 0) * D + (ok ? e : 0);
+                const double v = sample[off] - (uhat ? uhat[off] : 0.0);
+                u[k][I] = ok ? v : 0.0;
             }
-            cs[I] += u[k][I];
+        }
+#pragma unroll
+        for (int k = 0; k < KS; k++) {
+            int b = 0;
+#pragma unroll
+            for (int I = 0; I < DB; I++) {
+#pragma unroll
+                for (int J = 0; J <= I; J++) {
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(u[k][I], u[k][J], acc[b], 0, 0, 0);
+                    b++;
+                }
+                cs[I] += u[k][I];
+            }
         }
     }
 #pragma unroll

@@ -20,13 +20,15 @@
 namespace {
 
 template <int DP>
-__global__ __launch_bounds__(HS_THREADS) void k_hyper_partial(int D, int64_t N, const double *__restrict__ sample,
+__global__ __launch_bounds__(HS_THREADS) void k_hyper_partial(int D, int64_t N, int64_t rows_per_block,
+                                                               const double *__restrict__ sample,
                                                                const double *__restrict__ uhat, double *__restrict__ partial)
 {
     __shared__ double red[3 * HGeo<DP>::PSZ];
     __builtin_amdgcn_s_setprio(3);      // small and on the sweep's critical path, usually beside a chip-filling K1 launch
-    hyper_partial<DP, 4>(D, N, sample, uhat, (int64_t)blockIdx.x * HS_ROWS, partial + (int64_t)blockIdx.x * HGeo<DP>::PSZ, red,
-                         threadIdx.x);
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
+    hyper_partial<DP, 4>(D, N, sample, uhat, r0, r1, partial + (int64_t)blockIdx.x * HGeo<DP>::PSZ, red, threadIdx.x);
 }
 
 // ---- stage 2: fixed-order sum of the partials -----------------------------------------------------------------
@@ -85,7 +87,10 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
-    const int nblocks = (int)std::max<int64_t>(1, (N + HS_ROWS - 1) / HS_ROWS);
+    // HS_ROWS rows per workgroup, at most 2048 workgroups (a very large entity gives each several chunks)
+    const int64_t chunks = std::max<int64_t>(1, (N + HS_ROWS - 1) / HS_ROWS);
+    const int64_t rpb = HS_ROWS * ((chunks + 2047) / 2048);
+    const int nblocks = (int)std::max<int64_t>(1, (N + rpb - 1) / rpb);
     const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
     const int psz = DP == 16 ? HGeo<16>::PSZ : (DP == 32 ? HGeo<32>::PSZ : HGeo<64>::PSZ);
     void *scratch;
@@ -94,13 +99,13 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     double *part = (double *)scratch;
     const dim3 fgrid((psz + 15) / 16);
     if (DP == 16) {
-        hipLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, sample, uhat, part);
+        hipLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<16>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else if (DP == 32) {
-        hipLaunchKernelGGL(k_hyper_partial<32>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, sample, uhat, part);
+        hipLaunchKernelGGL(k_hyper_partial<32>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<32>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else {
-        hipLaunchKernelGGL(k_hyper_partial<64>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, sample, uhat, part);
+        hipLaunchKernelGGL(k_hyper_partial<64>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<64>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     }
     BDF_HIP(hipGetLastError());

@@ -389,3 +389,17 @@ def test_predict_and_running_mean(B, O, ctx):
     np.testing.assert_allclose(a, avg, rtol=1e-12)
     np.testing.assert_allclose(s, sq, rtol=1e-12)
     pairs.close()
+
+
+def test_hyper_sums_large_entity(B, ctx):
+    """more than 2048 x 128 rows: every workgroup of the sums kernel takes several 128-row chunks"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(77)
+    D, N = 8, 2048 * 128 * 2 + 77
+    S = rng.standard_normal((N, D))
+    S_t = ctx.tensor(S)
+    sumU, UUt = ctx.zeros(D), ctx.zeros(D, D)
+    check(lib().bdf_hyper_sums(ctx.handle, D, N, _p(S_t), None, _p(sumU), _p(UUt)))
+    ctx.sync()
+    np.testing.assert_allclose(sumU.cpu().numpy(), S.sum(0), rtol=1e-10, atol=1e-8)
+    np.testing.assert_allclose(UUt.cpu().numpy(), S.T @ S, rtol=1e-11, atol=1e-8)
