@@ -46,6 +46,8 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     BDF_HIP(hipMemsetAsync(c->flag_dev, 0, 16 * sizeof(int), c->stream));
     c->sweep_host = 0;
     c->scratch = nullptr;
+    c->scratch2 = nullptr;
+    c->scratch2_bytes = 0;
     c->scratch_bytes = 0;
     c->item_size = 192;
     *out = c;
@@ -61,6 +63,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     hipFree(ctx->sweep_dev);
     hipFree(ctx->flag_dev);
+    if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;
@@ -78,6 +81,20 @@ int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out)
         ctx->scratch_bytes = nb;
     }
     *out = ctx->scratch;
+    return BDF_OK;
+}
+
+int bdf_scratch2(bdf_ctx *ctx, size_t bytes, void **out)
+{
+    if (bytes > ctx->scratch2_bytes) {
+        BDF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->scratch2) BDF_HIP(hipFree(ctx->scratch2));
+        size_t nb = std::max(bytes, ctx->scratch2_bytes * 2);
+        nb = (nb + 255) & ~(size_t)255;
+        BDF_HIP(hipMalloc(&ctx->scratch2, nb));
+        ctx->scratch2_bytes = nb;
+    }
+    *out = ctx->scratch2;
     return BDF_OK;
 }
 

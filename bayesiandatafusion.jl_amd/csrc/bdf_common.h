@@ -34,11 +34,14 @@ struct bdf_ctx {
     // scratch (grown on demand, never shrunk)
     void *scratch;
     size_t scratch_bytes;
+    void *scratch2;            // second block: split-K partials of the dense products (used while `scratch` is held)
+    size_t scratch2_bytes;
     int *flag_dev;             // not-positive-definite flag
     int item_size;             // K1: observations per work item (rows longer than this are split)
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
+int bdf_scratch2(bdf_ctx *ctx, size_t bytes, void **out);
 
 struct bdf_mode_index {
     std::vector<int64_t> rowptr;   // host, dims+1

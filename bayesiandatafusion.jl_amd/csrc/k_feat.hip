@@ -28,25 +28,28 @@ struct GemmArgs {
     const double *bias; double *C2;
 };
 
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
+// blockIdx.z = K chunk (split-K): with more than one chunk the tile goes to part[z][i][j] (M x N row-major per chunk) and
+// k_gemm_reduce adds the chunks in order -- a tall-and-skinny F' T (K = rows of F) would otherwise run on a handful of CUs
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int64_t kchunk, double *part)
 {
     __shared__ double As[TK][TM + 1];
     __shared__ double Bs[TK][TN + 1];
     const int tid = threadIdx.x;
     const int tx = tid % 16, ty = tid / 16;
     const int64_t i0 = (int64_t)blockIdx.x * TM, j0 = (int64_t)blockIdx.y * TN;
+    const int64_t kb = (int64_t)blockIdx.z * kchunk, ke = (kb + kchunk < g.K) ? kb + kchunk : g.K;
     double acc[2][2] = {{0.0, 0.0}, {0.0, 0.0}};
     const bool a_fast_i = g.ars <= g.acs, b_fast_k = g.brs <= g.bcs;
-    for (int64_t k0 = 0; k0 < g.K; k0 += TK) {
+    for (int64_t k0 = kb; k0 < ke; k0 += TK) {
         for (int e = tid; e < TM * TK; e += 256) {
             const int ii = a_fast_i ? e % TM : e / TK, kk = a_fast_i ? e / TM : e % TK;
             const int64_t i = i0 + ii, k = k0 + kk;
-            As[kk][ii] = (i < g.M && k < g.K) ? g.A[i * g.ars + k * g.acs] : 0.0;
+            As[kk][ii] = (i < g.M && k < ke) ? g.A[i * g.ars + k * g.acs] : 0.0;
         }
         for (int e = tid; e < TN * TK; e += 256) {
             const int kk = b_fast_k ? e % TK : e / TN, jj = b_fast_k ? e / TK : e % TN;
             const int64_t k = k0 + kk, j = j0 + jj;
-            Bs[kk][jj] = (k < g.K && j < g.N) ? g.B[k * g.brs + j * g.bcs] : 0.0;
+            Bs[kk][jj] = (k < ke && j < g.N) ? g.B[k * g.brs + j * g.bcs] : 0.0;
         }
         __syncthreads();
 #pragma unroll
@@ -64,17 +67,202 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g)
         for (int v = 0; v < 2; v++) {
             const int64_t i = i0 + tx + 16 * u, j = j0 + ty + 16 * v;
             if (i < g.M && j < g.N) {
-                g.C[i * g.crs + j * g.ccs] = acc[u][v];
-                if (g.C2) g.C2[i * g.crs + j * g.ccs] = acc[u][v] + g.bias[j];
+                if (part) {
+                    part[((int64_t)blockIdx.z * g.M + i) * g.N + j] = acc[u][v];
+                } else {
+                    g.C[i * g.crs + j * g.ccs] = acc[u][v];
+                    if (g.C2) g.C2[i * g.crs + j * g.ccs] = acc[u][v] + g.bias[j];
+                }
             }
         }
+}
+
+__global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g, int nchunks, const double *part)
+{
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= g.M * g.N) return;
+    const int64_t i = e / g.N, j = e % g.N;
+    double s = 0.0;
+    for (int z = 0; z < nchunks; z++) s += part[(int64_t)z * g.M * g.N + e];       // fixed order
+    g.C[i * g.crs + j * g.ccs] = s;
+    if (g.C2) g.C2[i * g.crs + j * g.ccs] = s + g.bias[j];
 }
 
 int gemm(bdf_ctx *ctx, const GemmArgs &g)
 {
     if (g.M == 0 || g.N == 0) return BDF_OK;
-    dim3 grid((unsigned)((g.M + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN));
-    hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g);
+    const int64_t tiles = ((g.M + TM - 1) / TM) * ((g.N + TN - 1) / TN);
+    int nchunks = 1;
+    if (tiles < 512 && g.K >= 128) {                       // too few tiles to fill the chip and a long K: split it
+        nchunks = (int)std::min<int64_t>(64, std::min<int64_t>((g.K + 63) / 64, (1024 + tiles - 1) / tiles));
+        if (nchunks < 1) nchunks = 1;
+    }
+    dim3 grid((unsigned)((g.M + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)nchunks);
+    if (nchunks == 1) {
+        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, g.K, (double *)nullptr);
+    } else {
+        void *sc;
+        int rc = bdf_scratch2(ctx, (size_t)nchunks * g.M * g.N * sizeof(double), &sc);
+        if (rc) return rc;
+        const int64_t kchunk = ((g.K + nchunks - 1) / nchunks + TK - 1) / TK * TK;
+        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, kchunk, (double *)sc);
+        hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((g.M * g.N + 255) / 256)), dim3(256), 0, ctx->stream, g, nchunks,
+                           (const double *)sc);
+    }
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+// ---- dense feature matrices on the matrix cores (v_mfma_f64_16x16x4_f64), at most 64 right-hand columns --------------
+// F is N x numF column-major.  These are the two genuinely dense contractions of the path (F beta and F' T over
+// the 24 MB of a 6040 x 500 F, AI ~ 8 flop/B per pass).
+typedef double fd4 __attribute__((ext_vector_type(4)));
+constexpr int GK = 64;               // K chunk staged per round
+
+// Y(r, c) = sum_k F(r, k) B(k, c): a wave owns 16 rows x all columns; A operands straight from global (lane l: row l & 15,
+// k l >> 4 -- 16 consecutive rows of a column are one 128-byte read), B chunk of GK x 16 CB staged in LDS for the 4 waves
+template <int CB>
+__global__ __launch_bounds__(256) void k_dense_nn(const double *__restrict__ F, int64_t M, int64_t K, const double *__restrict__ B,
+                                                  int64_t brs, int64_t bcs, int ncol, double *__restrict__ Y, int64_t yrs,
+                                                  int64_t ycs, const double *__restrict__ bias, double *__restrict__ Y2)
+{
+    __shared__ double Bs[GK][16 * CB + 1];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, h = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 64 + 16 * wave;
+    const int64_t row = r0 + i;
+    fd4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) acc[cb] = fd4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t k0 = 0; k0 < K; k0 += GK) {
+        __syncthreads();
+        for (int e = tid; e < GK * 16 * CB; e += 256) {
+            const int kk = e / (16 * CB), c = e % (16 * CB);
+            Bs[kk][c] = (k0 + kk < K && c < ncol) ? B[(k0 + kk) * brs + (int64_t)c * bcs] : 0.0;
+        }
+        double a[GK / 4];
+#pragma unroll
+        for (int s = 0; s < GK / 4; s++) {
+            const int64_t k = k0 + 4 * s + h;
+            a[s] = (row < M && k < K) ? F[row + k * M] : 0.0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < GK / 4; s++)
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Bs[4 * s + h][16 * cb + i], acc[cb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int64_t rr = r0 + h + 4 * r;
+            const int c = 16 * cb + i;
+            if (rr < M && c < ncol) {
+                Y[rr * yrs + (int64_t)c * ycs] = acc[cb][r];
+                if (Y2) Y2[rr * yrs + (int64_t)c * ycs] = acc[cb][r] + bias[c];
+            }
+        }
+}
+
+// part[z][f][c] = sum over the rows of chunk z of F(row, f) B(row, c)   (= F' B by chunks; k_gemm_reduce adds the chunks
+// in order).  A workgroup owns 16 features and one row chunk; its waves take 64-row tiles in turn: the F tile goes through
+// LDS (read along the rows, 512 contiguous bytes per feature; the MFMA wants feature-major), B operands from global.
+template <int CB>
+__global__ __launch_bounds__(256) void k_dense_tn(const double *__restrict__ F, int64_t M, int64_t numF, const double *__restrict__ B,
+                                                  int64_t brs, int64_t bcs, int ncol, int64_t rows_per_chunk,
+                                                  double *__restrict__ part)
+{
+    __shared__ double tile[4][16][65];
+    __shared__ double red[3][CB][4][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 15, h = lane >> 4;
+    const int64_t f0 = (int64_t)blockIdx.x * 16;
+    const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk, c1 = (c0 + rows_per_chunk < M) ? c0 + rows_per_chunk : M;
+    fd4 acc[CB];
+#pragma unroll
+    for (int cb = 0; cb < CB; cb++) acc[cb] = fd4{0.0, 0.0, 0.0, 0.0};
+    for (int64_t rr = c0 + 64 * wave; rr < c1; rr += 256) {
+        const int64_t myrow = rr + lane;
+#pragma unroll
+        for (int ff = 0; ff < 16; ff++)
+            tile[wave][ff][lane] = (myrow < c1 && f0 + ff < numF) ? F[myrow + (f0 + ff) * M] : 0.0;
+        double b[16][CB];
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const int64_t row = rr + 4 * s + h;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const int c = 16 * cb + i;
+                b[s][cb] = (row < c1 && c < ncol) ? B[row * brs + (int64_t)c * bcs] : 0.0;
+            }
+        }
+        wave_sync();
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            const double a = tile[wave][i][4 * s + h];
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b[s][cb], acc[cb], 0, 0, 0);
+        }
+        wave_sync();
+    }
+    if (wave > 0)
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave - 1][cb][r][lane] = acc[cb][r];
+    __syncthreads();
+    if (wave == 0) {
+        double *p = part + (int64_t)blockIdx.y * numF * ncol;
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                double v = acc[cb][r];
+#pragma unroll
+                for (int w = 0; w < 3; w++) v += red[w][cb][r][lane];
+                const int64_t ff = f0 + h + 4 * r;
+                const int c = 16 * cb + i;
+                if (ff < numF && c < ncol) p[ff * ncol + c] = v;
+            }
+    }
+}
+
+// Y = A B for a dense column-major M x K matrix A (a feature matrix, or the precomputed F'F), ncol <= 64
+int dense_nn(bdf_ctx *ctx, const double *A, int64_t M, int64_t K, const double *B, int64_t brs, int64_t bcs, int ncol,
+             double *Y, int64_t yrs, int64_t ycs, const double *bias, double *Y2)
+{
+    const int CB = (ncol + 15) / 16;
+    dim3 grid((unsigned)((M + 63) / 64));
+#define NN(C) hipLaunchKernelGGL(k_dense_nn<C>, grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2)
+    if (CB == 1) NN(1); else if (CB == 2) NN(2); else if (CB == 3) NN(3); else NN(4);
+#undef NN
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+int dense_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B, int64_t brs, int64_t bcs, int ncol,
+                double *Y, int64_t yrs, int64_t ycs, const double *bias, double *Y2)
+{
+    const int CB = (ncol + 15) / 16;
+    if (!transpose) return dense_nn(ctx, f->dense_dev, f->m, f->n, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2);
+    const int64_t ftiles = (f->n + 15) / 16;
+    int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>((f->m + 255) / 256, (1024 + ftiles - 1) / ftiles));
+    const int64_t rpc = ((f->m + nchunks - 1) / nchunks + 63) / 64 * 64;
+    nchunks = (f->m + rpc - 1) / rpc;
+    void *sc;
+    int rc = bdf_scratch2(ctx, (size_t)nchunks * f->n * ncol * sizeof(double), &sc);
+    if (rc) return rc;
+    dim3 grid((unsigned)ftiles, (unsigned)nchunks);
+#define TN(C) hipLaunchKernelGGL(k_dense_tn<C>, grid, dim3(256), 0, ctx->stream, (const double *)f->dense_dev, f->m, f->n, B, brs, bcs, ncol, rpc, (double *)sc)
+    if (CB == 1) TN(1); else if (CB == 2) TN(2); else if (CB == 3) TN(3); else TN(4);
+#undef TN
+    GemmArgs g;
+    g.M = f->n; g.N = ncol; g.K = f->m; g.A = nullptr; g.ars = g.acs = 0; g.B = nullptr; g.brs = g.bcs = 0;
+    g.C = Y; g.crs = yrs; g.ccs = ycs; g.bias = bias; g.C2 = Y2;
+    hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((g.M * g.N + 255) / 256)), dim3(256), 0, ctx->stream, g, (int)nchunks,
+                       (const double *)sc);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -118,6 +306,7 @@ int spmm(bdf_ctx *ctx, const SpmmArgs &s)
 int feat_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B, int64_t brs, int64_t bcs, int ncol,
                double *Y, int64_t yrs, int64_t ycs, const double *bias = nullptr, double *Y2 = nullptr)
 {
+    if (f->kind == 0 && ncol <= 64 && f->m > 0 && f->n > 0) return dense_apply(ctx, f, transpose, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2);
     if (f->kind == 0) {
         GemmArgs g;
         g.M = transpose ? f->n : f->m; g.N = ncol; g.K = transpose ? f->m : f->n;
@@ -552,7 +741,13 @@ extern "C" int bdf_hyper_feature_terms(bdf_ctx *ctx, int D, int64_t numF, const 
     void *G;
     int rc = bdf_scratch(ctx, (size_t)D * D * sizeof(double), &G);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, beta, (double *)G);
+    {   // G = beta' beta (D x D) through the split-K product
+        GemmArgs g;
+        g.M = D; g.N = D; g.K = numF; g.A = beta; g.ars = numF; g.acs = 1; g.B = beta; g.brs = 1; g.bcs = numF;
+        g.C = (double *)G; g.crs = 1; g.ccs = D; g.bias = nullptr; g.C2 = nullptr;
+        int rcg = gemm(ctx, g);
+        if (rcg) return rcg;
+    }
     hipLaunchKernelGGL(k_tinv_feat, dim3((D * D + 255) / 256), dim3(256), 0, ctx->stream, D, (const double *)G, WI,
                        lambda_beta_dev, Tinv_out);
     BDF_HIP(hipGetLastError());
@@ -575,7 +770,9 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     BDF_HIP(hipGetLastError());
     for (int iter = 1; iter <= maxiter; iter++) {
         hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, iter);
-        if (use_ff) {
+        if (use_ff && D <= 64) {
+            if ((rc = dense_nn(ctx, f->FF_dev, numF, numF, P, 1, numF, D, Z, 1, numF, nullptr, nullptr))) return rc;
+        } else if (use_ff) {
             GemmArgs g;
             g.M = numF; g.N = D; g.K = numF; g.A = f->FF_dev; g.ars = 1; g.acs = numF;
             g.B = P; g.brs = 1; g.bcs = numF; g.C = Z; g.crs = 1; g.ccs = numF; g.bias = nullptr; g.C2 = nullptr;
@@ -652,7 +849,12 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
         if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (sample_lambda) {
-        hipLaunchKernelGGL(k_btb, dim3(1), dim3(256), 0, ctx->stream, D, numF, (const double *)beta_out, G);
+        {
+            GemmArgs g;
+            g.M = D; g.N = D; g.K = numF; g.A = beta_out; g.ars = numF; g.acs = 1; g.B = beta_out; g.brs = 1; g.bcs = numF;
+            g.C = G; g.crs = 1; g.ccs = D; g.bias = nullptr; g.C2 = nullptr;
+            if ((rc = gemm(ctx, g))) return rc;
+        }
         hipLaunchKernelGGL(k_lambda_beta, dim3(1), dim3(64), 0, ctx->stream, D, numF, (const double *)G, Lambda, lb_nu, lb_mu,
                            ctx->seed, ctx->sweep_host, entity_tag, lambda_beta_dev);
         BDF_HIP(hipGetLastError());
