@@ -459,10 +459,8 @@ __global__ __launch_bounds__(256) void k_cg_init(CgState s, const double *rhs, d
 }
 
 // top of iteration `iter` (1-based): residual check, direction update (parallel_cg.jl:74-83)
-__global__ __launch_bounds__(256) void k_cg_pre(CgState s, int iter)
+__device__ inline void cg_pre(const CgState &s, int iter, double *red, int &go)
 {
-    __shared__ double red[4];
-    __shared__ int go;
     const int d = blockIdx.x;
     if (!s.active[d]) return;
     const int64_t off = (int64_t)d * s.n;
@@ -483,10 +481,16 @@ __global__ __launch_bounds__(256) void k_cg_pre(CgState s, int iter)
     if (threadIdx.x == 0) { s.bkden[d] = bknum; s.bknum[d] = bknum; s.iters[d] = iter; }
 }
 
-// bottom of the iteration: z = Z + lambda p; ak = bknum / (z.p); x += ak p; r -= ak z (parallel_cg.jl:85-91)
-__global__ __launch_bounds__(256) void k_cg_post(CgState s, const double *lambda_p, int iter)
+__global__ __launch_bounds__(256) void k_cg_pre(CgState s, int iter)
 {
     __shared__ double red[4];
+    __shared__ int go;
+    cg_pre(s, iter, red, go);
+}
+
+// bottom of the iteration: z = Z + lambda p; ak = bknum / (z.p); x += ak p; r -= ak z (parallel_cg.jl:85-91)
+__device__ inline void cg_post(const CgState &s, const double *lambda_p, int iter, double *red)
+{
     const int d = blockIdx.x;
     if (!s.active[d] || s.iters[d] != iter) return;
     const double lambda = *lambda_p;
@@ -504,6 +508,17 @@ __global__ __launch_bounds__(256) void k_cg_post(CgState s, const double *lambda
         s.X[off + i] = fma(ak, s.P[off + i], s.X[off + i]);
         s.R[off + i] = fma(-ak, s.Z[off + i], s.R[off + i]);
     }
+}
+
+// bottom of iteration `iter` and top of iteration `iter + 1` in one launch (a column is one workgroup in both)
+__global__ __launch_bounds__(256) void k_cg_step(CgState s, const double *lambda_p, int iter, int maxiter)
+{
+    __shared__ double red[4];
+    __shared__ int go;
+    cg_post(s, lambda_p, iter, red);
+    __threadfence_block();
+    __syncthreads();
+    if (iter < maxiter) cg_pre(s, iter + 1, red, go);
 }
 
 // ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
@@ -768,8 +783,8 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
     hipLaunchKernelGGL(k_cg_init, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)rhs, tol);
     BDF_HIP(hipGetLastError());
+    hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, 1);
     for (int iter = 1; iter <= maxiter; iter++) {
-        hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, iter);
         if (use_ff && D <= 64) {
             if ((rc = dense_nn(ctx, f->FF_dev, numF, numF, P, 1, numF, D, Z, 1, numF, nullptr, nullptr))) return rc;
         } else if (use_ff) {
@@ -781,7 +796,8 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
             if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, 1, N))) return rc;
             if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
         }
-        hipLaunchKernelGGL(k_cg_post, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter);
+        // bottom of this iteration and top of the next in one launch
+        hipLaunchKernelGGL(k_cg_step, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         BDF_HIP(hipGetLastError());
         if (iter % 8 == 0 || iter == maxiter) {
             int nact = 0;
