@@ -1,5 +1,7 @@
 // bdf_api.hip -- C-ABI entry points: context, device memory, IndexedDF -> device CSR, row sampling front-end
 #include "bdf_common.h"
+#include <cstdlib>
+#include <cstring>
 #include <algorithm>
 #include <cmath>
 #include <numeric>
@@ -352,14 +354,20 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         T.nnz = t.rel->nnz;
         T.n_other = t.rel->n_modes - 1;
         int plane = 0;
-        bool lean = t.linear_values == nullptr && T.n_other <= 2;
+        bool lean = t.linear_values == nullptr && T.n_other <= 2, wide = false;
         for (int k = 0; k < t.rel->n_modes; k++) {
             if (k == t.mode) continue;
             BDF_REQUIRE(t.factors[k] != nullptr, BDF_ERR_ARG, "%s: terms[%d].factors[%d] is NULL", who, r, k);
             T.fac[plane++] = t.factors[k];
-            lean = lean && t.rel->dims[k] < (1 << 24) && t.rel->dims[k] * (int64_t)D * 8 < ((int64_t)1 << 32);
+            lean = lean && t.rel->dims[k] < ((int64_t)1 << 32);
+            wide = wide || !(t.rel->dims[k] < (1 << 24) && t.rel->dims[k] * (int64_t)D * 8 < ((int64_t)1 << 32));
         }
-        T.lean = lean ? 1 : 0;
+        T.lean = !lean ? 0 : (!wide ? 1 : (D > 32 ? 2 : 0));      // 2: 64-bit row offsets (compiled for D > 32 only)
+        {   // test hooks: BDF_GATHER=general | wide forces the general path / the 64-bit lean path (D > 32)
+            static const char *force = getenv("BDF_GATHER");
+            if (force && !strcmp(force, "general")) T.lean = 0;
+            if (force && !strcmp(force, "wide") && lean && D > 32) T.lean = 2;
+        }
         T.alpha = t.alpha;
         T.mean = t.mean_value;
     }

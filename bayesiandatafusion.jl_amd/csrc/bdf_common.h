@@ -185,7 +185,8 @@ struct TermDev {
     const double *fac[BDF_MAX_MODES - 1];
     int64_t nnz;
     int32_t n_other;
-    int32_t lean;              // K1: shared baseline, <= 2 other modes, factor matrices < 4 GiB with < 2^24 rows
+    int32_t lean;              // K1 lean gather: 1 = shared baseline, <= 2 other modes, factor matrices < 4 GiB with < 2^24
+                               // rows (32-bit offsets); 2 = the same with 64-bit row offsets (D > 32 only); 0 = general path
     double alpha, mean;
 };
 

@@ -194,7 +194,7 @@ __device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int l
 // Same pipeline as accumulate_reg, with what the general path pays per load taken out: wave-uniform (SGPR) bases with
 // 32-bit byte offsets, row offsets by one 24-bit mad, no predicated loads (indices are clamped to the item instead, and
 // only the item's last trip masks its operands).
-template <int DP, int NO, bool FULL>
+template <int DP, int NO, bool FULL, bool WIDE = false>
 __device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                        double (&bred)[Geo<DP>::DB])
 {
@@ -243,7 +243,8 @@ __device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int 
     _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
         _Pragma("unroll") for (int m = 0; m < NO; m++)                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
-                w[S][k][m][I] = *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I]));
+                w[S][k][m][I] = WIDE ? *(const double *)(fac[m] + ((uint64_t)ix[S][k][m] * rowb + eoff[I]))           \
+                                     : *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I]));
 #define TRIP(t, C, X)                                                                           \
     {                                                                                           \
         LOAD_DATA(X)  /* unconditional (ids are clamped to the item): a branch here would cost exact waitcnts */ \
@@ -304,7 +305,19 @@ __device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int l
                                       double (&bred)[Geo<DP>::DB])
 {
     const int no = a.t[it.term].n_other;
-    if (a.t[it.term].lean) {
+    if constexpr (DP == 64) {
+        if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
+            if (a.D == DP) {
+                if (no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
+                else accumulate_lean<DP, 2, true, true>(a, it, lane, acc, bred);
+            } else {
+                if (no == 1) accumulate_lean<DP, 1, false, true>(a, it, lane, acc, bred);
+                else accumulate_lean<DP, 2, false, true>(a, it, lane, acc, bred);
+            }
+            return;
+        }
+    }
+    if (a.t[it.term].lean == 1) {
         if (a.D == DP) {
             if (no == 1) accumulate_lean<DP, 1, true>(a, it, lane, acc, bred);
             else accumulate_lean<DP, 2, true>(a, it, lane, acc, bred);

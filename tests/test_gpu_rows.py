@@ -5,6 +5,7 @@ Every call goes through the C ABI (include/bdf.h).  Tolerances: integer / counte
 inv + chol(covar), the device factors the precision once -- see k_sample_rows.hip); normals to 1e-13.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -403,3 +404,45 @@ def test_hyper_sums_large_entity(B, ctx):
     ctx.sync()
     np.testing.assert_allclose(sumU.cpu().numpy(), S.sum(0), rtol=1e-10, atol=1e-8)
     np.testing.assert_allclose(UUt.cpu().numpy(), S.T @ S, rtol=1e-11, atol=1e-8)
+
+
+@pytest.mark.parametrize("mode", ["general", "wide"])
+def test_gather_paths_agree(B, ctx, mode):
+    """the lean gather (32-bit offsets), its 64-bit variant for factor matrices of 4 GiB and more, and the general path
+    give the same rows (BDF_GATHER is read once per process: run the forced path in a child)"""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import ctypes as C, numpy as np, sys
+        sys.path.insert(0, %r)
+        import bdf_amd as B
+        from bdf_amd._lib import Term, check, lib
+        rng = np.random.default_rng(5)
+        D, dims = 48, [70, 50]
+        ids = np.stack([rng.integers(1, d + 1, 3000) for d in dims], axis=1).astype(np.int64)
+        vals = rng.standard_normal(3000)
+        ctx = B.Context(seed=11)
+        dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+        ft = [ctx.tensor(rng.standard_normal((d, D))) for d in dims]
+        A = rng.standard_normal((D, D)); Lam = ctx.tensor(A @ A.T / D + np.eye(D)); mu = ctx.tensor(rng.standard_normal(D))
+        terms = (Term * 1)()
+        terms[0].rel = dr.handle; terms[0].mode = 0; terms[0].alpha = 1.3; terms[0].mean_value = 0.1
+        terms[0].factors[1] = ft[1].data_ptr()
+        out = ctx.zeros(dims[0], D)
+        ctx.set_sweep(2)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        check(lib().bdf_sample_rows(ctx.handle, D, dims[0], 1, terms, p(mu), 0, p(Lam), 1, 0, 1, p(out), None))
+        ctx.sync()
+        np.save(sys.argv[1], out.cpu().numpy())
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    outs = {}
+    for m in ("", mode):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npy")
+            env = dict(os.environ)
+            env.pop("BDF_GATHER", None)
+            if m:
+                env["BDF_GATHER"] = m
+            subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
+            outs[m] = np.load(f)
+    np.testing.assert_allclose(outs[mode], outs[""], rtol=1e-12, atol=1e-13)
