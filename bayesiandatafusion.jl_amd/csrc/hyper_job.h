@@ -166,6 +166,12 @@ __device__ inline void hyper_scatter(int D, int e, double s, double *sumU, doubl
 // Both "Cholesky factor of an inverse" steps come without forming the inverse (see k_hyper.hip): in index-reversed
 // coordinates (~)  W~ = L~ L~',  Z~ = L~^-T (J A),  Lam~ = Z~ Z~',  Lam~ = L2~ L2~',  mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N).
 // The two factorisations run on wave 0 in the accumulator layout (c_layout_chol.h), the rest on all threads.
+#ifdef BDF_HYPER_STAMPS
+#define HSTAMP(k) do { if (tid == 0 && a.params_out) ((unsigned long long *)a.params_out)[a.D + a.D * a.D + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define HSTAMP(k) do { } while (0)
+#endif
+
 template <int DP>
 __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthreads)
 {
@@ -177,6 +183,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
     const int j = lane & 15, h = lane >> 4;
     const int D = a.D;
     const double beta_N = a.b0 + a.N;
+    HSTAMP(0);
     if (tid < 64) {
         const int e = D - 1 - tid;
         s_muN[tid] = (e >= 0) ? (a.b0 * a.mu0[e] + a.sumU[e]) / beta_N : 0.0;      // reversed: s_muN[c] = mu_N[D-1-c]
@@ -198,6 +205,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
     }
     if (a.params_out && tid < DP && D - 1 - tid >= 0) a.params_out[D - 1 - tid] = s_muN[tid];
     __syncthreads();
+    HSTAMP(1);
 
     // the factorisation of the matrix in sL on wave 0; pivots' reciprocals and square roots to s_rd / s_sq
     auto factor_sL = [&](double &dv_out) {
@@ -228,6 +236,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
         s_sq[lane] = dv * fast_rsqrt(dv);
     }
     __syncthreads();
+    HSTAMP(2);
 
     // ---- Z~ = L~^-T A~  <=>  Lt' Z~ = diag(sqrt(d)) A~ : one thread per column, backward substitution over the packed factor
     if (tid < DP) {
@@ -247,22 +256,39 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
         for (int i = 0; i < DP; i++) sA[i * LD + tid] = z[i];
     }
     __syncthreads();
+    HSTAMP(3);
 
-    // ---- Lam~ = Z~ Z~' (identity on the padding), stored reversed in sL and natural in Lambda_out
-    for (int e = tid; e < DP * DP; e += nthreads) {
-        const int i = e / DP, c2 = e % DP;
-        const int ei = D - 1 - i, ej = D - 1 - c2;
-        double s = 0.0;
-        if (ei >= 0 && ej >= 0) {
-            // fixed summation order in c; (i,j) and (j,i) multiply the same pairs: the result is exactly symmetric
-            for (int c = 0; c < DP; c++) s = fma(sA[i * LD + c], sA[c2 * LD + c], s);
-            a.Lambda_out[ei + (int64_t)ej * D] = s;
-        } else {
-            s = (i == c2) ? 1.0 : 0.0;
+    // ---- Lam~ = Z~ Z~' on the matrix cores: block (I, J >= ... all blocks of the lower block-triangle, mirrored; the diagonal
+    // blocks multiply the same pairs in the same order for (i,j) and (j,i), so the result is exactly symmetric).  Stored
+    // reversed in sL (identity on the padding) and natural in Lambda_out.
+    {
+        const int nw = nthreads / 64;
+        for (int b = wave; b < NB; b += nw) {
+            int I = 0;
+            while ((I + 1) * (I + 2) / 2 <= b) I++;
+            const int J = b - I * (I + 1) / 2;
+            d4 acc = d4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < DP / 4; s++)
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(sA[(16 * I + j) * LD + 4 * s + h], sA[(16 * J + j) * LD + 4 * s + h], acc,
+                                                           0, 0, 0);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int i = 16 * I + h + 4 * r, c2 = 16 * J + j;
+                const int ei = D - 1 - i, ej = D - 1 - c2;
+                double v = acc[r];
+                if (ei < 0 || ej < 0) v = (i == c2) ? 1.0 : 0.0;
+                else {
+                    a.Lambda_out[ei + (int64_t)ej * D] = v;
+                    if (I != J) a.Lambda_out[ej + (int64_t)ei * D] = v;
+                }
+                sL[i * LD + c2] = v;
+                if (I != J) sL[c2 * LD + i] = v;
+            }
         }
-        sL[i * LD + c2] = s;
     }
     __syncthreads();
+    HSTAMP(4);
 
     // ---- mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
     if (wave == 0) {
@@ -279,6 +305,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
         if (lane < D) a.mu_out[ej] = mu_c;
         s_mu[lane] = (lane < D) ? mu_c : 0.0;                      // reversed: s_mu[c] = mu[D-1-c]
     }
+    HSTAMP(5);
     if (a.pack_out == nullptr) return;
     __syncthreads();
     // ---- what the row sampler needs of (mu, Lambda), written here so that it needs no pre-launch of its own:
@@ -300,6 +327,7 @@ __device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthrea
         const int J = b - I * (I + 1) / 2;
         a.pack_out[D + e * 64 + lane] = sL[(16 * I + (lane >> 4) + 4 * r) * LD + 16 * J + (lane & 15)];
     }
+    HSTAMP(6);
 }
 
 }  // namespace

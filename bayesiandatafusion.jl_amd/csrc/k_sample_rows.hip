@@ -555,6 +555,9 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, Geo<DP>::WAVES) void k_rows(Samp
     __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
+#ifdef BDF_K1_BASE_PRIO
+    __builtin_amdgcn_s_setprio(BDF_K1_BASE_PRIO);      // above the prediction update that may run beside this launch
+#endif
 #ifdef BDF_K1_PRIO
     // unequal issue priorities among the waves that share a SIMD (they come from different workgroups): the matrix pipe
     // then serves them more nearly one after the other than all at once, and they reach the VALU-bound factorisation at

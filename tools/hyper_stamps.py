@@ -24,7 +24,7 @@ for use_draws in (False, True):
                                      p(draws) if use_draws else None))
         ctx.sync()
     st = par.cpu().numpy()[D + D * D:].view(np.uint64).astype(np.int64)
-    print("draws ahead" if use_draws else "draws inside", "phase ticks:", np.diff(st[:9]), "total", st[8] - st[0])
+    print("draws ahead" if use_draws else "draws inside", "phase ticks [muN, assemble, factor1, Zsolve, ZZt, factor2+mean, pack]:", np.diff(st[:7]), "total", st[6] - st[0])
 import torch
 for n in (6040, 3952):
     S2 = ctx.tensor(rng.standard_normal((n, D)))
