@@ -127,11 +127,12 @@ struct OwnerStore;
                          : "=&s"(save) : "v"(addr), "v"(v0), "v"(v1), "v"(v2), "v"(v3), "n"(MASK), "n"(OFF) : "memory"); \
         }                                                                                                             \
     };
-// the last NV of the four registers of a block (rows below the column's first stored row are left out)
-BDF_OWNER_STORE(4, "ds_write_b64 %1, %2 offset:%7\n\tds_write_b64 %1, %3 offset:%7+8\n\tds_write_b64 %1, %4 offset:%7+16\n\tds_write_b64 %1, %5 offset:%7+24\n\t", , )
-BDF_OWNER_STORE(3, "ds_write_b64 %1, %3 offset:%7\n\tds_write_b64 %1, %4 offset:%7+8\n\tds_write_b64 %1, %5 offset:%7+16\n\t", , )
-BDF_OWNER_STORE(2, "ds_write_b64 %1, %4 offset:%7\n\tds_write_b64 %1, %5 offset:%7+8\n\t", , )
-BDF_OWNER_STORE(1, "ds_write_b64 %1, %5 offset:%7\n\t", , )
+// the last NV of the four registers of a block (rows below the column's first stored row are left out); OFF in doubles
+// from addr.  Two doubles per LDS instruction: with four active lanes the LDS pipe is paid per instruction, not per byte.
+BDF_OWNER_STORE(4, "ds_write2_b64 %1, %2, %3 offset0:%7 offset1:%7+1\n\tds_write2_b64 %1, %4, %5 offset0:%7+2 offset1:%7+3\n\t", , )
+BDF_OWNER_STORE(3, "ds_write_b64 %1, %3 offset:(%7)*8\n\tds_write2_b64 %1, %4, %5 offset0:%7+1 offset1:%7+2\n\t", , )
+BDF_OWNER_STORE(2, "ds_write2_b64 %1, %4, %5 offset0:%7 offset1:%7+1\n\t", , )
+BDF_OWNER_STORE(1, "ds_write_b64 %1, %5 offset:(%7)*8\n\t", , )
 #undef BDF_OWNER_STORE
 template <int MASK>
 __device__ inline void owner_keep(double &dst, double src)
@@ -152,7 +153,8 @@ __device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsig
     constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16), q = GG::col_first(k) / 4;
     constexpr int r0 = q - 4 * K;                       // first stored register of block (K, K): rows >= col_first(k)
     // block (K + Is, K), registers r >= (Is == 0 ? r0 : 0), to class-local positions 4 (K + Is) + r - q
-    (OwnerStore<(Is == 0 ? 4 - r0 : 4)>::template run<MASK, (cb + 4 * (K + Is) + (Is == 0 ? r0 : 0) - q) * 8>(
+    // (addr already points at the column: offsets stay within the 8-bit range of ds_write2_b64)
+    (OwnerStore<(Is == 0 ? 4 - r0 : 4)>::template run<MASK, 4 * (K + Is) + (Is == 0 ? r0 : 0) - q>(
          addr, A[GG::blk(K + Is, K) * 4], A[GG::blk(K + Is, K) * 4 + 1], A[GG::blk(K + Is, K) * 4 + 2],
          A[GG::blk(K + Is, K) * 4 + 3]), ...);
 }
@@ -166,7 +168,7 @@ __device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&b
     constexpr int MASK = 0x00010001 << kj;                     // lanes with (lane & 15) == kj, per 32-lane half
     const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
     constexpr int q = GG::col_first(k) / 4;                   // rows per class: DP / 4 - q
-    owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8), std::make_integer_sequence<int, DB - K>{});
+    owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8 + cb * 8), std::make_integer_sequence<int, DB - K>{});
     owner_keep<MASK>(ts[K], bv[K]);
     wave_sync();
     double raw[DB];
