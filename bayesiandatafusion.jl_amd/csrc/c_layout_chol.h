@@ -150,7 +150,7 @@ template <int DP, int k, int... Is>
 __device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
 {
     using GG = Geo<DP>;
-    constexpr int K = k / 16, cb = GG::col_base(k), MASK = 0x00010001 << (k % 16), q = GG::col_first(k) / 4;
+    constexpr int K = k / 16, MASK = 0x00010001 << (k % 16), q = GG::col_first(k) / 4;
     constexpr int r0 = q - 4 * K;                       // first stored register of block (K, K): rows >= col_first(k)
     // block (K + Is, K), registers r >= (Is == 0 ? r0 : 0), to class-local positions 4 (K + Is) + r - q
     // (addr already points at the column: offsets stay within the 8-bit range of ds_write2_b64)
@@ -159,14 +159,13 @@ __device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsig
          A[GG::blk(K + Is, K) * 4 + 3]), ...);
 }
 
-template <int DP, int k>
+template <int DP, int k, bool HAVE_RD = false>
 __device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
-                            double *tri, const FactorLanes &fl, double (&nm)[Geo<DP>::DB])
+                            double *tri, const FactorLanes &fl, double (&nm)[Geo<DP>::DB], double rd_ahead = 0.0)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
     constexpr int MASK = 0x00010001 << kj;                     // lanes with (lane & 15) == kj, per 32-lane half
-    const double d = readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh);
     constexpr int q = GG::col_first(k) / 4;                   // rows per class: DP / 4 - q
     owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8 + cb * 8), std::make_integer_sequence<int, DB - K>{});
     owner_keep<MASK>(ts[K], bv[K]);
@@ -175,7 +174,7 @@ __device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&b
     const int ri = fl.rd0 - q * fl.j3 + (cb - q);             // row 16 J + j of column k is at ri + 4 J
 #pragma unroll
     for (int J = K; J < DB; J++) raw[J] = tri[ri + 4 * J];
-    const double rd = fast_rcp(d);
+    const double rd = HAVE_RD ? rd_ahead : fast_rcp(readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh));
 #pragma unroll
     for (int J = K; J < DB; J++) nm[J] = -(raw[J] * rd);
 }
@@ -190,6 +189,13 @@ __device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Ge
     using GG = Geo<DP>;
     constexpr int DB = GG::DB;
     constexpr int K = k / 16, kj = k % 16;
+#ifdef BDF_CHOL_LOOKAHEAD
+    // the next pivot, d_(k+1) = a_(k+1,k+1) + Lt_(k+1,k) nm_(k+1): the very fma the update below performs on that element,
+    // done ahead on wave-uniform copies so that its reciprocal is ready when the step ends
+    constexpr int k1 = k + 1, K1 = k1 / 16, j1 = k1 % 16, h1 = j1 % 4, r1 = j1 / 4;
+    const double rd1 = fast_rcp(fma(readlane_f64(A[GG::blk(K1, K) * 4 + r1], kj + 16 * h1), readlane_f64(nm[K1], j1),
+                                    readlane_f64(A[GG::blk(K1, K1) * 4 + r1], j1 + 16 * h1)));
+#endif
 #pragma unroll
     for (int J = DB - 1; J > K; J--) {
 #pragma unroll
@@ -208,7 +214,11 @@ __device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Ge
         }
         fm1_self<kj>(bv[K], nm[K]);
     }
+#ifdef BDF_CHOL_LOOKAHEAD
+    prep<DP, k + 1, true>(A, bv, ts, tri, fl, nm, rd1);
+#else
     prep<DP, k + 1>(A, bv, ts, tri, fl, nm);
+#endif
 }
 
 template <int DP, int... Ks>

@@ -14,6 +14,7 @@
 // ordinary lower Cholesky factors:  W~ = L~ L~',  Z~ = L~^-T (J A),  Lam~ = Z~ Z~',  Lam~ = L2~ L2~',
 // mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N).
 #include "bdf_common.h"
+#define BDF_CHOL_LOOKAHEAD     // one lone workgroup: the next pivot's reciprocal ahead of the step (K1 is VALU-bound: off there)
 #include "hyper_job.h"
 #include <algorithm>
 
