@@ -85,6 +85,7 @@ struct PlanDev {
     double *partials;                            // n_split * PSZ doubles
     int32_t *arrived;                            // per split row: items that have published their partial (self-resetting)
     const int32_t *order;                        // launch order: wave w takes item order[w] of [split | direct]
+    int32_t decoupled, _pad;                     // 1: every row is accumulated by producer waves and finished by another wave
 };
 
 
@@ -437,7 +438,22 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     const bool is_split = wid < p.n_split;                      // wave-uniform
     const Item it = is_split ? p.split[wid] : p.direct[wid - p.n_split];
     row = it.row;
-    if (it.count > 0) accumulate_any<DP>(a, it, lane, acc, bv);
+    if (p.decoupled && !is_split) {
+        // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
+        // row's arrival counter, bounded so that a bug cannot hang the device
+        const SplitRow sr = p.rows[it.srow];
+        int seen = 0;
+        for (int spin = 0; spin < (1 << 22); spin++) {
+            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.arrived + it.srow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+            if (seen >= sr.n_slots) break;
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (seen < sr.n_slots && lane == 0) atomicOr(a.flag, 16);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
+        sum_partials<DP>(p, sr, lane, acc, bv);
+        STAMP(2);
+    } else if (it.count > 0) accumulate_any<DP>(a, it, lane, acc, bv);
     else {
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
@@ -464,7 +480,7 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (old != sr.n_slots - 1) return;                      // not the last item of the row
+        if (p.decoupled || old != sr.n_slots - 1) return;       // not the last item of the row (decoupled: never finishes)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
@@ -611,6 +627,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
     const int T = key.T;
     std::vector<Item> direct, split;
     std::vector<SplitRow> srows;
+    static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
     for (int32_t row : rows) {
         int n_items = 0;
         for (int r = 0; r < key.n_terms; r++) {
@@ -618,7 +635,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
             n_items += (int)((n + T - 1) / T);
         }
-        if (n_items <= 1) {
+        if (n_items <= 1 && !decoupled) {
             Item it{row, 0, 0, 0, -1, -1, 0};
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
@@ -630,6 +647,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
                 split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), 0});
                 srows.push_back(SplitRow{row, (int32_t)split.size() - 1, 1, 0});
+                if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, 0});
                 continue;
             }
             SplitRow sr{row, (int32_t)split.size(), n_items, 0};
@@ -645,13 +663,26 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             }
             srows.push_back(sr);
         }
+        if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, 0});      // the row's finisher
     }
     // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
     // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
     // so neighbours in launch order should differ in length: a fixed stride permutation of the sorted list.
     const int64_t total = (int64_t)split.size() + (int64_t)direct.size();
     std::vector<int32_t> order((size_t)total);
-    {
+    if (decoupled) {
+        // producers in list order; the finisher of row r a fixed number of producer launches after r's last producer, so
+        // that it normally finds the row complete and the resident waves are a mix of gathering and factorising ones
+        static const int64_t lag = getenv("BDF_K1_LAG") ? atoll(getenv("BDF_K1_LAG")) : 2048;
+        size_t pos = 0, next_f = 0;
+        const int64_t nP = (int64_t)split.size();
+        for (int64_t i = 0; i < nP; i++) {
+            order[pos++] = (int32_t)i;
+            while (next_f < srows.size() && srows[next_f].slot_begin + srows[next_f].n_slots - 1 + lag <= i)
+                order[pos++] = (int32_t)(nP + (int64_t)next_f++);
+        }
+        while (next_f < srows.size()) order[pos++] = (int32_t)(nP + (int64_t)next_f++);
+    } else {
         static const int mode = getenv("BDF_K1_ORDER") ? atoi(getenv("BDF_K1_ORDER")) : 1;
         int64_t stride = 1;
         if (mode == 1 && total > 2) {
@@ -676,6 +707,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
     plan.dev.partials = plan.partials_dev;
     plan.dev.arrived = plan.arrived_dev;
     plan.dev.order = plan.order_dev;
+    plan.dev.decoupled = decoupled;
     return BDF_OK;
 }
 
