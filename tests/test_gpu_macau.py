@@ -293,3 +293,51 @@ def test_full_prediction(B):
     p = res["predictions"]
     ids = rd.relations[0].test_vec.ids
     np.testing.assert_allclose(full[ids[:, 0] - 1, ids[:, 1] - 1], np.asarray(p["pred"]), rtol=1e-10, atol=1e-12)
+
+
+def test_movielens_d32_full_size_properties(B):
+    """BASELINE config 2 at its full size (MovieLens, 500,209 training ratings, D=32): properties that do not need the CPU
+    oracle at this size -- (a) two shards sample exactly the rows of the unsharded launch, bit for bit; (b) another item
+    size gives the same rows to rounding; (c) sampled rows equal chol(inv(P_i))' z + inv(P_i) b_i recomputed in numpy from the
+    row-system hook and the row's normals, on a sample of rows"""
+    import ctypes as C
+    from bdf_amd import datasets
+    from bdf_amd._lib import check, lib
+    rd, source = datasets.movielens_relation_data(B)
+    if source != "movielens_1m.mat":
+        pytest.skip("bundled data file missing")
+    D = 32
+    eng = B.GibbsEngine(rd, D, seed=7, device=0)
+    for i in range(1, 4):
+        eng.sweep(i)                    # a non-trivial state
+    eng.sync()
+    st = eng.ent[0]
+    terms = eng._terms(0)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    ctx = eng.ctx
+    ctx.set_sweep(9)
+    full = ctx.zeros(st.N, D)
+    check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, p(st.mu), 0, p(st.Lambda), st.tag, 0, 1, p(full), None))
+    halves = ctx.zeros(st.N, D)
+    for s in (0, 1):
+        check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, p(st.mu), 0, p(st.Lambda), st.tag, s, 2, p(halves), None))
+    ctx.sync()
+    a, b = full.cpu().numpy(), halves.cpu().numpy()
+    assert np.array_equal(a, b)                                                       # (a)
+    assert np.all(np.isfinite(a)) and 0.05 < np.abs(a).mean() < 5.0
+    ctx.set_item_size(64)
+    other = ctx.zeros(st.N, D)
+    check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, p(st.mu), 0, p(st.Lambda), st.tag, 0, 1, p(other), None))
+    ctx.sync()
+    ctx.set_item_size(192)
+    np.testing.assert_allclose(other.cpu().numpy(), a, rtol=1e-8, atol=1e-10)         # (b)
+    # (c) the reference's map on a sample of rows
+    P_t, b_t, z_t = ctx.zeros(st.N, D, D), ctx.zeros(st.N, D), ctx.zeros(st.N, D)
+    check(lib().bdf_row_system(ctx.handle, D, st.N, 1, terms, p(st.mu), 0, p(st.Lambda), p(P_t), p(b_t)))
+    check(lib().bdf_normals(ctx.handle, 1, st.tag, 0, st.N, D, p(z_t)))
+    ctx.sync()
+    P, bb, z = P_t.cpu().numpy(), b_t.cpu().numpy(), z_t.cpu().numpy()
+    for row in (0, 1, 17, 1000, 3333, 6039):
+        cov = np.linalg.inv(P[row])
+        np.testing.assert_allclose(a[row], np.linalg.cholesky(cov) @ z[row] + cov @ bb[row], rtol=1e-8, atol=1e-9)
+    eng.close()
