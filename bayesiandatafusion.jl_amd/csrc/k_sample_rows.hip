@@ -438,6 +438,11 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     const bool is_split = wid < p.n_split;                      // wave-uniform
     const Item it = is_split ? p.split[wid] : p.direct[wid - p.n_split];
     row = it.row;
+    // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
+    // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
+    double z = 0.0;
+    const bool early_z = !DUMP && !is_split && !p.decoupled;
+    if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
     if (p.decoupled && !is_split) {
         // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
         // row's arrival counter, bounded so that a bug cannot hang the device
@@ -526,7 +531,7 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     }
 
     // the row's normals: lane c < D (lane = column from here on) draws number D-1-c of the row's stream
-    const double z = (lane < D) ? bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane) : 0.0;
+    if (!early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
     STAMP(4);
 
     double A[NB * 4];
