@@ -85,6 +85,8 @@ _SIGS = {
     "bdf_hyper_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                    C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_hyper_draws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint32, C.c_void_p]),
+    "bdf_pairs_sort": (C.c_int, [C.c_void_p, C.c_int]),
+    "bdf_pairs_order": (C.c_int, [C.c_void_p, c_i64p]),
     "bdf_pairs_set_baseline": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_feat_linear": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]),
     "bdf_predict_sse": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p, C.c_void_p]),

@@ -73,6 +73,9 @@ struct bdf_pairs {
     double *avg_dev, *sq_dev;
     double count;         // counter_prob (macau.jl:171-183)
     const double *baseline_dev;   // nullable, borrowed: per-pair baseline replacing mean_value (relation features)
+    int32_t *orig_dev;            // nullable: storage position -> caller's index (bdf_pairs_sort)
+    std::vector<int32_t> ids_host, orig_host;
+    std::vector<double> values_host;
 };
 
 struct bdf_feat {

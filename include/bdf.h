@@ -158,6 +158,13 @@ int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *sumU, const d
  * buffer as `draws` to take the gamma rejection loops off the critical path.  Same streams, same values. */
 int bdf_hyper_draws(bdf_ctx *ctx, int D, int64_t N, double nu, uint32_t entity_tag, double *draws_out);
 
+/* Store the pairs sorted by their id in `mode` (stable sort): consecutive pairs then share that mode's factor row, which
+ * halves the gather traffic of bdf_predict / bdf_predict_update.  Call before the first update.  The caller's order is
+ * kept wherever the interface is per pair: bdf_predict's out and the baseline are indexed through the permutation;
+ * bdf_pairs_state returns the running state in STORAGE order, and bdf_pairs_order gives, for every storage position,
+ * the caller's index (identity when the pairs were never sorted). */
+int bdf_pairs_sort(bdf_pairs *pairs, int mode);
+int bdf_pairs_order(const bdf_pairs *pairs, int64_t *orig_host);
 /* per-pair baseline (dev, n doubles, borrowed; NULL to clear) that replaces mean_value in bdf_predict / bdf_predict_update for
  * these pairs: mean_value + F_test beta of pred(r, probe_vec, F) (src/sampling.jl:9-14) for a relation with features */
 int bdf_pairs_set_baseline(bdf_pairs *pairs, const double *baseline);

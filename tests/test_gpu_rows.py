@@ -446,3 +446,28 @@ def test_gather_paths_agree(B, ctx, mode):
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
             outs[m] = np.load(f)
     np.testing.assert_allclose(outs[mode], outs[""], rtol=1e-12, atol=1e-13)
+
+
+def test_sorted_pairs_keep_the_callers_order(B, O, ctx):
+    """bdf_pairs_sort: same predictions, running means and statistics as the unsorted pairs, in the caller's order"""
+    D = 12
+    rng = np.random.default_rng(14)
+    dims = [40, 25]
+    n = 3000
+    ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
+    y = rng.standard_normal(n) + 3
+    facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    plain, srt = B.DevicePairs(ctx, ids, y), B.DevicePairs(ctx, ids, y).sort(0)
+    np.testing.assert_array_equal(srt.predict(D, ft, 0.4).cpu().numpy(), plain.predict(D, ft, 0.4).cpu().numpy())
+    for phase in (0, 1, 2, 2):
+        for q in ft:
+            q.mul_(0.9)
+        s1 = plain.update(D, ft, 0.4, phase, [2.0, 4.0], 3.0).cpu().numpy().copy()
+        s2 = srt.update(D, ft, 0.4, phase, [2.0, 4.0], 3.0).cpu().numpy().copy()
+        np.testing.assert_allclose(s2, s1, rtol=1e-12)
+    a1, q1 = plain.state()
+    a2, q2 = srt.state()
+    np.testing.assert_array_equal(a2, a1)
+    np.testing.assert_array_equal(q2, q1)
+    plain.close(); srt.close()
