@@ -115,4 +115,77 @@ function update_beta!(c::Context, feat::Ptr{Cvoid}, D, sample, mu, Lambda, lambd
                 beta.p, C_NULL, C_NULL))
 end
 
+# ---- Entity.F operators (S4: F*B, At_mul_B(F,B); RelationData.jl:314-329) ----------------------------------------------
+"dense feature matrix (N x numF, column-major as a Julia Matrix{Float64})"
+function feat_dense(c::Context, F::Matrix{Float64})
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bdf_feat_create_dense, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                c.h, size(F, 1), size(F, 2), F, out))
+    out[]
+end
+"sparse features from 1-based COO rows/cols (Int32) and values; `vals === nothing`: binary (SparseBinMatrix / SparseBinMatrixCSR)"
+function feat_sparse(c::Context, m, n, rows::Vector{Int32}, cols::Vector{Int32}, vals=nothing)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    if vals === nothing
+        check(ccall((:bdf_feat_create_bin, lib), Cint, (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Ref{Ptr{Cvoid}}),
+                    c.h, m, n, length(rows), rows, cols, out))
+    else
+        check(ccall((:bdf_feat_create_csr, lib), Cint,
+                    (Ptr{Cvoid}, Int64, Int64, Int64, Ptr{Int32}, Ptr{Int32}, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                    c.h, m, n, length(rows), rows, cols, convert(Vector{Float64}, vals), out))
+    end
+    out[]
+end
+feat_destroy(f::Ptr{Cvoid}) = check(ccall((:bdf_feat_destroy, lib), Cint, (Ptr{Cvoid},), f))
+"out = F * B (transpose = false) or F' * B; B, out: device, column-major with `ncol` columns"
+feat_mul!(c::Context, f::Ptr{Cvoid}, B::DevArray, ncol, out::DevArray; transpose=false) =
+    check(ccall((:bdf_feat_mul, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Cint), c.h, f, B.p, ncol, out.p, transpose))
+"uhat = (F beta)' and mu .+ uhat (F_mul_beta, RelationData.jl:314-320; macau.jl:103-104)"
+uhat!(c::Context, f::Ptr{Cvoid}, D, beta::DevArray, mu::DevArray, uhat::DevArray, mu_matrix::DevArray) =
+    check(ccall((:bdf_uhat, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, f, D, beta.p, mu.p, uhat.p, mu_matrix.p))
+"T^-1 += beta' beta * lambda_beta (macau.jl:124-129)"
+hyper_feature_terms!(c::Context, D, numF, beta::DevArray, WI::DevArray, lambda_beta::DevArray, Tinv::DevArray) =
+    check(ccall((:bdf_hyper_feature_terms, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, D, numF, beta.p, WI.p, lambda_beta.p, Tinv.p))
+
+# ---- test-set prediction (pred(rel, test_vec, F) + running mean; src/sampling.jl:9-45, src/macau.jl:142-203) ----------
+mutable struct DevPairs
+    h::Ptr{Cvoid}
+    n::Int
+    function DevPairs(c::Context, ids::Matrix{Int64}, values::Vector{Float64})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bdf_pairs_create, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Cint, Ptr{Float64}, Ref{Ptr{Cvoid}}),
+                    c.h, size(ids, 2), size(ids, 1), ids, 8, values, out))
+        p = new(out[], size(ids, 1))
+        finalizer(x -> ccall((:bdf_pairs_destroy, lib), Cint, (Ptr{Cvoid},), x.h), p)
+        p
+    end
+end
+"running posterior mean / sum of squares / clamped errors / class hits; stats: DevArray of 4 doubles"
+function predict_update!(c::Context, p::DevPairs, D, factors::Vector{<:DevArray}, mean_value, phase, clamp_lo, clamp_hi, class_cut, stats::DevArray)
+    fp = Ptr{Cvoid}[f.p for f in factors]
+    check(ccall((:bdf_predict_update, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Cint, Float64, Float64, Float64, Ptr{Cvoid}),
+                c.h, p.h, D, fp, mean_value, phase, clamp_lo, clamp_hi, class_cut, stats.p))
+end
+
+# ---- relation model (src/macau.jl:83-92) ------------------------------------------------------------------------------
+"alpha = sample_alpha(alpha_lambda0, alpha_nu0, err) (src/sampling.jl:129-134); stats from predict_sse!, alpha_out: 1 double"
+function sample_alpha!(c::Context, p::DevPairs, D, factors::Vector{<:DevArray}, mean_value, lambda0, nu0, rel_tag, stats::DevArray, alpha_out::DevArray)
+    fp = Ptr{Cvoid}[f.p for f in factors]
+    check(ccall((:bdf_predict_sse, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, p.h, D, fp, mean_value, C_NULL, stats.p))
+    check(ccall((:bdf_sample_alpha, lib), Cint, (Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Cvoid}, UInt32, Ptr{Cvoid}),
+                c.h, lambda0, nu0, p.n, stats.p + 8, rel_tag, alpha_out.p))
+end
+"beta = sample_beta_rel(r); linear_values = mean_value + F beta (src/sampling.jl:322-337, src/macau.jl:89-92)"
+function sample_beta_rel!(c::Context, f::Ptr{Cvoid}, train::DevPairs, D, factors::Vector{<:DevArray}, mean_value, alpha, lambda_beta,
+                          rel_tag, beta::DevArray, linear_values::DevArray)
+    fp = Ptr{Cvoid}[x.p for x in factors]
+    check(ccall((:bdf_sample_beta_rel, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Float64, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, f, train.h, D, fp, mean_value, alpha, lambda_beta, rel_tag, beta.p, linear_values.p, C_NULL))
+end
+
 end # module
