@@ -46,6 +46,9 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     BDF_HIP(hipMalloc((void **)&c->flag_dev, 16 * sizeof(int)));      // [0] error flag, [1..] self-resetting arrival counters
     BDF_HIP(hipMemsetAsync(c->sweep_dev, 0, sizeof(uint32_t), c->stream));
     BDF_HIP(hipMemsetAsync(c->flag_dev, 0, 16 * sizeof(int), c->stream));
+    BDF_HIP(hipMalloc((void **)&c->rows_done_dev, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t)));
+    BDF_HIP(hipMemsetAsync(c->rows_done_dev, 0, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t), c->stream));
+    memset(c->rows_done_target, 0, sizeof(c->rows_done_target));
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
@@ -65,6 +68,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     hipFree(ctx->sweep_dev);
     hipFree(ctx->flag_dev);
+    hipFree(ctx->rows_done_dev);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -132,8 +136,82 @@ extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
     BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         BDF_HIP(hipMemset(ctx->flag_dev, 0, sizeof(int)));
+        if (flag & 32) {
+            bdf_set_error("bdf_rows_gate: timed out waiting for the row kernels of the other context (flag %d)", flag);
+            return BDF_ERR_HIP;
+        }
         bdf_set_error("a matrix that must be positive definite was not (flag %d)", flag);
         return BDF_ERR_NOTPD;
+    }
+    return BDF_OK;
+}
+
+// ---- cross-stream hand-over without events: a one-wave gate kernel on the waiting stream ---------------------------
+// hipEventRecord after a row kernel + hipStreamWaitEvent costs the recording stream ~9 us per launch (tools/event_cost3.hip);
+// completion counters written by the row kernel itself and a gate kernel polling them on the waiting stream cost it ~2.5.
+namespace {
+struct GateTargets { uint32_t t[BDF_GATE_COUNTERS]; };
+
+__global__ __launch_bounds__(64) void k_rows_gate(const uint32_t *counters, GateTargets tg, int *flag, long long max_ticks)
+{
+    const int lane = threadIdx.x;
+    const long long t0 = wall_clock64();                       // 100 MHz
+    const uint32_t want = tg.t[lane];
+    for (;;) {
+        const uint32_t c = __hip_atomic_load(counters + lane * BDF_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_ballot_w64((int32_t)(c - want) < 0) == 0) break;
+        __builtin_amdgcn_s_sleep(4);
+        if (wall_clock64() - t0 > max_ticks) {                 // bounded: a bug must not hang the device
+            if (lane == 0) atomicOr(flag, 32);
+            break;
+        }
+    }
+}
+
+__global__ void k_gate_bump(uint32_t *counters)
+{
+    if (threadIdx.x < BDF_GATE_COUNTERS)
+        __hip_atomic_fetch_add(counters + threadIdx.x * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+}  // namespace
+
+extern "C" int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer)
+{
+    BDF_REQUIRE(waiter && producer, BDF_ERR_ARG, "bdf_rows_gate: NULL context");
+    BDF_REQUIRE(waiter->device == producer->device, BDF_ERR_ARG, "bdf_rows_gate: the contexts are on different devices");
+    if (waiter->stream == producer->stream) return BDF_OK;     // same stream: already ordered
+    GateTargets tg;
+    memcpy(tg.t, producer->rows_done_target, sizeof(tg.t));
+    static const long long max_ticks = 100000000LL * (getenv("BDF_GATE_TIMEOUT_S") ? atoll(getenv("BDF_GATE_TIMEOUT_S")) : 30);
+    hipLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, producer->rows_done_dev, tg, waiter->flag_dev, max_ticks);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable)
+{
+    BDF_REQUIRE(waiter && producer && usable, BDF_ERR_ARG, "bdf_rows_gate_selftest: NULL argument");
+    *usable = 0;
+    if (waiter->device != producer->device) return BDF_OK;
+    if (waiter->stream == producer->stream) { *usable = 1; return BDF_OK; }
+    // the gate is enqueued FIRST and the kernel that satisfies it afterwards on the other stream: if the two streams
+    // cannot run side by side (they share a hardware queue), the gate times out (20 ms) instead of passing
+    BDF_HIP(hipStreamSynchronize(producer->stream));
+    BDF_HIP(hipStreamSynchronize(waiter->stream));
+    GateTargets tg;
+    for (int c = 0; c < BDF_GATE_COUNTERS; c++) tg.t[c] = ++producer->rows_done_target[c];
+    hipLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, producer->rows_done_dev, tg, waiter->flag_dev, 2000000LL);
+    hipLaunchKernelGGL(k_gate_bump, dim3(1), dim3(64), 0, producer->stream, producer->rows_done_dev);
+    BDF_HIP(hipGetLastError());
+    BDF_HIP(hipStreamSynchronize(waiter->stream));
+    BDF_HIP(hipStreamSynchronize(producer->stream));
+    int flag = 0;
+    BDF_HIP(hipMemcpy(&flag, waiter->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+    if (flag & 32) {
+        flag &= ~32;
+        BDF_HIP(hipMemcpy(waiter->flag_dev, &flag, sizeof(int), hipMemcpyHostToDevice));
+    } else {
+        *usable = 1;
     }
     return BDF_OK;
 }
@@ -379,6 +457,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
     a.sweep = ctx->sweep_host;
     a.seed = ctx->seed;
     a.flag = ctx->flag_dev;
+    a.done = ctx->rows_done_dev;
     return BDF_OK;
 }
 

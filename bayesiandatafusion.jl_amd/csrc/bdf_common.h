@@ -24,6 +24,9 @@ void bdf_set_error(const char *fmt, ...);
         if (!(cond)) { bdf_set_error(__VA_ARGS__); return (code); }                        \
     } while (0)
 
+#define BDF_GATE_COUNTERS 64
+#define BDF_GATE_STRIDE 16          // uint32 per counter slot (64 bytes)
+
 struct bdf_ctx {
     int device;
     hipStream_t stream;
@@ -38,6 +41,10 @@ struct bdf_ctx {
     size_t scratch2_bytes;
     int *flag_dev;             // not-positive-definite flag
     int item_size;             // K1: observations per work item (rows longer than this are split)
+    // row-kernel completion counters (bdf_rows_gate): counter c (one per 64 bytes) is incremented by every wave w of
+    // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
+    uint32_t *rows_done_dev;
+    uint32_t rows_done_target[BDF_GATE_COUNTERS];
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
@@ -207,6 +214,7 @@ struct SampleArgs {
     const double *prior_c;     // index-reversed Lambda in the accumulator layout, filled by the launch front-end
     double *P_dump, *b_dump;
     int *flag;
+    uint32_t *done;            // the context's completion counters (bdf_rows_gate)
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

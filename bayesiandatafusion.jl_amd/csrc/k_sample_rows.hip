@@ -564,7 +564,8 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
 #pragma unroll
     for (int q = 0; q < 4; q++) colq[q] = tri + cr.cbase + q * cr.nr4 - cr.q;     // row i at colq[i & 3][i >> 2]
     backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
-    if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
+    // write-through (sc1): a consumer gated on the completion counters (bdf_rows_gate) may start before this launch ends
+    if (lane < D) __hip_atomic_store(a.out + row * D + (D - 1 - lane), yh * rdv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(8);
 }
 
@@ -591,6 +592,10 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, Geo<DP>::WAVES) void k_rows(Samp
     }
 #endif
     if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+    // completion counters (bdf_rows_gate): every wave of the launch, item or not, counts once after its stores completed
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0)
+        __hip_atomic_fetch_add(a.done + (int)(w & (BDF_GATE_COUNTERS - 1)) * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -726,6 +731,9 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
         if (dump) hipLaunchKernelGGL((k_rows<DP, true>), grid, block, 0, ctx->stream, a, p);
         else      hipLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, a, p);
         BDF_HIP(hipGetLastError());
+        const int64_t launched = (int64_t)grid.x * WPB;
+        for (int c = 0; c < BDF_GATE_COUNTERS; c++)
+            ctx->rows_done_target[c] += (uint32_t)(launched / BDF_GATE_COUNTERS + (c < launched % BDF_GATE_COUNTERS ? 1 : 0));
     }
     return BDF_OK;
 }

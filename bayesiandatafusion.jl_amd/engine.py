@@ -351,6 +351,13 @@ class GibbsEngine:
         self.compute_ff_size = compute_ff_size
         self.rank, self.world = (0, 1) if shard is None else shard
         self._rowlists = {}
+        # hand-over of fresh rows to the other streams: completion counters of the row kernel + a gate kernel on the
+        # waiting stream (bdf_rows_gate) instead of an event recorded on the row stream -- when the streams really run
+        # side by side, and not with several ranks (the all-gather after the row kernel is not covered by the counters)
+        self.use_gate = False
+        if self.ctx_h is not self.ctx and self.world == 1 and not os.environ.get("BDF_NO_GATE"):
+            self.use_gate = all(self._gate_usable(c) for c in {id(self.ctx_h): self.ctx_h, id(self.ctx_p): self.ctx_p}.values()
+                                if c is not self.ctx)
         # ---- reset! (RelationData.jl:331-355)
         self.ent = []
         for j, en in enumerate(data.entities):
@@ -453,6 +460,11 @@ class GibbsEngine:
                                                 r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
         self.refresh_baselines()
 
+    def _gate_usable(self, waiter):
+        ok = C.c_int(0)
+        check(lib().bdf_rows_gate_selftest(waiter.handle, self.ctx.handle, C.byref(ok)))
+        return bool(ok.value)
+
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
     def sample_entity(self, j):
         en, st = self.data.entities[j], self.ent[j]
@@ -551,7 +563,9 @@ class GibbsEngine:
             if two:
                 self.prepare_prior(j, i)                 # side stream, beside the row sampling
             self.sample_entity(j)
-            if two:
+            if two and self.use_gate:
+                check(lib().bdf_rows_gate(self.ctx_h.handle, self.ctx.handle))
+            elif two:
                 ev = self._ev_rows.setdefault(j, torch.cuda.Event())
                 ev.record(main)
                 side.wait_event(ev)
@@ -559,15 +573,17 @@ class GibbsEngine:
             if two:
                 ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
                 ev.record(side)
-        if three:
-            self.ctx_p.stream.wait_event(self._ev_rows[len(self.ent) - 1])    # prediction updates read this sweep's rows
+        if three and self.use_gate:                          # prediction updates read this sweep's rows
+            check(lib().bdf_rows_gate(self.ctx_p.handle, self.ctx.handle))
+        elif three:
+            self.ctx_p.stream.wait_event(self._ev_rows[len(self.ent) - 1])
         for j in range(len(self.ent)):
             if self.ent[j].F is not None:
                 if two:
                     main.wait_event(self._ev_hyper[j])
                 self.update_beta(j)
                 if two:                                  # the next hyperprior of j reads beta / lambda_beta
-                    ev = self._ev_rows[j]
+                    ev = self._ev_rows.setdefault(j, torch.cuda.Event())
                     ev.record(main)
                     side.wait_event(ev)
 

@@ -69,6 +69,15 @@ int bdf_ctx_destroy(bdf_ctx *ctx);
  * the launches that follow by value. */
 int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
 int bdf_ctx_advance_sweep(bdf_ctx *ctx);
+/* Cross-stream hand-over of freshly sampled rows without an event: enqueues on `waiter`'s stream a one-wave kernel that
+ * returns once every row-kernel launch (bdf_sample_rows) enqueued so far on `producer` has completed and its rows are
+ * visible -- the ordering hipEventRecord(producer) + hipStreamWaitEvent(waiter) gives for those launches and everything
+ * before them on producer's stream, at a quarter of the cost to the producer's stream.  Bounded wait (30 s, env
+ * BDF_GATE_TIMEOUT_S): on time-out the waiter's next bdf_ctx_sync returns BDF_ERR_HIP.  Both contexts on one device.
+ * bdf_rows_gate_selftest: *usable = 1 if the two streams really run side by side (a gate enqueued before the kernel
+ * that satisfies it passes); callers fall back to events otherwise.  Synchronises both streams. */
+int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer);
+int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 192 */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
