@@ -49,6 +49,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     BDF_HIP(hipMalloc((void **)&c->rows_done_dev, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t)));
     BDF_HIP(hipMemsetAsync(c->rows_done_dev, 0, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t), c->stream));
     memset(c->rows_done_target, 0, sizeof(c->rows_done_target));
+    c->time_start = c->time_stop = nullptr;
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
@@ -174,6 +175,40 @@ __global__ void k_gate_bump(uint32_t *counters)
         __hip_atomic_fetch_add(counters + threadIdx.x * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 }  // namespace
+
+// ---- timing of a row-kernel launch by HIP events carried by the kernel's own dispatch packet ------------------------
+extern "C" int bdf_event_create(void **ev)
+{
+    BDF_REQUIRE(ev, BDF_ERR_ARG, "bdf_event_create: NULL argument");
+    hipEvent_t e;
+    BDF_HIP(hipEventCreate(&e));
+    *ev = (void *)e;
+    return BDF_OK;
+}
+
+extern "C" int bdf_event_destroy(void *ev)
+{
+    if (ev) BDF_HIP(hipEventDestroy((hipEvent_t)ev));
+    return BDF_OK;
+}
+
+extern "C" int bdf_event_elapsed_us(void *start, void *stop, double *us)
+{
+    BDF_REQUIRE(start && stop && us, BDF_ERR_ARG, "bdf_event_elapsed_us: NULL argument");
+    BDF_HIP(hipEventSynchronize((hipEvent_t)stop));
+    float ms = 0.f;
+    BDF_HIP(hipEventElapsedTime(&ms, (hipEvent_t)start, (hipEvent_t)stop));
+    *us = 1e3 * (double)ms;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_rows: ctx is NULL");
+    ctx->time_start = (hipEvent_t)start;
+    ctx->time_stop = (hipEvent_t)stop;
+    return BDF_OK;
+}
 
 extern "C" int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer)
 {

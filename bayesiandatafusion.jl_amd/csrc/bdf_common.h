@@ -1,6 +1,7 @@
 // bdf_common.h -- internal declarations shared by the HIP translation units of libbdf_hip.so
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <cstdint>
 #include <cstdio>
 #include <cstdarg>
@@ -44,6 +45,7 @@ struct bdf_ctx {
     // row-kernel completion counters (bdf_rows_gate): counter c (one per 64 bytes) is incremented by every wave w of
     // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
     uint32_t *rows_done_dev;
+    hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
     uint32_t rows_done_target[BDF_GATE_COUNTERS];
 };
 

@@ -729,6 +729,11 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
     if (waves > 0) {
         dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
         if (dump) hipLaunchKernelGGL((k_rows<DP, true>), grid, block, 0, ctx->stream, a, p);
+        else if (ctx->time_start || ctx->time_stop) {
+            // start / stop events on the dispatch packet itself: the kernel's own begin and end, no marker packets around it
+            hipExtLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p);
+            ctx->time_start = ctx->time_stop = nullptr;
+        }
         else      hipLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, a, p);
         BDF_HIP(hipGetLastError());
         const int64_t launched = (int64_t)grid.x * WPB;

@@ -45,6 +45,28 @@ def allgather_rows(sample, lists, rank, world):
             sample.index_copy_(0, lists[p], recv[p * nmax:p * nmax + counts[p]])
 
 
+class KernelTimer:
+    """a pair of HIP events that bdf_ctx_time_next_rows attaches to the next row-kernel dispatch (the kernel's own begin and
+    end on its stream; events recorded around the launch would add their marker packets to the interval)"""
+
+    def __init__(self):
+        self.start, self.stop = C.c_void_p(), C.c_void_p()
+        check(lib().bdf_event_create(C.byref(self.start)))
+        check(lib().bdf_event_create(C.byref(self.stop)))
+
+    def elapsed_us(self):
+        us = C.c_double(0.0)
+        check(lib().bdf_event_elapsed_us(self.start, self.stop, C.byref(us)))
+        return us.value
+
+    def __del__(self):
+        try:
+            lib().bdf_event_destroy(self.start)
+            lib().bdf_event_destroy(self.stop)
+        except Exception:
+            pass
+
+
 class Context:
     """bdf_ctx bound to a torch device and torch's current stream."""
 
@@ -336,28 +358,26 @@ class GibbsEngine:
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
         # second HIP stream: the hyperprior of entity j (reductions + Normal-Wishart draw) runs beside the row sampling
         # of entity j+1, which does not depend on it (macau.jl:96-134 draws them in this order; the values are the same)
+        self.rank, self.world = (0, 1) if shard is None else shard
+        # hand-over of fresh rows to the other streams: completion counters of the row kernel + a gate kernel on the
+        # waiting stream (bdf_rows_gate) instead of an event recorded on the row stream -- when the streams really run
+        # side by side (HIP multiplexes streams onto a few hardware queues: _side_context looks for one that does), and
+        # not with several ranks (the all-gather after the row kernel is not covered by the counters)
+        self.use_gate = self.world == 1 and not os.environ.get("BDF_NO_GATE") and not os.environ.get("BDF_NO_OVERLAP")
         self.ctx_h = self.ctx
         if not os.environ.get("BDF_NO_OVERLAP"):
-            self.ctx_h = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+            self.ctx_h = self._side_context(seed)
         # third stream for the prediction updates (test set, training set): they only read the sampled rows, and every
         # entity's rows alternate between two buffers, so the update of sweep t runs beside the rows of sweep t+1
         self.ctx_p = self.ctx
         if not os.environ.get("BDF_NO_OVERLAP") and all(feat.isempty(r.F) for r in data.relations):
-            self.ctx_p = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+            self.ctx_p = self._side_context(seed)
         self._ev_pred = None
         self._ev_rows, self._ev_hyper = {}, {}
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
-        self.rank, self.world = (0, 1) if shard is None else shard
         self._rowlists = {}
-        # hand-over of fresh rows to the other streams: completion counters of the row kernel + a gate kernel on the
-        # waiting stream (bdf_rows_gate) instead of an event recorded on the row stream -- when the streams really run
-        # side by side, and not with several ranks (the all-gather after the row kernel is not covered by the counters)
-        self.use_gate = False
-        if self.ctx_h is not self.ctx and self.world == 1 and not os.environ.get("BDF_NO_GATE"):
-            self.use_gate = all(self._gate_usable(c) for c in {id(self.ctx_h): self.ctx_h, id(self.ctx_p): self.ctx_p}.values()
-                                if c is not self.ctx)
         # ---- reset! (RelationData.jl:331-355)
         self.ent = []
         for j, en in enumerate(data.entities):
@@ -398,8 +418,8 @@ class GibbsEngine:
             dr.alpha_dev = self.ctx.zeros(1)
         self._test_pairs = None
         self._train_pairs = None
-        self.k1_events = None     # bench.py: list of (entity, start, end) HIP events around each K1 launch
-        self.k1_event_every = 1   # ... of every n-th sweep (an event pair costs the stream several microseconds)
+        self.k1_events = None     # bench.py: list of (entity, KernelTimer) of the timed K1 launches
+        self.k1_event_every = 1   # ... of every n-th sweep
         self._k1_sweep = 0
 
     def k1_algorithmic_bytes(self, j):
@@ -460,10 +480,26 @@ class GibbsEngine:
                                                 r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
         self.refresh_baselines()
 
-    def _gate_usable(self, waiter):
-        ok = C.c_int(0)
-        check(lib().bdf_rows_gate_selftest(waiter.handle, self.ctx.handle, C.byref(ok)))
-        return bool(ok.value)
+    def _side_context(self, seed):
+        """a context on another stream of the device; with gates in use, one whose stream passes bdf_rows_gate_selftest
+        against the row stream (a few candidates are tried; none passing turns the gates off for this engine)"""
+        first = None
+        for attempt in range(8 if self.use_gate else 1):
+            c = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+            if not self.use_gate:
+                return c
+            ok = C.c_int(0)
+            check(lib().bdf_rows_gate_selftest(c.handle, self.ctx.handle, C.byref(ok)))
+            if ok.value:
+                if first is not None:
+                    first.close()
+                return c
+            if first is None:
+                first = c
+            else:
+                c.close()
+        self.use_gate = False
+        return first
 
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
     def sample_entity(self, j):
@@ -477,8 +513,8 @@ class GibbsEngine:
             mu, is_matrix = st.mu_matrix, 1
         timed = self.k1_events is not None and self._k1_sweep % self.k1_event_every == 0
         if timed:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(self.ctx.stream)
+            timer = KernelTimer()
+            check(lib().bdf_ctx_time_next_rows(self.ctx.handle, timer.start, timer.stop))
         pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
         # written into the entity's other buffer (nothing this launch reads), which then becomes the current one: readers
         # of the previous sweep's rows on other streams (prediction updates) are never overwritten under their feet
@@ -486,8 +522,7 @@ class GibbsEngine:
                                     st.tag, self.rank, self.world, _ptr(st.sample_alt), _ptr(pack) if pack is not None else None))
         st.sample, st.sample_alt = st.sample_alt, st.sample
         if timed:
-            e1.record(self.ctx.stream)
-            self.k1_events.append((j, e0, e1))
+            self.k1_events.append((j, timer))
         if self.world > 1:
             self._allgather(j)
 

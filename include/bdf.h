@@ -77,6 +77,14 @@ int bdf_ctx_advance_sweep(bdf_ctx *ctx);
  * bdf_rows_gate_selftest: *usable = 1 if the two streams really run side by side (a gate enqueued before the kernel
  * that satisfies it passes); callers fall back to events otherwise.  Synchronises both streams. */
 int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer);
+/* Measurement support: HIP events (timing enabled) and "attach this pair to the next bdf_sample_rows launch of ctx":
+ * the events ride on the row kernel's own dispatch packet (hipExtLaunchKernelGGL), so start/stop are the kernel's begin and
+ * end on its stream without marker packets around it (an event pair recorded around a launch costs the stream ~6 us and
+ * is counted into the interval).  bdf_event_elapsed_us waits for `stop`.  Either event may be NULL. */
+int bdf_event_create(void **ev);
+int bdf_event_destroy(void *ev);
+int bdf_event_elapsed_us(void *start, void *stop, double *us);
+int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
 int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 192 */

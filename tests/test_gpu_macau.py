@@ -204,9 +204,39 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
     a3, _ = run(6)
     assert not np.array_equal(a1, a3)
+    monkeypatch.setenv("BDF_NO_GATE", "1")              # event hand-over instead of completion counters + gate kernel
+    a5, l5 = run(5)
+    assert np.array_equal(a1, a5) and np.array_equal(l1, l5)
     monkeypatch.setenv("BDF_NO_OVERLAP", "1")
     a4, l4 = run(5)
     assert np.array_equal(a1, a4) and np.array_equal(l1, l4)
+
+
+def test_rows_gate(B):
+    """bdf_rows_gate: the streams of the engine run side by side (self-test passes) and a consumer behind a gate on another
+    stream sees exactly the rows of the launch enqueued before the gate"""
+    import ctypes as C
+    import torch
+    from bdf_amd import _lib
+    from bdf_amd.engine import GibbsEngine
+    Y = _sprand(3000, 500, 0.05, 3)
+    rd = B.RelationData(Y, class_cut=0.5)
+    eng = GibbsEngine(rd, 16, seed=3)
+    assert eng.use_gate
+    L = _lib.lib()
+    for i in range(1, 6):
+        eng.ctx.set_sweep(i)
+        eng.ctx_h.set_sweep(i)
+        # consumer first: the gate must hold the copy back until the rows of THIS launch are there
+        before = eng.ent[0].sample_alt.clone()
+        torch.cuda.synchronize()
+        eng.sample_entity(0)                                  # writes sample_alt, then swaps
+        _lib.check(L.bdf_rows_gate(eng.ctx_h.handle, eng.ctx.handle))
+        with torch.cuda.stream(eng.ctx_h.stream):
+            seen = eng.ent[0].sample.clone()
+        eng.sync()
+        torch.cuda.synchronize()
+        assert torch.equal(seen, eng.ent[0].sample) and not torch.equal(seen, before)
 
 
 def test_argument_errors(B):
