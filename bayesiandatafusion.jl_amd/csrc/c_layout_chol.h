@@ -11,6 +11,9 @@
 #ifndef BDF_K1_WPB
 #define BDF_K1_WPB 4
 #endif
+#ifndef BDF_K1_WAVES32M
+#define BDF_K1_WAVES32M 6         // ... its variant for two-mode relations (78 registers)
+#endif
 #ifndef BDF_K1_WAVES32
 #define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
 #endif
@@ -27,6 +30,7 @@ struct Geo {
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
     static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
     static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
+    static constexpr int WAVES_MATRIX = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
     __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
     // packed factor in LDS: column k keeps rows col_first(k) = RG * (k / RG) .. DP-1, by row class:
     // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - col_first(k)) / 4.  Columns are one double further apart

@@ -300,8 +300,10 @@ __device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int 
     }
 }
 
-// path and other-mode count are wave-uniform
-template <int DP>
+// path and other-mode count are wave-uniform.  MATRIX: the kernel variant for launches whose terms are all two-mode
+// relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
+// 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
+template <int DP, bool MATRIX>
 __device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                       double (&bred)[Geo<DP>::DB])
 {
@@ -317,6 +319,11 @@ __device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int l
             }
             return;
         }
+    }
+    if constexpr (MATRIX) {                  // every term of the launch: two modes, lean gather (checked by the host)
+        if (a.D == DP) accumulate_lean<DP, 1, true>(a, it, lane, acc, bred);
+        else accumulate_lean<DP, 1, false>(a, it, lane, acc, bred);
+        return;
     }
     if (a.t[it.term].lean == 1) {
         if (a.D == DP) {
@@ -416,7 +423,7 @@ __device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int la
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP>
+template <int DP, bool DUMP, bool MATRIX>
 __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     using GG = Geo<DP>;
@@ -456,9 +463,10 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
         if (seen < sr.n_slots && lane == 0) atomicOr(a.flag, 16);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
+        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
-    } else if (it.count > 0) accumulate_any<DP>(a, it, lane, acc, bv);
+    } else if (it.count > 0) accumulate_any<DP, MATRIX>(a, it, lane, acc, bv);
     else {
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
@@ -489,6 +497,8 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
+        // the finisher's normals before the partial sums are loaded: the Box-Muller arithmetic needs ~40 registers
+        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
@@ -530,8 +540,6 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
         return;
     }
 
-    // the row's normals: lane c < D (lane = column from here on) draws number D-1-c of the row's stream
-    if (!early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
     STAMP(4);
 
     double A[NB * 4];
@@ -569,8 +577,8 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     STAMP(8);
 }
 
-template <int DP, bool DUMP>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, Geo<DP>::WAVES) void k_rows(SampleArgs a, PlanDev p)
+template <int DP, bool DUMP, bool MATRIX>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES) void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
     constexpr int WPB = GG::WPB;
@@ -591,7 +599,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, Geo<DP>::WAVES) void k_rows(Samp
     default: __builtin_amdgcn_s_setprio(3); break;
     }
 #endif
-    if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+    if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP, MATRIX>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
     // completion counters (bdf_rows_gate): every wave of the launch, item or not, counts once after its stores completed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0)
@@ -728,13 +736,16 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
         dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
-        if (dump) hipLaunchKernelGGL((k_rows<DP, true>), grid, block, 0, ctx->stream, a, p);
-        else if (ctx->time_start || ctx->time_stop) {
-            // start / stop events on the dispatch packet itself: the kernel's own begin and end, no marker packets around it
-            hipExtLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p);
-            ctx->time_start = ctx->time_stop = nullptr;
-        }
-        else      hipLaunchKernelGGL((k_rows<DP, false>), grid, block, 0, ctx->stream, a, p);
+        bool matrix = true;
+        for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
+        static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
+        matrix = matrix && !no_matrix;
+        auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
+                         : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>);
+        // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
+        // no marker packets around it
+        hipExtLaunchKernelGGL(kern, grid, block, 0, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
+        if (!dump) ctx->time_start = ctx->time_stop = nullptr;
         BDF_HIP(hipGetLastError());
         const int64_t launched = (int64_t)grid.x * WPB;
         for (int c = 0; c < BDF_GATE_COUNTERS; c++)
