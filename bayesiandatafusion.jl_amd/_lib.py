@@ -63,11 +63,13 @@ _SIGS = {
     "bdf_ctx_set_sweep": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
     "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
+    "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_rows_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bdf_event_destroy": (C.c_int, [C.c_void_p]),
     "bdf_event_elapsed_us": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bdf_ctx_time_next_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_ctx_time_next_hyper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_rows_gate_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "bdf_ctx_set_item_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

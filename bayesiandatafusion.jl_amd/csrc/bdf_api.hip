@@ -50,12 +50,14 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     BDF_HIP(hipMemsetAsync(c->rows_done_dev, 0, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t), c->stream));
     memset(c->rows_done_target, 0, sizeof(c->rows_done_target));
     c->time_start = c->time_stop = nullptr;
+    c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
     c->scratch2_bytes = 0;
     c->scratch_bytes = 0;
     c->item_size = 192;
+    c->piece_size = 128;
     *out = c;
     return BDF_OK;
 }
@@ -126,6 +128,15 @@ extern "C" int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations)
 {
     BDF_REQUIRE(ctx && observations >= 8 && observations <= (1 << 20), BDF_ERR_ARG, "bdf_ctx_set_item_size: 8..2^20 observations");
     ctx->item_size = observations;
+    ctx->piece_size = std::max(8, observations * 2 / 3);
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations)
+{
+    BDF_REQUIRE(ctx && observations >= 8 && observations <= ctx->item_size, BDF_ERR_ARG,
+                "bdf_ctx_set_piece_size: 8..item size (%d) observations", ctx ? ctx->item_size : 0);
+    ctx->piece_size = observations;
     return BDF_OK;
 }
 
@@ -207,6 +218,14 @@ extern "C" int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop)
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_rows: ctx is NULL");
     ctx->time_start = (hipEvent_t)start;
     ctx->time_stop = (hipEvent_t)stop;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_hyper: ctx is NULL");
+    ctx->time_h_start = (hipEvent_t)start;
+    ctx->time_h_stop = (hipEvent_t)stop;
     return BDF_OK;
 }
 

@@ -42,10 +42,12 @@ struct bdf_ctx {
     size_t scratch2_bytes;
     int *flag_dev;             // not-positive-definite flag
     int item_size;             // K1: observations per work item (rows longer than this are split)
+    int piece_size;            // K1: ... into pieces of at most this many observations
     // row-kernel completion counters (bdf_rows_gate): counter c (one per 64 bytes) is incremented by every wave w of
     // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
     uint32_t *rows_done_dev;
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
+    hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
     uint32_t rows_done_target[BDF_GATE_COUNTERS];
 };
 

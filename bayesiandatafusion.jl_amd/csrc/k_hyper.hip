@@ -100,15 +100,16 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     double *part = (double *)scratch;
     const dim3 fgrid((psz + 15) / 16);
     if (DP == 16) {
-        hipLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
+        hipExtLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<16>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else if (DP == 32) {
-        hipLaunchKernelGGL(k_hyper_partial<32>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
+        hipExtLaunchKernelGGL(k_hyper_partial<32>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<32>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else {
-        hipLaunchKernelGGL(k_hyper_partial<64>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, D, N, rpb, sample, uhat, part);
+        hipExtLaunchKernelGGL(k_hyper_partial<64>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
         hipLaunchKernelGGL(k_hyper_final<64>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     }
+    ctx->time_h_start = nullptr;
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -153,9 +154,10 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.D = D; a.N = (double)N; a.sumU = sumU; a.UUt = UUt; a.mu0 = mu0; a.Tinv = Tinv; a.b0 = b0; a.nu = nu;
     a.mu_out = mu_out; a.Lambda_out = Lambda_out; a.params_out = params_out; a.pack_out = prior_pack_out; a.draws = draws;
     a.flag = ctx->flag_dev;
-    if (D <= 16) hipLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, a);
-    else if (D <= 32) hipLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, a);
+    if (D <= 16) hipExtLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
+    else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
+    else hipExtLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
+    ctx->time_h_stop = nullptr;
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }

@@ -445,6 +445,13 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     const bool is_split = wid < p.n_split;                      // wave-uniform
     const Item it = is_split ? p.split[wid] : p.direct[wid - p.n_split];
     row = it.row;
+#ifdef BDF_K1_LONG_PRIO
+    // the launch ends with its longest chains: the pieces of split rows (full-length gathers, then the finisher's sum and
+    // factorisation) and the longest direct rows -- they get issue priority over the short rows that share their SIMD
+    if (is_split) __builtin_amdgcn_s_setprio(3);
+    else if (it.count > BDF_K1_LONG_PRIO) __builtin_amdgcn_s_setprio(2);
+    else if (it.count > BDF_K1_LONG_PRIO / 2) __builtin_amdgcn_s_setprio(1);
+#endif
     // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, MATRIX ? Geo<DP>::WAVES_MATRIX :
 struct PlanKey {
     uint64_t rel[BDF_MAX_TERMS];      // relation serials
     int mode[BDF_MAX_TERMS];
-    int n_terms, DP, T;
+    int n_terms, DP, T, Tp;
     int shard, n_shards;
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
@@ -653,6 +660,17 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
             n_items += (int)((n + T - 1) / T);
         }
+        // a row that is split anyway is cut into smaller pieces than the longest whole row: the launch ends with the split
+        // rows (their pieces gather at a sixth of the matrix pipe each, then one wave sums and finishes the row)
+        const int Tp = n_items > 1 ? key.Tp : T;
+        if (n_items > 1 && Tp != T) {
+            n_items = 0;
+            for (int r = 0; r < key.n_terms; r++) {
+                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
+                const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
+                n_items += (int)((n + Tp - 1) / Tp);
+            }
+        }
         if (n_items <= 1 && !decoupled) {
             Item it{row, 0, 0, 0, -1, -1, 0};
             for (int r = 0; r < key.n_terms; r++) {
@@ -672,7 +690,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
                 const int64_t beg = rp[(size_t)row], n = rp[(size_t)row + 1] - beg;
-                const int pieces = (int)((n + T - 1) / T);
+                const int pieces = (int)((n + Tp - 1) / Tp);
                 for (int s = 0; s < pieces; s++) {
                     // equal pieces rather than T, T, ..., remainder
                     const int64_t b0 = beg + n * s / pieces, b1 = beg + n * (s + 1) / pieces;
@@ -802,7 +820,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     PlanKey key;
     memset(&key, 0, sizeof(key));
     for (int r = 0; r < a.n_terms; r++) { key.rel[r] = rels[r]->serial; key.mode[r] = modes[r]; }
-    key.n_terms = a.n_terms; key.DP = DP; key.T = ctx->item_size; key.shard = shard; key.n_shards = n_shards;
+    key.n_terms = a.n_terms; key.DP = DP; key.T = ctx->item_size; key.Tp = std::min(ctx->piece_size, ctx->item_size); key.shard = shard; key.n_shards = n_shards;
 
     Plan *plan;
     {

@@ -90,6 +90,9 @@ class Context:
     def set_item_size(self, observations):
         check(lib().bdf_ctx_set_item_size(self.handle, int(observations)))
 
+    def set_piece_size(self, observations):
+        check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
+
     def set_sweep(self, i):
         check(lib().bdf_ctx_set_sweep(self.handle, C.c_uint32(int(i))))
 
@@ -356,6 +359,8 @@ class GibbsEngine:
         self.ctx = Context(device, seed)
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
+        if os.environ.get("BDF_PIECE_SIZE"):
+            self.ctx.set_piece_size(int(os.environ["BDF_PIECE_SIZE"]))
         # second HIP stream: the hyperprior of entity j (reductions + Normal-Wishart draw) runs beside the row sampling
         # of entity j+1, which does not depend on it (macau.jl:96-134 draws them in this order; the values are the same)
         self.rank, self.world = (0, 1) if shard is None else shard

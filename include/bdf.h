@@ -85,10 +85,15 @@ int bdf_event_create(void **ev);
 int bdf_event_destroy(void *ev);
 int bdf_event_elapsed_us(void *start, void *stop, double *us);
 int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
+/* the same for the hyperprior chain of ctx: `start` rides on the next bdf_hyper_sums' first kernel, `stop` on the next
+ * bdf_hyper_sample's kernel */
+int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
 int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
-/* tuning: observations per K1 work item (rows with more are split over several wavefronts); default 192 */
+/* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
+ * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
+int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
 /* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
 int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);
 int bdf_dev_free(bdf_ctx *ctx, void *dptr);

@@ -180,15 +180,17 @@ def test_shard_writes_only_its_rows(B, O, ctx):
     dr.close()
 
 
-@pytest.mark.parametrize("item", [8, 16, 1000])
-def test_item_size_does_not_change_results(B, O, ctx, item):
-    """rows longer than the item size are split over wavefronts and re-assembled in slot order"""
+@pytest.mark.parametrize("item,piece", [(8, None), (16, None), (1000, None), (64, 24), (192, 128), (100, 100)])
+def test_item_size_does_not_change_results(B, O, ctx, item, piece):
+    """rows longer than the item size are split into pieces (of the piece size) over wavefronts and re-assembled in slot order"""
     D = 32
     rng = np.random.default_rng(77)
     dims = [12, 50]
     ids, vals, facs, Lam, mu = _problem(rng, dims, 2500, D, empty_rows=True)
     c2 = B.Context(seed=SEED)
     c2.set_item_size(item)
+    if piece is not None:
+        c2.set_piece_size(piece)
     dr = B.DeviceRelation(c2, B.IndexedDF((ids, vals), dims))
     ft = [c2.tensor(f) for f in facs]
     terms = _dev_terms(B, c2, [(dr, 0, 1.3, 0.2, [None, ft[1]], None)])

@@ -35,7 +35,9 @@ __global__ void gate(unsigned* flag, unsigned value, long max_ticks, unsigned* e
     }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const unsigned evflags = hipEventDisableTiming | (argc > 1 ? hipEventReleaseToDevice : 0u);
+    printf("event flags 0x%x\n", evflags);
     hipStream_t m, s;
     CK(hipStreamCreateWithFlags(&m, hipStreamNonBlocking));
     CK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
@@ -47,7 +49,7 @@ int main() {
     const int NB = 1024, NT = 256;      // fills the chip like K1 does (spinning waves)
     const int N = 300;
     std::vector<hipEvent_t> evM(N + 1), evS(N + 1);
-    for (int i = 0; i <= N; i++) { CK(hipEventCreateWithFlags(&evM[i], hipEventDisableTiming)); CK(hipEventCreateWithFlags(&evS[i], hipEventDisableTiming)); }
+    for (int i = 0; i <= N; i++) { CK(hipEventCreateWithFlags(&evM[i], evflags)); CK(hipEventCreateWithFlags(&evS[i], evflags)); }
     unsigned base = 0;
     for (int mode = 0; mode < 8; mode++) {
         const char* names[] = {"main only", "main + independent side", "hipEventRecord both ways", "stopEvent on the kernels (hipExtLaunchKernelGGL)",
