@@ -729,6 +729,19 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
         for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i * stride) % total);
         if (mode == 2)
             for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i & 1) ? total - 1 - i / 2 : i / 2);
+        if (mode == 3 || mode == 4) {
+            // the pieces of split rows first (their rows end the launch: all pieces, then the finisher), then the whole rows
+            // in stride order (3) or by falling length (4)
+            const int64_t nS = (int64_t)split.size(), nD = (int64_t)direct.size();
+            for (int64_t i = 0; i < nS; i++) order[(size_t)i] = (int32_t)i;
+            int64_t st = 1;
+            if (mode == 3 && nD > 2) {
+                st = (int64_t)(0.6180339887 * (double)nD) | 1;
+                auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+                while (gcd(st, nD) != 1) st += 2;
+            }
+            for (int64_t i = 0; i < nD; i++) order[(size_t)(nS + i)] = (int32_t)(nS + (i * st) % nD);
+        }
     }
     int rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||

@@ -29,20 +29,32 @@ def shard_rows(order, world):
     return [np.ascontiguousarray(order[p::world]) for p in range(world)]
 
 
-def allgather_rows(sample, lists, rank, world):
-    """all-gather of the rows each rank sampled into every rank's replica of the factor (N x D tensor); shards are padded to
-    equal length for all_gather_into_tensor.  torch.distributed: RCCL over xGMI on the GPUs, gloo in the CPU tests."""
-    import torch.distributed as dist
+def allgather_plan(lists, rank, world):
+    """index tensors of allgather_rows for one entity (built once): the send selection padded to the longest shard, and
+    where every received row goes"""
     counts = [len(l) for l in lists]
     nmax = max(counts)
-    D = sample.shape[1]
-    send = torch.zeros(nmax, D, dtype=sample.dtype, device=sample.device)
-    send[:counts[rank]] = sample.index_select(0, lists[rank])
-    recv = torch.empty(world * nmax, D, dtype=sample.dtype, device=sample.device)
+    dev = lists[rank].device
+    own = lists[rank]
+    pad = own[:1].expand(nmax - counts[rank]) if counts[rank] else torch.zeros(nmax, dtype=torch.int64, device=dev)
+    send_sel = torch.cat([own, pad]) if nmax > counts[rank] else own        # padding rows repeat a row; never copied back
+    recv_sel = torch.cat([torch.arange(p * nmax, p * nmax + counts[p], dtype=torch.int64, device=dev)
+                          for p in range(world) if p != rank] or [torch.zeros(0, dtype=torch.int64, device=dev)])
+    dst = torch.cat([lists[p] for p in range(world) if p != rank] or [torch.zeros(0, dtype=torch.int64, device=dev)])
+    return send_sel, recv_sel, dst, nmax
+
+
+def allgather_rows(sample, lists, rank, world, plan=None):
+    """all-gather of the rows each rank sampled into every rank's replica of the factor (N x D tensor): one gather of the
+    own rows into a shard padded to the longest shard, one all_gather_into_tensor, one scatter of the other ranks' rows.
+    torch.distributed: RCCL over xGMI on the GPUs, gloo in the CPU tests."""
+    import torch.distributed as dist
+    send_sel, recv_sel, dst, nmax = plan if plan is not None else allgather_plan(lists, rank, world)
+    send = sample.index_select(0, send_sel)
+    recv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype, device=sample.device)
     dist.all_gather_into_tensor(recv, send)
-    for p in range(world):
-        if p != rank:
-            sample.index_copy_(0, lists[p], recv[p * nmax:p * nmax + counts[p]])
+    if dst.numel():
+        sample.index_copy_(0, dst, recv.index_select(0, recv_sel))
 
 
 class KernelTimer:
@@ -383,6 +395,7 @@ class GibbsEngine:
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
         self._rowlists = {}
+        self._ag_plans = {}
         # ---- reset! (RelationData.jl:331-355)
         self.ent = []
         for j, en in enumerate(data.entities):
@@ -533,7 +546,11 @@ class GibbsEngine:
 
     def _allgather(self, j):
         """RCCL all-gather of the rows each rank sampled (C1)"""
-        allgather_rows(self.ent[j].sample, self._rowlist(j), self.rank, self.world)
+        lists = self._rowlist(j)
+        if j not in self._ag_plans:
+            self._ag_plans[j] = allgather_plan(lists, self.rank, self.world)
+        with torch.cuda.stream(self.ctx.stream):
+            allgather_rows(self.ent[j].sample, lists, self.rank, self.world, self._ag_plans[j])
 
     # ---- macau.jl:119-134: hyperprior of entity j ----------------------------------------------------------------
     def _hyper_nu(self, j):

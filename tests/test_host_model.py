@@ -209,6 +209,15 @@ sample[mine] = mine[:, None].double() + 0.5 * torch.arange(D, dtype=torch.float6
 allgather_rows(sample, [torch.as_tensor(l.astype(np.int64)) for l in lists], rank, world)
 expect = torch.arange(N, dtype=torch.float64)[:, None] + 0.5 * torch.arange(D, dtype=torch.float64)[None, :]
 assert torch.equal(sample, expect), (rank, sample)
+# the cached plan the engine reuses every half-sweep (the ranks' shards differ in length: 19 and 18 rows)
+from bdf_amd.engine import allgather_plan
+tl = [torch.as_tensor(l.astype(np.int64)) for l in lists]
+plan = allgather_plan(tl, rank, world)
+for rep in range(2):
+    sample.fill_(-1.0)
+    sample[mine] = (rep + 1) * expect[mine]
+    allgather_rows(sample, tl, rank, world, plan)
+    assert torch.equal(sample, (rep + 1) * expect), (rank, rep)
 # nnz balance of the strided deal
 load = [int(counts[l].sum()) for l in lists]
 assert max(load) - min(load) <= counts.max()
