@@ -53,17 +53,43 @@ def synthetic_movielens_like(seed=0, n_users=6040, n_movies=3952, nnz=1000209):
     return {"X": sp.csc_matrix((vals, (rows, cols)), shape=(n_users, n_movies)), "Fu": None, "Fv": None}
 
 
-def movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, with_features=False, path=MOVIELENS_PATH):
+def replicate_users(X, test_ids, replicas):
+    """The weak-scaling workload of bench.py --gpus N: the rating matrix stacked `replicas` times along the users (disjoint
+    user blocks rating the same movies) and the held-out entries of every block.  X: CSC; test_ids: 1-based entry numbers
+    in X's column-major order.  Entry k of X (column c, position p of the n_c entries of c) is entry
+    replicas*colptr[c] + r*n_c + p of the stacked matrix for block r."""
+    import scipy.sparse as sp
+    X = X.tocsc()
+    big = sp.vstack([X] * replicas).tocsc()
+    colptr = X.indptr.astype(np.int64)
+    k = np.asarray(test_ids, dtype=np.int64) - 1
+    c = np.searchsorted(colptr, k, side="right") - 1
+    n_c, p = colptr[c + 1] - colptr[c], k - colptr[c]
+    ids = np.concatenate([replicas * colptr[c] + r * n_c + p for r in range(replicas)])
+    return big, np.sort(ids) + 1
+
+
+def movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, with_features=False, path=MOVIELENS_PATH,
+                            replicas=1):
     """The docs' MovieLens set-up (docs/index.md:42-56): entities users/movies, relation ratings, held-out test set,
-    precision alpha.  Returns (RelationData, source) with source 'movielens_1m.mat' or 'synthetic'."""
+    precision alpha.  Returns (RelationData, source) with source 'movielens_1m.mat' or 'synthetic'.  replicas > 1: the
+    users (ratings, held-out entries, features) repeated in that many disjoint blocks (replicate_users)."""
     if os.path.exists(path):
         d, source = load_movielens(path), "movielens_1m.mat"
     else:
         d, source = synthetic_movielens_like(), "synthetic"
-    users = B.Entity("users", F=d["Fu"] if with_features else None)
+    X, test_ids = d["X"], (split_test_ids(d["X"].nnz, ntest, seed) if ntest else None)
+    Fu = d["Fu"]
+    if replicas > 1:
+        import scipy.sparse as sp
+        X, test_ids = replicate_users(X, test_ids if ntest else np.zeros(0, dtype=np.int64), replicas)
+        Fu = sp.vstack([Fu] * replicas).tocsr() if Fu is not None else None
+        source += f" x{replicas} user blocks"
+    users = B.Entity("users", F=Fu if with_features else None)
     movies = B.Entity("movies", F=d["Fv"] if with_features else None)
-    ratings = B.Relation(d["X"], "ratings", [users, movies], class_cut=class_cut)
+    ratings = B.Relation(X, "ratings", [users, movies], class_cut=class_cut)
     if ntest:
-        B.assignToTest(ratings, split_test_ids(B.numData(ratings), ntest, seed))
+        assert B.numData(ratings) == X.nnz
+        B.assignToTest(ratings, test_ids)
     B.setPrecision(ratings, alpha)
     return B.RelationData(ratings), source

@@ -9,9 +9,13 @@ movies, hyperprior of movies, and the test-set prediction update of macau.jl:142
 reporting-only metrics are not).  W warm-up steps are the burn-in; the K timed steps are the posterior samples, so the
 RMSE printed is that of the posterior-mean prediction after W + K iterations on the 500,000 held-out ratings.
 
-N > 1: the same fixed workload, rows of each entity sharded over the ranks, RCCL all-gather of the freshly sampled factor
-after each half-sweep ("strong" scaling).  MovieLens is a ~100 us sweep, far too small to scale; the sharded path is here
-for correctness and for the synthetic 10M x 1M configuration (--workload c4).
+N > 1 (weak scaling): MovieLens is a ~130 us sweep, far too small to split, so the N-GPU workload is N MovieLens-sized
+units -- the rating matrix stacked over N disjoint user blocks that rate the same movies (N x 6040 users, N x 500,209
+training ratings, N x 500,000 held-out ratings; datasets.replicate_users).  One process per GPU; every rank holds the
+whole relation and a replica of both factors, samples its share of the rows of each entity (rank, rank + N, ... of the
+degree order), and the ranks exchange the freshly sampled rows by an RCCL all-gather after each half-sweep; the test
+ratings of user block r are predicted by rank r.  value = N units x sweeps/s, so that N = 1 is exactly the BASELINE
+configuration and ideal scaling is N x its value.  (--replicas R runs the R-unit workload on fewer GPUs.)
 
 Prints one JSON line (rank 0).  roofline: K1 (k_sample_rows) algorithmic bytes per launch over its mean
 launch duration from HIP events attached to the kernel dispatches (on the launch stream) inside the timed region.  cpu_baseline: the CPU oracle
@@ -77,6 +81,7 @@ def main():
     ap.add_argument("--k1-event-every", type=int, default=8,
                     help="time the K1 launches of every n-th step (HIP events attached to the kernel dispatch)")
     ap.add_argument("--no-predict", action="store_true", help="leave the test-set prediction update out of the step")
+    ap.add_argument("--replicas", type=int, default=0, help="user blocks of the workload (default: one per GPU)")
     args = ap.parse_args()
 
     import numpy as np
@@ -99,10 +104,21 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
     D = args.num_latent
-    rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
+    replicas = args.replicas if args.replicas > 0 else world
+    rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, replicas=replicas)
     rel = rd.relations[0]
     eng = B.GibbsEngine(rd, D, seed=args.seed, device=local_rank, shard=(rank, world))
-    test = eng.test_pairs()
+    if world > 1:
+        # rank r predicts the held-out ratings of the user blocks r, r + world, ...
+        from bdf_amd.engine import DevicePairs
+        tv = rel.test_vec
+        tids = np.asarray(tv.ids).reshape(-1, 2)
+        block = (tids[:, 0] - 1) // (rel.data.dims[0] // replicas)
+        mine = np.nonzero(block % world == rank)[0]
+        test = DevicePairs(eng.ctx_p, tids[mine], np.asarray(tv.values)[mine])
+    else:
+        test = eng.test_pairs()
+    n_test_total = len(np.asarray(rel.test_vec.values))
     clamp = [1.0, 5.0]
 
     def step(i, phase):
@@ -143,33 +159,40 @@ def main():
     # WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), if recorded
     traffic = None
     tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tj) and world == 1:
+    if os.path.exists(tj) and world == 1 and replicas == 1:
         try:
             traffic = json.load(open(tj))["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"]
         except (KeyError, ValueError):
             traffic = None
 
-    stats = test.stats.cpu().numpy() if not args.no_predict else None
-    rmse = float(np.sqrt(stats[0] / len(rel.test_vec))) if stats is not None else None
+    rmse = None
+    if not args.no_predict:
+        sse = test.stats[:1].clone()
+        if dist is not None:
+            dist.all_reduce(sse)                       # every rank holds the squared error of its share of the test ratings
+        rmse = float(np.sqrt(float(sse.item()) / n_test_total))
 
     if rank == 0:
         out = {
             "metric": "Gibbs sweeps/sec (both entities) + test RMSE, MovieLens-1M D=32",
-            "value": round(args.steps / elapsed, 3),
+            "value": round(replicas * args.steps / elapsed, 3),
             "unit": "sweeps/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(1e3 * elapsed / args.steps, 4),
             "higher_is_better": True,
-            "scaling": "strong",
+            "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": source,
             "config": {"workload": f"BPMF MovieLens-1M 6040x3952, 500209 training ratings (500000 held out), D={D}, alpha=1.5, "
-                                   f"step = rows of both entities + hyperpriors{'' if args.no_predict else ' + test prediction update'}",
-                       "num_latent": D, "burnin": args.warmup, "psamples": args.steps,
-                       "parallelism": f"rows sharded over {world} GPU(s), all-gather per half-sweep" if world > 1 else "1 GPU"},
+                                   f"step = rows of both entities + hyperpriors{'' if args.no_predict else ' + test prediction update'}"
+                                   + (f"; {replicas} such units: the ratings stacked over {replicas} disjoint user blocks, "
+                                      f"value = {replicas} x sweeps/s" if replicas > 1 else ""),
+                       "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
+                       "parallelism": (f"rows of each entity dealt over {world} GPUs, RCCL all-gather of the sampled rows per "
+                                       f"half-sweep, test ratings split by user block") if world > 1 else "1 GPU"},
             "test_rmse": None if rmse is None else round(rmse, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,

@@ -281,3 +281,28 @@ def test_data_reading_formats(tmp_path):
     B.write_matrix_market(m, np.array([[1, 2, 0.5], [3, 1, -2.0]]))
     A = B.read_matrix_market(m)
     assert A.shape == (3, 2) and A[0, 1] == 0.5 and A[2, 0] == -2.0
+
+
+def test_replicated_users_workload():
+    """bench.py --gpus N (weak scaling): the rating matrix stacked over N disjoint user blocks; every block holds out the
+    same entries and keeps the same training ratings"""
+    import scipy.sparse as sp
+    import bdf_amd as B
+    from bdf_amd import datasets
+    rng = np.random.default_rng(0)
+    X = sp.random(30, 12, density=0.3, random_state=1, format="csc")
+    X.data[:] = rng.integers(1, 6, X.nnz)
+    tid = datasets.split_test_ids(X.nnz, 20, 1)
+    base = B.Relation(X, "r", [B.Entity("u"), B.Entity("m")], class_cut=2.5)
+    B.assignToTest(base, tid)
+    big, ids = datasets.replicate_users(X, tid, 3)
+    rel = B.Relation(big, "r", [B.Entity("u"), B.Entity("m")], class_cut=2.5)
+    B.assignToTest(rel, ids)
+    assert B.numTest(rel) == 3 * B.numTest(base) and B.numData(rel) == 3 * B.numData(base)
+
+    def cells(vec):
+        t = np.asarray(vec.ids).reshape(-1, 2)
+        return sorted(zip(t[:, 0].tolist(), t[:, 1].tolist(), np.asarray(vec.values).tolist()))
+    bt, btr = cells(base.test_vec), cells(base.data)
+    assert cells(rel.test_vec) == sorted((u + 30 * k, m, v) for (u, m, v) in bt for k in range(3))
+    assert cells(rel.data) == sorted((u + 30 * k, m, v) for (u, m, v) in btr for k in range(3))
