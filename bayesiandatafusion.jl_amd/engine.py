@@ -51,8 +51,14 @@ def allgather_rows(sample, lists, rank, world, plan=None):
     import torch.distributed as dist
     send_sel, recv_sel, dst, nmax = plan if plan is not None else allgather_plan(lists, rank, world)
     send = sample.index_select(0, send_sel)
-    recv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype, device=sample.device)
-    dist.all_gather_into_tensor(recv, send)
+    if sample.is_cuda and dist.get_backend() == "gloo":
+        # test rig only (several ranks sharing one GPU, where RCCL refuses to run): the collective staged through the host
+        hrecv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype)
+        dist.all_gather_into_tensor(hrecv, send.cpu())
+        recv = hrecv.to(sample.device)
+    else:
+        recv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype, device=sample.device)
+        dist.all_gather_into_tensor(recv, send)
     if dst.numel():
         sample.index_copy_(0, dst, recv.index_select(0, recv_sel))
 

@@ -96,12 +96,21 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    # test rig: BDF_DIST_BACKEND=gloo runs all ranks on GPU 0 with the collectives staged through the host (RCCL needs one
+    # GPU per rank); it checks the N > 1 logic on a 1-GPU box, its timings mean nothing
+    backend = os.environ.get("BDF_DIST_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    red_dev = "cpu" if backend == "gloo" else "cuda"
 
     D = args.num_latent
     replicas = args.replicas if args.replicas > 0 else world
@@ -127,9 +136,10 @@ def main():
             test.update(D, eng.factors_of(rel), rel.model.mean_value, phase, clamp, rel.class_cut)
 
     def fence():
+        torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
 
     for i in range(1, args.warmup + 1):
         step(i, 0)
@@ -144,7 +154,7 @@ def main():
     elapsed = time.perf_counter() - t0
     eng.sync()
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -167,7 +177,7 @@ def main():
 
     rmse = None
     if not args.no_predict:
-        sse = test.stats[:1].clone()
+        sse = test.stats[:1].clone().to(red_dev if dist is not None else "cuda")
         if dist is not None:
             dist.all_reduce(sse)                       # every rank holds the squared error of its share of the test ratings
         rmse = float(np.sqrt(float(sse.item()) / n_test_total))

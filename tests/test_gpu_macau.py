@@ -371,3 +371,26 @@ def test_movielens_d32_full_size_properties(B):
         cov = np.linalg.inv(P[row])
         np.testing.assert_allclose(a[row], np.linalg.cholesky(cov) @ z[row] + cov @ bb[row], rtol=1e-8, atol=1e-9)
     eng.close()
+
+
+def test_two_ranks_match_one(B):
+    """bench.py's N > 1 path (rows dealt over the ranks, all-gather of the sampled rows, test ratings split by user block,
+    RMSE all-reduced) gives the chain of the single-process run of the same 2-unit workload.  Two ranks on the one GPU of the
+    box: RCCL needs a GPU per rank, so the collectives are staged through the host by gloo (BDF_DIST_BACKEND=gloo)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, BDF_DIST_BACKEND="gloo")
+    port = str(29600 + os.getpid() % 300)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6"],
+                         env=env, capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["n_gpus"] == 2 and d2["config"]["units_per_sweep"] == 2 and d2["scaling"] == "weak"
+    assert abs(d2["test_rmse"] - d1["test_rmse"]) < 2e-5, (d2["test_rmse"], d1["test_rmse"])
