@@ -322,7 +322,8 @@ class EntityState:
     def __init__(self, ctx, en, D, tag):
         self.ctx, self.D, self.N, self.tag = ctx, D, en.count, tag
         self.sample = ctx.zeros(en.count, D)
-        self.sample_alt = ctx.zeros(en.count, D)     # the rows of the next sweep are written here, then the two swap
+        self.sample_alt = ctx.zeros(en.count, D)     # the rows of the next sweep are written here, then the three rotate:
+        self.sample_alt2 = ctx.zeros(en.count, D)    # a launch overwrites the rows of three sweeps ago
         self.mu = ctx.zeros(D)
         self.Lambda = (5.0 * torch.eye(D, dtype=torch.float64)).to(ctx.device)
         self.mu0 = ctx.zeros(D)
@@ -540,11 +541,12 @@ class GibbsEngine:
             timer = KernelTimer()
             check(lib().bdf_ctx_time_next_rows(self.ctx.handle, timer.start, timer.stop))
         pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
-        # written into the entity's other buffer (nothing this launch reads), which then becomes the current one: readers
-        # of the previous sweep's rows on other streams (prediction updates) are never overwritten under their feet
+        # written into another buffer of the entity (nothing this launch reads), which then becomes the current one; the
+        # buffers rotate in threes, so readers of the previous two sweeps' rows on other streams (prediction updates) are
+        # never overwritten under their feet
         check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
                                     st.tag, self.rank, self.world, _ptr(st.sample_alt), _ptr(pack) if pack is not None else None))
-        st.sample, st.sample_alt = st.sample_alt, st.sample
+        st.sample, st.sample_alt, st.sample_alt2 = st.sample_alt, st.sample_alt2, st.sample
         if timed:
             self.k1_events.append((j, timer))
         if self.world > 1:
@@ -613,10 +615,13 @@ class GibbsEngine:
             self.ctx_h.set_sweep(i)
         three = self.ctx_p is not self.ctx
         if three:
-            # this sweep overwrites the buffers that held the rows of sweep i-2: the prediction updates that read them
-            # were all enqueued before the previous sweep began (a wait on a finished event is nearly free)
+            # The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep i-2.  The prediction
+            # updates that read those were all enqueued before the previous sweep began: the event recorded then has long
+            # completed.  Even a satisfied wait costs a stream ~6 us (tools/chain_timeline.py), so it is the side stream
+            # that waits, here where it idles until this sweep's first row kernel ends -- every row kernel of the next
+            # sweep waits for a hyperprior event recorded on the side stream after this point.
             if self._ev_pred is not None:
-                main.wait_event(self._ev_pred)
+                side.wait_event(self._ev_pred)
             self._ev_pred = torch.cuda.Event()
             self._ev_pred.record(self.ctx_p.stream)
         self.update_relations()
