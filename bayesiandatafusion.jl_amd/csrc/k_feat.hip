@@ -524,9 +524,10 @@ __device__ inline double block_sum(double v, double *red)
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_cg_init(CgState s, const double *rhs, double tol)
+// The CG kernels take one workgroup per column (no grid-wide reduction); long columns get 1024 threads (CG_THREADS_LONG)
+__global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, double tol)
 {
-    __shared__ double red[4];
+    __shared__ double red[16];
     const int d = blockIdx.x;
     const int64_t off = (int64_t)d * s.n;
     double nb = 0.0;
@@ -566,9 +567,9 @@ __device__ inline void cg_pre(const CgState &s, int iter, double *red, int &go)
     if (threadIdx.x == 0) { s.bkden[d] = bknum; s.bknum[d] = bknum; s.iters[d] = iter; }
 }
 
-__global__ __launch_bounds__(256) void k_cg_pre(CgState s, int iter)
+__global__ __launch_bounds__(1024) void k_cg_pre(CgState s, int iter)
 {
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ int go;
     cg_pre(s, iter, red, go);
 }
@@ -596,9 +597,9 @@ __device__ inline void cg_post(const CgState &s, const double *lambda_p, int ite
 }
 
 // bottom of iteration `iter` and top of iteration `iter + 1` in one launch (a column is one workgroup in both)
-__global__ __launch_bounds__(256) void k_cg_step(CgState s, const double *lambda_p, int iter, int maxiter)
+__global__ __launch_bounds__(1024) void k_cg_step(CgState s, const double *lambda_p, int iter, int maxiter)
 {
-    __shared__ double red[4];
+    __shared__ double red[16];
     __shared__ int go;
     cg_post(s, lambda_p, iter, red);
     __threadfence_block();
@@ -866,9 +867,10 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     s.n = numF; s.D = D; s.X = beta_out; s.R = R; s.P = P; s.Z = Z;
     s.bknum = scal; s.bkden = scal + D; s.tolb = scal + 2 * D;
     s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
-    hipLaunchKernelGGL(k_cg_init, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)rhs, tol);
+    const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
+    hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol);
     BDF_HIP(hipGetLastError());
-    hipLaunchKernelGGL(k_cg_pre, dim3(D), dim3(256), 0, ctx->stream, s, 1);
+    hipLaunchKernelGGL(k_cg_pre, dim3(D), cgb, 0, ctx->stream, s, 1);
     for (int iter = 1; iter <= maxiter; iter++) {
         if (use_ff && D <= 64) {
             if ((rc = dense_nn(ctx, f->FF_dev, numF, numF, P, 1, numF, D, Z, 1, numF, nullptr, nullptr))) return rc;
@@ -882,7 +884,7 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
             if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
         }
         // bottom of this iteration and top of the next in one launch
-        hipLaunchKernelGGL(k_cg_step, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         BDF_HIP(hipGetLastError());
         if (iter % 8 == 0 || iter == maxiter) {
             int nact = 0;
