@@ -646,6 +646,8 @@ int to_device(const std::vector<T> &v, T **out)
     return BDF_OK;
 }
 
+constexpr int64_t MAX_PIECES = 64;
+
 int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, const std::vector<int32_t> &rows, int psz,
                Plan &plan)
 {
@@ -658,8 +660,10 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
         for (int r = 0; r < key.n_terms; r++) {
             const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
             const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
-            n_items += (int)((n + T - 1) / T);
+            n_items += (int)std::min<int64_t>((n + T - 1) / T, MAX_PIECES);
         }
+        // (at most MAX_PIECES per relation: the row's finisher adds the partial sums one slot after the other, ~0.5 us each
+        // -- a 78,000-observation row of config C5 in 128-observation pieces would keep it busy for 0.3 ms)
         // a row that is split anyway is cut into smaller pieces than the longest whole row: the launch ends with the split
         // rows (their pieces gather at a sixth of the matrix pipe each, then one wave sums and finishes the row)
         const int Tp = n_items > 1 ? key.Tp : T;
@@ -668,7 +672,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
                 const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
-                n_items += (int)((n + Tp - 1) / Tp);
+                n_items += (int)std::min<int64_t>((n + Tp - 1) / Tp, MAX_PIECES);
             }
         }
         if (n_items <= 1 && !decoupled) {
@@ -690,7 +694,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             for (int r = 0; r < key.n_terms; r++) {
                 const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
                 const int64_t beg = rp[(size_t)row], n = rp[(size_t)row + 1] - beg;
-                const int pieces = (int)((n + Tp - 1) / Tp);
+                const int pieces = (int)std::min<int64_t>((n + Tp - 1) / Tp, MAX_PIECES);
                 for (int s = 0; s < pieces; s++) {
                     // equal pieces rather than T, T, ..., remainder
                     const int64_t b0 = beg + n * s / pieces, b1 = beg + n * (s + 1) / pieces;

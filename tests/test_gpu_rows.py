@@ -204,6 +204,27 @@ def test_item_size_does_not_change_results(B, O, ctx, item, piece):
     c2.close()
 
 
+def test_piece_cap(B, O, ctx):
+    """a row with more than 64 pieces' worth of observations is cut into 64 (longer) pieces: two rows of ~1250 observations at
+    item size 8 would be 157 pieces each"""
+    D = 16
+    rng = np.random.default_rng(78)
+    dims = [2, 3000]
+    ids, vals, facs, Lam, mu = _problem(rng, dims, 2500, D, empty_rows=False)
+    c2 = B.Context(seed=SEED)
+    c2.set_item_size(8)
+    dr = B.DeviceRelation(c2, B.IndexedDF((ids, vals), dims))
+    ft = [c2.tensor(f) for f in facs]
+    terms = _dev_terms(B, c2, [(dr, 0, 0.7, -0.1, [None, ft[1]], None)])
+    c2.set_sweep(2)
+    out_t = c2.zeros(2, D)
+    _run_rows(B, c2, D, 2, terms, c2.tensor(mu), c2.tensor(Lam), 3, out_t)
+    exp = O.sample_rows(D, 2, [O.Term(ids, vals, dims, 0, 0.7, -0.1, [None, facs[1]])], mu, Lam, SEED, 2, 3)
+    np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    dr.close()
+    c2.close()
+
+
 def test_row_moments(B, O, ctx):
     """sampled moments of one row over many sweeps: mean within 5 sigma/sqrt(n), covariance within 5% (Frobenius)"""
     D = 6
