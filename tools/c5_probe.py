@@ -38,10 +38,11 @@ B.addRelation(rd, r1)
 B.addRelation(rd, r2)
 assert len(A.relations) == 2
 t0 = time.time()
-res = None if os.environ.get('C5_SWEEPS_ONLY') else B.macau(rd, burnin=10, psamples=10, num_latent=32, verbose=False, compute_ff_size=0, seed=3)
+nb = int(os.environ.get("C5_BURNIN", "10"))
+res = None if os.environ.get("C5_SWEEPS_ONLY") else B.macau(rd, burnin=nb, psamples=nb, num_latent=32, verbose=False, compute_ff_size=0, seed=3)
 wall = time.time() - t0
 if res is not None:
-  print(f"C5 on one GPU: 20 sweeps + set-up in {wall:.1f} s; held-out RMSE of relation abc {res['RMSE']:.4f} (noise 0.1, "
+  print(f"C5 on one GPU: {2 * nb} sweeps + set-up in {wall:.1f} s; held-out RMSE of relation abc {res['RMSE']:.4f} (noise 0.1, "
       f"value std {v1.std():.3f}); lambda_beta {A.lambda_beta:.2f}")
 from bdf_amd.engine import GibbsEngine
 eng = GibbsEngine(rd, 32, seed=3, compute_ff_size=0)
