@@ -511,7 +511,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
     a.sweep = ctx->sweep_host;
     a.seed = ctx->seed;
     a.flag = ctx->flag_dev;
-    a.done = ctx->rows_done_dev;
+    a.done = getenv("BDF_EXP_NO_DONE") ? nullptr : ctx->rows_done_dev;
     return BDF_OK;
 }
 

@@ -63,7 +63,7 @@ struct Geo {
 // ---- DPP row-broadcast fma: d += (s of lane KJ of this lane's row of 16) * m.  Inline asm is opaque to the compiler's
 // hazard recogniser (a VALU write of a DPP source needs 2 wait states before the DPP read), hence the leading s_nop. ----
 template <int KJ>
-__device__ inline void fm4(double &d0, double &d1, double &d2, double &d3, double s0, double s1, double s2, double s3,
+__device__ __forceinline__ void fm4(double &d0, double &d1, double &d2, double &d3, double s0, double s1, double s2, double s3,
                            double m)
 {
     asm volatile("s_nop 1\n\t"
@@ -75,7 +75,7 @@ __device__ inline void fm4(double &d0, double &d1, double &d2, double &d3, doubl
                  : "v"(s0), "v"(s1), "v"(s2), "v"(s3), "v"(m), "n"(KJ));
 }
 template <int KJ>
-__device__ inline void fm4_self(double &d0, double &d1, double &d2, double &d3, double m)
+__device__ __forceinline__ void fm4_self(double &d0, double &d1, double &d2, double &d3, double m)
 {
     asm volatile("s_nop 1\n\t"
                  "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
@@ -86,14 +86,14 @@ __device__ inline void fm4_self(double &d0, double &d1, double &d2, double &d3, 
                  : "v"(m), "n"(KJ));
 }
 template <int KJ>
-__device__ inline void fm1(double &d, double s, double m)
+__device__ __forceinline__ void fm1(double &d, double s, double m)
 {
     asm volatile("s_nop 1\n\t"
                  "v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
                  : "+v"(d) : "v"(s), "v"(m), "n"(KJ));
 }
 template <int KJ>
-__device__ inline void fm1_self(double &d, double m)
+__device__ __forceinline__ void fm1_self(double &d, double m)
 {
     asm volatile("s_nop 1\n\t"
                  "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
@@ -139,7 +139,7 @@ BDF_OWNER_STORE(2, "ds_write2_b64 %1, %4, %5 offset0:%7 offset1:%7+1\n\t", , )
 BDF_OWNER_STORE(1, "ds_write_b64 %1, %5 offset:(%7)*8\n\t", , )
 #undef BDF_OWNER_STORE
 template <int MASK>
-__device__ inline void owner_keep(double &dst, double src)
+__device__ __forceinline__ void owner_keep(double &dst, double src)
 {
     unsigned long long save;
     asm volatile("s_mov_b64 %1, exec\n\t"
@@ -151,7 +151,7 @@ __device__ inline void owner_keep(double &dst, double src)
 }
 
 template <int DP, int k, int... Is>
-__device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
+__device__ __forceinline__ void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsigned addr, std::integer_sequence<int, Is...>)
 {
     using GG = Geo<DP>;
     constexpr int K = k / 16, MASK = 0x00010001 << (k % 16), q = GG::col_first(k) / 4;
@@ -164,7 +164,7 @@ __device__ inline void owner_store_all(const double (&A)[Geo<DP>::NB * 4], unsig
 }
 
 template <int DP, int k, bool HAVE_RD = false>
-__device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+__device__ __forceinline__ void prep(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
                             double *tri, const FactorLanes &fl, double (&nm)[Geo<DP>::DB], double rd_ahead = 0.0)
 {
     using GG = Geo<DP>;
@@ -187,7 +187,7 @@ __device__ inline void prep(const double (&A)[Geo<DP>::NB * 4], const double (&b
 // broadcast, and the update of block column K rewrites it.  No masking of finished columns (<= k) in block column K:
 // their registers are dead (a column is read for the last time at its own step).
 template <int DP, int k>
-__device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+__device__ __forceinline__ void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
                                    double *tri, const FactorLanes &fl, int j, double (&nm)[Geo<DP>::DB])
 {
     using GG = Geo<DP>;
@@ -226,7 +226,7 @@ __device__ inline void factor_step(double (&A)[Geo<DP>::NB * 4], double (&bv)[Ge
 }
 
 template <int DP, int... Ks>
-__device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+__device__ __forceinline__ void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
                                   double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
 {
     using GG = Geo<DP>;
@@ -246,14 +246,14 @@ __device__ inline void factor_all(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo
 
 // ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----
 template <int DP, int i>
-__device__ inline void backward_step(double &yh, double rdv, const double *const (&colq)[4], int lane)
+__device__ __forceinline__ void backward_step(double &yh, double rdv, const double *const (&colq)[4], int lane)
 {
     const double xi = readlane_f64(yh * rdv, i);
     if (lane < i) yh = fma(-colq[i & 3][i >> 2], xi, yh);
 }
 
 template <int DP, int... Is>
-__device__ inline void backward_all(double &yh, double rdv, const double *const (&colq)[4], int lane, int D,
+__device__ __forceinline__ void backward_all(double &yh, double rdv, const double *const (&colq)[4], int lane, int D,
                                     std::integer_sequence<int, Is...>)
 {
     (((DP - 1 - Is) < D ? backward_step<DP, DP - 1 - Is>(yh, rdv, colq, lane) : (void)0), ...);

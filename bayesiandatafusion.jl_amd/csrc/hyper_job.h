@@ -40,7 +40,7 @@ struct NWArgs {
 // block-triangle accumulates in the MFMA C layout.  The waves take every NW-th 4-row step, all of a wave's loads are
 // issued before its first MFMA, and the waves' results are added in wave order.
 template <int DP, int NW>
-__device__ inline void hyper_partial(int D, int64_t N, const double *__restrict__ sample, const double *__restrict__ uhat,
+__device__ __forceinline__ void hyper_partial(int D, int64_t N, const double *__restrict__ sample, const double *__restrict__ uhat,
                                      int64_t r0, int64_t r1, double *__restrict__ p, double *red, int tid)
 {
     constexpr int DB = HGeo<DP>::DB, NB = HGeo<DP>::NB, PSZ = HGeo<DP>::PSZ;
@@ -120,7 +120,7 @@ __device__ inline void hyper_partial(int D, int64_t N, const double *__restrict_
 
 // element e of the summed partials, in the order k_hyper_final adds them: chain q takes blocks q, q+16, ..., then the
 // butterfly (8, 4, 2, 1) as lane 0 of 16 sees it
-__device__ inline double hyper_sum_element(const double *partial, int psz, int nblocks, int e)
+__device__ __forceinline__ double hyper_sum_element(const double *partial, int psz, int nblocks, int e)
 {
     double c[16];
 #pragma unroll
@@ -139,7 +139,7 @@ __device__ inline double hyper_sum_element(const double *partial, int psz, int n
 
 // scatter of a summed C-layout element to U U' (and its mirror image) / the column sums
 template <int DP>
-__device__ inline void hyper_scatter(int D, int e, double s, double *sumU, double *UUt)
+__device__ __forceinline__ void hyper_scatter(int D, int e, double s, double *sumU, double *UUt)
 {
     constexpr int NB = HGeo<DP>::NB;
     if (e < NB * 4 * 64) {
@@ -173,7 +173,7 @@ __device__ inline void hyper_scatter(int D, int e, double s, double *sumU, doubl
 #endif
 
 template <int DP>
-__device__ inline void nw_draw(const NWArgs &a, double *lds, int tid, int nthreads)
+__device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, int nthreads)
 {
     using GG = Geo<DP>;
     constexpr int LD = HGeo<DP>::LD, DB = GG::DB, NB = GG::NB;

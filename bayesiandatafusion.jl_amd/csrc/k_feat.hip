@@ -512,7 +512,7 @@ struct CgState {
     int *active, *iters, *nactive;
 };
 
-__device__ inline double block_sum(double v, double *red)
+__device__ __forceinline__ double block_sum(double v, double *red)
 {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
@@ -545,7 +545,7 @@ __global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, 
 }
 
 // top of iteration `iter` (1-based): residual check, direction update (parallel_cg.jl:74-83)
-__device__ inline void cg_pre(const CgState &s, int iter, double *red, int &go)
+__device__ __forceinline__ void cg_pre(const CgState &s, int iter, double *red, int &go)
 {
     const int d = blockIdx.x;
     if (!s.active[d]) return;
@@ -575,7 +575,7 @@ __global__ __launch_bounds__(1024) void k_cg_pre(CgState s, int iter)
 }
 
 // bottom of the iteration: z = Z + lambda p; ak = bknum / (z.p); x += ak p; r -= ak z (parallel_cg.jl:85-91)
-__device__ inline void cg_post(const CgState &s, const double *lambda_p, int iter, double *red)
+__device__ __forceinline__ void cg_post(const CgState &s, const double *lambda_p, int iter, double *red)
 {
     const int d = blockIdx.x;
     if (!s.active[d] || s.iters[d] != iter) return;

@@ -95,7 +95,7 @@ struct PlanDev {
 // factor rows of trip t+1 are in flight while the MFMAs of trip t issue.  Lane (j = l & 15, h = l >> 4) handles
 // observations h, h+4, h+8, ... of the item and elements 16 I + j of their factor rows (index-reversed).
 template <int DP, int NO>
-__device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+__device__ __forceinline__ void accumulate_reg(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                   double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
@@ -196,7 +196,7 @@ __device__ inline void accumulate_reg(const SampleArgs &a, const Item &it, int l
 // 32-bit byte offsets, row offsets by one 24-bit mad, no predicated loads (indices are clamped to the item instead, and
 // only the item's last trip masks its operands).
 template <int DP, int NO, bool FULL, bool WIDE = false>
-__device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+__device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                        double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
@@ -304,7 +304,7 @@ __device__ inline void accumulate_lean(const SampleArgs &a, const Item &it, int 
 // relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
 // 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
 template <int DP, bool MATRIX>
-__device__ inline void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+__device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                       double (&bred)[Geo<DP>::DB])
 {
     const int no = a.t[it.term].n_other;
@@ -385,7 +385,7 @@ __global__ __launch_bounds__(256) void k_prior(int D, int DP, int64_t nrows, con
 
 // ---- sum the partials of a split row in slot order (fixed order: the result does not depend on which wave does it) ---
 template <int DP>
-__device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int lane, d4 (&acc)[Geo<DP>::NB],
+__device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &sr, int lane, d4 (&acc)[Geo<DP>::NB],
                                     double (&bred)[Geo<DP>::DB])
 {
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, PSZ = Geo<DP>::PSZ;
@@ -424,7 +424,7 @@ __device__ inline void sum_partials(const PlanDev &p, const SplitRow &sr, int la
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
 template <int DP, bool DUMP, bool MATRIX>
-__device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
+__device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, NB = GG::NB, PSZ = GG::PSZ;
@@ -445,13 +445,6 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     const bool is_split = wid < p.n_split;                      // wave-uniform
     const Item it = is_split ? p.split[wid] : p.direct[wid - p.n_split];
     row = it.row;
-#ifdef BDF_K1_LONG_PRIO
-    // the launch ends with its longest chains: the pieces of split rows (full-length gathers, then the finisher's sum and
-    // factorisation) and the longest direct rows -- they get issue priority over the short rows that share their SIMD
-    if (is_split) __builtin_amdgcn_s_setprio(3);
-    else if (it.count > BDF_K1_LONG_PRIO) __builtin_amdgcn_s_setprio(2);
-    else if (it.count > BDF_K1_LONG_PRIO / 2) __builtin_amdgcn_s_setprio(1);
-#endif
     // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
@@ -557,9 +550,6 @@ __device__ inline void process_item(const SampleArgs &a, const PlanDev &p, const
     double ts[DB];                                // ts[J] in lane j: t_(16 J + j) once its step has passed; the last column's
 #pragma unroll                                    // (and any column's before its step) is still in bv
     for (int J = 0; J < DB; J++) ts[J] = 0.0;
-#ifdef BDF_K1_FACTOR_PRIO
-    __builtin_amdgcn_s_setprio(BDF_K1_FACTOR_PRIO);      // the factorisation is a chain of dependent steps: let it issue when ready
-#endif
     factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
     STAMP(5);
 
@@ -592,24 +582,10 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, MATRIX ? Geo<DP>::WAVES_MATRIX :
     __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
-#ifdef BDF_K1_BASE_PRIO
-    __builtin_amdgcn_s_setprio(BDF_K1_BASE_PRIO);      // above the prediction update that may run beside this launch
-#endif
-#ifdef BDF_K1_PRIO
-    // unequal issue priorities among the waves that share a SIMD (they come from different workgroups): the matrix pipe
-    // then serves them more nearly one after the other than all at once, and they reach the VALU-bound factorisation at
-    // different times
-    switch ((blockIdx.x / BDF_K1_PRIO) & 3) {
-    case 0: __builtin_amdgcn_s_setprio(0); break;
-    case 1: __builtin_amdgcn_s_setprio(1); break;
-    case 2: __builtin_amdgcn_s_setprio(2); break;
-    default: __builtin_amdgcn_s_setprio(3); break;
-    }
-#endif
     if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP, MATRIX>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
     // completion counters (bdf_rows_gate): every wave of the launch, item or not, counts once after its stores completed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0)
+    if (lane == 0 && a.done)
         __hip_atomic_fetch_add(a.done + (int)(w & (BDF_GATE_COUNTERS - 1)) * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -731,21 +707,6 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
             while (gcd(stride, total) != 1) stride += 2;
         }
         for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i * stride) % total);
-        if (mode == 2)
-            for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i & 1) ? total - 1 - i / 2 : i / 2);
-        if (mode == 3 || mode == 4) {
-            // the pieces of split rows first (their rows end the launch: all pieces, then the finisher), then the whole rows
-            // in stride order (3) or by falling length (4)
-            const int64_t nS = (int64_t)split.size(), nD = (int64_t)direct.size();
-            for (int64_t i = 0; i < nS; i++) order[(size_t)i] = (int32_t)i;
-            int64_t st = 1;
-            if (mode == 3 && nD > 2) {
-                st = (int64_t)(0.6180339887 * (double)nD) | 1;
-                auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
-                while (gcd(st, nD) != 1) st += 2;
-            }
-            for (int64_t i = 0; i < nD; i++) order[(size_t)(nS + i)] = (int32_t)(nS + (i * st) % nD);
-        }
     }
     int rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||

@@ -18,7 +18,7 @@
 #define WL_CH 8
 #endif
 
-__device__ inline void wave_sync()
+__device__ __forceinline__ void wave_sync()
 {
     // orders this wave's LDS writes before its later LDS reads (the LDS pipe is in-order per wave; this only stops the
     // compiler from moving accesses across it)
@@ -27,7 +27,7 @@ __device__ inline void wave_sync()
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-__device__ inline double fast_rcp(double x)
+__device__ __forceinline__ double fast_rcp(double x)
 {
     double y = __builtin_amdgcn_rcp(x);
     double e = fma(-x, y, 1.0);
@@ -36,7 +36,7 @@ __device__ inline double fast_rcp(double x)
     return fma(y, e, y);
 }
 
-__device__ inline double fast_rsqrt(double x)
+__device__ __forceinline__ double fast_rsqrt(double x)
 {
     double y = __builtin_amdgcn_rsq(x);
     double e = fma(-x * y, y, 1.0);
@@ -61,7 +61,7 @@ struct WL {
 };
 
 template <int DP, bool SHARE = false>
-__device__ inline bool wl_factor(double (&col)[DP], double &p_own, double &rp_own, double *tri, int lane)
+__device__ __forceinline__ bool wl_factor(double (&col)[DP], double &p_own, double &rp_own, double *tri, int lane)
 {
     using W = WL<DP>;
     const int grp = lane / DP, c = lane % DP;
@@ -107,7 +107,7 @@ __device__ inline bool wl_factor(double (&col)[DP], double &p_own, double &rp_ow
     return notpd;
 }
 
-__device__ inline double wl_bcast(double v, int src_lane)
+__device__ __forceinline__ double wl_bcast(double v, int src_lane)
 {
     return __shfl(v, src_lane);
 }
@@ -115,7 +115,7 @@ __device__ inline double wl_bcast(double v, int src_lane)
 // forward solve Ah wh = b on masked rows (lane c holds row c; rp_own = 1 / p_c).
 // Returns b'_c = wh_c * p_c (the reduced right-hand side).
 template <int DP>
-__device__ inline double wl_forward(const double (&rowm)[DP], double b, double rp_own, int lane)
+__device__ __forceinline__ double wl_forward(const double (&rowm)[DP], double b, double rp_own, int lane)
 {
     const int base = (lane / DP) * DP;
 #pragma unroll
@@ -128,7 +128,7 @@ __device__ inline double wl_forward(const double (&rowm)[DP], double b, double r
 
 // backward solve Ah' x = yh reading the factor's columns from tri (lane c uses column c).  Returns x_c.
 template <int DP, bool SHARE = false>
-__device__ inline double wl_backward(const double *tri, double yh, double rp_own, int lane)
+__device__ __forceinline__ double wl_backward(const double *tri, double yh, double rp_own, int lane)
 {
     using W = WL<DP>;
     const int grp = lane / DP, c = lane % DP, base = grp * DP;
