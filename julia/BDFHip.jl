@@ -33,6 +33,19 @@ end
 
 set_sweep!(c::Context, i) = check(ccall((:bdf_ctx_set_sweep, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, i))
 sync(c::Context) = check(ccall((:bdf_ctx_sync, lib), Cint, (Ptr{Cvoid},), c.h))
+# K1 tuning: rows with more than `item` observations are split into pieces of at most `piece` (defaults 192 / 128)
+set_item_size!(c::Context, item) = check(ccall((:bdf_ctx_set_item_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, item))
+set_piece_size!(c::Context, piece) = check(ccall((:bdf_ctx_set_piece_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, piece))
+# a second context (own HIP stream) for the hyperprior / prediction work that runs beside the row kernels, and the hand-over
+# of fresh rows to it without an event: `rows_gate!(side, main)` holds `side`'s stream until every sample_rows! enqueued so
+# far on `main` has completed (use `gate_usable` once; fall back to events when the two streams share a hardware queue)
+rows_gate!(waiter::Context, producer::Context) =
+    check(ccall((:bdf_rows_gate, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), waiter.h, producer.h))
+function gate_usable(waiter::Context, producer::Context)
+    ok = Ref{Cint}(0)
+    check(ccall((:bdf_rows_gate_selftest, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), waiter.h, producer.h, ok))
+    return ok[] != 0
+end
 
 "device copy of a Julia array (column-major as is)"
 mutable struct DevArray{T}
