@@ -64,6 +64,7 @@ _SIGS = {
     "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
     "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
     "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "bdf_rows_unfinished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bdf_rows_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bdf_event_destroy": (C.c_int, [C.c_void_p]),

@@ -752,6 +752,26 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 
 }  // namespace
 
+// parity hook: split rows whose pieces did not all arrive in the launches so far (their arrival counters reset themselves
+// when the last piece arrives, so any non-zero counter after a completed launch is a row that was never finished)
+extern "C" int bdf_rows_unfinished(bdf_ctx *ctx, int64_t *count)
+{
+    BDF_REQUIRE(ctx && count, BDF_ERR_ARG, "bdf_rows_unfinished: NULL argument");
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    *count = 0;
+    std::lock_guard<std::mutex> lock(g_cache_mutex);
+    auto it = g_caches.find(ctx);
+    if (it == g_caches.end()) return BDF_OK;
+    for (auto &kv : it->second.plans) {
+        const int n = kv.second.dev.n_split_rows;
+        if (n <= 0) continue;
+        std::vector<int32_t> h((size_t)n);
+        BDF_HIP(hipMemcpy(h.data(), kv.second.arrived_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+        for (int32_t v : h) *count += v != 0;
+    }
+    return BDF_OK;
+}
+
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
 {
     std::lock_guard<std::mutex> lock(g_cache_mutex);

@@ -108,6 +108,12 @@ class Context:
     def set_item_size(self, observations):
         check(lib().bdf_ctx_set_item_size(self.handle, int(observations)))
 
+    def rows_unfinished(self):
+        """parity hook: split rows left unfinished by the row-kernel launches so far (must be 0)"""
+        n = C.c_int64(0)
+        check(lib().bdf_rows_unfinished(self.handle, C.byref(n)))
+        return n.value
+
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 

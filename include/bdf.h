@@ -154,6 +154,8 @@ int bdf_prior_pack_doubles(int D);
 int bdf_row_system(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                    const double *mu, int mu_is_matrix, const double *Lambda,
                    double *P_out, double *b_out);
+/* parity hook: number of split rows (rows cut into several work items) that the launches so far left unfinished: 0 */
+int bdf_rows_unfinished(bdf_ctx *ctx, int64_t *count);
 /* parity hook: n standard normals per row of stream (purpose, entity_tag, row) -> dev n x n_rows */
 int bdf_normals(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, int64_t row_begin,
                 int64_t n_rows, int n, double *out);

@@ -370,6 +370,7 @@ def test_movielens_d32_full_size_properties(B):
     for row in (0, 1, 17, 1000, 3333, 6039):
         cov = np.linalg.inv(P[row])
         np.testing.assert_allclose(a[row], np.linalg.cholesky(cov) @ z[row] + cov @ bb[row], rtol=1e-8, atol=1e-9)
+    assert ctx.rows_unfinished() == 0                     # every split row of every launch so far was finished
     eng.close()
 
 

@@ -221,6 +221,7 @@ def test_piece_cap(B, O, ctx):
     _run_rows(B, c2, D, 2, terms, c2.tensor(mu), c2.tensor(Lam), 3, out_t)
     exp = O.sample_rows(D, 2, [O.Term(ids, vals, dims, 0, 0.7, -0.1, [None, facs[1]])], mu, Lam, SEED, 2, 3)
     np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+    assert c2.rows_unfinished() == 0
     dr.close()
     c2.close()
 
