@@ -245,18 +245,68 @@ __device__ __forceinline__ void factor_all(double (&A)[Geo<DP>::NB * 4], double 
 }
 
 // ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----
-template <int DP, int i>
-__device__ __forceinline__ void backward_step(double &yh, double rdv, const double *const (&colq)[4], int lane)
+// The entries a lane needs (row i of its column, i = D-1 ... 1) do not depend on the solve, so they are read from LDS a
+// batch of rows ahead, under a compile-time EXEC mask (lanes c < i; the others have no such entry), and the dependent
+// chain of a step is only: multiply by the pivot's reciprocal, read lane i, one masked fma.  (A load + branch per step,
+// as the plain loop compiles, leaves an LDS round trip in every link of the chain: 190 cycles per step against ~40.)
+template <int i>
+struct BwMask {
+    static constexpr unsigned long long M = (i >= 64) ? ~0ull : ((1ull << i) - 1ull);
+    static constexpr unsigned LO = (unsigned)(M & 0xffffffffull), HI = (unsigned)(M >> 32);
+};
+
+template <int i>
+__device__ __forceinline__ void backward_load(double &L, unsigned addr)
 {
-    const double xi = readlane_f64(yh * rdv, i);
-    if (lane < i) yh = fma(-colq[i & 3][i >> 2], xi, yh);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %3\n\t"
+                 "s_mov_b32 exec_hi, %4\n\t"
+                 "ds_read_b64 %0, %2 offset:%5\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=v"(L), "=&s"(save) : "v"(addr), "n"(BwMask<i>::LO), "n"(BwMask<i>::HI), "n"((i >> 2) * 8) : "memory");
 }
 
-template <int DP, int... Is>
-__device__ __forceinline__ void backward_all(double &yh, double rdv, const double *const (&colq)[4], int lane, int D,
-                                    std::integer_sequence<int, Is...>)
+template <int i>
+__device__ __forceinline__ void backward_fma(double &yh, double L, double xi)
 {
-    (((DP - 1 - Is) < D ? backward_step<DP, DP - 1 - Is>(yh, rdv, colq, lane) : (void)0), ...);
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %4\n\t"
+                 "s_mov_b32 exec_hi, %5\n\t"
+                 "v_fma_f64 %0, -%2, %3, %0\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(yh), "=&s"(save) : "v"(L), "s"(xi), "n"(BwMask<i>::LO), "n"(BwMask<i>::HI));
+}
+
+// rows I0, I0 - 1, ..., I0 - N + 1 (those >= 1): their entries loaded first, then the steps.  No test against D: the rows
+// of the padding (D <= i < DP) have x_i = 0 and entries 0 -- the factorisation never stores them, so the caller zeroes
+// the packed factor once when D < DP (zero_packed_factor) -- and a wave-uniform skip per step would make every step a merge
+// point of all the batch's registers.
+template <int DP, int I0, int N, int... Ns>
+__device__ __forceinline__ void backward_batch(double &yh, double rdv, const unsigned (&colq)[4], std::integer_sequence<int, Ns...>)
+{
+    double L[N];
+    (((I0 - Ns >= 1) ? backward_load<(I0 - Ns >= 1 ? I0 - Ns : 1)>(L[Ns], colq[(I0 - Ns) & 3]) : (void)0), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (((I0 - Ns >= 1)
+          ? backward_fma<(I0 - Ns >= 1 ? I0 - Ns : 1)>(yh, L[Ns], readlane_f64(yh * rdv, (I0 - Ns >= 1 ? I0 - Ns : 1)))
+          : (void)0), ...);
+}
+
+// the packed factor of a wave, zeroed (needed once per wave when D < DP, see backward_batch)
+template <int DP>
+__device__ __forceinline__ void zero_packed_factor(double *tri, int lane)
+{
+    for (int e = lane; e < Geo<DP>::TRI_D; e += 64) tri[e] = 0.0;
+    wave_sync();
+}
+
+template <int DP, int... Bs>
+__device__ __forceinline__ void backward_all(double &yh, double rdv, const unsigned (&colq)[4], std::integer_sequence<int, Bs...>)
+{
+    constexpr int N = 16;                             // rows per batch (32 registers of entries in flight)
+    (backward_batch<DP, DP - 1 - N * Bs, N>(yh, rdv, colq, std::make_integer_sequence<int, N>{}), ...);
 }
 
 }  // namespace

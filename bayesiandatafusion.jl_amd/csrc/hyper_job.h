@@ -184,6 +184,8 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     const int D = a.D;
     const double beta_N = a.b0 + a.N;
     HSTAMP(0);
+    if (D < DP)                                     // the padding's entries of the packed factor are never stored: zero (backward_batch)
+        for (int e = tid; e < GG::TRI_D; e += nthreads) tri[e] = 0.0;
     if (tid < 64) {
         const int e = D - 1 - tid;
         s_muN[tid] = (e >= 0) ? (a.b0 * a.mu0[e] + a.sumU[e]) / beta_N : 0.0;      // reversed: s_muN[c] = mu_N[D-1-c]
@@ -297,10 +299,11 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
         const int ej = D - 1 - lane;
         const double rdv = fast_rcp(dv);
         double yh = (lane < D) ? a.draws[D * D + ej] * (dv * fast_rsqrt(dv)) : 0.0;
-        const double *colq[4];
+        unsigned colq[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) colq[q] = tri + cr.cbase + q * cr.nr4 - cr.q;
-        backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
+        for (int q = 0; q < 4; q++)
+            colq[q] = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + cr.cbase + q * cr.nr4 - cr.q);
+        backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
         const double mu_c = s_muN[lane] + (yh * rdv) / sqrt(beta_N);
         if (lane < D) a.mu_out[ej] = mu_c;
         s_mu[lane] = (lane < D) ? mu_c : 0.0;                      // reversed: s_mu[c] = mu[D-1-c]

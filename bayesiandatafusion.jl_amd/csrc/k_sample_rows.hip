@@ -550,6 +550,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     double ts[DB];                                // ts[J] in lane j: t_(16 J + j) once its step has passed; the last column's
 #pragma unroll                                    // (and any column's before its step) is still in bv
     for (int J = 0; J < DB; J++) ts[J] = 0.0;
+    if (D < DP) zero_packed_factor<DP>(tri, lane);
     factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
     STAMP(5);
 
@@ -565,10 +566,11 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     const double rdv = fast_rcp(dv);
     // L w = b, y = w + z carried as yh = y sqrt(d) = t + z sqrt(d);  then Lt' x = yh
     double yh = fma(z, dv * fast_rsqrt(dv), tv);
-    const double *colq[4];
+    unsigned colq[4];                              // LDS byte addresses: row i of this lane's column at colq[i & 3] + 8 (i >> 2)
 #pragma unroll
-    for (int q = 0; q < 4; q++) colq[q] = tri + cr.cbase + q * cr.nr4 - cr.q;     // row i at colq[i & 3][i >> 2]
-    backward_all<DP>(yh, rdv, colq, lane, D, std::make_integer_sequence<int, DP>{});
+    for (int q = 0; q < 4; q++)
+        colq[q] = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + cr.cbase + q * cr.nr4 - cr.q);
+    backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
     // write-through (sc1): a consumer gated on the completion counters (bdf_rows_gate) may start before this launch ends
     if (lane < D) __hip_atomic_store(a.out + row * D + (D - 1 - lane), yh * rdv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     STAMP(8);
