@@ -117,51 +117,76 @@ int gemm(bdf_ctx *ctx, const GemmArgs &g)
 // F is N x numF column-major.  These are the two genuinely dense contractions of the path (F beta and F' T over
 // the 24 MB of a 6040 x 500 F, AI ~ 8 flop/B per pass).
 typedef double fd4 __attribute__((ext_vector_type(4)));
-constexpr int GK = 64;               // K chunk staged per round
 
-// Y(r, c) = sum_k F(r, k) B(k, c): a wave owns 16 rows x all columns; A operands straight from global (lane l: row l & 15,
-// k l >> 4 -- 16 consecutive rows of a column are one 128-byte read), B chunk of GK x 16 CB staged in LDS for the 4 waves
-template <int CB>
+// Y(r, c) = sum_k F(r, k) B(k, c) for a column-major F: one wave per 16 rows x all columns, every operand straight from
+// global memory in the MFMA's lane layout, no LDS, no barrier.  Lane (i = l & 15, h = l >> 4) supplies F(row i, k) -- 16
+// consecutive rows of a column are one 128-byte read -- and B(k, column i).  Which k of a 16-chunk a lane takes in MFMA
+// step t is free as long as A and B agree: k = 4h + t when B is column-major (the lane's four values of B are then 32
+// contiguous bytes), k = 4t + h otherwise (the 16 lanes of an h read 128 contiguous bytes of a row of B).  B is small
+// (K x ncol) and shared by all waves: it stays in L1/L2.  The chunk after the current one is loaded before the current
+// one's MFMAs.  The four waves of a workgroup share the 16 rows and split K (a 500 x 500 F'F has only 32 row tiles), wave
+// 0 adds their results in wave order.  (A version that staged B through LDS for four waves of different rows took 36 us
+// for the 6040 x 500 x 32 product and as long for the 500 x 500 x 32 one: 95 resp. 8 workgroups, two barriers per 64 k.)
+template <int CB, bool CM>
 __global__ __launch_bounds__(256) void k_dense_nn(const double *__restrict__ F, int64_t M, int64_t K, const double *__restrict__ B,
-                                                  int64_t brs, int64_t bcs, int ncol, double *__restrict__ Y, int64_t yrs,
-                                                  int64_t ycs, const double *__restrict__ bias, double *__restrict__ Y2)
+                                                 int64_t brs, int64_t bcs, int ncol, double *__restrict__ Y, int64_t yrs,
+                                                 int64_t ycs, const double *__restrict__ bias, double *__restrict__ Y2)
 {
-    __shared__ double Bs[GK][16 * CB + 1];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = lane & 15, h = lane >> 4;
-    const int64_t r0 = (int64_t)blockIdx.x * 64 + 16 * wave;
+    __shared__ double red[3][CB][4][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, h = lane >> 4;
+    const int64_t r0 = (int64_t)blockIdx.x * 16;
     const int64_t row = r0 + i;
+    const bool rok = row < M;
+    const int64_t kq = ((K + 3) / 4 + 15) / 16 * 16;      // this wave's K range: [kb, ke)
+    const int64_t kb = wave * kq, ke = (kb + kq < K) ? kb + kq : K;
     fd4 acc[CB];
 #pragma unroll
     for (int cb = 0; cb < CB; cb++) acc[cb] = fd4{0.0, 0.0, 0.0, 0.0};
-    for (int64_t k0 = 0; k0 < K; k0 += GK) {
-        __syncthreads();
-        for (int e = tid; e < GK * 16 * CB; e += 256) {
-            const int kk = e / (16 * CB), c = e % (16 * CB);
-            Bs[kk][c] = (k0 + kk < K && c < ncol) ? B[(k0 + kk) * brs + (int64_t)c * bcs] : 0.0;
+    double a[2][4], b[2][CB][4];
+    auto load = [&](int64_t k0, int S) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) {
+            const int64_t k = k0 + (CM ? 4 * h + t : 4 * t + h);
+            const bool kok = k < ke;
+            a[S][t] = (rok && kok) ? F[row + k * M] : 0.0;
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) {
+                const int c = 16 * cb + i;
+                b[S][cb][t] = (kok && c < ncol) ? B[k * brs + (int64_t)c * bcs] : 0.0;
+            }
         }
-        double a[GK / 4];
+    };
+    load(kb, 0);
+    for (int64_t k0 = kb; k0 < ke; k0 += 32) {
+        load(k0 + 16, 1);                               // beyond the range: zeros
 #pragma unroll
-        for (int s = 0; s < GK / 4; s++) {
-            const int64_t k = k0 + 4 * s + h;
-            a[s] = (row < M && k < K) ? F[row + k * M] : 0.0;
-        }
-        __syncthreads();
+        for (int t = 0; t < 4; t++)
 #pragma unroll
-        for (int s = 0; s < GK / 4; s++)
+            for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[0][t], b[0][cb][t], acc[cb], 0, 0, 0);
+        load(k0 + 32, 0);
 #pragma unroll
-            for (int cb = 0; cb < CB; cb++)
-                acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], Bs[4 * s + h][16 * cb + i], acc[cb], 0, 0, 0);
+        for (int t = 0; t < 4; t++)
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[1][t], b[1][cb][t], acc[cb], 0, 0, 0);
     }
+    if (wave > 0) {
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) red[wave - 1][cb][r][lane] = acc[cb][r];
+    }
+    __syncthreads();
+    if (wave > 0) return;
 #pragma unroll
     for (int cb = 0; cb < CB; cb++)
 #pragma unroll
         for (int r = 0; r < 4; r++) {
+            const double v = ((acc[cb][r] + red[0][cb][r][lane]) + red[1][cb][r][lane]) + red[2][cb][r][lane];
             const int64_t rr = r0 + h + 4 * r;
             const int c = 16 * cb + i;
             if (rr < M && c < ncol) {
-                Y[rr * yrs + (int64_t)c * ycs] = acc[cb][r];
-                if (Y2) Y2[rr * yrs + (int64_t)c * ycs] = acc[cb][r] + bias[c];
+                Y[rr * yrs + (int64_t)c * ycs] = v;
+                if (Y2) Y2[rr * yrs + (int64_t)c * ycs] = v + bias[c];
             }
         }
 }
@@ -234,8 +259,10 @@ int dense_nn(bdf_ctx *ctx, const double *A, int64_t M, int64_t K, const double *
              double *Y, int64_t yrs, int64_t ycs, const double *bias, double *Y2)
 {
     const int CB = (ncol + 15) / 16;
-    dim3 grid((unsigned)((M + 63) / 64));
-#define NN(C) hipLaunchKernelGGL(k_dense_nn<C>, grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2)
+    const bool cm = brs == 1 && bcs != 1;         // column-major B
+    dim3 grid((unsigned)((M + 15) / 16));
+#define NN(C) do { if (cm) hipLaunchKernelGGL((k_dense_nn<C, true>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2); \
+                   else hipLaunchKernelGGL((k_dense_nn<C, false>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2); } while (0)
     if (CB == 1) NN(1); else if (CB == 2) NN(2); else if (CB == 3) NN(3); else NN(4);
 #undef NN
     BDF_HIP(hipGetLastError());
