@@ -105,7 +105,7 @@ struct bdf_feat {
 // ---------------------------------------------------------------------------------------
 struct u32x4 { uint32_t x, y, z, w; };
 
-__host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
+__host__ __device__ __forceinline__ u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1)
 {
 #pragma unroll
     for (int r = 0; r < 10; r++) {
@@ -123,7 +123,7 @@ __host__ __device__ inline u32x4 philox4x32_10(u32x4 c, uint32_t k0, uint32_t k1
     return c;
 }
 
-__host__ __device__ inline u32x4 bdf_draw(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+__host__ __device__ __forceinline__ u32x4 bdf_draw(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                                           uint64_t row, uint32_t pair)
 {
     u32x4 c;
@@ -134,14 +134,14 @@ __host__ __device__ inline u32x4 bdf_draw(uint64_t seed, uint32_t sweep, uint32_
     return philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
 }
 
-__host__ __device__ inline double bdf_u01(uint32_t lo, uint32_t hi)
+__host__ __device__ __forceinline__ double bdf_u01(uint32_t lo, uint32_t hi)
 {
     uint64_t x = ((uint64_t)hi << 32) | lo;
     return ((double)(x >> 11) + 0.5) * 0x1.0p-53;
 }
 
 // standard normal number `n` (0-based) of stream (purpose, entity, row): pair n/2, element n%2
-__device__ inline double bdf_normal(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+__device__ __forceinline__ double bdf_normal(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                                     uint64_t row, int n)
 {
     u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, (uint32_t)(n >> 1));
@@ -151,7 +151,7 @@ __device__ inline double bdf_normal(uint64_t seed, uint32_t sweep, uint32_t purp
     return (n & 1) ? r * sin(t) : r * cos(t);
 }
 
-__device__ inline double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+__device__ __forceinline__ double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                                      uint64_t row, uint32_t pair)
 {
     u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, pair);
@@ -159,7 +159,7 @@ __device__ inline double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t pur
 }
 
 // Gamma(a, 1), Marsaglia-Tsang; variate index g addresses the stream, the attempt is the pair
-__device__ inline double bdf_gamma(uint64_t seed, uint32_t sweep, uint32_t entity, uint64_t g, double a)
+__device__ __forceinline__ double bdf_gamma(uint64_t seed, uint32_t sweep, uint32_t entity, uint64_t g, double a)
 {
     double boost = 1.0;
     if (a < 1.0) {
@@ -182,7 +182,7 @@ __device__ inline double bdf_gamma(uint64_t seed, uint32_t sweep, uint32_t entit
 // ---------------------------------------------------------------------------------------
 // wave-level helpers (wave = 64 lanes)
 // ---------------------------------------------------------------------------------------
-__device__ inline double readlane_f64(double v, int lane)   // lane must be wave-uniform
+__device__ __forceinline__ double readlane_f64(double v, int lane)   // lane must be wave-uniform
 {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
     int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);

@@ -480,27 +480,44 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
                                                      const double *mu, const double *scale_sq, uint64_t seed,
                                                      uint32_t sweep, uint32_t purpose, uint32_t entity, double *T)
 {
+    // 64 rows per workgroup.  Phase 1, all 256 threads: the rows' normals (a Philox block + log + sin/cos per pair is ~40x
+    // the arithmetic of the solve), scaled by sqrt(p_j), into LDS.  Phase 2, one thread per row: the substitution.
     __shared__ double sL[DP * DP + 2 * DP];
-    for (int e = threadIdx.x; e < DP * DP + 2 * DP; e += blockDim.x) sL[e] = Lr[e];
+    __shared__ double sz[64][DP + 1];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < DP * DP + 2 * DP; e += 256) sL[e] = Lr[e];
+    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int npairs = (D + 1) / 2;
+    for (int e = tid; e < 64 * DP; e += 256) sz[e / DP][e % DP] = 0.0;
     __syncthreads();
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    double e[DP];
-#pragma unroll
+    for (int e = tid; e < 64 * npairs; e += 256) {
+        const int lr = e / npairs, pr = e % npairs;
+        const int64_t i = r0 + lr;
+        if (i >= n) continue;
+        const u32x4 o = bdf_draw(seed, sweep, purpose, entity, (uint64_t)i, (uint32_t)pr);
+        const double u1 = bdf_u01(o.x, o.y), u2 = bdf_u01(o.z, o.w);
+        const double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925286766559 * u2;
+        // normal number ej of the row belongs to reversed position j = D - 1 - ej
+        const int e0 = 2 * pr, e1 = 2 * pr + 1;
+        sz[lr][D - 1 - e0] = r * cos(t) * sL[DP * DP + DP + (D - 1 - e0)];
+        if (e1 < D) sz[lr][D - 1 - e1] = r * sin(t) * sL[DP * DP + DP + (D - 1 - e1)];
+    }
+    __syncthreads();
+    const int64_t i = r0 + tid;
+    if (tid >= 64 || i >= n) return;
+    // in place in the row's LDS line (a register array of DP entries, fully unrolled, drags the whole factor into registers)
     for (int j = DP - 1; j >= 0; j--) {
-        const int ej = D - 1 - j;
-        double s = (ej >= 0) ? bdf_normal(seed, sweep, purpose, entity, (uint64_t)i, ej) * sL[DP * DP + DP + j] : 0.0;
-#pragma unroll
-        for (int m = j + 1; m < DP; m++) s = fma(-sL[m * DP + j], e[m], s);
-        e[j] = s * sL[DP * DP + j];
+        double s = sz[tid][j];
+#pragma unroll 4
+        for (int m = j + 1; m < DP; m++) s = fma(-sL[m * DP + j], sz[tid][m], s);
+        sz[tid][j] = s * sL[DP * DP + j];
     }
     const double scale = scale_sq ? sqrt(*scale_sq) : 1.0;
-#pragma unroll
     for (int j = 0; j < DP; j++) {
         const int ej = D - 1 - j;
         if (ej >= 0) {
             const int64_t off = i * D + ej;
-            T[off] = sample ? (sample[off] - mu[ej]) + e[j] : scale * e[j];
+            T[off] = sample ? (sample[off] - mu[ej]) + sz[tid][j] : scale * sz[tid][j];
         }
     }
 }
@@ -514,7 +531,7 @@ int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr,
         BDF_HIP(hipGetLastError());
     }
     if (n > 0) {
-        hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, D, n, Lr,
+        hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, D, n, Lr,
                            sample, mu, scale_sq, ctx->seed, ctx->sweep_host, purpose, entity, T);
         BDF_HIP(hipGetLastError());
     }
