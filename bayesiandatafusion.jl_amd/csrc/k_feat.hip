@@ -924,8 +924,9 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
             g.B = P; g.brs = 1; g.bcs = numF; g.C = Z; g.crs = 1; g.ccs = numF; g.bias = nullptr; g.C2 = nullptr;
             if ((rc = gemm(ctx, g))) return rc;
         } else {
-            if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, 1, N))) return rc;
-            if ((rc = feat_apply(ctx, f, true, Tm, 1, N, D, Z, 1, numF))) return rc;
+            // the N x D intermediate row-major: contiguous writes of the first product, contiguous operand rows of the second
+            if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, D, 1))) return rc;
+            if ((rc = feat_apply(ctx, f, true, Tm, D, 1, D, Z, 1, numF))) return rc;
         }
         // bottom of this iteration and top of the next in one launch
         hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
