@@ -269,13 +269,16 @@ int dense_nn(bdf_ctx *ctx, const double *A, int64_t M, int64_t K, const double *
     return BDF_OK;
 }
 
+#ifndef BDF_TN_WGS
+#define BDF_TN_WGS 1024       // workgroups the F' B product aims at (feature tiles x row chunks)
+#endif
 int dense_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B, int64_t brs, int64_t bcs, int ncol,
                 double *Y, int64_t yrs, int64_t ycs, const double *bias, double *Y2)
 {
     const int CB = (ncol + 15) / 16;
     if (!transpose) return dense_nn(ctx, f->dense_dev, f->m, f->n, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2);
     const int64_t ftiles = (f->n + 15) / 16;
-    int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>((f->m + 255) / 256, (1024 + ftiles - 1) / ftiles));
+    int64_t nchunks = std::max<int64_t>(1, std::min<int64_t>((f->m + 255) / 256, (BDF_TN_WGS + ftiles - 1) / ftiles));
     const int64_t rpc = ((f->m + nchunks - 1) / nchunks + 63) / 64 * 64;
     nchunks = (f->m + rpc - 1) / rpc;
     void *sc;
