@@ -85,6 +85,7 @@ struct bdf_pairs {
     double count;         // counter_prob (macau.jl:171-183)
     const double *baseline_dev;   // nullable, borrowed: per-pair baseline replacing mean_value (relation features)
     int32_t *orig_dev;            // nullable: storage position -> caller's index (bdf_pairs_sort)
+    int sorted_mode;              // the mode bdf_pairs_sort sorted by, -1: caller's order
     std::vector<int32_t> ids_host, orig_host;
     std::vector<double> values_host;
 };

@@ -686,10 +686,11 @@ class GibbsEngine:
         r = self.data.relations[0]
         if self._test_pairs is None:
             self._test_pairs = DevicePairs(self.ctx_p, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
-            if os.environ.get("BDF_PAIR_SORT"):
-                # optional: stored sorted by the mode with the most rows (neighbouring pairs share its factor rows);
-                # measured on MovieLens: no gain, the update is not bound by its gathers
-                self._test_pairs.sort(int(np.argmax(r.data.dims)))
+            if len(r.entities) == 2 and not os.environ.get("BDF_NO_PAIR_SORT"):
+                # stored sorted by the mode with the fewest rows (most pairs per row): the update keeps that mode's factor
+                # row in registers over a run of pairs and gathers only the other mode's (k_predict_runs); results stay in
+                # the caller's order
+                self._test_pairs.sort(int(np.argmin(r.data.dims)))
             dr = self.rel[0]
             if dr.F is not None:             # pred(r, probe_vec, F) = udot + F_test beta + mean_value (sampling.jl:9-14)
                 if feat.isempty(r.test_F):

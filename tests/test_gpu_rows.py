@@ -472,17 +472,18 @@ def test_gather_paths_agree(B, ctx, mode):
     np.testing.assert_allclose(outs[mode], outs[""], rtol=1e-12, atol=1e-13)
 
 
-def test_sorted_pairs_keep_the_callers_order(B, O, ctx):
-    """bdf_pairs_sort: same predictions, running means and statistics as the unsorted pairs, in the caller's order"""
-    D = 12
-    rng = np.random.default_rng(14)
+@pytest.mark.parametrize("D,mode", [(12, 0), (32, 1), (32, 0), (10, 1), (4, 0)])
+def test_sorted_pairs_keep_the_callers_order(B, O, ctx, D, mode):
+    """bdf_pairs_sort: same predictions, running means and statistics as the unsorted pairs, in the caller's order (D a
+    multiple of 4 up to 32: the run kernel that keeps the sorted mode's row in registers; otherwise the general kernel)"""
+    rng = np.random.default_rng(14 + D + mode)
     dims = [40, 25]
     n = 3000
     ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
     y = rng.standard_normal(n) + 3
     facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
     ft = [ctx.tensor(f) for f in facs]
-    plain, srt = B.DevicePairs(ctx, ids, y), B.DevicePairs(ctx, ids, y).sort(0)
+    plain, srt = B.DevicePairs(ctx, ids, y), B.DevicePairs(ctx, ids, y).sort(mode)
     np.testing.assert_array_equal(srt.predict(D, ft, 0.4).cpu().numpy(), plain.predict(D, ft, 0.4).cpu().numpy())
     for phase in (0, 1, 2, 2):
         for q in ft:
