@@ -9,7 +9,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 20 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1)
+(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 300 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
 for c in FETCH_SIZE WRITE_SIZE; do
   (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $out/pmc_$c.log 2>&1)
