@@ -30,6 +30,9 @@ def __getattr__(name):
     if name in ("macau", "pred", "pred_all", "AUC_ROC", "makeClamped"):
         import importlib
         return getattr(importlib.import_module(__name__ + ".driver"), name)
+    if name in ("Block", "sample_users_blocked"):
+        import importlib
+        return getattr(importlib.import_module(__name__ + ".blocked"), name)
     if name in ("GibbsEngine", "Context", "DeviceRelation", "DevicePairs", "FeatOperator"):
         import importlib
         return getattr(importlib.import_module(__name__ + ".engine"), name)

@@ -496,3 +496,32 @@ def test_sorted_pairs_keep_the_callers_order(B, O, ctx, D, mode):
     np.testing.assert_array_equal(a2, a1)
     np.testing.assert_array_equal(q2, q1)
     plain.close(); srt.close()
+
+
+def test_sample_users_blocked(B, O, ctx):
+    """Block / sample_users_blocked (sampling.jl:236-249): the users of a block share one covariance;
+    covar = inv(Lambda + alpha MM MM'), mu = covar (alpha MM Yma + Lambda mu_u), sample = chol(covar)' z + mu"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(31)
+    D, M = 12, 40
+    sample_mt = rng.standard_normal((D, M))
+    vx = np.array([3, 7, 8, 20, 33, 40])
+    ux = np.array([5, 2, 9, 11])
+    Yma = rng.standard_normal((len(vx), len(ux)))
+    A = rng.standard_normal((D, D))
+    Lam, mu, alpha = A @ A.T / D + np.eye(D), rng.standard_normal(D), 1.7
+    blk = B.Block(ux, vx, Yma)
+    ctx.set_sweep(9)
+    got = B.sample_users_blocked(blk, sample_mt, alpha, mu, Lam, ctx=ctx, entity_tag=6)
+    assert got.shape == (D, len(ux))
+    z_t = ctx.zeros(len(ux), D)
+    check(lib().bdf_normals(ctx.handle, 1, 6, 0, len(ux), D, _p(z_t)))
+    ctx.sync()
+    z = z_t.cpu().numpy().T
+    MM = sample_mt[:, vx - 1]
+    covar = np.linalg.inv(Lam + alpha * (MM @ MM.T))
+    mean = covar @ (alpha * MM @ Yma + (Lam @ mu)[:, None])
+    np.testing.assert_allclose(got, np.linalg.cholesky(covar) @ z + mean, rtol=1e-8, atol=1e-9)
+    with pytest.raises(B.DimensionMismatch):
+        B.Block(ux, vx, Yma.T)
+    assert B.sample_users_blocked(B.Block([], vx, np.zeros((len(vx), 0))), sample_mt, alpha, mu, Lam, ctx=ctx).shape == (D, 0)
