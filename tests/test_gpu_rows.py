@@ -430,10 +430,11 @@ def test_hyper_sums_large_entity(B, ctx):
     np.testing.assert_allclose(UUt.cpu().numpy(), S.T @ S, rtol=1e-11, atol=1e-8)
 
 
-@pytest.mark.parametrize("mode", ["general", "wide"])
+@pytest.mark.parametrize("mode", ["general", "wide", "general_kernel"])
 def test_gather_paths_agree(B, ctx, mode):
-    """the lean gather (32-bit offsets), its 64-bit variant for factor matrices of 4 GiB and more, and the general path
-    give the same rows (BDF_GATHER is read once per process: run the forced path in a child)"""
+    """the lean gather (32-bit offsets), its 64-bit variant for factor matrices of 4 GiB and more, the general path, and the
+    general kernel variant in place of the two-mode one (BDF_K1_GENERAL_KERNEL) give the same rows (the hooks are read
+    once per process: run the forced path in a child)"""
     import subprocess, sys, textwrap
     code = textwrap.dedent('''
         import ctypes as C, numpy as np, sys
@@ -465,7 +466,10 @@ def test_gather_paths_agree(B, ctx, mode):
             f = os.path.join(td, "o.npy")
             env = dict(os.environ)
             env.pop("BDF_GATHER", None)
-            if m:
+            env.pop("BDF_K1_GENERAL_KERNEL", None)
+            if m == "general_kernel":
+                env["BDF_K1_GENERAL_KERNEL"] = "1"
+            elif m:
                 env["BDF_GATHER"] = m
             subprocess.run([sys.executable, "-c", code, f], check=True, env=env, timeout=300)
             outs[m] = np.load(f)
