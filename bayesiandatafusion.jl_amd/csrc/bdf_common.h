@@ -141,15 +141,56 @@ __host__ __device__ __forceinline__ double bdf_u01(uint32_t lo, uint32_t hi)
     return ((double)(x >> 11) + 0.5) * 0x1.0p-53;
 }
 
+// sin(2 pi u), cos(2 pi u) for u in (0, 1).  The argument is reduced in u, exactly: q = nearest integer to 4u, r = u - q/4
+// in [-1/8, 1/8]; then the fdlibm kernel polynomials on |2 pi r| <= pi/4 and the quadrant.  Within ~2e-16 of sin / cos of the
+// rounded product 2 pi u (the oracle's libm calls) at a seventh of the instructions: the library routines carry a
+// Payne-Hanek path and double-double arithmetic for arguments this code never sees, and Box-Muller was a quarter of the
+// row kernel's VALU instructions.
+__device__ __forceinline__ void bdf_sincos2pi(double u, double &s, double &c)
+{
+    const double q = rint(4.0 * u);
+    const double x = 6.283185307179586476925286766559 * fma(q, -0.25, u);
+    const double z = x * x;
+    const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                                                   2.75573137070700676789e-06), -1.98412698298579493134e-04),
+                                     8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                                                   -2.75573143513906633035e-07), 2.48015872894767294178e-05),
+                                     -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double sx = fma(x * z, ps, x);
+    const double cx = fma(z * z, pc, fma(z, -0.5, 1.0));
+    const int iq = (int)q & 3;
+    const double sa = (iq & 1) ? cx : sx, ca = (iq & 1) ? sx : cx;
+    s = (iq & 2) ? -sa : sa;
+    c = (iq == 1 || iq == 2) ? -ca : ca;
+}
+
+// log(x) for a normal x in (0, 1) -- bdf_u01 never returns 0, 1 or a denormal: the fdlibm algorithm (x = 2^k m, m in
+// [sqrt(2)/2, sqrt(2)), log m from s = f / (2 + f), f = m - 1), < 1 ulp, without the library routine's special cases
+__device__ __forceinline__ double bdf_log01(double x)
+{
+    int k;
+    double m = frexp(x, &k);                        // m in [0.5, 1)
+    if (m < 0.70710678118654752440) { m *= 2.0; k -= 1; }
+    const double f = m - 1.0, dk = (double)k;
+    const double s = f / (2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * fma(w, fma(w, 1.531383769920937332e-01, 2.222219843214978396e-01), 3.999999999940941908e-01);
+    const double t2 = z * fma(w, fma(w, fma(w, 1.479819860511658591e-01, 1.818357216161805012e-01), 2.857142874366239149e-01),
+                              6.666666666666735130e-01);
+    const double R = t2 + t1, hfsq = 0.5 * f * f;
+    return dk * 6.93147180369123816490e-01 - ((hfsq - fma(s, hfsq + R, dk * 1.90821492927058770002e-10)) - f);
+}
+
 // standard normal number `n` (0-based) of stream (purpose, entity, row): pair n/2, element n%2
 __device__ __forceinline__ double bdf_normal(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                                     uint64_t row, int n)
 {
     u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, (uint32_t)(n >> 1));
     double u1 = bdf_u01(o.x, o.y), u2 = bdf_u01(o.z, o.w);
-    double r = sqrt(-2.0 * log(u1));
-    double t = 6.283185307179586476925286766559 * u2;
-    return (n & 1) ? r * sin(t) : r * cos(t);
+    double r = sqrt(-2.0 * bdf_log01(u1));
+    double s, c;
+    bdf_sincos2pi(u2, s, c);
+    return (n & 1) ? r * s : r * c;
 }
 
 __device__ __forceinline__ double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
