@@ -395,3 +395,14 @@ def test_two_ranks_match_one(B):
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["config"]["units_per_sweep"] == 2 and d2["scaling"] == "weak"
     assert abs(d2["test_rmse"] - d1["test_rmse"]) < 2e-5, (d2["test_rmse"], d1["test_rmse"])
+
+
+def test_stream_schedule_soak(B):
+    """two runs of 1,500 sweeps of the bench workload (three streams, rows rotating through three buffers, gate hand-overs,
+    prediction updates beside the rows) end bit-identical and leave no split row unfinished -- tools/soak_determinism.py runs
+    20,000"""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_determinism.py"), "1500"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "bit-identical: True" in r.stdout and "unfinished=0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
