@@ -471,7 +471,8 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
     for (int r = 0; r < n_terms; r++) {
         const bdf_term &t = terms[r];
         BDF_REQUIRE(t.rel != nullptr, BDF_ERR_ARG, "%s: terms[%d].rel is NULL", who, r);
-        BDF_REQUIRE(t.rel->ctx == ctx, BDF_ERR_ARG, "%s: terms[%d].rel belongs to another context", who, r);
+        // a relation may be used from any context (stream) of the device it was created on
+        BDF_REQUIRE(t.rel->ctx->device == ctx->device, BDF_ERR_ARG, "%s: terms[%d].rel lives on another device", who, r);
         BDF_REQUIRE(t.mode >= 0 && t.mode < t.rel->n_modes, BDF_ERR_ARG, "%s: terms[%d].mode=%d out of range", who, r, t.mode);
         BDF_REQUIRE(t.rel->dims[t.mode] == N, BDF_ERR_ARG,
                     "%s: entity has %lld instances, relation %d has data for %lld (ArgumentError)", who, (long long)N, r,

@@ -369,6 +369,7 @@ class EntityState:
         t = getattr(self, name)
         if t is None:
             return np.zeros((0, 0))
+        torch.cuda.synchronize(t.device)      # the state is written on several streams (rows, hyperprior): wait for all of them
         a = t.detach().cpu().numpy()
         return a.T.copy() if a.ndim == 2 else a.copy()
 
