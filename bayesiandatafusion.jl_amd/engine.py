@@ -374,6 +374,9 @@ class EntityState:
         return a.T.copy() if a.ndim == 2 else a.copy()
 
 
+_SIDE_STREAMS = {}      # (device, role) -> torch stream: the side streams of the process's first engine, reused by later ones
+
+
 class GibbsEngine:
     """Device state of a RelationData and the per-iteration steps of macau.jl:80-140."""
 
@@ -383,6 +386,7 @@ class GibbsEngine:
             raise ArgumentError(f"num_latent={num_latent} must be in 1..{_lib.BDF_MAX_D}")
         self.data, self.D = data, int(num_latent)
         self.ctx = Context(device, seed)
+        self._n_side = 0
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
         if os.environ.get("BDF_PIECE_SIZE"):
@@ -514,17 +518,26 @@ class GibbsEngine:
 
     def _side_context(self, seed):
         """a context on another stream of the device; with gates in use, one whose stream passes bdf_rows_gate_selftest
-        against the row stream (a few candidates are tried; none passing turns the gates off for this engine)"""
+        against the row stream (a few candidates are tried; none passing turns the gates off for this engine).  The streams
+        that served the first engine of the process are kept and handed to later engines in the same roles: HIP multiplexes
+        streams onto a few hardware queues, and the second engine of a process, on fresh streams, was measured 35 % slower
+        (tools/exp_second_engine.py)."""
+        key = (self.ctx.device.index, self._n_side)
+        self._n_side += 1
         first = None
         for attempt in range(8 if self.use_gate else 1):
-            c = Context(self.ctx.device.index, seed, stream=torch.cuda.Stream(self.ctx.device))
+            reuse = attempt == 0 and key in _SIDE_STREAMS
+            st = _SIDE_STREAMS[key] if reuse else torch.cuda.Stream(self.ctx.device)
+            c = Context(self.ctx.device.index, seed, stream=st)
             if not self.use_gate:
+                _SIDE_STREAMS.setdefault(key, st)
                 return c
             ok = C.c_int(0)
             check(lib().bdf_rows_gate_selftest(c.handle, self.ctx.handle, C.byref(ok)))
             if ok.value:
                 if first is not None:
                     first.close()
+                _SIDE_STREAMS[key] = st
                 return c
             if first is None:
                 first = c

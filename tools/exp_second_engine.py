@@ -1,6 +1,6 @@
-"""Four engines on the same data, one after the other in one process: sweep time and row-kernel times of each.  Round 1: the
-second engine of a process runs its movies launch 20 us slower (62 instead of 43 us) than the first, third and fourth -- same
-streams test, different device addresses of its relation / plan arrays; not understood yet (what comes next)."""
+"""Four engines on the same data, one after the other in one process: sweep time and row-kernel times of each.  On fresh side
+streams per engine the second one ran 35 % slower (its movies launch 62 instead of 43 us: another mapping of streams onto
+hardware queues); the engine therefore reuses the first engine's side streams (engine._SIDE_STREAMS) -- all four equal."""
 import os, sys, time
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
 import torch
@@ -30,3 +30,5 @@ if mode == "burn":
     for k in range(int(sys.argv[2])): torch.cuda.Stream(torch.device("cuda", 0))
 for k in range(4):
     run(f"engine {k}")
+    if mode == "empty":
+        torch.cuda.empty_cache()
