@@ -406,7 +406,7 @@ class GibbsEngine:
         # entity's rows alternate between two buffers, so the update of sweep t runs beside the rows of sweep t+1
         self.ctx_p = self.ctx
         if not os.environ.get("BDF_NO_OVERLAP") and all(feat.isempty(r.F) for r in data.relations):
-            self.ctx_p = self._side_context(seed)
+            self.ctx_p = self._side_context(seed, apart_from=[self.ctx_h])
         self._ev_pred = None
         self._ev_rows, self._ev_hyper = {}, {}
         self.full_lambda_u = bool(full_lambda_u)
@@ -516,12 +516,13 @@ class GibbsEngine:
                                                 r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
         self.refresh_baselines()
 
-    def _side_context(self, seed):
+    def _side_context(self, seed, apart_from=()):
         """a context on another stream of the device; with gates in use, one whose stream passes bdf_rows_gate_selftest
         against the row stream (a few candidates are tried; none passing turns the gates off for this engine).  The streams
         that served the first engine of the process are kept and handed to later engines in the same roles: HIP multiplexes
-        streams onto a few hardware queues, and the second engine of a process, on fresh streams, was measured 35 % slower
-        (tools/exp_second_engine.py)."""
+        streams onto a few hardware queues, and a hyperprior stream and a prediction stream that land on the same queue
+        serialise each other (171 instead of 125 us per sweep: tools/exp_stream_pairs.py, exp_second_engine.py) -- so the new
+        stream must also pass the self-test against the contexts in `apart_from`."""
         key = (self.ctx.device.index, self._n_side)
         self._n_side += 1
         first = None
@@ -534,6 +535,9 @@ class GibbsEngine:
                 return c
             ok = C.c_int(0)
             check(lib().bdf_rows_gate_selftest(c.handle, self.ctx.handle, C.byref(ok)))
+            for other in apart_from:
+                if ok.value and other is not self.ctx:
+                    check(lib().bdf_rows_gate_selftest(c.handle, other.handle, C.byref(ok)))
             if ok.value:
                 if first is not None:
                     first.close()
