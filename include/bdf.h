@@ -75,8 +75,11 @@ int bdf_ctx_advance_sweep(bdf_ctx *ctx);
  * before them on producer's stream, at a quarter of the cost to the producer's stream.  Bounded wait (30 s, env
  * BDF_GATE_TIMEOUT_S): on time-out the waiter's next bdf_ctx_sync returns BDF_ERR_HIP.  Both contexts on one device.
  * bdf_rows_gate_selftest: *usable = 1 if the two streams really run side by side (a gate enqueued before the kernel
- * that satisfies it passes); callers fall back to events otherwise.  Synchronises both streams. */
+ * that satisfies it passes); callers fall back to events otherwise.  Synchronises both streams.  HIP multiplexes streams
+ * onto a few hardware queues: two streams that fail this test share one, and work on them is serialised whatever the
+ * hand-over mechanism (worth testing between any two streams that are meant to run side by side). */
 int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer);
+int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
 /* Measurement support: HIP events (timing enabled) and "attach this pair to the next bdf_sample_rows launch of ctx":
  * the events ride on the row kernel's own dispatch packet (hipExtLaunchKernelGGL), so start/stop are the kernel's begin and
  * end on its stream without marker packets around it (an event pair recorded around a launch costs the stream ~6 us and
@@ -88,7 +91,6 @@ int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
 /* the same for the hyperprior chain of ctx: `start` rides on the next bdf_hyper_sums' first kernel, `stop` on the next
  * bdf_hyper_sample's kernel */
 int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
-int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
