@@ -66,11 +66,15 @@ _SIGS = {
     "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_rows_unfinished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bdf_rows_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_gate_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_rows_gate_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bdf_event_destroy": (C.c_int, [C.c_void_p]),
     "bdf_event_elapsed_us": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bdf_ctx_time_next_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_ctx_time_next_hyper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_ctx_time_next_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_ctx_nop": (C.c_int, [C.c_void_p]),
     "bdf_rows_gate_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "bdf_ctx_set_item_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

@@ -51,6 +51,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     memset(c->rows_done_target, 0, sizeof(c->rows_done_target));
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
+    c->time_gate_stop = nullptr;
     c->sweep_host = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
@@ -239,6 +240,46 @@ extern "C" int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer)
     static const long long max_ticks = 100000000LL * (getenv("BDF_GATE_TIMEOUT_S") ? atoll(getenv("BDF_GATE_TIMEOUT_S")) : 30);
     hipLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, producer->rows_done_dev, tg, waiter->flag_dev, max_ticks);
     BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_gate_snapshot(const bdf_ctx *producer, uint32_t *targets)
+{
+    BDF_REQUIRE(producer && targets, BDF_ERR_ARG, "bdf_gate_snapshot: NULL argument");
+    memcpy(targets, producer->rows_done_target, sizeof(producer->rows_done_target));
+    return BDF_OK;
+}
+
+extern "C" int bdf_rows_gate_at(bdf_ctx *waiter, const bdf_ctx *producer, const uint32_t *targets)
+{
+    BDF_REQUIRE(waiter && producer && targets, BDF_ERR_ARG, "bdf_rows_gate_at: NULL argument");
+    BDF_REQUIRE(waiter->device == producer->device, BDF_ERR_ARG, "bdf_rows_gate_at: the contexts are on different devices");
+    if (waiter->stream == producer->stream) return BDF_OK;
+    GateTargets tg;
+    memcpy(tg.t, targets, sizeof(tg.t));
+    static const long long max_ticks = 100000000LL * (getenv("BDF_GATE_TIMEOUT_S") ? atoll(getenv("BDF_GATE_TIMEOUT_S")) : 30);
+    // (the end of the gate, not the start event of the kernel behind it, is when that kernel can begin: an event attached
+    // to a dispatch that waits behind a spinning gate is stamped while it waits)
+    hipExtLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, nullptr, waiter->time_gate_stop, 0,
+                          producer->rows_done_dev, tg, waiter->flag_dev, max_ticks);
+    waiter->time_gate_stop = nullptr;
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+namespace { __global__ void k_nop() {} }
+extern "C" int bdf_ctx_nop(bdf_ctx *ctx)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_nop: ctx is NULL");
+    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, ctx->stream);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_gate: ctx is NULL");
+    ctx->time_gate_stop = (hipEvent_t)stop;
     return BDF_OK;
 }
 

@@ -47,6 +47,7 @@ struct bdf_ctx {
     // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
     uint32_t *rows_done_dev;
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
+    hipEvent_t time_gate_stop;             // bdf_ctx_time_next_gate: end of the next gate kernel enqueued on this context
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
     uint32_t rows_done_target[BDF_GATE_COUNTERS];
 };

@@ -409,6 +409,12 @@ class GibbsEngine:
             self.ctx_p = self._side_context(seed, apart_from=[self.ctx_h])
         self._ev_pred = None
         self._ev_rows, self._ev_hyper = {}, {}
+        # the way back (hyperprior -> rows) through the draw kernel's completion count and a gate on the row stream: a
+        # satisfied event wait costs the row stream ~6 us, the gate kernel ~3 (sweep 128 -> 122 us)
+        self._snap_hyper = {}
+        self._ev_hyper_sweep = {}
+        self._gate_back = not os.environ.get("BDF_NO_GATE_BACK") and self.use_gate and self.ctx_h is not self.ctx \
+            and all(feat.isempty(en.F) for en in data.entities) and self._gate_ok_pair(self.ctx, self.ctx_h)
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
@@ -515,6 +521,11 @@ class GibbsEngine:
                 check(lib().bdf_sample_beta_rel(self.ctx.handle, dr.F.handle, dr.train.handle, self.D, fp, r.model.mean_value,
                                                 r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
         self.refresh_baselines()
+
+    def _gate_ok_pair(self, waiter, producer):
+        ok = C.c_int(0)
+        check(lib().bdf_rows_gate_selftest(waiter.handle, producer.handle, C.byref(ok)))
+        return bool(ok.value)
 
     def _side_context(self, seed, apart_from=()):
         """a context on another stream of the device; with gates in use, one whose stream passes bdf_rows_gate_selftest
@@ -650,7 +661,13 @@ class GibbsEngine:
             self._ev_pred.record(self.ctx_p.stream)
         self.update_relations()
         for j in range(len(self.ent)):
-            if two and j in self._ev_hyper:
+            timed = self.k1_events is not None and i % self.k1_event_every == 0
+            if two and self._gate_back and j in self._snap_hyper and not (timed and self._ev_hyper_sweep.get(j) == i - 1):
+                # (mu, Lambda) of entity j from the previous iteration: a gate on the draw kernel's completion count.  A
+                # row kernel whose duration is measured waits for an event instead (recorded only ahead of such a sweep):
+                # the start event attached to a dispatch that sits behind a spinning gate is stamped while it waits
+                check(lib().bdf_rows_gate_at(self.ctx.handle, self.ctx_h.handle, self._snap_hyper[j]))
+            elif two and j in self._ev_hyper:
                 main.wait_event(self._ev_hyper[j])       # (mu, Lambda) of entity j from the previous iteration
             if two:
                 self.prepare_prior(j, i)                 # side stream, beside the row sampling
@@ -662,9 +679,14 @@ class GibbsEngine:
                 ev.record(main)
                 side.wait_event(ev)
             self.update_prior(j, i)
-            if two:
-                ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
+            next_timed = self.k1_events is not None and (i + 1) % self.k1_event_every == 0
+            if two and self._gate_back:
+                snap = self._snap_hyper.setdefault(j, (C.c_uint32 * 64)())
+                check(lib().bdf_gate_snapshot(self.ctx_h.handle, snap))
+            if two and (not self._gate_back or next_timed):
+                ev = self._ev_hyper.setdefault(j, torch.cuda.Event())      # (with gates: only ahead of a timed sweep)
                 ev.record(side)
+                self._ev_hyper_sweep[j] = i
         if three and self.use_gate:                          # prediction updates read this sweep's rows
             check(lib().bdf_rows_gate(self.ctx_p.handle, self.ctx.handle))
         elif three:

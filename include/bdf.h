@@ -80,6 +80,11 @@ int bdf_ctx_advance_sweep(bdf_ctx *ctx);
  * hand-over mechanism (worth testing between any two streams that are meant to run side by side). */
 int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer);
 int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
+/* The gate at an earlier point of the producer's stream: bdf_gate_snapshot copies the producer's completion targets (64
+ * counters) as they stand after the launches enqueued so far -- row kernels and hyperprior draws (bdf_hyper_sample) count
+ * themselves -- and bdf_rows_gate_at waits for exactly those, whatever was enqueued on the producer since. */
+int bdf_gate_snapshot(const bdf_ctx *producer, uint32_t *targets);
+int bdf_rows_gate_at(bdf_ctx *waiter, const bdf_ctx *producer, const uint32_t *targets);
 /* Measurement support: HIP events (timing enabled) and "attach this pair to the next bdf_sample_rows launch of ctx":
  * the events ride on the row kernel's own dispatch packet (hipExtLaunchKernelGGL), so start/stop are the kernel's begin and
  * end on its stream without marker packets around it (an event pair recorded around a launch costs the stream ~6 us and
@@ -91,6 +96,12 @@ int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
 /* the same for the hyperprior chain of ctx: `start` rides on the next bdf_hyper_sums' first kernel, `stop` on the next
  * bdf_hyper_sample's kernel */
 int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
+/* `stop` rides on the next bdf_rows_gate_at kernel enqueued on ctx: the moment the kernel behind the gate can begin (the
+ * start event of a dispatch that waits behind a spinning gate is stamped while it waits) */
+int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop);
+/* an empty kernel on ctx's stream: between a gate and a timed row kernel, so that the row kernel's start event is stamped
+ * after the gate has ended (measurement only) */
+int bdf_ctx_nop(bdf_ctx *ctx);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */

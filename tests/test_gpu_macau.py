@@ -204,6 +204,9 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
     a3, _ = run(6)
     assert not np.array_equal(a1, a3)
+    monkeypatch.setenv("BDF_NO_GATE_BACK", "1")         # hyperprior -> rows by event instead of the draw kernel's completion count
+    a6, l6 = run(5)
+    assert np.array_equal(a1, a6) and np.array_equal(l1, l6)
     monkeypatch.setenv("BDF_NO_GATE", "1")              # event hand-over instead of completion counters + gate kernel
     a5, l5 = run(5)
     assert np.array_equal(a1, a5) and np.array_equal(l1, l5)
