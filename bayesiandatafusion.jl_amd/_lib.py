@@ -74,7 +74,6 @@ _SIGS = {
     "bdf_ctx_time_next_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_ctx_time_next_hyper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_ctx_time_next_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bdf_ctx_nop": (C.c_int, [C.c_void_p]),
     "bdf_rows_gate_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "bdf_ctx_set_item_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),

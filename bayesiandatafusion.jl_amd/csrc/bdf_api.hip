@@ -267,15 +267,6 @@ extern "C" int bdf_rows_gate_at(bdf_ctx *waiter, const bdf_ctx *producer, const 
     return BDF_OK;
 }
 
-namespace { __global__ void k_nop() {} }
-extern "C" int bdf_ctx_nop(bdf_ctx *ctx)
-{
-    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_nop: ctx is NULL");
-    hipLaunchKernelGGL(k_nop, dim3(1), dim3(64), 0, ctx->stream);
-    BDF_HIP(hipGetLastError());
-    return BDF_OK;
-}
-
 extern "C" int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_gate: ctx is NULL");

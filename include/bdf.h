@@ -99,9 +99,6 @@ int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
 /* `stop` rides on the next bdf_rows_gate_at kernel enqueued on ctx: the moment the kernel behind the gate can begin (the
  * start event of a dispatch that waits behind a spinning gate is stamped while it waits) */
 int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop);
-/* an empty kernel on ctx's stream: between a gate and a timed row kernel, so that the row kernel's start event is stamped
- * after the gate has ended (measurement only) */
-int bdf_ctx_nop(bdf_ctx *ctx);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
