@@ -146,7 +146,7 @@ def main():
     eng.sync()
     fence()
     eng.k1_events = []
-    eng.k1_event_every = args.k1_event_every
+    eng.k1_event_every = max(1, min(args.k1_event_every, args.steps // 4))     # a short run still times a few launches
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(args.warmup + 1 + k, 1 if k == 0 else 2)
