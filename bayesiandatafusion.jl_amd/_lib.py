@@ -64,6 +64,7 @@ _SIGS = {
     "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
     "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
     "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
+    "bdf_ctx_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_rows_unfinished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
     "bdf_rows_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_gate_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -123,6 +124,8 @@ _SIGS = {
     "bdf_sample_beta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "bdf_synth_ratings": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, c_i32p, c_i32p,
+                                    c_dp, C.c_void_p]),
 }
 
 _LIB = None

@@ -59,6 +59,10 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->scratch_bytes = 0;
     c->item_size = 192;
     c->piece_size = 128;
+    {
+        const char *force = getenv("BDF_GATHER");
+        c->gather_mode = force && !strcmp(force, "general") ? 1 : (force && !strcmp(force, "wide") ? 2 : 0);
+    }
     *out = c;
     return BDF_OK;
 }
@@ -130,6 +134,13 @@ extern "C" int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations)
     BDF_REQUIRE(ctx && observations >= 8 && observations <= (1 << 20), BDF_ERR_ARG, "bdf_ctx_set_item_size: 8..2^20 observations");
     ctx->item_size = observations;
     ctx->piece_size = std::max(8, observations * 2 / 3);
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_gather(bdf_ctx *ctx, int mode)
+{
+    BDF_REQUIRE(ctx && mode >= 0 && mode <= 2, BDF_ERR_ARG, "bdf_ctx_set_gather: mode must be 0 (auto), 1 (general) or 2 (64-bit offsets)");
+    ctx->gather_mode = mode;
     return BDF_OK;
 }
 
@@ -528,11 +539,9 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
             wide = wide || !(t.rel->dims[k] < (1 << 24) && t.rel->dims[k] * (int64_t)D * 8 < ((int64_t)1 << 32));
         }
         T.lean = !lean ? 0 : (!wide ? 1 : (D > 32 ? 2 : 0));      // 2: 64-bit row offsets (compiled for D > 32 only)
-        {   // test hooks: BDF_GATHER=general | wide forces the general path / the 64-bit lean path (D > 32)
-            static const char *force = getenv("BDF_GATHER");
-            if (force && !strcmp(force, "general")) T.lean = 0;
-            if (force && !strcmp(force, "wide") && lean && D > 32) T.lean = 2;
-        }
+        // parity hook (bdf_ctx_set_gather): force the general path / the 64-bit lean path (D > 32)
+        if (ctx->gather_mode == 1) T.lean = 0;
+        if (ctx->gather_mode == 2 && lean && D > 32) T.lean = 2;
         T.alpha = t.alpha;
         T.mean = t.mean_value;
     }

@@ -43,6 +43,7 @@ struct bdf_ctx {
     int *flag_dev;             // not-positive-definite flag
     int item_size;             // K1: observations per work item (rows longer than this are split)
     int piece_size;            // K1: ... into pieces of at most this many observations
+    int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)
     // row-kernel completion counters (bdf_rows_gate): counter c (one per 64 bytes) is incremented by every wave w of
     // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
     uint32_t *rows_done_dev;

@@ -117,6 +117,10 @@ class Context:
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 
+    def set_gather(self, mode):
+        """parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (num_latent > 32)"""
+        check(lib().bdf_ctx_set_gather(self.handle, int(mode)))
+
     def set_sweep(self, i):
         check(lib().bdf_ctx_set_sweep(self.handle, C.c_uint32(int(i))))
 
@@ -217,9 +221,30 @@ class DevicePairs:
     def _facs(self, factors):
         return (C.c_void_p * len(factors))(*[f.data_ptr() for f in factors])
 
+    def _on_own_stream(self):
+        """the pairs' stream ordered after the caller's current stream (where the factors were produced), as a context
+        manager under which torch allocates and fills on the pairs' stream"""
+        cur = torch.cuda.current_stream(self.ctx.device)
+        if cur != self.ctx.stream:
+            self.ctx.stream.wait_stream(cur)
+        return cur, torch.cuda.stream(self.ctx.stream)
+
+    def _hand_back(self, cur, *tensors):
+        """results written on the pairs' stream become visible to the caller's stream (a later .cpu() / kernel there)"""
+        if cur != self.ctx.stream:
+            cur.wait_stream(self.ctx.stream)
+            for t in tensors:
+                t.record_stream(cur)
+
     def predict(self, D, factors, mean_value):
-        out = self.ctx.zeros(self.n)
-        check(lib().bdf_predict(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, _ptr(out)))
+        # the pairs of an engine live on its prediction stream (engine.test_pairs): `out` is allocated, zero-filled and
+        # written there, and the caller's stream waits for it -- a plain ctx.zeros() here raced the side-stream kernel
+        # against a null-stream fill and read-back (round-1 smoke)
+        cur, own = self._on_own_stream()
+        with own:
+            out = torch.zeros(self.n, dtype=torch.float64, device=self.ctx.device)
+            check(lib().bdf_predict(self.ctx.handle, self.handle, D, self._facs(factors), mean_value, _ptr(out)))
+        self._hand_back(cur, out)
         return out
 
     def sse(self, D, factors, mean_value, linear=None):

@@ -61,18 +61,37 @@ class IndexedDF:
         self.dims = [int(d) for d in dims]
         if len(self.dims) != n_modes:
             raise ArgumentError(f"dims has {len(self.dims)} entries but the table has {n_modes} id columns")
-        self._build_index()
+        self._index = None          # built on first use: a 100M-row relation that only goes to the device never needs it here
+        if self.ids.shape[0] <= (1 << 22):
+            self._build_index()     # (small tables: at once, so that an id outside 1..dims raises here as in the reference)
+        else:
+            for m, d in enumerate(self.dims):
+                col = self.ids[:, m]
+                if col.size and (int(col.min()) < 1 or int(col.max()) > d):
+                    raise _lib.BoundsError(f"id of mode {m + 1} outside 1..{d} (BoundsError)")
+
+    @property
+    def _rowptr(self):
+        if self._index is None:
+            self._build_index()
+        return self._index[0]
+
+    @property
+    def _rowids(self):
+        if self._index is None:
+            self._build_index()
+        return self._index[1]
 
     def _build_index(self):
         nnz, n_modes = self.ids.shape
         dims = np.asarray(self.dims, dtype=np.int64)
-        self._rowptr = [np.zeros(d + 1, dtype=np.int64) for d in self.dims]
-        self._rowids = [np.zeros(max(nnz, 1), dtype=np.int64) for _ in self.dims]
-        rp = (c_i64p * n_modes)(*[a.ctypes.data_as(c_i64p) for a in self._rowptr])
-        ri = (c_i64p * n_modes)(*[a.ctypes.data_as(c_i64p) for a in self._rowids])
+        rowptr = [np.zeros(d + 1, dtype=np.int64) for d in self.dims]
+        rowids = [np.zeros(max(nnz, 1), dtype=np.int64) for _ in self.dims]
+        rp = (c_i64p * n_modes)(*[a.ctypes.data_as(c_i64p) for a in rowptr])
+        ri = (c_i64p * n_modes)(*[a.ctypes.data_as(c_i64p) for a in rowids])
         _lib.check(_lib.lib().bdf_index_build(n_modes, dims.ctypes.data_as(c_i64p), nnz, self.ids.ctypes.data_as(C.c_void_p),
                                               self.ids.dtype.itemsize, rp, ri))
-        self._rowids = [r[:nnz] for r in self._rowids]
+        self._index = (rowptr, [r[:nnz] for r in rowids])
 
     # ---- the reference's accessors (1-based mode / entity numbers) ------------------------------------------
     @property

@@ -104,6 +104,10 @@ int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a ke
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
+/* parity hook: which gather path the row kernel takes.  0 = chosen by the sizes (default; env BDF_GATHER=general|wide sets the
+ * initial value), 1 = the general path (any number of modes, per-observation baselines), 2 = the lean path with 64-bit row
+ * offsets (num_latent > 32; what a factor matrix of 4 GiB or more needs, e.g. 10M rows at D = 64).  Same values on every path. */
+int bdf_ctx_set_gather(bdf_ctx *ctx, int mode);
 /* device memory for hosts without an allocator of their own (Julia); torch hosts pass tensors */
 int bdf_dev_alloc(bdf_ctx *ctx, size_t bytes, void **dptr);
 int bdf_dev_free(bdf_ctx *ctx, void *dptr);
@@ -279,6 +283,17 @@ int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *f, int D, const double *sample
                     const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
                     int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
                     double *beta_out, double *rhs_out, int32_t *iters_out);
+
+/* ---- synthetic sparse relation of configuration C4 (host-only, needs no GPU) ---------------------------------------
+ * The reference's large-scale benchmark draws its relation with sprand (test/benchmark_parallel_latent.jl:8-12).
+ * Observations k_begin .. k_end-1 of the relation `seed`: row uniform on 1..n_rows; column Zipf-like, p(c) ~ 1/(c + zipf_offset)
+ * (continuous inverse CDF; zipf_offset 0 = uniform); value clip(round(3.5 + <u*_row, v*_col> + 0.5 eps), 1, 5) from a planted
+ * rank-8 model with 0.5 N(0,1) factors; held_out[k] = 1 for a test_fraction of the observations (nullable).  Counter-based
+ * (Philox, key = seed): observation k does not depend on the range or the number of threads, so every rank of a multi-GPU
+ * run can generate the relation (or its part) independently.  rows/cols 1-based int32. */
+int bdf_synth_ratings(uint64_t seed, int64_t n_rows, int64_t n_cols, int64_t k_begin, int64_t k_end,
+                      double zipf_offset, double test_fraction, int32_t *rows_out, int32_t *cols_out,
+                      double *vals_out, uint8_t *held_out);
 
 #ifdef __cplusplus
 }

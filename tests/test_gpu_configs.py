@@ -1,0 +1,265 @@
+"""BASELINE.json configurations C3, C4 and C5 as GPU tests (C1/C2 are in test_gpu_macau.py).
+
+Per configuration: (a) whole Gibbs iterations against the CPU oracle at a reduced size with the configuration's
+structure (same number of modes / relations / feature kind / num_latent); (b) at the configuration's full size (C4: a
+C4-shaped relation that fits the test budget, with the 64-bit gather the full size needs forced on) properties that
+need no oracle -- the union of two shards is bit-equal to the unsharded launch, another item size gives the same rows to
+rounding, sampled rows equal the reference's map chol(inv(P_i))' z + inv(P_i) b_i (src/sampling.jl:200-212, 266-289)
+recomputed in numpy from the row-system hook, the beta update solves the reference's system (src/sampling.jl:291-320);
+(c) the planted / published model quality.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _oracle_feat(O, F):
+    """the oracle's operator for an Entity.F (dense array or scipy sparse with unit entries)"""
+    if hasattr(F, "tocoo"):
+        coo = F.tocsr().tocoo()
+        return O.Feat.from_bincsr(coo.row, coo.col, F.shape[0], F.shape[1]), np.asarray(F.todense()) if F.shape[0] * F.shape[1] < 5e7 else None
+    F = np.asarray(F, dtype=np.float64)
+    return O.Feat.from_dense(F), F
+
+
+def oracle_macau(O, rd, D, seed, iters, use_ff):
+    """macau.jl:80-140 on the CPU oracle for any RelationData without relation-level features: every entity's rows (sum
+    over its relations, tensor relations by Hadamard products), hyperpriors, then the beta updates"""
+    ents, rels = rd.entities, rd.relations
+    N = [e.count for e in ents]
+    S = [np.zeros((n, D)) for n in N]
+    mu = [np.zeros(D) for _ in ents]
+    Lam = [5.0 * np.eye(D) for _ in ents]
+    feats = [None if e.F is None else _oracle_feat(O, e.F) for e in ents]
+    beta = [None if f is None else np.zeros((f[0].n, D)) for f in feats]
+    lb = [1.0 for _ in ents]
+    eidx = lambda e: [x is e for x in ents].index(True)
+    index = [O.index_build(r.data.ids, list(r.data.dims)) for r in rels]
+    means = [r.data.valueMean() for r in rels]
+    for it in range(1, iters + 1):
+        for j, en in enumerate(ents):
+            terms = []
+            for r in en.relations:
+                ri = [x is r for x in rels].index(True)
+                mode = [e is en for e in r.entities].index(True)
+                facs = [None if k == mode else S[eidx(e)] for k, e in enumerate(r.entities)]
+                terms.append(O.Term(r.data.ids, r.data.values, list(r.data.dims), mode, r.model.alpha, means[ri], facs, index=index[ri]))
+            if feats[j] is not None:
+                uhat = np.stack([feats[j][0].mul(beta[j][:, d]) for d in range(D)], axis=1)
+                S[j] = O.sample_rows(D, N[j], terms, mu[j] + uhat, Lam[j], seed, it, j + 1)
+                U, nu, Tinv = S[j] - uhat, D + feats[j][0].n, np.eye(D) + beta[j].T @ beta[j] * lb[j]
+            else:
+                S[j] = O.sample_rows(D, N[j], terms, mu[j], Lam[j], seed, it, j + 1)
+                U, nu, Tinv = S[j], float(D), np.eye(D)
+            mu_N, beta_N, T_N, nu_N = O.hyper_params(U, np.zeros(D), 2.0, Tinv, nu)
+            mu[j], Lam[j] = O.hyper_draw(mu_N, beta_N, T_N, nu_N, seed, it, j + 1)
+        for j in range(len(ents)):
+            if feats[j] is not None:
+                beta[j], _, _ = O.sample_beta(feats[j][0], S[j], mu[j], Lam[j], lb[j], use_ff, None, seed, it, j + 1)
+                lb[j] = O.sample_lambda_beta(beta[j], Lam[j], 1e-3, 1.0, seed, it, j + 1)
+    return S, mu, Lam, beta, lb
+
+
+def _compare(rd, S, mu, Lam, beta, lb, tol=1e-6):
+    for j, en in enumerate(rd.entities):
+        np.testing.assert_allclose(en.model.sample.T, S[j], rtol=tol, atol=tol, err_msg=f"sample of {en.name}")
+        np.testing.assert_allclose(en.model.mu, mu[j], rtol=tol, atol=tol)
+        np.testing.assert_allclose(en.model.Lambda, Lam[j], rtol=tol, atol=tol)
+        if beta[j] is not None:
+            np.testing.assert_allclose(en.model.beta, beta[j], rtol=10 * tol, atol=tol, err_msg=f"beta of {en.name}")
+            assert abs(en.lambda_beta - lb[j]) <= 1e-5 * lb[j]
+
+
+def _shards_items_map(eng, j, D, rows_checked, mu_is_matrix=False, tol=1e-8):
+    """full-size properties of the row kernel on entity j of a warmed-up engine: (i) two shards == one launch, bit for bit;
+    (ii) item size 64 == default to rounding; (iii) the reference's map recomputed from bdf_row_system + the row's normals"""
+    from bdf_amd._lib import check, lib
+    st, ctx, terms = eng.ent[j], eng.ctx, eng._terms(j)
+    nt = len(terms)
+    mu, ism = (st.mu_matrix, 1) if mu_is_matrix else (st.mu, 0)
+    ctx.set_sweep(9)
+
+    def rows(shards=1):
+        out = ctx.zeros(st.N, D)
+        for s in range(shards):
+            check(lib().bdf_sample_rows(ctx.handle, D, st.N, nt, terms, _p(mu), ism, _p(st.Lambda), st.tag, s, shards, _p(out), None))
+        ctx.sync()
+        return out.cpu().numpy()
+
+    a = rows(1)
+    assert np.array_equal(a, rows(2)), "union of two shards differs from the unsharded launch"
+    assert np.all(np.isfinite(a))
+    ctx.set_item_size(64)
+    b = rows(1)
+    ctx.set_item_size(192)
+    np.testing.assert_allclose(b, a, rtol=tol, atol=tol)
+    P_t, b_t, z_t = ctx.zeros(st.N, D, D), ctx.zeros(st.N, D), ctx.zeros(st.N, D)
+    check(lib().bdf_row_system(ctx.handle, D, st.N, nt, terms, _p(mu), ism, _p(st.Lambda), _p(P_t), _p(b_t)))
+    check(lib().bdf_normals(ctx.handle, 1, st.tag, 0, st.N, D, _p(z_t)))
+    ctx.sync()
+    import torch
+    sel = torch.as_tensor(np.asarray(rows_checked), device=P_t.device)
+    P, bb, z = P_t[sel].cpu().numpy(), b_t[sel].cpu().numpy(), z_t[sel].cpu().numpy()
+    for q, row in enumerate(rows_checked):
+        cov = np.linalg.inv(P[q])
+        np.testing.assert_allclose(a[row], np.linalg.cholesky(cov) @ z[q] + cov @ bb[q], rtol=1e-7, atol=1e-8)
+    assert ctx.rows_unfinished() == 0
+    return a
+
+
+# ---- C3: Macau MovieLens + dense user side information 6040 x 500, D = 32 ---------------------------------------------
+@pytest.mark.parametrize("use_ff", [True, False])
+def test_c3_reduced_whole_iterations_match_oracle(B, O, use_ff):
+    """C3's structure at a size the oracle finishes in seconds: dense features with numF = 96 > 64 (the FF path's blocked
+    direct solve, sampling.jl:314-320, or CG, parallel_cg.jl:63-94), D = 32, lambda_beta sampled"""
+    rng = np.random.default_rng(33)
+    N1, N2, D, nnz, numF = 400, 300, 32, 14000, 96
+    ids = np.stack([rng.integers(1, N1 + 1, nnz), rng.integers(1, N2 + 1, nnz)], axis=1)
+    vals = np.clip(np.round(3.5 + rng.standard_normal(nnz)), 1, 5)
+    F = rng.standard_normal((N1, numF))
+    rel = B.Relation({"u": ids[:, 0], "v": ids[:, 1], "y": vals}, "r", [B.Entity("u", F=F), B.Entity("v")], dims=[N1, N2])
+    B.setPrecision(rel, 1.5)
+    rd = B.RelationData(rel)
+    B.macau(rd, burnin=2, psamples=0, num_latent=D, verbose=False, seed=21, compute_ff_size=6500 if use_ff else 0)
+    _compare(rd, *oracle_macau(O, rd, D, 21, 2, use_ff))
+
+
+@pytest.mark.parametrize("kind,use_ff", [("iid", True), ("iid", False), ("correlated", True), ("correlated", False)])
+def test_c3_full_size_properties(B, kind, use_ff):
+    from bdf_amd import datasets
+    from bdf_amd._lib import check, lib
+    import torch
+    rd, source = datasets.c3_relation_data(B, kind)
+    D = 32
+    eng = B.GibbsEngine(rd, D, seed=7, compute_ff_size=6500 if use_ff else 0)
+    for i in range(1, 4):
+        eng.sweep(i)
+    eng.sync()
+    st, en = eng.ent[0], rd.entities[0]
+    assert st.numF == 500 and en.use_FF is use_ff
+    # the beta update solves (F'F + lambda_beta I) beta = rhs of sampling.jl:298-312: residual from the operator itself
+    eng.ctx.set_sweep(5)
+    lam0 = float(st.lambda_beta.item())
+    beta, rhs, its = eng.ctx.zeros(D, st.numF), eng.ctx.zeros(D, st.numF), torch.zeros(D, dtype=torch.int32, device=eng.ctx.device)
+    lb = eng.ctx.tensor([lam0])
+    check(lib().bdf_sample_beta(eng.ctx.handle, st.F.handle, D, _p(st.sample), _p(st.mu), _p(st.Lambda), _p(lb), int(use_ff),
+                                float("nan"), 0, 0, 1e-3, 1.0, st.tag, _p(beta), _p(rhs), _p(its)))
+    Ab = st.F.AtA_mul(beta, lam0)
+    eng.ctx.sync()
+    res = (Ab - rhs).norm(dim=1) / rhs.norm(dim=1)
+    its = its.cpu().numpy()
+    if use_ff:
+        assert float(res.max()) < 1e-10, float(res.max())          # direct solve
+        assert its.max() == 0
+    else:
+        # cg_AtA stops when ||r|| < eps * numF * ||b|| or after numF iterations (parallel_cg.jl:65-75)
+        assert float(res.max()) < (1e-9 if kind == "iid" else 1e-6), float(res.max())
+        assert 5 <= its.min() and its.max() <= 500
+        if kind == "correlated":
+            assert its.max() > 30          # 20 dominant directions on top of a flat spectrum: slower than the i.i.d. case
+    _shards_items_map(eng, 0, D, (0, 17, 1000, 6039), mu_is_matrix=True)
+    eng.close()
+
+
+def test_c3_quality(B):
+    """Macau on MovieLens with 500 uninformative dense user features, D = 32, CG forced (BASELINE configs[2]): the sampled
+    lambda_beta shrinks the link matrix, the held-out RMSE stays at BPMF's (0.860 after 20+20)"""
+    from bdf_amd import datasets
+    rd, source = datasets.c3_relation_data(B, "iid")
+    res = B.macau(rd, burnin=20, psamples=20, num_latent=32, verbose=False, clamp=[1.0, 5.0], seed=3, compute_ff_size=0)
+    assert rd.entities[0].use_FF is False
+    assert 0.84 < res["RMSE"] < 0.885, res["RMSE"]
+    assert rd.entities[0].lambda_beta > 1.0
+
+
+# ---- C5: 3-mode tensor + matrix sharing an entity, binary sparse features, D = 32 --------------------------------------
+@pytest.mark.parametrize("use_ff", [False, True])
+def test_c5_reduced_whole_iterations_match_oracle(B, O, use_ff):
+    from bdf_amd import datasets
+    rd, _ = datasets.c5_relation_data(B, nA=600, nB=12, nC=40, nT=30, n1=30000, n2=6000, n_feat=150, feat_per_row=6)
+    D = 32
+    B.macau(rd, burnin=2, psamples=0, num_latent=D, verbose=False, seed=31, compute_ff_size=6500 if use_ff else 0)
+    assert len(rd.entities) == 4 and len(rd.entities[0].relations) == 2 and rd.entities[0].use_FF is use_ff
+    _compare(rd, *oracle_macau(O, rd, D, 31, 2, use_ff))
+
+
+def test_c5_full_size_properties_and_quality(B):
+    from bdf_amd import datasets
+    rd, info = datasets.c5_relation_data(B)
+    D = 32
+    res = B.macau(rd, burnin=12, psamples=12, num_latent=D, verbose=False, compute_ff_size=0, seed=3)
+    # planted rank-8 CP model, noise 0.1 on values of unit scale: the held-out cells are predicted far below the value spread
+    assert res["RMSE"] < 0.45 * info["value_std"], (res["RMSE"], info)
+    eng = rd._engine
+    its = eng.ent[0].cg_iters.cpu().numpy()
+    assert 3 <= its.min() and its.max() <= 200
+    # entity A: two relations (3-mode + 2-mode), per-row prior means from the binary features, split rows
+    _shards_items_map(eng, 0, D, (0, 5, 40000, 99999), mu_is_matrix=True)
+    # entity B: 64 rows of ~78,000 observations each (every row split into the maximum number of pieces)
+    _shards_items_map(eng, 1, D, (0, 63))
+    eng.close()
+
+
+# ---- C4: large two-mode relation, D = 64 -------------------------------------------------------------------------------
+def test_c4_reduced_whole_iterations_match_oracle(B, O):
+    """D = 64 with the 64-bit gather offsets the full configuration needs (10M x 64 x 8 B = 5.1 GB factor)"""
+    from bdf_amd import datasets
+    from bdf_amd.engine import GibbsEngine
+    rd = datasets.c4_relation_data(B, 500, 120, 9000, test_fraction=0.0)
+    D = 64
+    eng = GibbsEngine(rd, D, seed=13)
+    eng.ctx.set_gather(2)
+    for i in range(1, 3):
+        eng.sweep(i)
+    eng.sync()
+    _compare(rd, *oracle_macau(O, rd, D, 13, 2, True), tol=1e-6)
+    eng.close()
+
+
+def test_c4_shaped_full_size_properties_and_quality(B):
+    """a C4-shaped relation that fits the test budget: 1M x 100k, 20M observations (1 % held out), D = 64, 64-bit gather forced"""
+    from bdf_amd import datasets
+    from bdf_amd._lib import check, lib
+    from bdf_amd.engine import GibbsEngine
+    rd = datasets.c4_relation_data(B, 1_000_000, 100_000, 20_000_000)
+    rel = rd.relations[0]
+    D = 64
+    eng = GibbsEngine(rd, D, seed=5)
+    eng.ctx.set_gather(2)
+    test = eng.test_pairs()
+    for i in range(1, 21):
+        eng.sweep(i)
+        stats = test.update(D, eng.factors_of(rel), rel.model.mean_value, 0 if i <= 10 else (1 if i == 11 else 2), [1.0, 5.0], rel.class_cut)
+    eng.sync()
+    rmse = float(np.sqrt(stats.cpu().numpy()[0] / test.n))
+    tv = np.asarray(rel.test_vec.values)
+    # 10 + 10 sweeps on ~20 ratings per user beat the mean predictor (0.88); the generator's floor is sqrt(0.25 + 1/12) = 0.58
+    assert 0.55 < rmse < 0.965 * tv.std(), (rmse, tv.std())
+    # items (100k rows, Zipf-like: the head rows are split into the maximum number of pieces), wide gather
+    a = _shards_items_map(eng, 1, D, (0, 1, 99, 5000, 99999))
+    # the same launch with 32-bit offsets (the factor matrices of this size allow both): identical arithmetic
+    st, terms, ctx = eng.ent[1], eng._terms(1), eng.ctx
+    ctx.set_gather(0)
+    out = ctx.zeros(st.N, D)
+    check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, _p(st.mu), 0, _p(st.Lambda), st.tag, 0, 1, _p(out), None))
+    ctx.sync()
+    assert np.array_equal(out.cpu().numpy(), a)
+    # users: shards and item sizes only (the row-system dump of 1M rows would be 33 GB)
+    ctx.set_gather(2)
+    st, terms = eng.ent[0], eng._terms(0)
+    full, halves = ctx.zeros(st.N, D), ctx.zeros(st.N, D)
+    check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, _p(st.mu), 0, _p(st.Lambda), st.tag, 0, 1, _p(full), None))
+    for s in range(3):
+        check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, _p(st.mu), 0, _p(st.Lambda), st.tag, s, 3, _p(halves), None))
+    ctx.sync()
+    import torch
+    assert torch.equal(full, halves)
+    assert ctx.rows_unfinished() == 0
+    eng.close()

@@ -337,3 +337,24 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
     assert occ["_ZN12_GLOBAL__N_16k_rowsILi32ELb0ELb0EEEv10SampleArgsNS_7PlanDevE"] >= 5
     assert occ["_ZN12_GLOBAL__N_16k_rowsILi64ELb0ELb1EEEv10SampleArgsNS_7PlanDevE"] >= 2
     assert occ["_ZN12_GLOBAL__N_16k_rowsILi16ELb0ELb1EEEv10SampleArgsNS_7PlanDevE"] >= 8
+
+
+def test_synth_ratings_is_counter_based(B):
+    """bdf_synth_ratings (configuration C4's generator, host-only): observation k does not depend on the range generated,
+    ids stay in range, the column law is Zipf-like and about test_fraction of the observations are held out"""
+    from bdf_amd import datasets
+    r, c, v, h = datasets.synth_ratings(50_000, 4_000, 300_000, seed=777)
+    r2, c2, v2, h2 = datasets.synth_ratings(50_000, 4_000, 1_000, seed=777, k_begin=123_456)
+    s = slice(123_456, 124_456)
+    assert np.array_equal(r[s], r2) and np.array_equal(c[s], c2) and np.array_equal(v[s], v2) and np.array_equal(h[s], h2)
+    assert r.min() >= 1 and r.max() <= 50_000 and c.min() >= 1 and c.max() <= 4_000
+    assert set(np.unique(v)) <= {1.0, 2.0, 3.0, 4.0, 5.0} and 3.2 < v.mean() < 3.8
+    assert abs(h.mean() - 0.01) < 0.002
+    cnt = np.bincount(c - 1, minlength=4_000).astype(float)
+    # p(c) ~ 1 / (c + 100): the first 100 columns hold ln(2) / ln(41) of the mass
+    assert abs(cnt[:100].sum() / cnt.sum() - np.log(2.0) / np.log(41.0)) < 0.01
+    r3, _, _, _ = datasets.synth_ratings(50_000, 4_000, 1_000, seed=778)
+    assert not np.array_equal(r3, r[:1000])
+    rd = datasets.c4_relation_data(B, 5_000, 400, 40_000)
+    rel = rd.relations[0]
+    assert B.numData(rel) + B.numTest(rel) == 40_000 and rel.data.ids.dtype == np.int32 and rel.model.alpha == 2.0
