@@ -53,6 +53,9 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->time_h_start = c->time_h_stop = nullptr;
     c->time_gate_stop = nullptr;
     c->sweep_host = 0;
+    c->skip_flag = nullptr;
+    c->cg_status = nullptr;
+    c->cg_gen = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
     c->scratch2_bytes = 0;
@@ -78,6 +81,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     hipFree(ctx->flag_dev);
     hipFree(ctx->rows_done_dev);
     if (ctx->scratch2) hipFree(ctx->scratch2);
+    if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;

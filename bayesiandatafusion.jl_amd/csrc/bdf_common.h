@@ -51,6 +51,11 @@ struct bdf_ctx {
     hipEvent_t time_gate_stop;             // bdf_ctx_time_next_gate: end of the next gate kernel enqueued on this context
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
     uint32_t rows_done_target[BDF_GATE_COUNTERS];
+    // batched CG (k_feat.hip): device flag that lets product kernels enqueued ahead return at once (NULL outside a solve),
+    // and the host-mapped words through which the device reports (iteration, active columns)
+    const int *skip_flag;
+    volatile uint64_t *cg_status;
+    uint32_t cg_gen;
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
@@ -101,7 +106,12 @@ struct bdf_feat {
     int64_t *rowptr_dev; int32_t *colind_dev; double *rvals_dev;
     int64_t *colptr_dev; int32_t *rowind_dev; double *cvals_dev;
     double *FF_dev;       // n x n (F'F), built on first use_ff
+    double *chol_ws;      // workspace of the blocked direct solve (k_chol.hip), allocated on first use
+    size_t chol_ws_doubles;
 };
+
+// (FF + lambda I) \ rhs for all D right-hand sides by blocked Cholesky (solve_full, src/sampling.jl:314-320)
+int bdf_chol_solve(bdf_ctx *ctx, bdf_feat *f, int D, const double *lambda_dev, const double *rhs, double *beta);
 
 // ---------------------------------------------------------------------------------------
 // Philox4x32-10 + Box-Muller (host+device).  Counter layout: DESIGN.md "RNG contract".

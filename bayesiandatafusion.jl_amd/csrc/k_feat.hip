@@ -30,8 +30,9 @@ struct GemmArgs {
 
 // blockIdx.z = K chunk (split-K): with more than one chunk the tile goes to part[z][i][j] (M x N row-major per chunk) and
 // k_gemm_reduce adds the chunks in order -- a tall-and-skinny F' T (K = rows of F) would otherwise run on a handful of CUs
-__global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int64_t kchunk, double *part)
+__global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int64_t kchunk, double *part, const int *skip)
 {
+    if (skip && *skip == 0) return;
     __shared__ double As[TK][TM + 1];
     __shared__ double Bs[TK][TN + 1];
     const int tid = threadIdx.x;
@@ -77,8 +78,9 @@ __global__ __launch_bounds__(256) void k_gemm(GemmArgs g, int64_t kchunk, double
         }
 }
 
-__global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g, int nchunks, const double *part)
+__global__ __launch_bounds__(256) void k_gemm_reduce(GemmArgs g, int nchunks, const double *part, const int *skip)
 {
+    if (skip && *skip == 0) return;
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= g.M * g.N) return;
     const int64_t i = e / g.N, j = e % g.N;
@@ -99,15 +101,15 @@ int gemm(bdf_ctx *ctx, const GemmArgs &g)
     }
     dim3 grid((unsigned)((g.M + TM - 1) / TM), (unsigned)((g.N + TN - 1) / TN), (unsigned)nchunks);
     if (nchunks == 1) {
-        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, g.K, (double *)nullptr);
+        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, g.K, (double *)nullptr, ctx->skip_flag);
     } else {
         void *sc;
         int rc = bdf_scratch2(ctx, (size_t)nchunks * g.M * g.N * sizeof(double), &sc);
         if (rc) return rc;
         const int64_t kchunk = ((g.K + nchunks - 1) / nchunks + TK - 1) / TK * TK;
-        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, kchunk, (double *)sc);
+        hipLaunchKernelGGL(k_gemm, grid, dim3(256), 0, ctx->stream, g, kchunk, (double *)sc, ctx->skip_flag);
         hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((g.M * g.N + 255) / 256)), dim3(256), 0, ctx->stream, g, nchunks,
-                           (const double *)sc);
+                           (const double *)sc, ctx->skip_flag);
     }
     BDF_HIP(hipGetLastError());
     return BDF_OK;
@@ -130,9 +132,11 @@ typedef double fd4 __attribute__((ext_vector_type(4)));
 template <int CB, bool CM>
 __global__ __launch_bounds__(256) void k_dense_nn(const double *__restrict__ F, int64_t M, int64_t K, const double *__restrict__ B,
                                                  int64_t brs, int64_t bcs, int ncol, double *__restrict__ Y, int64_t yrs,
-                                                 int64_t ycs, const double *__restrict__ bias, double *__restrict__ Y2)
+                                                 int64_t ycs, const double *__restrict__ bias, double *__restrict__ Y2,
+                                                 const int *skip)
 {
     __shared__ double red[3][CB][4][64];
+    if (skip && *skip == 0) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, h = lane >> 4;
     const int64_t r0 = (int64_t)blockIdx.x * 16;
     const int64_t row = r0 + i;
@@ -197,9 +201,10 @@ __global__ __launch_bounds__(256) void k_dense_nn(const double *__restrict__ F, 
 template <int CB>
 __global__ __launch_bounds__(256) void k_dense_tn(const double *__restrict__ F, int64_t M, int64_t numF, const double *__restrict__ B,
                                                   int64_t brs, int64_t bcs, int ncol, int64_t rows_per_chunk,
-                                                  double *__restrict__ part)
+                                                  double *__restrict__ part, const int *skip)
 {
     __shared__ double tile[4][16][65];
+    if (skip && *skip == 0) return;
     __shared__ double red[3][CB][4][64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 15, h = lane >> 4;
@@ -261,8 +266,8 @@ int dense_nn(bdf_ctx *ctx, const double *A, int64_t M, int64_t K, const double *
     const int CB = (ncol + 15) / 16;
     const bool cm = brs == 1 && bcs != 1;         // column-major B
     dim3 grid((unsigned)((M + 15) / 16));
-#define NN(C) do { if (cm) hipLaunchKernelGGL((k_dense_nn<C, true>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2); \
-                   else hipLaunchKernelGGL((k_dense_nn<C, false>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2); } while (0)
+#define NN(C) do { if (cm) hipLaunchKernelGGL((k_dense_nn<C, true>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2, ctx->skip_flag); \
+                   else hipLaunchKernelGGL((k_dense_nn<C, false>), grid, dim3(256), 0, ctx->stream, A, M, K, B, brs, bcs, ncol, Y, yrs, ycs, bias, Y2, ctx->skip_flag); } while (0)
     if (CB == 1) NN(1); else if (CB == 2) NN(2); else if (CB == 3) NN(3); else NN(4);
 #undef NN
     BDF_HIP(hipGetLastError());
@@ -285,14 +290,14 @@ int dense_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B
     int rc = bdf_scratch2(ctx, (size_t)nchunks * f->n * ncol * sizeof(double), &sc);
     if (rc) return rc;
     dim3 grid((unsigned)ftiles, (unsigned)nchunks);
-#define TN(C) hipLaunchKernelGGL(k_dense_tn<C>, grid, dim3(256), 0, ctx->stream, (const double *)f->dense_dev, f->m, f->n, B, brs, bcs, ncol, rpc, (double *)sc)
+#define TN(C) hipLaunchKernelGGL(k_dense_tn<C>, grid, dim3(256), 0, ctx->stream, (const double *)f->dense_dev, f->m, f->n, B, brs, bcs, ncol, rpc, (double *)sc, ctx->skip_flag)
     if (CB == 1) TN(1); else if (CB == 2) TN(2); else if (CB == 3) TN(3); else TN(4);
 #undef TN
     GemmArgs g;
     g.M = f->n; g.N = ncol; g.K = f->m; g.A = nullptr; g.ars = g.acs = 0; g.B = nullptr; g.brs = g.bcs = 0;
     g.C = Y; g.crs = yrs; g.ccs = ycs; g.bias = bias; g.C2 = Y2;
     hipLaunchKernelGGL(k_gemm_reduce, dim3((unsigned)((g.M * g.N + 255) / 256)), dim3(256), 0, ctx->stream, g, (int)nchunks,
-                       (const double *)sc);
+                       (const double *)sc, ctx->skip_flag);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -316,8 +321,9 @@ struct SpmmArgs {
 __global__ __launch_bounds__(256) void k_spmm_rm(int64_t m, int ncol, const int64_t *__restrict__ rowptr,
                                                  const int32_t *__restrict__ colind, const double *__restrict__ vals,
                                                  const double *__restrict__ B, int64_t ldb, double *__restrict__ Y, int64_t ldy,
-                                                 const double *__restrict__ bias, double *__restrict__ Y2)
+                                                 const double *__restrict__ bias, double *__restrict__ Y2, const int *skip)
 {
+    if (skip && *skip == 0) return;
     const int c0 = threadIdx.x % 32;
     const int64_t r = (int64_t)blockIdx.x * 8 + threadIdx.x / 32;
     if (r >= m) return;
@@ -344,9 +350,10 @@ __global__ __launch_bounds__(256) void k_spmm_rm(int64_t m, int ncol, const int6
 
 // out[i*ncol + c] = in[i*irs + c*ics]  (32 x 32 tiles through LDS: coalesced on both sides for a column-major `in`)
 __global__ __launch_bounds__(256) void k_to_rowmajor(int64_t n, int ncol, const double *__restrict__ in, int64_t irs, int64_t ics,
-                                                     double *__restrict__ out)
+                                                     double *__restrict__ out, const int *skip)
 {
     __shared__ double t[32][33];
+    if (skip && *skip == 0) return;
     const int64_t i0 = (int64_t)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32, a = threadIdx.x % 32;
     for (int b = threadIdx.x / 32; b < 32; b += 8) {
@@ -365,9 +372,10 @@ __global__ __launch_bounds__(256) void k_to_rowmajor(int64_t n, int ncol, const 
 // out[i*ors + c*ocs] = in[i*ncol + c]  (+ the biased copy out2)
 __global__ __launch_bounds__(256) void k_from_rowmajor(int64_t n, int ncol, const double *__restrict__ in, double *__restrict__ out,
                                                        int64_t ors, int64_t ocs, const double *__restrict__ bias,
-                                                       double *__restrict__ out2)
+                                                       double *__restrict__ out2, const int *skip)
 {
     __shared__ double t[32][33];
+    if (skip && *skip == 0) return;
     const int64_t i0 = (int64_t)blockIdx.x * 32;
     const int c0 = blockIdx.y * 32, a = threadIdx.x % 32;
     for (int b = threadIdx.x / 32; b < 32; b += 8) {
@@ -403,16 +411,16 @@ int spmm(bdf_ctx *ctx, const SpmmArgs &s)
         if (!b_rm) {
             if (s.kin > 0)
                 hipLaunchKernelGGL(k_to_rowmajor, dim3((unsigned)((s.kin + 31) / 32), (unsigned)((s.ncol + 31) / 32)), dim3(256), 0,
-                                   ctx->stream, s.kin, s.ncol, s.B, s.brs, s.bcs, tb);
+                                   ctx->stream, s.kin, s.ncol, s.B, s.brs, s.bcs, tb, ctx->skip_flag);
             B = tb; ldb = s.ncol;
         }
         if (!y_rm) { Y = ty; ldy = s.ncol; }
     }
     hipLaunchKernelGGL(k_spmm_rm, dim3((unsigned)((s.m + 7) / 8)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind, s.vals,
-                       B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr);
+                       B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
     if (!y_rm)
         hipLaunchKernelGGL(k_from_rowmajor, dim3((unsigned)((s.m + 31) / 32), (unsigned)((s.ncol + 31) / 32)), dim3(256), 0,
-                           ctx->stream, s.m, s.ncol, (const double *)Y, s.Y, s.yrs, s.ycs, s.bias, s.Y2);
+                           ctx->stream, s.m, s.ncol, (const double *)Y, s.Y, s.yrs, s.ycs, s.bias, s.Y2, ctx->skip_flag);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -557,6 +565,9 @@ struct CgState {
     double *X, *R, *P, *Z;               // n x D column-major
     double *bknum, *bkden, *tolb;        // D
     int *active, *iters, *nactive;
+    int *done_blocks;                    // columns (workgroups) that have finished the current k_cg_step
+    volatile uint64_t *status;           // host-mapped: [0] = generation << 32 | last completed iteration, [1] = active columns
+    uint32_t gen;
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red)
@@ -587,7 +598,7 @@ __global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, 
     if (threadIdx.x == 0) {
         s.tolb[d] = tol * sqrt(nb);      // tol = tol * norm(b), parallel_cg.jl:65
         s.bkden[d] = 0.0; s.active[d] = 1; s.iters[d] = 0;
-        if (d == 0) *s.nactive = s.D;
+        if (d == 0) { *s.nactive = s.D; *s.done_blocks = 0; }
     }
 }
 
@@ -648,10 +659,31 @@ __global__ __launch_bounds__(1024) void k_cg_step(CgState s, const double *lambd
 {
     __shared__ double red[16];
     __shared__ int go;
+    if (*s.nactive == 0) {                // every column has stopped: a launch the host had enqueued ahead
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            s.status[1] = 0;
+            __threadfence_system();
+            s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+        }
+        return;
+    }
     cg_post(s, lambda_p, iter, red);
     __threadfence_block();
     __syncthreads();
     if (iter < maxiter) cg_pre(s, iter + 1, red, go);
+    // the last column to finish reports (iteration, active columns) to the host, which enqueues ahead of the device and
+    // stops when it reads 0 active columns: no stream synchronisation inside the solve
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(s.done_blocks, 1) == s.D - 1) {
+            *s.done_blocks = 0;
+            const int na = __hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s.status[1] = (uint64_t)(iter < maxiter ? na : 0);
+            __threadfence_system();
+            s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+        }
+    }
 }
 
 // ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
@@ -838,7 +870,7 @@ extern "C" int bdf_feat_destroy(bdf_feat *f)
     hipSetDevice(f->ctx->device);
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->dense_dev); hipFree(f->rowptr_dev); hipFree(f->colind_dev); hipFree(f->rvals_dev);
-    hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev);
+    hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev); hipFree(f->chol_ws);
     delete f;
     return BDF_OK;
 }
@@ -914,11 +946,39 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     s.n = numF; s.D = D; s.X = beta_out; s.R = R; s.P = P; s.Z = Z;
     s.bknum = scal; s.bkden = scal + D; s.tolb = scal + 2 * D;
     s.active = ints; s.iters = ints + D; s.nactive = ints + 2 * D;
+    s.done_blocks = ints + 2 * D + 1;
+    if (!ctx->cg_status) {
+        BDF_HIP(hipHostMalloc((void **)&ctx->cg_status, 2 * sizeof(uint64_t), hipHostMallocMapped));
+        ctx->cg_status[0] = ctx->cg_status[1] = 0;
+    }
+    struct SkipGuard { bdf_ctx *c; ~SkipGuard() { c->skip_flag = nullptr; } } guard{ctx};
+    s.status = ctx->cg_status;
+    s.gen = ++ctx->cg_gen;
     const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
     hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol);
     BDF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cg_pre, dim3(D), cgb, 0, ctx->stream, s, 1);
+    // The host enqueues iterations AHEAD of the device (no stream synchronisation: the device never idles between
+    // iterations) and reads the (iteration, active columns) word the device writes to host-mapped memory after every
+    // iteration.  Run-ahead is bounded to CG_AHEAD iterations; once every column has stopped, the launches already enqueued
+    // return at once (product kernels through ctx->skip_flag, k_cg_step by itself).
+    constexpr int CG_AHEAD = 3;
+    ctx->skip_flag = s.nactive;
     for (int iter = 1; iter <= maxiter; iter++) {
+        if (iter > CG_AHEAD) {
+            const uint64_t want = ((uint64_t)s.gen << 32) | (uint32_t)(iter - CG_AHEAD);
+            uint64_t st;
+            long spins = 0;
+            while ((st = s.status[0]) < want || (st >> 32) != s.gen) {
+                if (++spins > 2000000000L || ((spins & 0xfffff) == 0 && hipStreamQuery(ctx->stream) != hipErrorNotReady)) {
+                    // the stream drained without the report (a device fault): stop enqueuing
+                    st = s.status[0];
+                    if (st < want || (st >> 32) != s.gen) { bdf_set_error("cg_solve: the device did not report iteration %d", iter - CG_AHEAD); return BDF_ERR_HIP; }
+                    break;
+                }
+            }
+            if (s.status[1] == 0) break;
+        }
         if (use_ff && D <= 64) {
             if ((rc = dense_nn(ctx, f->FF_dev, numF, numF, P, 1, numF, D, Z, 1, numF, nullptr, nullptr))) return rc;
         } else if (use_ff) {
@@ -934,13 +994,8 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
         // bottom of this iteration and top of the next in one launch
         hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         BDF_HIP(hipGetLastError());
-        if (iter % 8 == 0 || iter == maxiter) {
-            int nact = 0;
-            BDF_HIP(hipMemcpyAsync(&nact, s.nactive, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-            BDF_HIP(hipStreamSynchronize(ctx->stream));
-            if (nact == 0) break;
-        }
     }
+    ctx->skip_flag = nullptr;
     *iters_dev = s.iters;
     return BDF_OK;
 }
@@ -962,7 +1017,7 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
     size_t nLr = (size_t)DP * DP + 2 * DP, nT = (size_t)D * N, nE2 = (size_t)D * numF, nB = (size_t)numF * D, nTm = (size_t)N * D;
     size_t total = nLr + nT + nE2 + nB * 4 + nTm + 3 * (size_t)D + 64 + (size_t)D * D;
     void *sv;
-    int rc = bdf_scratch(ctx, total * sizeof(double) + (2 * (size_t)D + 16) * sizeof(int), &sv);
+    int rc = bdf_scratch(ctx, total * sizeof(double) + (2 * (size_t)D + 16) * sizeof(int), &sv);      // ints: active D | iters D | nactive | done
     if (rc) return rc;
     double *Lr = (double *)sv, *T = Lr + nLr, *E2s = T + nT, *rhs = E2s + nE2, *R = rhs + nB, *P = R + nB, *Z = P + nB,
            *Tm = Z + nB, *scal = Tm + nTm, *G = scal + 3 * D + 64;
@@ -984,19 +1039,19 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
     }
     if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, rhs, nB * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
 
-    bool direct = use_ff && numF <= 64;
     if (use_ff && (rc = ensure_FF(f))) return rc;
-    if (direct) {
-        // solve_full (sampling.jl:314-320) by Cholesky on one wave
+    if (use_ff) {
+        // solve_full (sampling.jl:314-320): a direct solve, Cholesky on one wave up to 64 features, blocked on the matrix cores above
         if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
         else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
-        else hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
+        else if (numF <= 64) hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, D, f->FF_dev, lambda_beta_dev, rhs, beta_out, ctx->flag_dev);
+        else if ((rc = bdf_chol_solve(ctx, f, D, lambda_beta_dev, rhs, beta_out))) return rc;
         BDF_HIP(hipGetLastError());
         if (iters_out) BDF_HIP(hipMemsetAsync(iters_out, 0, D * sizeof(int32_t), ctx->stream));
     } else {
-        // D simultaneous cg_AtA solves; with use_ff the operator is the precomputed F'F (same system, numF > 64)
+        // D simultaneous cg_AtA solves (solve_cg2, parallel_matrix.jl:488-507)
         int *cg_iters = nullptr;
-        if ((rc = cg_solve(ctx, f, use_ff != 0, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+        if ((rc = cg_solve(ctx, f, false, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
         if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
     }
     if (sample_lambda) {
@@ -1105,16 +1160,11 @@ extern "C" int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *fc, const bdf_p
     BDF_HIP(hipGetLastError());
     if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, t, numF * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if ((rc = ensure_FF(f))) return rc;
-    if (numF <= 64) {
-        if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
-        else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
-        else hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
-        BDF_HIP(hipGetLastError());
-    } else {
-        int *it = nullptr;
-        if ((rc = cg_solve(ctx, f, true, 1, lam, rs, beta_out, 2.220446049250313e-16 * (double)numF, (int)numF, R, P, Z, Tm, scal, ints, &it)))
-            return rc;
-    }
+    if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+    else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+    else if (numF <= 64) hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
+    else if ((rc = bdf_chol_solve(ctx, f, 1, lam, rs, beta_out))) return rc;
+    BDF_HIP(hipGetLastError());
     // linear_values = mean_value + F beta (macau.jl:91)
     if ((rc = feat_apply(ctx, f, false, beta_out, 1, numF, 1, linear_out, 1, N))) return rc;
     if (N > 0) {
