@@ -54,6 +54,25 @@ class Term(C.Structure):
                 ("mean_value", C.c_double), ("linear_values", C.c_void_p), ("factors", C.c_void_p * BDF_MAX_MODES)]
 
 
+BDF_COMM_ID_BYTES = 128
+
+
+class _GibbsTerm(C.Structure):
+    _fields_ = [("rel", C.c_void_p), ("mode", C.c_int32), ("entity_of_mode", C.c_int32 * BDF_MAX_MODES),
+                ("alpha", C.c_double), ("mean_value", C.c_double)]
+
+
+class GibbsEntity(C.Structure):
+    """bdf_gibbs_entity"""
+    _fields_ = [("N", C.c_int64), ("n_real", C.c_int64), ("tag", C.c_uint32), ("n_terms", C.c_int32),
+                ("terms", _GibbsTerm * BDF_MAX_TERMS), ("sample", C.c_void_p * 3),
+                ("mu", C.c_void_p), ("Lambda", C.c_void_p), ("mu0", C.c_void_p), ("WI", C.c_void_p), ("sumU", C.c_void_p),
+                ("UUt", C.c_void_p), ("params", C.c_void_p), ("prior_pack", C.c_void_p), ("draws", C.c_void_p),
+                ("b0", C.c_double), ("nu0", C.c_double)]
+
+
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+
 _SIGS = {
     # name: (restype, argtypes)
     "bdf_last_error": (C.c_char_p, []),
@@ -66,16 +85,11 @@ _SIGS = {
     "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_ctx_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_rows_unfinished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),
-    "bdf_rows_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bdf_gate_snapshot": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bdf_rows_gate_at": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_event_create": (C.c_int, [C.POINTER(C.c_void_p)]),
     "bdf_event_destroy": (C.c_int, [C.c_void_p]),
     "bdf_event_elapsed_us": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_double)]),
     "bdf_ctx_time_next_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_ctx_time_next_hyper": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
-    "bdf_ctx_time_next_gate": (C.c_int, [C.c_void_p, C.c_void_p]),
-    "bdf_rows_gate_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]),
     "bdf_ctx_set_item_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_dev_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "bdf_dev_free": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -124,6 +138,28 @@ _SIGS = {
     "bdf_sample_beta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "bdf_ctx_create_side": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "bdf_ctx_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bdf_layout_build": (C.c_int, [C.c_int64, c_i64p, C.c_int, C.c_int, c_i32p, c_i64p]),
+    "bdf_relation_create_sharded": (C.c_int, [C.c_void_p, C.c_int, c_i64p, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(c_i32p),
+                                              c_i64p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bdf_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "bdf_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
+    "bdf_comm_create_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bdf_comm_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "bdf_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
+    "bdf_allgather_join": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_gibbs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(GibbsEntity), C.POINTER(C.c_void_p)]),
+    "bdf_gibbs_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_gibbs_contexts": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]),
+    "bdf_gibbs_set_test": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double,
+                                     C.c_void_p]),
+    "bdf_gibbs_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_gibbs_sweep": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
+    "bdf_gibbs_current": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
+    "bdf_gibbs_time_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bdf_gibbs_sync": (C.c_int, [C.c_void_p]),
     "bdf_synth_ratings": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, c_i32p, c_i32p,
                                     c_dp, C.c_void_p]),
 }

@@ -46,12 +46,8 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     BDF_HIP(hipMalloc((void **)&c->flag_dev, 16 * sizeof(int)));      // [0] error flag, [1..] self-resetting arrival counters
     BDF_HIP(hipMemsetAsync(c->sweep_dev, 0, sizeof(uint32_t), c->stream));
     BDF_HIP(hipMemsetAsync(c->flag_dev, 0, 16 * sizeof(int), c->stream));
-    BDF_HIP(hipMalloc((void **)&c->rows_done_dev, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t)));
-    BDF_HIP(hipMemsetAsync(c->rows_done_dev, 0, BDF_GATE_COUNTERS * BDF_GATE_STRIDE * sizeof(uint32_t), c->stream));
-    memset(c->rows_done_target, 0, sizeof(c->rows_done_target));
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
-    c->time_gate_stop = nullptr;
     c->sweep_host = 0;
     c->skip_flag = nullptr;
     c->cg_status = nullptr;
@@ -79,7 +75,6 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch) hipFree(ctx->scratch);
     hipFree(ctx->sweep_dev);
     hipFree(ctx->flag_dev);
-    hipFree(ctx->rows_done_dev);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
@@ -164,44 +159,17 @@ extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
     BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         BDF_HIP(hipMemset(ctx->flag_dev, 0, sizeof(int)));
-        if (flag & 32) {
-            bdf_set_error("bdf_rows_gate: timed out waiting for the row kernels of the other context (flag %d)", flag);
+        if (flag & 16) {
+            bdf_set_error("row sampler: a split row's pieces did not all arrive in time (flag %d)", flag);
             return BDF_ERR_HIP;
         }
-        bdf_set_error("a matrix that must be positive definite was not (flag %d)", flag);
+        // bits: 1 a row's P_i, 2 the Normal-Wishart draw, 4 Lambda of the beta noise, 8 FF + lambda I of the direct solve
+        bdf_set_error("a matrix that must be positive definite was not (flag %d: %s%s%s%s)", flag, flag & 1 ? "row system " : "",
+                      flag & 2 ? "hyperprior " : "", flag & 4 ? "noise precision " : "", flag & 8 ? "FF + lambda I" : "");
         return BDF_ERR_NOTPD;
     }
     return BDF_OK;
 }
-
-// ---- cross-stream hand-over without events: a one-wave gate kernel on the waiting stream ---------------------------
-// hipEventRecord after a row kernel + hipStreamWaitEvent costs the recording stream ~9 us per launch (tools/event_cost3.hip);
-// completion counters written by the row kernel itself and a gate kernel polling them on the waiting stream cost it ~2.5.
-namespace {
-struct GateTargets { uint32_t t[BDF_GATE_COUNTERS]; };
-
-__global__ __launch_bounds__(64) void k_rows_gate(const uint32_t *counters, GateTargets tg, int *flag, long long max_ticks)
-{
-    const int lane = threadIdx.x;
-    const long long t0 = wall_clock64();                       // 100 MHz
-    const uint32_t want = tg.t[lane];
-    for (;;) {
-        const uint32_t c = __hip_atomic_load(counters + lane * BDF_GATE_STRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (__builtin_amdgcn_ballot_w64((int32_t)(c - want) < 0) == 0) break;
-        __builtin_amdgcn_s_sleep(4);
-        if (wall_clock64() - t0 > max_ticks) {                 // bounded: a bug must not hang the device
-            if (lane == 0) atomicOr(flag, 32);
-            break;
-        }
-    }
-}
-
-__global__ void k_gate_bump(uint32_t *counters)
-{
-    if (threadIdx.x < BDF_GATE_COUNTERS)
-        __hip_atomic_fetch_add(counters + threadIdx.x * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-}  // namespace
 
 // ---- timing of a row-kernel launch by HIP events carried by the kernel's own dispatch packet ------------------------
 extern "C" int bdf_event_create(void **ev)
@@ -242,78 +210,6 @@ extern "C" int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop)
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_hyper: ctx is NULL");
     ctx->time_h_start = (hipEvent_t)start;
     ctx->time_h_stop = (hipEvent_t)stop;
-    return BDF_OK;
-}
-
-extern "C" int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer)
-{
-    BDF_REQUIRE(waiter && producer, BDF_ERR_ARG, "bdf_rows_gate: NULL context");
-    BDF_REQUIRE(waiter->device == producer->device, BDF_ERR_ARG, "bdf_rows_gate: the contexts are on different devices");
-    if (waiter->stream == producer->stream) return BDF_OK;     // same stream: already ordered
-    GateTargets tg;
-    memcpy(tg.t, producer->rows_done_target, sizeof(tg.t));
-    static const long long max_ticks = 100000000LL * (getenv("BDF_GATE_TIMEOUT_S") ? atoll(getenv("BDF_GATE_TIMEOUT_S")) : 30);
-    hipLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, producer->rows_done_dev, tg, waiter->flag_dev, max_ticks);
-    BDF_HIP(hipGetLastError());
-    return BDF_OK;
-}
-
-extern "C" int bdf_gate_snapshot(const bdf_ctx *producer, uint32_t *targets)
-{
-    BDF_REQUIRE(producer && targets, BDF_ERR_ARG, "bdf_gate_snapshot: NULL argument");
-    memcpy(targets, producer->rows_done_target, sizeof(producer->rows_done_target));
-    return BDF_OK;
-}
-
-extern "C" int bdf_rows_gate_at(bdf_ctx *waiter, const bdf_ctx *producer, const uint32_t *targets)
-{
-    BDF_REQUIRE(waiter && producer && targets, BDF_ERR_ARG, "bdf_rows_gate_at: NULL argument");
-    BDF_REQUIRE(waiter->device == producer->device, BDF_ERR_ARG, "bdf_rows_gate_at: the contexts are on different devices");
-    if (waiter->stream == producer->stream) return BDF_OK;
-    GateTargets tg;
-    memcpy(tg.t, targets, sizeof(tg.t));
-    static const long long max_ticks = 100000000LL * (getenv("BDF_GATE_TIMEOUT_S") ? atoll(getenv("BDF_GATE_TIMEOUT_S")) : 30);
-    // (the end of the gate, not the start event of the kernel behind it, is when that kernel can begin: an event attached
-    // to a dispatch that waits behind a spinning gate is stamped while it waits)
-    hipExtLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, nullptr, waiter->time_gate_stop, 0,
-                          producer->rows_done_dev, tg, waiter->flag_dev, max_ticks);
-    waiter->time_gate_stop = nullptr;
-    BDF_HIP(hipGetLastError());
-    return BDF_OK;
-}
-
-extern "C" int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop)
-{
-    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_time_next_gate: ctx is NULL");
-    ctx->time_gate_stop = (hipEvent_t)stop;
-    return BDF_OK;
-}
-
-extern "C" int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable)
-{
-    BDF_REQUIRE(waiter && producer && usable, BDF_ERR_ARG, "bdf_rows_gate_selftest: NULL argument");
-    *usable = 0;
-    if (waiter->device != producer->device) return BDF_OK;
-    if (waiter->stream == producer->stream) { *usable = 1; return BDF_OK; }
-    // the gate is enqueued FIRST and the kernel that satisfies it afterwards on the other stream: if the two streams
-    // cannot run side by side (they share a hardware queue), the gate times out (20 ms) instead of passing
-    BDF_HIP(hipStreamSynchronize(producer->stream));
-    BDF_HIP(hipStreamSynchronize(waiter->stream));
-    GateTargets tg;
-    for (int c = 0; c < BDF_GATE_COUNTERS; c++) tg.t[c] = ++producer->rows_done_target[c];
-    hipLaunchKernelGGL(k_rows_gate, dim3(1), dim3(64), 0, waiter->stream, producer->rows_done_dev, tg, waiter->flag_dev, 2000000LL);
-    hipLaunchKernelGGL(k_gate_bump, dim3(1), dim3(64), 0, producer->stream, producer->rows_done_dev);
-    BDF_HIP(hipGetLastError());
-    BDF_HIP(hipStreamSynchronize(waiter->stream));
-    BDF_HIP(hipStreamSynchronize(producer->stream));
-    int flag = 0;
-    BDF_HIP(hipMemcpy(&flag, waiter->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
-    if (flag & 32) {
-        flag &= ~32;
-        BDF_HIP(hipMemcpy(waiter->flag_dev, &flag, sizeof(int), hipMemcpyHostToDevice));
-    } else {
-        *usable = 1;
-    }
     return BDF_OK;
 }
 
@@ -400,8 +296,32 @@ extern "C" int bdf_index_build(int n_modes, const int64_t *dims, int64_t nnz, co
     return BDF_OK;
 }
 
-extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz,
-                                   const void *ids, int id_bytes, const double *values, bdf_rel **out)
+// ---- row layout of an entity shared by several GPUs (host-only) ------------------------------------------------------------
+// Rows in falling order of degree (stable) are dealt to the ranks round-robin (the reference deals rows i:P:N to its P
+// workers, src/sampling.jl:154), a rank's rows round-robin to `chunks` chunks; row r of chunk c of rank p sits at internal
+// position (c * world + p) * cmax + r: every chunk is one contiguous, rank-major region of the factor matrix -- what an
+// in-place all-gather fills -- and the row kernel of chunk c + 1 can run while chunk c is exchanged.
+extern "C" int bdf_layout_build(int64_t N, const int64_t *degree, int world, int chunks, int32_t *pos_out, int64_t *cmax_out)
+{
+    BDF_REQUIRE(N >= 0 && N < (int64_t)0x7fffffff && (N == 0 || (degree && pos_out)) && cmax_out, BDF_ERR_ARG, "bdf_layout_build: bad argument");
+    BDF_REQUIRE(world >= 1 && chunks >= 1, BDF_ERR_ARG, "bdf_layout_build: world and chunks must be positive");
+    const int64_t per_rank = (N + world - 1) / world;
+    const int64_t cmax = std::max<int64_t>(1, (per_rank + chunks - 1) / chunks);
+    BDF_REQUIRE(cmax * world * chunks < (int64_t)0x7fffffff, BDF_ERR_ARG, "bdf_layout_build: layout too large");
+    std::vector<int32_t> ord((size_t)N);
+    std::iota(ord.begin(), ord.end(), 0);
+    std::stable_sort(ord.begin(), ord.end(), [&](int32_t x, int32_t y) { return degree[x] > degree[y]; });
+    for (int64_t s = 0; s < N; s++) {
+        const int64_t p = s % world, r = s / world, c = r % chunks, i = r / chunks;
+        pos_out[ord[(size_t)s]] = (int32_t)((c * world + p) * cmax + i);
+    }
+    *cmax_out = cmax;
+    return BDF_OK;
+}
+
+static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz, const void *ids, int id_bytes,
+                           const double *values, const int32_t *const *pos, const int64_t *cmax, int rank, int world, int chunks,
+                           bdf_rel **out)
 {
     BDF_REQUIRE(ctx && dims && out, BDF_ERR_ARG, "bdf_relation_create: NULL argument");
     BDF_REQUIRE(n_modes >= 2 && n_modes <= BDF_MAX_MODES, BDF_ERR_ARG,
@@ -411,16 +331,28 @@ extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dim
     BDF_REQUIRE(nnz == 0 || (ids && values), BDF_ERR_ARG, "bdf_relation_create: ids/values NULL");
     for (int m = 0; m < n_modes; m++)
         BDF_REQUIRE(dims[m] >= 0 && dims[m] < (int64_t)0x7fffffff, BDF_ERR_ARG, "bdf_relation_create: dims[%d]=%lld unsupported", m, (long long)dims[m]);
+    const bool sharded = pos != nullptr;
+    if (sharded) {
+        BDF_REQUIRE(cmax && world >= 1 && rank >= 0 && rank < world && chunks >= 1, BDF_ERR_ARG, "bdf_relation_create_sharded: bad rank / world / chunks");
+        for (int m = 0; m < n_modes; m++) BDF_REQUIRE(pos[m] != nullptr && cmax[m] >= 1, BDF_ERR_ARG, "bdf_relation_create_sharded: mode %d has no layout", m);
+    }
     BDF_HIP(hipSetDevice(ctx->device));
     auto idat = [&](int64_t i, int m) -> int64_t { return id_at(ids, id_bytes, nnz, i, m); };
 
     static std::atomic<uint64_t> next_serial{1};
     bdf_rel *r = new bdf_rel();
+    struct Guard { bdf_rel *r; ~Guard() { if (r) bdf_relation_destroy(r); } } guard{r};        // error paths free what was built
     r->ctx = ctx;
     r->serial = next_serial.fetch_add(1);
     r->n_modes = n_modes;
     r->nnz = nnz;
-    for (int m = 0; m < n_modes; m++) r->dims[m] = dims[m];
+    r->sharded = sharded ? 1 : 0; r->rank = sharded ? rank : 0; r->world = sharded ? world : 1; r->chunks = sharded ? chunks : 1;
+    for (int m = 0; m < n_modes; m++) {
+        r->dims[m] = dims[m];
+        r->nint[m] = sharded ? cmax[m] * world * chunks : dims[m];
+        r->idx[m].rowptr_dev = nullptr; r->idx[m].colidx_dev = nullptr; r->idx[m].vals_dev = nullptr; r->idx[m].perm_dev = nullptr;
+        r->idx[m].order_dev = nullptr; r->idx[m].own_nnz = 0;
+    }
     double s = 0.0;
     for (int64_t i = 0; i < nnz; i++) s += values[i];
     r->value_mean = nnz ? s / (double)nnz : NAN;
@@ -434,39 +366,103 @@ extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dim
             ris[m] = r->idx[m].rowids.data();
         }
         int rc = bdf_index_build(n_modes, dims, nnz, ids, id_bytes, rps, ris);
-        if (rc) { delete r; return rc; }
+        if (rc) return rc;
     }
     for (int m = 0; m < n_modes; m++) {
         bdf_mode_index &ix = r->idx[m];
         const int64_t N = dims[m];
-        std::vector<int32_t> colidx((size_t)nnz * (size_t)(n_modes - 1));
-        std::vector<double> vals((size_t)nnz);
-        std::vector<int32_t> perm((size_t)nnz);
-        for (int64_t q = 0; q < nnz; q++) {
-            int64_t i = ix.rowids[(size_t)q] - 1;
-            perm[(size_t)q] = (int32_t)i;
-            vals[(size_t)q] = values[i];
-            int plane = 0;
-            for (int k = 0; k < n_modes; k++) {
-                if (k == m) continue;
-                colidx[(size_t)plane * (size_t)nnz + (size_t)q] = (int32_t)(idat(i, k) - 1);
-                plane++;
-            }
-        }
         ix.order.resize((size_t)N);
         std::iota(ix.order.begin(), ix.order.end(), 0);
         std::stable_sort(ix.order.begin(), ix.order.end(), [&](int32_t x, int32_t y) {
             return (ix.rowptr[(size_t)x + 1] - ix.rowptr[(size_t)x]) > (ix.rowptr[(size_t)y + 1] - ix.rowptr[(size_t)y]);
         });
         int rc;
-        if ((rc = upload(ctx, ix.rowptr, &ix.rowptr_dev))) return rc;
+        if (!sharded) {
+            std::vector<int32_t> colidx((size_t)nnz * (size_t)(n_modes - 1));
+            std::vector<double> vals((size_t)nnz);
+            std::vector<int32_t> perm((size_t)nnz);
+            for (int64_t q = 0; q < nnz; q++) {
+                int64_t i = ix.rowids[(size_t)q] - 1;
+                perm[(size_t)q] = (int32_t)i;
+                vals[(size_t)q] = values[i];
+                int plane = 0;
+                for (int k = 0; k < n_modes; k++) {
+                    if (k == m) continue;
+                    colidx[(size_t)plane * (size_t)nnz + (size_t)q] = (int32_t)(idat(i, k) - 1);
+                    plane++;
+                }
+            }
+            if ((rc = upload(ctx, ix.rowptr, &ix.rowptr_dev))) return rc;
+            if ((rc = upload(ctx, colidx, &ix.colidx_dev))) return rc;
+            if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
+            if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
+            if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
+            ix.own_nnz = nnz;
+            continue;
+        }
+        // the rows this rank owns, by internal position (chunk-major): position (c * world + rank) * cmax + i
+        const int64_t cm = cmax[m];
+        std::vector<int32_t> at((size_t)(cm * chunks), -1);         // owned slot -> original row
+        for (int64_t row = 0; row < N; row++) {
+            const int64_t p = pos[m][row];
+            BDF_REQUIRE(p >= 0 && p < r->nint[m], BDF_ERR_ARG, "bdf_relation_create_sharded: position %lld of mode %d out of range", (long long)p, m);
+            const int64_t blk = p / cm, c = blk / world;
+            if (blk % world == rank) at[(size_t)(c * cm + p % cm)] = (int32_t)row;
+        }
+        ix.chunk_begin.assign((size_t)chunks + 1, 0);
+        ix.own_q.assign(1, 0);
+        for (int c = 0; c < chunks; c++) {
+            ix.chunk_begin[(size_t)c] = (int64_t)ix.own_orig.size();
+            for (int64_t i = 0; i < cm; i++) {
+                const int32_t row = at[(size_t)(c * cm + i)];
+                if (row < 0) continue;
+                ix.own_orig.push_back(row);
+                ix.own_pos.push_back((int32_t)(((int64_t)c * world + rank) * cm + i));
+                ix.own_q.push_back(ix.own_q.back() + (ix.rowptr[(size_t)row + 1] - ix.rowptr[(size_t)row]));
+            }
+        }
+        ix.chunk_begin[(size_t)chunks] = (int64_t)ix.own_orig.size();
+        const int64_t on = ix.own_q.back();
+        ix.own_nnz = on;
+        std::vector<int32_t> colidx((size_t)on * (size_t)(n_modes - 1));
+        std::vector<double> vals((size_t)on);
+        std::vector<int32_t> perm((size_t)on);
+        for (size_t o = 0; o < ix.own_orig.size(); o++) {
+            const int64_t row = ix.own_orig[o];
+            int64_t dst = ix.own_q[o];
+            for (int64_t q = ix.rowptr[(size_t)row]; q < ix.rowptr[(size_t)row + 1]; q++, dst++) {
+                const int64_t i = ix.rowids[(size_t)q] - 1;
+                perm[(size_t)dst] = (int32_t)i;
+                vals[(size_t)dst] = values[i];
+                int plane = 0;
+                for (int k = 0; k < n_modes; k++) {
+                    if (k == m) continue;
+                    colidx[(size_t)plane * (size_t)on + (size_t)dst] = pos[k][idat(i, k) - 1];
+                    plane++;
+                }
+            }
+        }
         if ((rc = upload(ctx, colidx, &ix.colidx_dev))) return rc;
         if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
         if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
-        if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
     }
+    guard.r = nullptr;
     *out = r;
     return BDF_OK;
+}
+
+extern "C" int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz,
+                                   const void *ids, int id_bytes, const double *values, bdf_rel **out)
+{
+    return relation_create(ctx, n_modes, dims, nnz, ids, id_bytes, values, nullptr, nullptr, 0, 1, 1, out);
+}
+
+extern "C" int bdf_relation_create_sharded(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz, const void *ids,
+                                           int id_bytes, const double *values, const int32_t *const *pos, const int64_t *cmax,
+                                           int rank, int world, int chunks, bdf_rel **out)
+{
+    BDF_REQUIRE(pos, BDF_ERR_ARG, "bdf_relation_create_sharded: pos is NULL");
+    return relation_create(ctx, n_modes, dims, nnz, ids, id_bytes, values, pos, cmax, rank, world, chunks, out);
 }
 
 extern "C" int bdf_relation_destroy(bdf_rel *rel)
@@ -521,9 +517,10 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         // a relation may be used from any context (stream) of the device it was created on
         BDF_REQUIRE(t.rel->ctx->device == ctx->device, BDF_ERR_ARG, "%s: terms[%d].rel lives on another device", who, r);
         BDF_REQUIRE(t.mode >= 0 && t.mode < t.rel->n_modes, BDF_ERR_ARG, "%s: terms[%d].mode=%d out of range", who, r, t.mode);
-        BDF_REQUIRE(t.rel->dims[t.mode] == N, BDF_ERR_ARG,
+        BDF_REQUIRE(t.rel->nint[t.mode] == N, BDF_ERR_ARG,
                     "%s: entity has %lld instances, relation %d has data for %lld (ArgumentError)", who, (long long)N, r,
-                    (long long)t.rel->dims[t.mode]);
+                    (long long)t.rel->nint[t.mode]);
+        BDF_REQUIRE(r == 0 || t.rel->sharded == terms[0].rel->sharded, BDF_ERR_ARG, "%s: relations with and without a layout mixed", who);
         const bdf_mode_index &ix = t.rel->idx[t.mode];
         TermDev &T = a.t[r];
         T.rowptr = ix.rowptr_dev;
@@ -531,7 +528,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         T.vals = ix.vals_dev;
         T.perm = ix.perm_dev;
         T.linear = t.linear_values;
-        T.nnz = t.rel->nnz;
+        T.nnz = ix.own_nnz;                 // plane stride of colidx: the observations held on this device
         T.n_other = t.rel->n_modes - 1;
         int plane = 0;
         bool lean = t.linear_values == nullptr && T.n_other <= 2, wide = false;
@@ -539,8 +536,8 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
             if (k == t.mode) continue;
             BDF_REQUIRE(t.factors[k] != nullptr, BDF_ERR_ARG, "%s: terms[%d].factors[%d] is NULL", who, r, k);
             T.fac[plane++] = t.factors[k];
-            lean = lean && t.rel->dims[k] < ((int64_t)1 << 32);
-            wide = wide || !(t.rel->dims[k] < (1 << 24) && t.rel->dims[k] * (int64_t)D * 8 < ((int64_t)1 << 32));
+            lean = lean && t.rel->nint[k] < ((int64_t)1 << 32);
+            wide = wide || !(t.rel->nint[k] < (1 << 24) && t.rel->nint[k] * (int64_t)D * 8 < ((int64_t)1 << 32));
         }
         T.lean = !lean ? 0 : (!wide ? 1 : (D > 32 ? 2 : 0));      // 2: 64-bit row offsets (compiled for D > 32 only)
         // parity hook (bdf_ctx_set_gather): force the general path / the 64-bit lean path (D > 32)
@@ -557,7 +554,6 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
     a.sweep = ctx->sweep_host;
     a.seed = ctx->seed;
     a.flag = ctx->flag_dev;
-    a.done = getenv("BDF_EXP_NO_DONE") ? nullptr : ctx->rows_done_dev;
     return BDF_OK;
 }
 
@@ -570,6 +566,15 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     if (rc) return rc;
     BDF_REQUIRE(out != nullptr, BDF_ERR_ARG, "bdf_sample_rows: out is NULL");
     BDF_REQUIRE(n_shards >= 1 && shard >= 0 && shard < n_shards, BDF_ERR_ARG, "bdf_sample_rows: shard %d of %d", shard, n_shards);
+    if (terms[0].rel->sharded) {
+        // a relation created with a layout holds this rank's rows only: (shard, n_shards) = (chunk, chunks)
+        BDF_REQUIRE(n_shards == terms[0].rel->chunks, BDF_ERR_ARG, "bdf_sample_rows: the relation was created with %d chunks: pass (chunk, %d)",
+                    terms[0].rel->chunks, terms[0].rel->chunks);
+        for (int r = 1; r < n_terms; r++)
+            BDF_REQUIRE(terms[r].rel->sharded && terms[r].rel->chunks == terms[0].rel->chunks && terms[r].rel->rank == terms[0].rel->rank &&
+                            terms[r].rel->idx[terms[r].mode].own_orig == terms[0].rel->idx[terms[0].mode].own_orig,
+                        BDF_ERR_ARG, "bdf_sample_rows: the entity's relations were created with different layouts");
+    }
     const bdf_rel *rels[BDF_MAX_TERMS];
     int modes[BDF_MAX_TERMS];
     for (int r = 0; r < n_terms; r++) {

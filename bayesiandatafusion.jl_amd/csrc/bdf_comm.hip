@@ -1,0 +1,172 @@
+// bdf_comm.hip -- the exchange step of the multi-GPU sweep: after a rank has sampled its rows of an entity, every rank needs
+// every row before the next entity's rows are sampled (the reference ships the whole factor to every worker per call,
+// src/sampling.jl:155-167).  With the row layout of bdf_layout_build a chunk of the factor matrix is one contiguous,
+// rank-major region, so the exchange is an IN-PLACE all-gather -- no packing kernels -- on its own stream, and the row
+// kernel of chunk c + 1 runs while chunk c is exchanged.
+//
+// Transport: RCCL (ncclAllGather over xGMI), resolved with dlopen at the first use so that the library loads on hosts
+// without RCCL; or a host callback (test rigs with several ranks on one GPU, where RCCL refuses to run: the block is staged
+// through host memory and the caller's function -- e.g. a gloo all-gather -- does the exchange).
+#include "bdf_common.h"
+#include <dlfcn.h>
+
+namespace {
+struct NcclId { char internal[128]; };
+typedef int (*fn_get_id)(NcclId *);
+typedef int (*fn_init_rank)(void **, int, NcclId, int);
+typedef int (*fn_all_gather)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef int (*fn_destroy)(void *);
+typedef const char *(*fn_err)(int);
+struct Rccl {
+    void *h = nullptr;
+    fn_get_id get_id = nullptr; fn_init_rank init_rank = nullptr; fn_all_gather all_gather = nullptr; fn_destroy destroy = nullptr;
+    fn_err err = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl()
+{
+    if (g_rccl.h) return BDF_OK;
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    void *h = nullptr;
+    for (const char *n : names)
+        if ((h = dlopen(n, RTLD_NOW | RTLD_GLOBAL))) break;
+    BDF_REQUIRE(h, BDF_ERR_HIP, "bdf_comm: librccl.so not found (%s)", dlerror());
+    g_rccl.get_id = (fn_get_id)dlsym(h, "ncclGetUniqueId");
+    g_rccl.init_rank = (fn_init_rank)dlsym(h, "ncclCommInitRank");
+    g_rccl.all_gather = (fn_all_gather)dlsym(h, "ncclAllGather");
+    g_rccl.destroy = (fn_destroy)dlsym(h, "ncclCommDestroy");
+    g_rccl.err = (fn_err)dlsym(h, "ncclGetErrorString");
+    BDF_REQUIRE(g_rccl.get_id && g_rccl.init_rank && g_rccl.all_gather && g_rccl.destroy, BDF_ERR_HIP, "bdf_comm: librccl.so lacks a symbol");
+    g_rccl.h = h;
+    return BDF_OK;
+}
+#define BDF_NCCL(expr)                                                                                        \
+    do {                                                                                                      \
+        int e__ = (expr);                                                                                     \
+        if (e__ != 0) { bdf_set_error("%s failed: %s", #expr, g_rccl.err ? g_rccl.err(e__) : "?"); return BDF_ERR_HIP; } \
+    } while (0)
+}  // namespace
+
+struct bdf_comm {
+    bdf_ctx *ctx;
+    int rank, world;
+    void *nccl;                      // ncclComm_t, or NULL with the host transport
+    bdf_exchange_fn cb;
+    void *cb_user;
+    hipStream_t stream;              // the exchange runs here
+    hipEvent_t ev_rows, ev_done;
+    std::vector<char> hsend, hrecv;
+};
+
+extern "C" int bdf_comm_unique_id(void *id_out)
+{
+    BDF_REQUIRE(id_out, BDF_ERR_ARG, "bdf_comm_unique_id: NULL argument");
+    int rc = load_rccl();
+    if (rc) return rc;
+    NcclId id;
+    BDF_NCCL(g_rccl.get_id(&id));
+    memcpy(id_out, &id, sizeof(id));
+    return BDF_OK;
+}
+
+static int comm_new(bdf_ctx *ctx, int rank, int world, bdf_comm **out)
+{
+    BDF_REQUIRE(ctx && out && world >= 1 && rank >= 0 && rank < world, BDF_ERR_ARG, "bdf_comm_create: bad argument");
+    BDF_HIP(hipSetDevice(ctx->device));
+    bdf_comm *c = new bdf_comm();
+    c->ctx = ctx; c->rank = rank; c->world = world; c->nccl = nullptr; c->cb = nullptr; c->cb_user = nullptr;
+    BDF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    BDF_HIP(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
+    BDF_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    *out = c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_comm_create(bdf_ctx *ctx, int rank, int world, const void *unique_id, bdf_comm **out)
+{
+    BDF_REQUIRE(unique_id, BDF_ERR_ARG, "bdf_comm_create: unique_id is NULL");
+    int rc = load_rccl();
+    if (rc) return rc;
+    bdf_comm *c;
+    if ((rc = comm_new(ctx, rank, world, &c))) return rc;
+    NcclId id;
+    memcpy(&id, unique_id, sizeof(id));
+    int e = g_rccl.init_rank(&c->nccl, world, id, rank);
+    if (e != 0) {
+        bdf_set_error("ncclCommInitRank failed: %s", g_rccl.err ? g_rccl.err(e) : "?");
+        bdf_comm_destroy(c);
+        return BDF_ERR_HIP;
+    }
+    *out = c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_comm_create_host(bdf_ctx *ctx, int rank, int world, bdf_exchange_fn fn, void *user, bdf_comm **out)
+{
+    BDF_REQUIRE(fn, BDF_ERR_ARG, "bdf_comm_create_host: fn is NULL");
+    bdf_comm *c;
+    int rc = comm_new(ctx, rank, world, &c);
+    if (rc) return rc;
+    c->cb = fn; c->cb_user = user;
+    *out = c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_comm_destroy(bdf_comm *c)
+{
+    if (!c) return BDF_OK;
+    (void)hipSetDevice(c->ctx->device);
+    (void)hipStreamSynchronize(c->stream);
+    if (c->nccl && g_rccl.destroy) g_rccl.destroy(c->nccl);
+    (void)hipEventDestroy(c->ev_rows); (void)hipEventDestroy(c->ev_done);
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_comm_size(const bdf_comm *c, int *rank, int *world)
+{
+    BDF_REQUIRE(c && rank && world, BDF_ERR_ARG, "bdf_comm_size: NULL argument");
+    *rank = c->rank; *world = c->world;
+    return BDF_OK;
+}
+
+// chunk `chunk` of `chunks` of the N x D factor matrix `sample` (N = chunks * world * cmax rows): every rank contributes its
+// block [(chunk * world + rank) * cmax, + cmax) and receives the others', in place.  Ordered after the work enqueued so far
+// on ctx's stream; runs on the communicator's stream; bdf_allgather_join makes ctx's stream wait for every exchange so far.
+extern "C" int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *c, int D, int64_t N, double *sample, int chunk, int chunks)
+{
+    BDF_REQUIRE(ctx && c && sample, BDF_ERR_ARG, "bdf_allgather_rows: NULL argument");
+    BDF_REQUIRE(chunks >= 1 && chunk >= 0 && chunk < chunks && N % ((int64_t)chunks * c->world) == 0, BDF_ERR_ARG,
+                "bdf_allgather_rows: %lld rows are not %d chunks x %d ranks x cmax", (long long)N, chunks, c->world);
+    const int64_t cmax = N / ((int64_t)chunks * c->world);
+    const size_t count = (size_t)cmax * (size_t)D;                         // doubles per rank
+    double *region = sample + (size_t)chunk * (size_t)c->world * count;
+    if (c->world == 1 || count == 0) return BDF_OK;
+    if (c->nccl) {
+        BDF_HIP(hipEventRecord(c->ev_rows, ctx->stream));
+        BDF_HIP(hipStreamWaitEvent(c->stream, c->ev_rows, 0));
+        BDF_NCCL(g_rccl.all_gather(region + (size_t)c->rank * count, region, count, 8 /* ncclFloat64 */, c->nccl, c->stream));
+        return BDF_OK;
+    }
+    // host transport (test rigs): synchronous
+    const size_t bytes = count * sizeof(double);
+    c->hsend.resize(bytes); c->hrecv.resize(bytes * (size_t)c->world);
+    BDF_HIP(hipMemcpyAsync(c->hsend.data(), region + (size_t)c->rank * count, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = c->cb(c->cb_user, c->hsend.data(), c->hrecv.data(), bytes);
+    BDF_REQUIRE(rc == 0, BDF_ERR_HIP, "bdf_allgather_rows: the host exchange function returned %d", rc);
+    BDF_HIP(hipMemcpyAsync(region, c->hrecv.data(), bytes * (size_t)c->world, hipMemcpyHostToDevice, ctx->stream));
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    return BDF_OK;
+}
+
+extern "C" int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *c)
+{
+    BDF_REQUIRE(ctx && c, BDF_ERR_ARG, "bdf_allgather_join: NULL argument");
+    if (!c->nccl || c->world == 1) return BDF_OK;
+    BDF_HIP(hipEventRecord(c->ev_done, c->stream));
+    BDF_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
+    return BDF_OK;
+}

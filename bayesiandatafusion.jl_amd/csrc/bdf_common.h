@@ -25,9 +25,6 @@ void bdf_set_error(const char *fmt, ...);
         if (!(cond)) { bdf_set_error(__VA_ARGS__); return (code); }                        \
     } while (0)
 
-#define BDF_GATE_COUNTERS 64
-#define BDF_GATE_STRIDE 16          // uint32 per counter slot (64 bytes)
-
 struct bdf_ctx {
     int device;
     hipStream_t stream;
@@ -44,13 +41,8 @@ struct bdf_ctx {
     int item_size;             // K1: observations per work item (rows longer than this are split)
     int piece_size;            // K1: ... into pieces of at most this many observations
     int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)
-    // row-kernel completion counters (bdf_rows_gate): counter c (one per 64 bytes) is incremented by every wave w of
-    // every row-kernel launch with w % 64 == c when its stores have completed; the host keeps the running totals
-    uint32_t *rows_done_dev;
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
-    hipEvent_t time_gate_stop;             // bdf_ctx_time_next_gate: end of the next gate kernel enqueued on this context
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
-    uint32_t rows_done_target[BDF_GATE_COUNTERS];
     // batched CG (k_feat.hip): device flag that lets product kernels enqueued ahead return at once (NULL outside a solve),
     // and the host-mapped words through which the device reports (iteration, active columns)
     const int *skip_flag;
@@ -70,6 +62,13 @@ struct bdf_mode_index {
     double  *vals_dev;             // nnz values in mode order
     int32_t *perm_dev;             // nnz: 0-based COO row number in mode order
     int32_t *order_dev;
+    // relation created with a layout (bdf_relation_create_sharded): the device arrays hold only the observations of the rows
+    // this rank owns, chunk after chunk in internal-position order, and colidx holds INTERNAL positions of the other modes
+    std::vector<int32_t> own_orig;     // original id of every owned row
+    std::vector<int32_t> own_pos;      // its internal position (row of the factor matrix)
+    std::vector<int64_t> own_q;        // offsets of the owned rows' observations in the device arrays (owned + 1)
+    std::vector<int64_t> chunk_begin;  // first owned row of every chunk (chunks + 1)
+    int64_t own_nnz;
 };
 
 struct bdf_rel {
@@ -80,6 +79,9 @@ struct bdf_rel {
     int64_t nnz;
     double value_mean;
     bdf_mode_index idx[BDF_MAX_MODES];
+    int sharded;                       // created with a layout
+    int rank, world, chunks;
+    int64_t nint[BDF_MAX_MODES];       // rows of the factor matrix of every mode (== dims without a layout)
 };
 
 struct bdf_pairs {
@@ -272,7 +274,6 @@ struct SampleArgs {
     const double *prior_c;     // index-reversed Lambda in the accumulator layout, filled by the launch front-end
     double *P_dump, *b_dump;
     int *flag;
-    uint32_t *done;            // the context's completion counters (bdf_rows_gate)
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

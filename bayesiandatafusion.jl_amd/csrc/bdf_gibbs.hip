@@ -1,0 +1,282 @@
+// bdf_gibbs.hip -- one Gibbs iteration of macau (src/macau.jl:80-203) enqueued from native code: the latent rows of every
+// entity (sample_latent_all2! / sample_user2_all!, src/sampling.jl:149-289), the exchange of the sampled rows between GPUs,
+// every entity's hyperprior (src/sampling.jl:116-127, src/normal_wishart.jl:38-42) and the test-set prediction update
+// (macau.jl:142-184) -- the BPMF iteration and the one the multi-GPU path runs.  (Side information adds the beta update and
+// per-row prior means; those iterations are enqueued step by step through the entry points of bdf.h.)
+//
+// Three HIP streams: rows | hyperpriors | prediction updates.  The hyperprior of entity j runs beside the rows of entity
+// j+1, the prediction update of sweep t beside the rows of sweep t+1 (every entity's rows rotate through three buffers).
+// Hand-overs are HIP events that ride on the producing kernel's own dispatch packet (hipExtLaunchKernelGGL stop events):
+// no marker packets on the row stream, no polling kernels.
+#include "bdf_common.h"
+#include <algorithm>
+#include <cstdlib>
+
+struct bdf_gibbs {
+    bdf_ctx *rows, *hyper, *pred;        // rows: the caller's context; hyper / pred: owned (own streams)
+    int D;
+    struct Ent {
+        bdf_gibbs_entity d;
+        int cur;                         // buffer holding the current rows
+        hipEvent_t ev_rows, ev_hyper;    // rows of this sweep complete (and exchanged) | (mu, Lambda) of this sweep complete
+        bool hyper_recorded;
+        hipEvent_t t_start, t_stop;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
+    };
+    std::vector<Ent> ent;
+    bdf_pairs *test;
+    int32_t test_entity[BDF_MAX_MODES];
+    double test_mean, clamp_lo, clamp_hi, class_cut;
+    double *stats_dev;
+    hipEvent_t ev_pred[2];
+    int pred_flip;
+    bool pred_recorded;
+    bdf_comm *comm;                      // nullable: exchange of the sampled rows between the ranks after every entity
+};
+
+namespace {
+
+// do kernels on the two streams run side by side?  HIP multiplexes streams onto a few hardware queues; two streams on one
+// queue serialise whatever the hand-over mechanism.  Timing test: a 60 us spin on each, together.
+__global__ void k_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
+int streams_overlap(hipStream_t a, hipStream_t b, bool *yes)
+{
+    hipEvent_t e0, e1, e2;
+    BDF_HIP(hipEventCreate(&e0)); BDF_HIP(hipEventCreate(&e1)); BDF_HIP(hipEventCreate(&e2));
+    BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
+    float best = 1e9f;
+    for (int rep = 0; rep < 3; rep++) {
+        BDF_HIP(hipEventRecord(e0, a));
+        BDF_HIP(hipStreamWaitEvent(b, e0, 0));
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, 6000LL);       // 100 MHz clock: 60 us
+        hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, 6000LL);
+        BDF_HIP(hipEventRecord(e1, b));
+        BDF_HIP(hipStreamWaitEvent(a, e1, 0));
+        BDF_HIP(hipEventRecord(e2, a));
+        BDF_HIP(hipEventSynchronize(e2));
+        float ms = 0.f;
+        BDF_HIP(hipEventElapsedTime(&ms, e0, e2));
+        best = std::min(best, ms);
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *yes = best < 0.100f;               // side by side: ~0.065 ms; serialised: ~0.125 ms
+    return BDF_OK;
+}
+
+int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bdf_ctx **out)
+{
+    // a few candidate streams; the first that overlaps with the row stream and with every stream in `apart`
+    bdf_ctx *fallback = nullptr;
+    for (int attempt = 0; attempt < 8; attempt++) {
+        hipStream_t st;
+        BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        bdf_ctx *c;
+        int rc = bdf_ctx_create(main->device, (void *)st, main->seed, &c);
+        if (rc) { (void)hipStreamDestroy(st); return rc; }
+        c->own_stream = true;
+        bool ok = true;
+        static const bool no_test = getenv("BDF_NO_STREAM_TEST") != nullptr;
+        if (!no_test) {
+            if ((rc = streams_overlap(st, main->stream, &ok))) return rc;
+            for (bdf_ctx *o : apart)
+                if (ok && (rc = streams_overlap(st, o->stream, &ok))) return rc;
+        }
+        if (ok) {
+            if (fallback) bdf_ctx_destroy(fallback);
+            *out = c;
+            return BDF_OK;
+        }
+        if (!fallback) fallback = c; else bdf_ctx_destroy(c);
+    }
+    *out = fallback;                    // no candidate runs beside the others: correct, only slower
+    return BDF_OK;
+}
+
+}  // namespace
+
+extern "C" int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, bdf_ctx **out)
+{
+    BDF_REQUIRE(main_ctx && out && n_apart >= 0 && (n_apart == 0 || apart), BDF_ERR_ARG, "bdf_ctx_create_side: bad argument");
+    std::vector<bdf_ctx *> ap(apart, apart + n_apart);
+    return make_side_ctx(main_ctx, ap, out);
+}
+
+extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const bdf_gibbs_entity *ents, bdf_gibbs **out)
+{
+    BDF_REQUIRE(rows_ctx && ents && out, BDF_ERR_ARG, "bdf_gibbs_create: NULL argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_gibbs_create: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    BDF_REQUIRE(n_entities >= 1 && n_entities <= 64, BDF_ERR_ARG, "bdf_gibbs_create: 1..64 entities");
+    for (int j = 0; j < n_entities; j++) {
+        const bdf_gibbs_entity &e = ents[j];
+        BDF_REQUIRE(e.n_terms >= 1 && e.n_terms <= BDF_MAX_TERMS, BDF_ERR_ARG, "bdf_gibbs_create: entity %d takes part in %d relations (1..%d)", j, e.n_terms, BDF_MAX_TERMS);
+        BDF_REQUIRE(e.sample[0] && e.sample[1] && e.sample[2] && e.mu && e.Lambda && e.mu0 && e.WI && e.sumU && e.UUt && e.prior_pack && e.draws,
+                    BDF_ERR_ARG, "bdf_gibbs_create: entity %d has a NULL buffer", j);
+        for (int t = 0; t < e.n_terms; t++) {
+            BDF_REQUIRE(e.terms[t].rel, BDF_ERR_ARG, "bdf_gibbs_create: entity %d term %d has no relation", j, t);
+            for (int k = 0; k < e.terms[t].rel->n_modes; k++)
+                BDF_REQUIRE(e.terms[t].entity_of_mode[k] >= 0 && e.terms[t].entity_of_mode[k] < n_entities, BDF_ERR_ARG,
+                            "bdf_gibbs_create: entity %d term %d mode %d names entity %d", j, t, k, e.terms[t].entity_of_mode[k]);
+        }
+    }
+    BDF_HIP(hipSetDevice(rows_ctx->device));
+    bdf_gibbs *g = new bdf_gibbs();
+    g->rows = rows_ctx; g->hyper = g->pred = nullptr; g->D = D; g->test = nullptr; g->stats_dev = nullptr;
+    g->pred_flip = 0; g->pred_recorded = false; g->comm = nullptr;
+    int rc;
+    if ((rc = make_side_ctx(rows_ctx, {}, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
+    g->ent.resize((size_t)n_entities);
+    for (int j = 0; j < n_entities; j++) {
+        auto &E = g->ent[(size_t)j];
+        E.d = ents[j]; E.cur = 0; E.hyper_recorded = false; E.t_start = E.t_stop = nullptr;
+        BDF_HIP(hipEventCreate(&E.ev_rows));          // (they ride on dispatch packets: plain events)
+        BDF_HIP(hipEventCreate(&E.ev_hyper));
+    }
+    BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[0], hipEventDisableTiming));
+    BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[1], hipEventDisableTiming));
+    *out = g;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
+{
+    if (!g) return BDF_OK;
+    if (g->rows) (void)hipStreamSynchronize(g->rows->stream);
+    for (auto &E : g->ent) { (void)hipEventDestroy(E.ev_rows); (void)hipEventDestroy(E.ev_hyper); }
+    if (!g->ent.empty()) { (void)hipEventDestroy(g->ev_pred[0]); (void)hipEventDestroy(g->ev_pred[1]); }
+    if (g->pred) bdf_ctx_destroy(g->pred);
+    if (g->hyper) bdf_ctx_destroy(g->hyper);
+    delete g;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_contexts(bdf_gibbs *g, bdf_ctx **hyper, bdf_ctx **pred)
+{
+    BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_contexts: NULL argument");
+    if (hyper) *hyper = g->hyper;
+    if (pred) *pred = g->pred;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_stream(const bdf_ctx *ctx, void **stream)
+{
+    BDF_REQUIRE(ctx && stream, BDF_ERR_ARG, "bdf_ctx_stream: NULL argument");
+    *stream = (void *)ctx->stream;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_set_test(bdf_gibbs *g, bdf_pairs *pairs, const int32_t *entity_of_mode, double mean_value,
+                                  double clamp_lo, double clamp_hi, double class_cut, double *stats_dev)
+{
+    BDF_REQUIRE(g && pairs && entity_of_mode && stats_dev, BDF_ERR_ARG, "bdf_gibbs_set_test: NULL argument");
+    for (int k = 0; k < pairs->n_modes; k++) {
+        BDF_REQUIRE(entity_of_mode[k] >= 0 && entity_of_mode[k] < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_set_test: mode %d names entity %d", k, entity_of_mode[k]);
+        g->test_entity[k] = entity_of_mode[k];
+    }
+    g->test = pairs; g->test_mean = mean_value; g->clamp_lo = clamp_lo; g->clamp_hi = clamp_hi; g->class_cut = class_cut;
+    g->stats_dev = stats_dev;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm)
+{
+    BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_set_comm: NULL argument");
+    g->comm = comm;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop)
+{
+    BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_time_rows: bad entity");
+    g->ent[(size_t)entity].t_start = (hipEvent_t)start;
+    g->ent[(size_t)entity].t_stop = (hipEvent_t)stop;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer)
+{
+    BDF_REQUIRE(g && buffer && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_current: bad argument");
+    *buffer = g->ent[(size_t)entity].cur;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
+{
+    BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_sweep: NULL argument");
+    bdf_ctx *R = g->rows, *H = g->hyper, *P = g->pred;
+    const int D = g->D, n = (int)g->ent.size();
+    int rc;
+    R->sweep_host = H->sweep_host = P->sweep_host = sweep;
+    // The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep - 2; the prediction updates that
+    // read them were enqueued before the previous sweep began.  The hyperprior stream waits for them here (where it idles
+    // anyway); every row kernel of the next sweep waits for a hyperprior event recorded after this point.
+    if (g->test && predict_phase >= 0) {
+        if (g->pred_recorded) BDF_HIP(hipStreamWaitEvent(H->stream, g->ev_pred[g->pred_flip], 0));
+        g->pred_flip ^= 1;
+        BDF_HIP(hipEventRecord(g->ev_pred[g->pred_flip], P->stream));
+        g->pred_recorded = true;
+    }
+    for (int j = 0; j < n; j++) {
+        auto &E = g->ent[(size_t)j];
+        const bdf_gibbs_entity &e = E.d;
+        if (E.hyper_recorded) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));      // (mu, Lambda) of the previous iteration
+        // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows
+        if ((rc = bdf_hyper_draws(H, D, e.n_real, e.nu0, e.tag, e.draws))) return rc;
+        bdf_term terms[BDF_MAX_TERMS];
+        for (int t = 0; t < e.n_terms; t++) {
+            terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
+            terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
+            for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
+            for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
+                const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
+                terms[t].factors[k] = O.d.sample[O.cur];
+            }
+        }
+        const int nxt = (E.cur + 1) % 3;
+        // the completion event rides on the row kernel's dispatch (a caller-supplied timing pair takes its place)
+        hipEvent_t done = E.t_stop ? E.t_stop : E.ev_rows;
+        const int nch = e.terms[0].rel->chunks;                    // 1 unless the relations were created with a layout
+        for (int c = 0; c < nch; c++) {
+            R->time_start = (c == 0) ? E.t_start : nullptr;
+            R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
+            if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
+                                      E.hyper_recorded ? e.prior_pack : nullptr)))
+                return rc;
+            if (g->comm && (rc = bdf_allgather_rows(R, g->comm, D, e.N, e.sample[nxt], c, nch))) return rc;
+        }
+        if (g->comm) {
+            if ((rc = bdf_allgather_join(R, g->comm))) return rc;       // the row stream continues after the last chunk's exchange
+            BDF_HIP(hipEventRecord(done, R->stream));
+        }
+        E.t_start = E.t_stop = nullptr;
+        E.cur = nxt;
+        BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
+        if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], nullptr, e.sumU, e.UUt))) return rc;
+        H->time_h_stop = E.ev_hyper;
+        if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, e.WI, e.nu0, e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
+            return rc;
+        E.hyper_recorded = true;
+        if (j == n - 1 && g->test && predict_phase >= 0) BDF_HIP(hipStreamWaitEvent(P->stream, done, 0));
+    }
+    if (g->test && predict_phase >= 0) {
+        const double *fac[BDF_MAX_MODES];
+        for (int k = 0; k < g->test->n_modes; k++) {
+            const auto &O = g->ent[(size_t)g->test_entity[k]];
+            fac[k] = O.d.sample[O.cur];
+        }
+        if ((rc = bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
+            return rc;
+    }
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_sync(bdf_gibbs *g)
+{
+    BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_sync: NULL argument");
+    int rc;
+    if ((rc = bdf_ctx_sync(g->pred)) || (rc = bdf_ctx_sync(g->hyper))) return rc;
+    return bdf_ctx_sync(g->rows);
+}

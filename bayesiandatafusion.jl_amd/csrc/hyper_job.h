@@ -32,7 +32,6 @@ struct NWArgs {
     const double *draws;       // Bartlett matrix (D x D row-major) + D mean normals, from k_hyper_draws
     double *pack_out;          // nullable: Lambda mu (D) then the accumulator-layout image of the reversed Lambda (K1)
     int *flag;
-    uint32_t *done;            // the context's completion counters (bdf_rows_gate_at): the draw counts itself like a row kernel
 };
 
 // ---- stage 1: partial sums of rows [r0, r0 + HS_ROWS) by NW waves; red: (NW-1) * PSZ doubles of LDS -----------------------

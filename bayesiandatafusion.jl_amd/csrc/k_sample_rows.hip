@@ -63,13 +63,13 @@ namespace {
 
 
 struct Item {             // one wave's accumulation work
-    int32_t row;          // entity row
+    int32_t row;          // entity row: where the sample is written (the row's position in the factor matrix)
     int32_t term;
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
     int32_t slot;         // partial slot, or -1 for a direct row
     int32_t srow;         // index of the row in the split-row table (split items)
-    int32_t _pad;
+    int32_t orig;         // the row's ORIGINAL id: keys its random stream (== row unless the relation was created with a layout)
 };
 
 struct SplitRow {
@@ -449,7 +449,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
     const bool early_z = !DUMP && !is_split && !p.decoupled;
-    if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
+    if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
     if (p.decoupled && !is_split) {
         // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
         // row's arrival counter, bounded so that a bug cannot hang the device
@@ -463,7 +463,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         if (seen < sr.n_slots && lane == 0) atomicOr(a.flag, 16);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
-        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
+        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     } else if (it.count > 0) accumulate_any<DP, MATRIX>(a, it, lane, acc, bv);
@@ -498,7 +498,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
         // the finisher's normals before the partial sums are loaded: the Box-Muller arithmetic needs ~40 registers
-        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)row, D - 1 - lane);
+        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
@@ -571,8 +571,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     for (int q = 0; q < 4; q++)
         colq[q] = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + cr.cbase + q * cr.nr4 - cr.q);
     backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
-    // write-through (sc1): a consumer gated on the completion counters (bdf_rows_gate) may start before this launch ends
-    if (lane < D) __hip_atomic_store(a.out + row * D + (D - 1 - lane), yh * rdv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
     STAMP(8);
 }
 
@@ -585,10 +584,6 @@ __global__ __launch_bounds__(64 * Geo<DP>::WPB, MATRIX ? Geo<DP>::WAVES_MATRIX :
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP, MATRIX>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
-    // completion counters (bdf_rows_gate): every wave of the launch, item or not, counts once after its stores completed
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0 && a.done)
-        __hip_atomic_fetch_add(a.done + (int)(w & (BDF_GATE_COUNTERS - 1)) * BDF_GATE_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -626,20 +621,24 @@ int to_device(const std::vector<T> &v, T **out)
 
 constexpr int64_t MAX_PIECES = 64;
 
-int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, const std::vector<int32_t> &rows, int psz,
-               Plan &plan)
+// one row of the launch as the plan sees it: where its sample goes, its original id, and per term its observations in
+// that term's device arrays
+struct RowRef {
+    int32_t out, orig;
+    int64_t qb[BDF_MAX_TERMS];
+    int64_t cnt[BDF_MAX_TERMS];
+};
+
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, Plan &plan)
 {
     const int T = key.T;
     std::vector<Item> direct, split;
     std::vector<SplitRow> srows;
     static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
-    for (int32_t row : rows) {
+    for (const RowRef &rr : rows) {
+        const int32_t row = rr.out;
         int n_items = 0;
-        for (int r = 0; r < key.n_terms; r++) {
-            const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
-            const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
-            n_items += (int)std::min<int64_t>((n + T - 1) / T, MAX_PIECES);
-        }
+        for (int r = 0; r < key.n_terms; r++) n_items += (int)std::min<int64_t>((rr.cnt[r] + T - 1) / T, MAX_PIECES);
         // (at most MAX_PIECES per relation: the row's finisher adds the partial sums one slot after the other, ~0.5 us each
         // -- a 78,000-observation row of config C5 in 128-observation pieces would keep it busy for 0.3 ms)
         // a row that is split anyway is cut into smaller pieces than the longest whole row: the launch ends with the split
@@ -647,41 +646,33 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const bdf_rel *const *rels, con
         const int Tp = n_items > 1 ? key.Tp : T;
         if (n_items > 1 && Tp != T) {
             n_items = 0;
-            for (int r = 0; r < key.n_terms; r++) {
-                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
-                const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
-                n_items += (int)std::min<int64_t>((n + Tp - 1) / Tp, MAX_PIECES);
-            }
+            for (int r = 0; r < key.n_terms; r++) n_items += (int)std::min<int64_t>((rr.cnt[r] + Tp - 1) / Tp, MAX_PIECES);
         }
         if (n_items <= 1 && !decoupled) {
-            Item it{row, 0, 0, 0, -1, -1, 0};
-            for (int r = 0; r < key.n_terms; r++) {
-                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
-                const int64_t n = rp[(size_t)row + 1] - rp[(size_t)row];
-                if (n > 0) { it.term = r; it.q_begin = rp[(size_t)row]; it.count = (int32_t)n; }
-            }
+            Item it{row, 0, 0, 0, -1, -1, rr.orig};
+            for (int r = 0; r < key.n_terms; r++)
+                if (rr.cnt[r] > 0) { it.term = r; it.q_begin = rr.qb[r]; it.count = (int32_t)rr.cnt[r]; }
             direct.push_back(it);
         } else {
             if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
-                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), 0});
+                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), rr.orig});
                 srows.push_back(SplitRow{row, (int32_t)split.size() - 1, 1, 0});
-                if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, 0});
+                if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});
                 continue;
             }
             SplitRow sr{row, (int32_t)split.size(), n_items, 0};
             for (int r = 0; r < key.n_terms; r++) {
-                const auto &rp = rels[r]->idx[key.mode[r]].rowptr;
-                const int64_t beg = rp[(size_t)row], n = rp[(size_t)row + 1] - beg;
+                const int64_t beg = rr.qb[r], n = rr.cnt[r];
                 const int pieces = (int)std::min<int64_t>((n + Tp - 1) / Tp, MAX_PIECES);
                 for (int s = 0; s < pieces; s++) {
                     // equal pieces rather than T, T, ..., remainder
                     const int64_t b0 = beg + n * s / pieces, b1 = beg + n * (s + 1) / pieces;
-                    split.push_back(Item{row, r, b0, (int32_t)(b1 - b0), (int32_t)split.size(), (int32_t)srows.size(), 0});
+                    split.push_back(Item{row, r, b0, (int32_t)(b1 - b0), (int32_t)split.size(), (int32_t)srows.size(), rr.orig});
                 }
             }
             srows.push_back(sr);
         }
-        if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, 0});      // the row's finisher
+        if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});      // the row's finisher
     }
     // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
     // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
@@ -742,12 +733,10 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
                          : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>);
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
-        hipExtLaunchKernelGGL(kern, grid, block, 0, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
+        static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
+        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
         if (!dump) ctx->time_start = ctx->time_stop = nullptr;
         BDF_HIP(hipGetLastError());
-        const int64_t launched = (int64_t)grid.x * WPB;
-        for (int c = 0; c < BDF_GATE_COUNTERS; c++)
-            ctx->rows_done_target[c] += (uint32_t)(launched / BDF_GATE_COUNTERS + (c < launched % BDF_GATE_COUNTERS ? 1 : 0));
     }
     return BDF_OK;
 }
@@ -800,7 +789,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     SampleArgs a = a_in;
     if (a.prior_b == nullptr) {         // no prior pack from bdf_hyper_sample: derive Lambda mu and the image here
         // prior part of b: Lambda mu (one vector) or Lambda mu_i for every row (per-row prior means, macau.jl:104)
-        const int64_t N = rels[0]->dims[modes[0]];
+        const int64_t N = rels[0]->nint[modes[0]];
         const int64_t nr = a.mu_is_matrix ? N : 1;
         const int DPp = a.D <= 16 ? 16 : (a.D <= 32 ? 32 : 64);
         const int nimg = (DPp / 16) * (DPp / 16 + 1) / 2 * 4;          // (block, register) pairs of the image
@@ -828,13 +817,35 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         PlanCache &cache = g_caches[ctx];
         auto it = cache.plans.find(key);
         if (it == cache.plans.end()) {
-            // rows of this shard: positions shard, shard + n_shards, ... of the degree-descending order of the first
-            // relation (the reference deals rows i:P:N to its P workers for the same balance, sampling.jl:154)
-            const std::vector<int32_t> &order = rels[0]->idx[modes[0]].order;
-            std::vector<int32_t> rows;
-            for (size_t pos = (size_t)shard; pos < order.size(); pos += (size_t)n_shards) rows.push_back(order[pos]);
+            std::vector<RowRef> rows;
+            if (rels[0]->sharded) {
+                // a relation created with a layout holds this rank's rows only, chunk after chunk: `shard` is the chunk
+                const bdf_mode_index &ix0 = rels[0]->idx[modes[0]];
+                for (int64_t o = ix0.chunk_begin[(size_t)shard]; o < ix0.chunk_begin[(size_t)shard + 1]; o++) {
+                    RowRef rr;
+                    rr.out = ix0.own_pos[(size_t)o]; rr.orig = ix0.own_orig[(size_t)o];
+                    for (int r = 0; r < a.n_terms; r++) {
+                        const bdf_mode_index &ix = rels[r]->idx[modes[r]];
+                        rr.qb[r] = ix.own_q[(size_t)o]; rr.cnt[r] = ix.own_q[(size_t)o + 1] - ix.own_q[(size_t)o];
+                    }
+                    rows.push_back(rr);
+                }
+            } else {
+                // rows of this shard: positions shard, shard + n_shards, ... of the degree-descending order of the first
+                // relation (the reference deals rows i:P:N to its P workers for the same balance, sampling.jl:154)
+                const std::vector<int32_t> &order = rels[0]->idx[modes[0]].order;
+                for (size_t pos = (size_t)shard; pos < order.size(); pos += (size_t)n_shards) {
+                    RowRef rr;
+                    rr.out = rr.orig = order[pos];
+                    for (int r = 0; r < a.n_terms; r++) {
+                        const auto &rp = rels[r]->idx[modes[r]].rowptr;
+                        rr.qb[r] = rp[(size_t)rr.orig]; rr.cnt[r] = rp[(size_t)rr.orig + 1] - rp[(size_t)rr.orig];
+                    }
+                    rows.push_back(rr);
+                }
+            }
             Plan np;
-            int rc = build_plan(ctx, key, rels, rows, psz, np);
+            int rc = build_plan(ctx, key, rows, psz, np);
             if (rc) return rc;
             it = cache.plans.emplace(key, np).first;
         }

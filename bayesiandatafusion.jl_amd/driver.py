@@ -81,13 +81,15 @@ def macau(data, num_latent=10, lambda_beta=float("nan"), burnin=500, psamples=20
     verbose and print("Sampling")
     for i in range(1, burnin + psamples + 1):
         time0 = time.time()
-        eng.sweep(i)        # relation models (alpha, relation beta) first, then rows, hyperpriors, beta: macau.jl:83-140
-
+        # relation models (alpha, relation beta) first, then rows, hyperpriors, beta (macau.jl:83-140), then the reporting
+        # step on the test pairs (macau.jl:142-184); without side information all of it is one native call
         phase = 0 if i <= burnin else (1 if i == burnin + 1 else 2)
-        facs = eng.factors_of(rel)
         stats = None
         if haveTest:
-            stats = test.update(D, facs, rel.model.mean_value, phase, clamp, rel.class_cut)
+            stats = eng.step(i, phase, clamp, rel.class_cut)
+        else:
+            eng.sweep(i)
+        facs = eng.factors_of(rel)
         if full_prediction and i > burnin:
             yhat_full += eng.pred_all(rel)                    # macau.jl:145-147: a plain dense product, on the device
         if i > burnin:

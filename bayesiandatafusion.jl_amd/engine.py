@@ -1,11 +1,19 @@
 """GibbsEngine -- host-side orchestration of one macau() run on one MI355X (one process per GPU).
 
-Everything numeric is a call into libbdf_hip.so (include/bdf.h).  torch is used for what the task calls plumbing:
-device allocations (tensors), the HIP stream, and -- when torch.distributed is initialised -- the RCCL all-gather of a
-freshly sampled factor matrix (reference: sample_latent_all2! ships every factor to every worker each half-sweep,
-src/sampling.jl:155-167).
+Everything numeric is a call into libbdf_hip.so (include/bdf.h).  torch is used for what the task calls plumbing: device
+allocations (tensors) and, with several ranks, the channel over which rank 0 hands the RCCL unique id to the others.
 
-Layout: an entity's sample is the reference's D x N column-major matrix == a contiguous torch tensor of shape (N, D).
+* Without side information the whole iteration (rows of every entity, exchange between the GPUs, hyperpriors, test
+  prediction update) is ONE native call, bdf_gibbs_sweep (csrc/bdf_gibbs.hip).  With side information the same steps plus
+  uhat / beta are enqueued from here through the entry points of bdf.h, on the same three-stream schedule.
+* Several ranks (shard=(rank, world)): every entity's rows are shared out by bdf_layout_build -- dealt over the ranks in
+  falling order of degree as the reference deals rows i:P:N to its workers (src/sampling.jl:154) -- and stored at INTERNAL
+  positions, so that a rank's rows of a chunk are one contiguous block and the exchange is an in-place all-gather
+  (bdf_allgather_rows: RCCL over xGMI).  A rank holds the observations of its own rows only
+  (bdf_relation_create_sharded) and a replica of every factor matrix.  Random streams are keyed by the original row id.
+
+Layout: an entity's sample is the reference's D x N column-major matrix == a contiguous torch tensor of shape (N, D)
+(N = chunks * world * cmax rows with a layout; EntityState.host() returns the reference's orientation and order).
 """
 import ctypes as C
 import os
@@ -16,51 +24,38 @@ import torch
 
 from . import _lib
 from . import features as feat
-from ._lib import ArgumentError, Term, check, lib
+from ._lib import ArgumentError, GibbsEntity, Term, check, lib
 
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
 
 
-def shard_rows(order, world):
-    """rows of each rank: positions rank, rank + world, ... of the degree-descending launch order -- the reference deals
-    rows i:P:N to its P workers for the same balance (sampling.jl:154); bdf_sample_rows(shard, n_shards) samples exactly these"""
-    return [np.ascontiguousarray(order[p::world]) for p in range(world)]
+class Layout:
+    """internal row positions of an entity (bdf_layout_build); world == 1: the identity"""
 
+    def __init__(self, N, degree=None, world=1, chunks=1):
+        self.N, self.world, self.chunks = int(N), int(world), int(chunks)
+        if world == 1 and chunks == 1:
+            self.pos, self.cmax, self.nint = None, self.N, self.N
+            return
+        degree = np.ascontiguousarray(degree, dtype=np.int64)
+        self.pos = np.zeros(self.N, dtype=np.int32)
+        cmax = C.c_int64(0)
+        check(lib().bdf_layout_build(self.N, degree.ctypes.data_as(_lib.c_i64p), world, chunks,
+                                     self.pos.ctypes.data_as(_lib.c_i32p), C.byref(cmax)))
+        self.cmax = cmax.value
+        self.nint = self.chunks * self.world * self.cmax
 
-def allgather_plan(lists, rank, world):
-    """index tensors of allgather_rows for one entity (built once): the send selection padded to the longest shard, and
-    where every received row goes"""
-    counts = [len(l) for l in lists]
-    nmax = max(counts)
-    dev = lists[rank].device
-    own = lists[rank]
-    pad = own[:1].expand(nmax - counts[rank]) if counts[rank] else torch.zeros(nmax, dtype=torch.int64, device=dev)
-    send_sel = torch.cat([own, pad]) if nmax > counts[rank] else own        # padding rows repeat a row; never copied back
-    recv_sel = torch.cat([torch.arange(p * nmax, p * nmax + counts[p], dtype=torch.int64, device=dev)
-                          for p in range(world) if p != rank] or [torch.zeros(0, dtype=torch.int64, device=dev)])
-    dst = torch.cat([lists[p] for p in range(world) if p != rank] or [torch.zeros(0, dtype=torch.int64, device=dev)])
-    return send_sel, recv_sel, dst, nmax
+    def to_internal(self, ids1):
+        """1-based original ids -> 1-based internal positions"""
+        ids1 = np.asarray(ids1)
+        return ids1 if self.pos is None else self.pos[ids1 - 1].astype(np.int64) + 1
 
-
-def allgather_rows(sample, lists, rank, world, plan=None):
-    """all-gather of the rows each rank sampled into every rank's replica of the factor (N x D tensor): one gather of the
-    own rows into a shard padded to the longest shard, one all_gather_into_tensor, one scatter of the other ranks' rows.
-    torch.distributed: RCCL over xGMI on the GPUs, gloo in the CPU tests."""
-    import torch.distributed as dist
-    send_sel, recv_sel, dst, nmax = plan if plan is not None else allgather_plan(lists, rank, world)
-    send = sample.index_select(0, send_sel)
-    if sample.is_cuda and dist.get_backend() == "gloo":
-        # test rig only (several ranks sharing one GPU, where RCCL refuses to run): the collective staged through the host
-        hrecv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype)
-        dist.all_gather_into_tensor(hrecv, send.cpu())
-        recv = hrecv.to(sample.device)
-    else:
-        recv = torch.empty(world * nmax, sample.shape[1], dtype=sample.dtype, device=sample.device)
-        dist.all_gather_into_tensor(recv, send)
-    if dst.numel():
-        sample.index_copy_(0, dst, recv.index_select(0, recv_sel))
+    def block(self, rank, chunk):
+        """[begin, end) of the rows of (rank, chunk) in the factor matrix"""
+        b = (chunk * self.world + rank) * self.cmax
+        return b, b + self.cmax
 
 
 class KernelTimer:
@@ -102,6 +97,30 @@ class Context:
         # finalises things in (a relation / feature handle points back into the context)
         self._children = weakref.WeakSet()
 
+    @classmethod
+    def wrap(cls, handle, device, seed, owned=False):
+        """a context created by the library (bdf_ctx_create_side, bdf_gibbs_contexts): the stream is the library's"""
+        self = cls.__new__(cls)
+        self.device = device
+        self.handle = C.c_void_p(handle) if not isinstance(handle, C.c_void_p) else handle
+        st = C.c_void_p()
+        check(lib().bdf_ctx_stream(self.handle, C.byref(st)))
+        self.stream = torch.cuda.ExternalStream(st.value or 0, device=device)
+        self.seed = int(seed)
+        self._children = weakref.WeakSet()
+        self._owned = owned
+        return self
+
+    @classmethod
+    def side(cls, main, apart=()):
+        """a context on another stream of main's device, chosen by the library so that kernels on it really run beside those
+        of `main` and of the contexts in `apart` (HIP multiplexes streams onto a few hardware queues; two streams on one
+        queue serialise each other: 171 instead of 125 us per sweep, tools/exp_stream_pairs.py)"""
+        h = C.c_void_p()
+        arr = (C.c_void_p * max(len(apart), 1))(*[a.handle for a in apart])
+        check(lib().bdf_ctx_create_side(main.handle, arr, len(apart), C.byref(h)))
+        return cls.wrap(h, main.device, main.seed, owned=True)
+
     def adopt(self, child):
         self._children.add(child)
 
@@ -140,7 +159,8 @@ class Context:
         if self.handle:
             for ch in list(self._children):
                 ch.close()
-            lib().bdf_ctx_destroy(self.handle)
+            if getattr(self, "_owned", True):      # (contexts of a bdf_gibbs object are destroyed with it)
+                lib().bdf_ctx_destroy(self.handle)
             self.handle = C.c_void_p()
 
     def __del__(self):
@@ -153,15 +173,24 @@ class Context:
 class DeviceRelation:
     """bdf_rel: Relation.data (IndexedDF) as per-mode CSR in HBM."""
 
-    def __init__(self, ctx, idf):
+    def __init__(self, ctx, idf, layouts=None, rank=0):
+        """layouts: one Layout per mode (several ranks): the device then holds this rank's rows only, at internal positions"""
         self.ctx = ctx
         self.handle = C.c_void_p()
         dims = np.asarray(idf.dims, dtype=np.int64)
         vals = np.ascontiguousarray(idf.values, dtype=np.float64)
         ids = idf.ids
-        check(lib().bdf_relation_create(ctx.handle, len(idf.dims), dims.ctypes.data_as(_lib.c_i64p), idf.nnz(),
-                                        ids.ctypes.data_as(C.c_void_p), ids.dtype.itemsize, vals.ctypes.data_as(_lib.c_dp),
-                                        C.byref(self.handle)))
+        if layouts is None or all(l.pos is None for l in layouts):
+            check(lib().bdf_relation_create(ctx.handle, len(idf.dims), dims.ctypes.data_as(_lib.c_i64p), idf.nnz(),
+                                            ids.ctypes.data_as(C.c_void_p), ids.dtype.itemsize, vals.ctypes.data_as(_lib.c_dp),
+                                            C.byref(self.handle)))
+        else:
+            pos = (_lib.c_i32p * len(layouts))(*[l.pos.ctypes.data_as(_lib.c_i32p) for l in layouts])
+            cmax = np.asarray([l.cmax for l in layouts], dtype=np.int64)
+            check(lib().bdf_relation_create_sharded(ctx.handle, len(idf.dims), dims.ctypes.data_as(_lib.c_i64p), idf.nnz(),
+                                                    ids.ctypes.data_as(C.c_void_p), ids.dtype.itemsize, vals.ctypes.data_as(_lib.c_dp),
+                                                    pos, cmax.ctypes.data_as(_lib.c_i64p), rank, layouts[0].world,
+                                                    layouts[0].chunks, C.byref(self.handle)))
         self.dims = list(idf.dims)
         self.nnz = idf.nnz()
         ctx.adopt(self)
@@ -350,11 +379,14 @@ class FeatOperator:
 class EntityState:
     """Device-resident EntityModel (RelationData.jl:14-40, initModel! :66-90)."""
 
-    def __init__(self, ctx, en, D, tag):
-        self.ctx, self.D, self.N, self.tag = ctx, D, en.count, tag
-        self.sample = ctx.zeros(en.count, D)
-        self.sample_alt = ctx.zeros(en.count, D)     # the rows of the next sweep are written here, then the three rotate:
-        self.sample_alt2 = ctx.zeros(en.count, D)    # a launch overwrites the rows of three sweeps ago
+    def __init__(self, ctx, en, D, tag, layout):
+        self.ctx, self.D, self.tag, self.layout = ctx, D, tag, layout
+        self.n_real = en.count
+        self.N = layout.nint                     # rows of the factor matrix (rows nobody owns stay zero)
+        # the rows of the next sweep are written to another buffer, then the three rotate: a launch overwrites the rows of
+        # three sweeps ago, so readers of the previous two sweeps' rows on other streams are never overwritten under their feet
+        self.bufs = [ctx.zeros(self.N, D) for _ in range(3)]
+        self.cur = 0
         self.mu = ctx.zeros(D)
         self.Lambda = (5.0 * torch.eye(D, dtype=torch.float64)).to(ctx.device)
         self.mu0 = ctx.zeros(D)
@@ -390,67 +422,73 @@ class EntityState:
             self.lambda_beta = ctx.tensor([en.lambda_beta])
             self.cg_iters = torch.zeros(D, dtype=torch.int32, device=ctx.device)
 
+    @property
+    def sample(self):
+        return self.bufs[self.cur]
+
+    @property
+    def sample_next(self):
+        return self.bufs[(self.cur + 1) % 3]
+
+    def rotate(self):
+        self.cur = (self.cur + 1) % 3
+
     def host(self, name):
         t = getattr(self, name)
         if t is None:
             return np.zeros((0, 0))
         torch.cuda.synchronize(t.device)      # the state is written on several streams (rows, hyperprior): wait for all of them
         a = t.detach().cpu().numpy()
+        if name == "sample" and self.layout.pos is not None:
+            a = a[self.layout.pos]            # internal positions -> the reference's row order
         return a.T.copy() if a.ndim == 2 else a.copy()
-
-
-_SIDE_STREAMS = {}      # (device, role) -> torch stream: the side streams of the process's first engine, reused by later ones
 
 
 class GibbsEngine:
     """Device state of a RelationData and the per-iteration steps of macau.jl:80-140."""
 
     def __init__(self, data, num_latent, seed=0, device=None, lambda_beta=float("nan"), compute_ff_size=6500,
-                 full_lambda_u=True, tol=float("nan"), shard=None):
+                 full_lambda_u=True, tol=float("nan"), shard=None, chunks=None):
         if not (1 <= num_latent <= _lib.BDF_MAX_D):
             raise ArgumentError(f"num_latent={num_latent} must be in 1..{_lib.BDF_MAX_D}")
         self.data, self.D = data, int(num_latent)
         self.ctx = Context(device, seed)
-        self._n_side = 0
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
         if os.environ.get("BDF_PIECE_SIZE"):
             self.ctx.set_piece_size(int(os.environ["BDF_PIECE_SIZE"]))
-        # second HIP stream: the hyperprior of entity j (reductions + Normal-Wishart draw) runs beside the row sampling
-        # of entity j+1, which does not depend on it (macau.jl:96-134 draws them in this order; the values are the same)
         self.rank, self.world = (0, 1) if shard is None else shard
-        # hand-over of fresh rows to the other streams: completion counters of the row kernel + a gate kernel on the
-        # waiting stream (bdf_rows_gate) instead of an event recorded on the row stream -- when the streams really run
-        # side by side (HIP multiplexes streams onto a few hardware queues: _side_context looks for one that does), and
-        # not with several ranks (the all-gather after the row kernel is not covered by the counters)
-        self.use_gate = self.world == 1 and not os.environ.get("BDF_NO_GATE") and not os.environ.get("BDF_NO_OVERLAP")
-        self.ctx_h = self.ctx
-        if not os.environ.get("BDF_NO_OVERLAP"):
-            self.ctx_h = self._side_context(seed)
-        # third stream for the prediction updates (test set, training set): they only read the sampled rows, and every
-        # entity's rows alternate between two buffers, so the update of sweep t runs beside the rows of sweep t+1
-        self.ctx_p = self.ctx
-        if not os.environ.get("BDF_NO_OVERLAP") and all(feat.isempty(r.F) for r in data.relations):
-            self.ctx_p = self._side_context(seed, apart_from=[self.ctx_h])
-        self._ev_pred = None
-        self._ev_rows, self._ev_hyper = {}, {}
-        # the way back (hyperprior -> rows) through the draw kernel's completion count and a gate on the row stream: a
-        # satisfied event wait costs the row stream ~6 us, the gate kernel ~3 (sweep 128 -> 122 us)
-        self._snap_hyper = {}
-        self._ev_hyper_sweep = {}
-        self._gate_back = not os.environ.get("BDF_NO_GATE_BACK") and self.use_gate and self.ctx_h is not self.ctx \
-            and all(feat.isempty(en.F) for en in data.entities) and self._gate_ok_pair(self.ctx, self.ctx_h)
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
-        self._rowlists = {}
-        self._ag_plans = {}
+        has_feat = any(not feat.isempty(en.F) for en in data.entities) or any(not feat.isempty(r.F) for r in data.relations)
+        if self.world > 1 and has_feat:
+            raise ArgumentError("side information with several GPUs is not implemented: the multi-GPU path is the BPMF iteration")
+        # the whole iteration in one native call unless something needs the step-by-step path
+        self.native = not has_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
+        if self.world > 1 and not self.native:
+            raise ArgumentError("several GPUs: alpha sampling is not implemented on the multi-GPU path")
+        # ---- row layouts (several ranks): degree of a row = its observations over all the entity's relations
+        if chunks is None:
+            chunks = int(os.environ.get("BDF_CHUNKS", "0"))
+        self.layouts = []
+        for en in data.entities:
+            if self.world == 1:
+                self.layouts.append(Layout(en.count))
+                continue
+            deg = np.zeros(en.count, dtype=np.int64)
+            for r in en.relations:
+                m = [e is en for e in r.entities].index(True)
+                deg += np.bincount(np.asarray(r.data.ids[:, m], dtype=np.int64) - 1, minlength=en.count)
+            per_rank = -(-en.count // self.world)
+            ch = chunks if chunks > 0 else (4 if per_rank >= 200_000 else 1)      # chunked exchange pays for large entities only
+            self.layouts.append(Layout(en.count, deg, self.world, ch))
         # ---- reset! (RelationData.jl:331-355)
         self.ent = []
         for j, en in enumerate(data.entities):
             if not np.isnan(lambda_beta):
                 en.lambda_beta = float(lambda_beta)
-            st = EntityState(self.ctx, en, self.D, j + 1)
+            st = EntityState(self.ctx, en, self.D, j + 1, self.layouts[j])
             en.modes = [[e is en for e in r.entities].index(True) + 1 for r in en.relations]
             en.modes_other = [[k + 1 for k, e in enumerate(r.entities) if e is not en] for r in en.relations]
             if st.F is not None:
@@ -463,7 +501,11 @@ class GibbsEngine:
         for r in data.relations:
             if len(r.entities) != len(r.data.dims):
                 raise ArgumentError(f"Relation {r.name} has {len(r.entities)} entities but its data implies {r.data.size()}.")
-            dr = DeviceRelation(self.ctx, r.data)
+            lays = [self.layouts[self._entity_index(e)] for e in r.entities]
+            if self.world > 1 and len({l.chunks for l in lays}) > 1:
+                # one chunk count per relation: take the entities' largest
+                raise ArgumentError("entities of one relation were given different chunk counts: pass chunks=")
+            dr = DeviceRelation(self.ctx, r.data, lays if self.world > 1 else None, self.rank)
             r.model.mean_value = dr.value_mean()
             r._dev = dr
             self.rel.append(dr)
@@ -485,15 +527,66 @@ class GibbsEngine:
             dr.alpha_dev = self.ctx.zeros(1)
         self._test_pairs = None
         self._train_pairs = None
+        self._test_opts = None
         self.k1_events = None     # bench.py: list of (entity, KernelTimer) of the timed K1 launches
         self.k1_event_every = 1   # ... of every n-th sweep
         self._k1_sweep = 0
+        # ---- streams: rows (main) | hyperpriors | prediction updates
+        self.gibbs = None
+        self.comm = None
+        self._ev_pred = None
+        self._ev_rows, self._ev_hyper = {}, {}
+        if self.native:
+            self._create_native()
+        else:
+            self.ctx_h = self.ctx_p = self.ctx
+            if not os.environ.get("BDF_NO_OVERLAP"):
+                self.ctx_h = Context.side(self.ctx)
+                if all(feat.isempty(r.F) for r in data.relations):
+                    self.ctx_p = Context.side(self.ctx, [self.ctx_h])
+
+    # ---- the native iteration (bdf_gibbs) -----------------------------------------------------------------------------
+    def _create_native(self):
+        ents = (GibbsEntity * len(self.ent))()
+        for j, (en, st) in enumerate(zip(self.data.entities, self.ent)):
+            g = ents[j]
+            g.N, g.n_real, g.tag, g.n_terms = st.N, st.n_real, st.tag, len(en.relations)
+            if not en.relations:
+                raise ArgumentError(f"Entity {en.name} takes part in no relation")
+            for t, r in enumerate(en.relations):
+                ri = [x is r for x in self.data.relations].index(True)
+                g.terms[t].rel = self.rel[ri].handle
+                g.terms[t].mode = en.modes[t] - 1
+                for k, e2 in enumerate(r.entities):
+                    g.terms[t].entity_of_mode[k] = self._entity_index(e2)
+                g.terms[t].alpha = r.model.alpha
+                g.terms[t].mean_value = r.model.mean_value
+            for b in range(3):
+                g.sample[b] = st.bufs[b].data_ptr()
+            for name in ("mu", "Lambda", "mu0", "WI", "sumU", "UUt", "params", "prior_pack", "draws"):
+                setattr(g, name, getattr(st, name).data_ptr())
+            g.b0, g.nu0 = st.b0, st.nu0
+        self.gibbs = C.c_void_p()
+        check(lib().bdf_gibbs_create(self.ctx.handle, self.D, len(self.ent), ents, C.byref(self.gibbs)))
+        h, p = C.c_void_p(), C.c_void_p()
+        check(lib().bdf_gibbs_contexts(self.gibbs, C.byref(h), C.byref(p)))
+        self.ctx_h = Context.wrap(h, self.ctx.device, self.ctx.seed)
+        self.ctx_p = Context.wrap(p, self.ctx.device, self.ctx.seed)
+        if self.world > 1:
+            self.comm = make_comm(self.ctx, self.rank, self.world)
+            check(lib().bdf_gibbs_set_comm(self.gibbs, self.comm.handle))
+
+    def set_alpha(self):
+        """(native iteration) the relations' precisions are launch arguments held by the bdf_gibbs object: rebuild it after
+        setPrecision! on an initialised model"""
+        if self.gibbs:
+            raise ArgumentError("change the precision before the engine is built")
 
     def k1_algorithmic_bytes(self, j):
         """bytes one K1 launch over all rows of entity j must move, summed over its relations:
         nnz*((4 + 8D)*(n_modes-1) + 8) + N*(8D + 8) [+ N*8D per-row prior mean] + 8D^2 + 8D"""
         en, st, D = self.data.entities[j], self.ent[j], self.D
-        b = st.N * (8 * D + 8) + 8 * D * D + 8 * D + (st.N * 8 * D if st.F is not None else 0)
+        b = st.n_real * (8 * D + 8) + 8 * D * D + 8 * D + (st.n_real * 8 * D if st.F is not None else 0)
         for r in en.relations:
             b += r.data.nnz() * ((4 + 8 * D) * (len(r.entities) - 1) + 8)
         return b
@@ -515,15 +608,6 @@ class GibbsEngine:
             for k, e2 in enumerate(r.entities):
                 terms[t].factors[k] = self.ent[self._entity_index(e2)].sample.data_ptr()
         return terms
-
-    def _rowlist(self, j):
-        if j not in self._rowlists:
-            en = self.data.entities[j]
-            r0 = en.relations[0]
-            ri = [x is r0 for x in self.data.relations].index(True)
-            order = self.rel[ri].order(en.modes[0] - 1)
-            self._rowlists[j] = [self.ctx.tensor(p, dtype=torch.int64) for p in shard_rows(order, self.world)]
-        return self._rowlists[j]
 
     # ---- macau.jl:83-92: relation models (alpha, relation-level beta) -----------------------------------------------
     def update_relations(self):
@@ -547,45 +631,6 @@ class GibbsEngine:
                                                 r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
         self.refresh_baselines()
 
-    def _gate_ok_pair(self, waiter, producer):
-        ok = C.c_int(0)
-        check(lib().bdf_rows_gate_selftest(waiter.handle, producer.handle, C.byref(ok)))
-        return bool(ok.value)
-
-    def _side_context(self, seed, apart_from=()):
-        """a context on another stream of the device; with gates in use, one whose stream passes bdf_rows_gate_selftest
-        against the row stream (a few candidates are tried; none passing turns the gates off for this engine).  The streams
-        that served the first engine of the process are kept and handed to later engines in the same roles: HIP multiplexes
-        streams onto a few hardware queues, and a hyperprior stream and a prediction stream that land on the same queue
-        serialise each other (171 instead of 125 us per sweep: tools/exp_stream_pairs.py, exp_second_engine.py) -- so the new
-        stream must also pass the self-test against the contexts in `apart_from`."""
-        key = (self.ctx.device.index, self._n_side)
-        self._n_side += 1
-        first = None
-        for attempt in range(8 if self.use_gate else 1):
-            reuse = attempt == 0 and key in _SIDE_STREAMS
-            st = _SIDE_STREAMS[key] if reuse else torch.cuda.Stream(self.ctx.device)
-            c = Context(self.ctx.device.index, seed, stream=st)
-            if not self.use_gate:
-                _SIDE_STREAMS.setdefault(key, st)
-                return c
-            ok = C.c_int(0)
-            check(lib().bdf_rows_gate_selftest(c.handle, self.ctx.handle, C.byref(ok)))
-            for other in apart_from:
-                if ok.value and other is not self.ctx:
-                    check(lib().bdf_rows_gate_selftest(c.handle, other.handle, C.byref(ok)))
-            if ok.value:
-                if first is not None:
-                    first.close()
-                _SIDE_STREAMS[key] = st
-                return c
-            if first is None:
-                first = c
-            else:
-                c.close()
-        self.use_gate = False
-        return first
-
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
     def sample_entity(self, j):
         en, st = self.data.entities[j], self.ent[j]
@@ -601,24 +646,12 @@ class GibbsEngine:
             timer = KernelTimer()
             check(lib().bdf_ctx_time_next_rows(self.ctx.handle, timer.start, timer.stop))
         pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
-        # written into another buffer of the entity (nothing this launch reads), which then becomes the current one; the
-        # buffers rotate in threes, so readers of the previous two sweeps' rows on other streams (prediction updates) are
-        # never overwritten under their feet
+        # written into the entity's next buffer (nothing this launch reads), which then becomes the current one
         check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
-                                    st.tag, self.rank, self.world, _ptr(st.sample_alt), _ptr(pack) if pack is not None else None))
-        st.sample, st.sample_alt, st.sample_alt2 = st.sample_alt, st.sample_alt2, st.sample
+                                    st.tag, 0, 1, _ptr(st.sample_next), _ptr(pack) if pack is not None else None))
+        st.rotate()
         if timed:
             self.k1_events.append((j, timer))
-        if self.world > 1:
-            self._allgather(j)
-
-    def _allgather(self, j):
-        """RCCL all-gather of the rows each rank sampled (C1)"""
-        lists = self._rowlist(j)
-        if j not in self._ag_plans:
-            self._ag_plans[j] = allgather_plan(lists, self.rank, self.world)
-        with torch.cuda.stream(self.ctx.stream):
-            allgather_rows(self.ent[j].sample, lists, self.rank, self.world, self._ag_plans[j])
 
     # ---- macau.jl:119-134: hyperprior of entity j ----------------------------------------------------------------
     def _hyper_nu(self, j):
@@ -628,7 +661,7 @@ class GibbsEngine:
     def prepare_prior(self, j, sweep):
         """the data-independent part of update_prior(j) of this sweep; may be issued before the rows of j are sampled"""
         st = self.ent[j]
-        check(lib().bdf_hyper_draws(self.ctx_h.handle, self.D, st.N, self._hyper_nu(j), st.tag, _ptr(st.draws)))
+        check(lib().bdf_hyper_draws(self.ctx_h.handle, self.D, st.n_real, self._hyper_nu(j), st.tag, _ptr(st.draws)))
         st.draws_sweep = sweep
 
     def update_prior(self, j, sweep=None):
@@ -643,7 +676,7 @@ class GibbsEngine:
             nu += st.numF
             check(L.bdf_hyper_feature_terms(h, self.D, st.numF, _ptr(st.beta), _ptr(st.WI), _ptr(st.lambda_beta), _ptr(st.Tinv)))
             Tinv = st.Tinv
-        check(L.bdf_hyper_sample(h, self.D, st.N, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
+        check(L.bdf_hyper_sample(h, self.D, st.n_real, _ptr(st.sumU), _ptr(st.UUt), _ptr(st.mu0), st.b0, _ptr(Tinv),
                                  nu, st.tag, _ptr(st.mu), _ptr(st.Lambda), _ptr(st.params), _ptr(st.prior_pack),
                                  _ptr(draws) if draws is not None else None))
         st.prior_pack_valid = True
@@ -665,56 +698,72 @@ class GibbsEngine:
             if dr.F is not None:
                 r.model.beta = dr.beta.cpu().numpy().copy()
 
-    # ---- one Gibbs iteration without reporting (the timed unit of bench.py) ---------------------------------------
-    def sweep(self, i):
+    # ---- one Gibbs iteration (the timed unit of bench.py) ------------------------------------------------------
+    def step(self, i, phase, clamp=(), class_cut=0.0):
+        """iteration i and the reporting step of macau.jl:142-184 on the test pairs (phase 0 burn-in, 1 first posterior
+        sample, 2 later ones); returns the pairs' device stats"""
+        test = self.test_pairs()
+        if self.native:
+            opts = (tuple(clamp), float(class_cut))
+            if self._test_opts != opts:
+                lo, hi = (clamp[0], clamp[1]) if len(clamp) else (1.0, -1.0)
+                r = self.data.relations[0]
+                eom = (C.c_int32 * len(r.entities))(*[self._entity_index(e) for e in r.entities])
+                check(lib().bdf_gibbs_set_test(self.gibbs, test.handle, eom, r.model.mean_value, lo, hi, class_cut, _ptr(test.stats)))
+                self._test_opts = opts
+            self.sweep(i, phase)
+            return test.stats
+        self.sweep(i)
+        r = self.data.relations[0]
+        return test.update(self.D, self.factors_of(r), r.model.mean_value, phase, list(clamp), class_cut)
+
+    def sweep(self, i, predict_phase=None):
+        """iteration i without reporting (native: with the prediction update of `predict_phase` on the registered test pairs)"""
+        self._k1_sweep = i
+        if self.native:
+            timed = self.k1_events is not None and i % self.k1_event_every == 0
+            if timed:
+                for j in range(len(self.ent)):
+                    timer = KernelTimer()
+                    check(lib().bdf_gibbs_time_rows(self.gibbs, j, timer.start, timer.stop))
+                    self.k1_events.append((j, timer))
+            check(lib().bdf_gibbs_sweep(self.gibbs, C.c_uint32(int(i)), -1 if (predict_phase is None or self._test_opts is None) else int(predict_phase)))
+            for st in self.ent:
+                st.rotate()
+                st.prior_pack_valid = True
+            return
         main, side = self.ctx.stream, self.ctx_h.stream
         two = self.ctx_h is not self.ctx
-        self._k1_sweep = i
         self.ctx.set_sweep(i)
         if two:
             self.ctx_h.set_sweep(i)
         three = self.ctx_p is not self.ctx
         if three:
+            self.ctx_p.set_sweep(i)
             # The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep i-2.  The prediction
-            # updates that read those were all enqueued before the previous sweep began: the event recorded then has long
-            # completed.  Even a satisfied wait costs a stream ~6 us (tools/chain_timeline.py), so it is the side stream
-            # that waits, here where it idles until this sweep's first row kernel ends -- every row kernel of the next
-            # sweep waits for a hyperprior event recorded on the side stream after this point.
+            # updates that read those were all enqueued before the previous sweep began.  The side stream waits for them
+            # here, where it idles until this sweep's first row kernel ends; every row kernel of the next sweep waits for a
+            # hyperprior event recorded on the side stream after this point.
             if self._ev_pred is not None:
                 side.wait_event(self._ev_pred)
             self._ev_pred = torch.cuda.Event()
             self._ev_pred.record(self.ctx_p.stream)
         self.update_relations()
         for j in range(len(self.ent)):
-            timed = self.k1_events is not None and i % self.k1_event_every == 0
-            if two and self._gate_back and j in self._snap_hyper and not (timed and self._ev_hyper_sweep.get(j) == i - 1):
-                # (mu, Lambda) of entity j from the previous iteration: a gate on the draw kernel's completion count.  A
-                # row kernel whose duration is measured waits for an event instead (recorded only ahead of such a sweep):
-                # the start event attached to a dispatch that sits behind a spinning gate is stamped while it waits
-                check(lib().bdf_rows_gate_at(self.ctx.handle, self.ctx_h.handle, self._snap_hyper[j]))
-            elif two and j in self._ev_hyper:
+            if two and j in self._ev_hyper:
                 main.wait_event(self._ev_hyper[j])       # (mu, Lambda) of entity j from the previous iteration
             if two:
                 self.prepare_prior(j, i)                 # side stream, beside the row sampling
             self.sample_entity(j)
-            if two and self.use_gate:
-                check(lib().bdf_rows_gate(self.ctx_h.handle, self.ctx.handle))
-            elif two:
+            if two:
                 ev = self._ev_rows.setdefault(j, torch.cuda.Event())
                 ev.record(main)
                 side.wait_event(ev)
             self.update_prior(j, i)
-            next_timed = self.k1_events is not None and (i + 1) % self.k1_event_every == 0
-            if two and self._gate_back:
-                snap = self._snap_hyper.setdefault(j, (C.c_uint32 * 64)())
-                check(lib().bdf_gate_snapshot(self.ctx_h.handle, snap))
-            if two and (not self._gate_back or next_timed):
-                ev = self._ev_hyper.setdefault(j, torch.cuda.Event())      # (with gates: only ahead of a timed sweep)
+            if two:
+                ev = self._ev_hyper.setdefault(j, torch.cuda.Event())
                 ev.record(side)
-                self._ev_hyper_sweep[j] = i
-        if three and self.use_gate:                          # prediction updates read this sweep's rows
-            check(lib().bdf_rows_gate(self.ctx_p.handle, self.ctx.handle))
-        elif three:
+        if three:                                         # prediction updates read this sweep's rows
             self.ctx_p.stream.wait_event(self._ev_rows[len(self.ent) - 1])
         for j in range(len(self.ent)):
             if self.ent[j].F is not None:
@@ -727,6 +776,9 @@ class GibbsEngine:
                     side.wait_event(ev)
 
     def sync(self):
+        if self.gibbs:
+            check(lib().bdf_gibbs_sync(self.gibbs))
+            return
         if self.ctx_p is not self.ctx:
             self.ctx_p.sync()
         if self.ctx_h is not self.ctx:
@@ -739,7 +791,10 @@ class GibbsEngine:
 
     def pred_all(self, r):
         """pred_all(r) (sampling.jl:91-97): udot over every cell + mean_value, as one library GEMM / einsum on the device"""
-        S = self.factors_of(r)                                  # each (N_k, D)
+        S = []
+        for e in r.entities:
+            st = self.ent[self._entity_index(e)]
+            S.append(st.sample if st.layout.pos is None else st.sample[torch.as_tensor(st.layout.pos.astype(np.int64), device=st.sample.device)])
         with torch.cuda.stream(self.ctx.stream):
             if len(S) == 2:
                 return torch.mm(S[0], S[1].T) + r.model.mean_value
@@ -747,10 +802,23 @@ class GibbsEngine:
             expr = ",".join(f"{c}z" for c in letters) + "->" + letters
             return torch.einsum(expr, *S) + r.model.mean_value
 
-    def test_pairs(self):
+    def _pairs(self, ctx, r, ids, values):
+        """test_vec / the training table as device pairs, ids at the entities' internal positions"""
+        ids = np.asarray(ids).reshape(len(values), len(r.entities))
+        if self.world > 1:
+            ids = np.stack([self.layouts[self._entity_index(e)].to_internal(ids[:, k]) for k, e in enumerate(r.entities)], axis=1)
+        return DevicePairs(ctx, ids, values)
+
+    def test_pairs(self, subset=None):
+        """the relation's test_vec on the device (subset: the rows of test_vec this rank predicts)"""
         r = self.data.relations[0]
         if self._test_pairs is None:
-            self._test_pairs = DevicePairs(self.ctx_p, r.test_vec.ids.reshape(len(r.test_vec), len(r.entities)), r.test_vec.values)
+            ids = r.test_vec.ids.reshape(len(r.test_vec), len(r.entities))
+            vals = np.asarray(r.test_vec.values)
+            if subset is not None:
+                ids, vals = ids[subset], vals[subset]
+            # native iteration: the pairs belong to the row context (the library updates them on its own prediction stream)
+            self._test_pairs = self._pairs(self.ctx if self.native else self.ctx_p, r, ids, vals)
             if len(r.entities) == 2 and not os.environ.get("BDF_NO_PAIR_SORT"):
                 # stored sorted by the mode with the fewest rows (most pairs per row): the update keeps that mode's factor
                 # row in registers over a run of pairs and gathers only the other mode's (k_predict_runs); results stay in
@@ -777,10 +845,16 @@ class GibbsEngine:
         if self._train_pairs is None and self.rel[0].train is not None:
             self._train_pairs = self.rel[0].train
         if self._train_pairs is None:
-            self._train_pairs = DevicePairs(self.ctx_p, r.data.ids, r.data.values)
+            self._train_pairs = self._pairs(self.ctx_p if not self.native else self.ctx, r, r.data.ids, r.data.values)
         return self._train_pairs
 
     def close(self):
+        if not self.ctx.handle:
+            return
+        try:
+            self.sync()
+        except Exception:
+            pass
         for p in (self._test_pairs, self._train_pairs):
             if p is not None:
                 p.close()
@@ -789,8 +863,57 @@ class GibbsEngine:
                 st.F.close()
         for dr in self.rel:
             dr.close()
-        if self.ctx_p is not self.ctx:
-            self.ctx_p.close()
-        if self.ctx_h is not self.ctx:
-            self.ctx_h.close()
+        if self.gibbs:
+            lib().bdf_gibbs_destroy(self.gibbs)          # (and its two contexts)
+            self.gibbs = None
+            self.ctx_h.handle = self.ctx_p.handle = C.c_void_p()
+        else:
+            if self.ctx_p is not self.ctx:
+                self.ctx_p.close()
+            if self.ctx_h is not self.ctx:
+                self.ctx_h.close()
+        if self.comm is not None:
+            self.comm.close()
+            self.comm = None
         self.ctx.close()
+
+
+# ---- the communicator of a multi-rank run ----------------------------------------------------------------------------
+class Comm:
+    """bdf_comm: RCCL (one GPU per rank; the unique id travels over torch.distributed's channel), or -- several ranks on one
+    GPU, the test rig BDF_DIST_BACKEND=gloo -- the library's host transport with a gloo all-gather behind it"""
+
+    def __init__(self, ctx, rank, world):
+        import torch.distributed as dist
+        self.handle = C.c_void_p()
+        self._cb = None
+        if dist.get_backend() == "nccl":
+            buf = torch.zeros(_lib.BDF_COMM_ID_BYTES, dtype=torch.uint8)
+            if rank == 0:
+                raw = (C.c_char * _lib.BDF_COMM_ID_BYTES)()
+                check(lib().bdf_comm_unique_id(raw))
+                buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            dev = buf.to(ctx.device)
+            dist.broadcast(dev, src=0)
+            raw = bytes(dev.cpu().numpy().tobytes())
+            check(lib().bdf_comm_create(ctx.handle, rank, world, raw, C.byref(self.handle)))
+        else:
+            def exchange(user, send, recv, nbytes):
+                try:
+                    s = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8)
+                    r = torch.frombuffer((C.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+                    dist.all_gather_into_tensor(r, s)
+                    return 0
+                except Exception:        # noqa: BLE001 -- reported through the library's error code
+                    return 1
+            self._cb = _lib.EXCHANGE_FN(exchange)
+            check(lib().bdf_comm_create_host(ctx.handle, rank, world, self._cb, None, C.byref(self.handle)))
+
+    def close(self):
+        if self.handle:
+            lib().bdf_comm_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+
+def make_comm(ctx, rank, world):
+    return Comm(ctx, rank, world)

@@ -5,23 +5,29 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
 A step is one Gibbs iteration of src/macau.jl:80 on the device: latent rows of users, hyperprior of users, latent rows of
-movies, hyperprior of movies, and the test-set prediction update of macau.jl:142-184 (kept inside the timed region; the
-reporting-only metrics are not).  W warm-up steps are the burn-in; the K timed steps are the posterior samples, so the
-RMSE printed is that of the posterior-mean prediction after W + K iterations on the 500,000 held-out ratings.
+movies, hyperprior of movies, and the test-set prediction update of macau.jl:142-184 (inside the timed region; the
+reporting-only metrics are not) -- one native call, bdf_gibbs_sweep.  W warm-up steps are the burn-in; the K timed steps
+are the posterior samples, so the RMSE printed is that of the posterior-mean prediction after W + K iterations on the
+500,000 held-out ratings.
 
-N > 1 (weak scaling): MovieLens is a ~130 us sweep, far too small to split, so the N-GPU workload is N MovieLens-sized
-units -- the rating matrix stacked over N disjoint user blocks that rate the same movies (N x 6040 users, N x 500,209
-training ratings, N x 500,000 held-out ratings; datasets.replicate_users).  One process per GPU; every rank holds the
-whole relation and a replica of both factors, samples its share of the rows of each entity (rank, rank + N, ... of the
-degree order), and the ranks exchange the freshly sampled rows by an RCCL all-gather after each half-sweep; the test
-ratings of user block r are predicted by rank r.  value = N units x sweeps/s, so that N = 1 is exactly the BASELINE
-configuration and ideal scaling is N x its value.  (--replicas R runs the R-unit workload on fewer GPUs.)
+The JSON line has two measurements:
+ * value / ms_per_step: the BASELINE metric.  N = 1 is exactly the BASELINE configuration.  N > 1 is WEAK scaling of it:
+   MovieLens is a ~120 us sweep, far too small to split, so the N-GPU workload is N MovieLens-sized units -- the rating
+   matrix stacked over N disjoint user blocks that rate the same movies (datasets.replicate_users) -- value = N x sweeps/s.
+ * "c4": STRONG scaling on BASELINE configuration 4, the synthetic 10M x 1M relation with 100M observations at D = 64
+   (datasets.c4_relation_data / bdf_synth_ratings): the same relation on 1, 2, 4, 8 GPUs, c4.sweeps_per_s.  (--c4-nnz etc.
+   shrink it; --no-c4 skips it.)
+In both, with N > 1: one process per GPU; every rank holds the observations of its own rows and a replica of both factor
+matrices (rows shared out by bdf_layout_build), samples its rows and takes part in an in-place RCCL all-gather per
+half-sweep (bdf_allgather_rows); the test ratings are split over the ranks.
 
-Prints one JSON line (rank 0).  roofline: K1 (k_sample_rows) algorithmic bytes per launch over its mean
-launch duration from HIP events attached to the kernel dispatches (on the launch stream) inside the timed region.  cpu_baseline: the CPU oracle
-(a C port of the reference algorithm, OpenMP over rows like the reference's latent_pids workers) timed on this box.
+roofline: K1 (k_rows) algorithmic bytes per launch over its mean launch duration from HIP events attached to
+the kernel dispatches (on the launch stream), from the timed region and -- so that at least 200 launches are averaged --
+from further sweeps after it.  cpu_baseline: the CPU oracle (a C port of the reference algorithm, OpenMP over rows like
+the reference's latent_pids workers) timed on this box.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -70,6 +76,21 @@ def cpu_baseline(rd, D, seed, budget_s=12.0):
             "value_1thread": round(single, 4)}
 
 
+def recorded_traffic():
+    """HBM bytes of one K1 launch from the committed PMC passes (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
+    separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured by this run: returned
+    only while the row kernel's source is the one the passes ran on, with the file named next to it."""
+    tj = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    try:
+        d = json.load(open(tj))
+        src = open(os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc", "k_sample_rows.hip"), "rb").read()
+        if d.get("k_sample_rows_sha1") != hashlib.sha1(src).hexdigest():
+            return None, None
+        return d["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"], "profiles/r02_hbm_traffic.json (rocprofv3 --pmc passes of this workload on this kernel source; not measured by this run)"
+    except (OSError, KeyError, ValueError):
+        return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -80,8 +101,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--k1-event-every", type=int, default=8,
                     help="time the K1 launches of every n-th step (HIP events attached to the kernel dispatch)")
-    ap.add_argument("--no-predict", action="store_true", help="leave the test-set prediction update out of the step")
+    ap.add_argument("--k1-min-launches", type=int, default=200, help="K1 launches averaged for the roofline (further sweeps after the timed region)")
     ap.add_argument("--replicas", type=int, default=0, help="user blocks of the workload (default: one per GPU)")
+    ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
+    ap.add_argument("--c4-rows", type=int, default=10_000_000)
+    ap.add_argument("--c4-cols", type=int, default=1_000_000)
+    ap.add_argument("--c4-nnz", type=int, default=100_000_000)
+    ap.add_argument("--c4-latent", type=int, default=64)
+    ap.add_argument("--c4-sweeps", type=int, default=5, help="warm-up and timed sweeps of the C4 measurement (5 + 5: SURVEY M-C4)")
     args = ap.parse_args()
 
     import numpy as np
@@ -96,7 +123,7 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    # test rig: BDF_DIST_BACKEND=gloo runs all ranks on GPU 0 with the collectives staged through the host (RCCL needs one
+    # test rig: BDF_DIST_BACKEND=gloo runs all ranks on GPU 0 with the exchange staged through the host (RCCL needs one
     # GPU per rank); it checks the N > 1 logic on a 1-GPU box, its timings mean nothing
     backend = os.environ.get("BDF_DIST_BACKEND", "nccl")
     if backend == "gloo":
@@ -112,76 +139,68 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
     red_dev = "cpu" if backend == "gloo" else "cuda"
 
-    D = args.num_latent
-    replicas = args.replicas if args.replicas > 0 else world
-    rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, replicas=replicas)
-    rel = rd.relations[0]
-    eng = B.GibbsEngine(rd, D, seed=args.seed, device=local_rank, shard=(rank, world))
-    if world > 1:
-        # rank r predicts the held-out ratings of the user blocks r, r + world, ...
-        from bdf_amd.engine import DevicePairs
-        tv = rel.test_vec
-        tids = np.asarray(tv.ids).reshape(-1, 2)
-        block = (tids[:, 0] - 1) // (rel.data.dims[0] // replicas)
-        mine = np.nonzero(block % world == rank)[0]
-        test = DevicePairs(eng.ctx_p, tids[mine], np.asarray(tv.values)[mine])
-    else:
-        test = eng.test_pairs()
-    n_test_total = len(np.asarray(rel.test_vec.values))
-    clamp = [1.0, 5.0]
-
-    def step(i, phase):
-        eng.sweep(i)
-        if not args.no_predict:
-            test.update(D, eng.factors_of(rel), rel.model.mean_value, phase, clamp, rel.class_cut)
-
     def fence():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=red_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def my_share(n):
+        """the test pairs this rank predicts: a contiguous slice"""
+        return np.arange(n * rank // world, n * (rank + 1) // world)
+
+    # ---- the BASELINE metric: MovieLens (N > 1: N stacked units) ------------------------------------------------------------
+    D = args.num_latent
+    replicas = args.replicas if args.replicas > 0 else world
+    rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, replicas=replicas)
+    rel = rd.relations[0]
+    eng = B.GibbsEngine(rd, D, seed=args.seed, device=local_rank, shard=(rank, world))
+    n_test_total = len(np.asarray(rel.test_vec.values))
+    test = eng.test_pairs(subset=my_share(n_test_total) if world > 1 else None)
+    clamp = [1.0, 5.0]
+
     for i in range(1, args.warmup + 1):
-        step(i, 0)
+        eng.step(i, 0, clamp, rel.class_cut)
     eng.sync()
     fence()
     eng.k1_events = []
     eng.k1_event_every = max(1, min(args.k1_event_every, args.steps // 4))     # a short run still times a few launches
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(args.warmup + 1 + k, 1 if k == 0 else 2)
+        eng.step(args.warmup + 1 + k, 1 if k == 0 else 2, clamp, rel.class_cut)
     fence()
-    elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(time.perf_counter() - t0)
     eng.sync()
+    rmse = None
+    sse = test.stats[:1].clone().to(red_dev if dist is not None else "cuda")
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=red_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        dist.all_reduce(sse)                       # every rank holds the squared error of its share of the test ratings
+    rmse = float(np.sqrt(float(sse.item()) / n_test_total))
 
-    # K1 roofline from the events recorded inside the timed region
+    # K1 roofline: the launches timed inside the timed region, then further sweeps (every launch timed) up to the minimum
+    in_region = len(eng.k1_events)
+    eng.k1_event_every = 1
+    it = args.warmup + args.steps
+    while len(eng.k1_events) < args.k1_min_launches and it < args.warmup + args.steps + 2000:
+        it += 1
+        eng.sweep(it, 2)
+    eng.sync()
     k1_ms = sum(t.elapsed_us() for (_, t) in eng.k1_events) / 1e3
     k1_bytes = sum(eng.k1_algorithmic_bytes(j) for (j, _) in eng.k1_events) / max(world, 1)
     n_launch = max(len(eng.k1_events), 1)
+    k1_ms_region = sum(t.elapsed_us() for (_, t) in eng.k1_events[:in_region]) / 1e3
     achieved = (k1_bytes / 1e9) / (k1_ms / 1e3) if k1_ms > 0 else 0.0
     eng.k1_events = None
+    traffic, traffic_source = recorded_traffic() if (world == 1 and replicas == 1 and D == 32) else (None, None)
 
-    # HBM traffic of one K1 launch from the PMC passes of the same workload (tools/profile_round.sh: FETCH_SIZE and
-    # WRITE_SIZE in separate passes; FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950), if recorded
-    traffic = None
-    tj = os.path.join(ROOT, "profiles", "r01_hbm_traffic.json")
-    if os.path.exists(tj) and world == 1 and replicas == 1:
-        try:
-            traffic = json.load(open(tj))["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"]
-        except (KeyError, ValueError):
-            traffic = None
-
-    rmse = None
-    if not args.no_predict:
-        sse = test.stats[:1].clone().to(red_dev if dist is not None else "cuda")
-        if dist is not None:
-            dist.all_reduce(sse)                       # every rank holds the squared error of its share of the test ratings
-        rmse = float(np.sqrt(float(sse.item()) / n_test_total))
-
+    out = None
     if rank == 0:
         out = {
             "metric": "Gibbs sweeps/sec (both entities) + test RMSE, MovieLens-1M D=32",
@@ -197,23 +216,71 @@ def main():
             "dtype": "f64",
             "data": source,
             "config": {"workload": f"BPMF MovieLens-1M 6040x3952, 500209 training ratings (500000 held out), D={D}, alpha=1.5, "
-                                   f"step = rows of both entities + hyperpriors{'' if args.no_predict else ' + test prediction update'}"
+                                   f"step = rows of both entities + hyperpriors + test prediction update (one native call)"
                                    + (f"; {replicas} such units: the ratings stacked over {replicas} disjoint user blocks, "
                                       f"value = {replicas} x sweeps/s" if replicas > 1 else ""),
                        "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
-                       "parallelism": (f"rows of each entity dealt over {world} GPUs, RCCL all-gather of the sampled rows per "
-                                       f"half-sweep, test ratings split by user block") if world > 1 else "1 GPU"},
+                       "parallelism": (f"rows of each entity shared out over {world} GPUs (a rank holds its rows' observations only), "
+                                       f"in-place RCCL all-gather of the sampled rows per half-sweep, test ratings split over the ranks")
+                       if world > 1 else "1 GPU"},
             "test_rmse": None if rmse is None else round(rmse, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "k_sample_rows", "launches_timed": n_launch,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel": "k_rows (k_sample_rows.hip)", "launches_timed": n_launch,
+                         "launches_timed_in_region": in_region,
                          "avg_launch_us": round(1e3 * k1_ms / n_launch, 2),
+                         "avg_launch_us_in_region": round(1e3 * k1_ms_region / max(in_region, 1), 2),
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rd, D, args.seed)
-        print(json.dumps(out), flush=True)
     eng.close()
+    del eng, rd, rel, test
+
+    # ---- strong scaling on configuration C4 ---------------------------------------------------------------------------------
+    if not args.no_c4:
+        c4 = {"workload": f"synthetic {args.c4_rows} x {args.c4_cols}, {args.c4_nnz} observations (1% held out), BPMF D={args.c4_latent}, "
+                          f"alpha=2, {args.c4_sweeps}+{args.c4_sweeps} sweeps (SURVEY M-C4: bdf_synth_ratings seed 777, Zipf-like columns)",
+              "n_gpus": world, "scaling": "strong"}
+        try:
+            t0 = time.time()
+            rd4 = datasets.c4_relation_data(B, args.c4_rows, args.c4_cols, args.c4_nnz)
+            t_gen = time.time() - t0
+            rel4 = rd4.relations[0]
+            t0 = time.time()
+            eng4 = B.GibbsEngine(rd4, args.c4_latent, seed=5, device=local_rank, shard=(rank, world))
+            n4 = len(np.asarray(rel4.test_vec.values))
+            test4 = eng4.test_pairs(subset=my_share(n4) if world > 1 else None)
+            eng4.step(1, 0, clamp, rel4.class_cut)
+            eng4.sync()
+            t_setup = time.time() - t0
+            for i in range(2, args.c4_sweeps + 1):
+                eng4.step(i, 0, clamp, rel4.class_cut)
+            eng4.sync()
+            fence()
+            t0 = time.perf_counter()
+            for k in range(args.c4_sweeps):
+                eng4.step(args.c4_sweeps + 1 + k, 1 if k == 0 else 2, clamp, rel4.class_cut)
+            fence()
+            el4 = max_over_ranks(time.perf_counter() - t0)
+            eng4.sync()
+            sse4 = test4.stats[:1].clone().to(red_dev if dist is not None else "cuda")
+            if dist is not None:
+                dist.all_reduce(sse4)
+            bytes_sweep = sum(eng4.k1_algorithmic_bytes(j) for j in range(2))
+            c4.update({"sweeps_per_s": round(args.c4_sweeps / el4, 3), "ms_per_sweep": round(1e3 * el4 / args.c4_sweeps, 3),
+                       "test_rmse": round(float(np.sqrt(float(sse4.item()) / max(n4, 1))), 5),
+                       "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
+                       "algorithmic_tb_per_s": round(bytes_sweep / (el4 / args.c4_sweeps) / 1e12, 3),
+                       "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
+                       "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
+            eng4.close()
+        except Exception as e:      # noqa: BLE001 -- the BASELINE metric above must still be reported
+            c4["error"] = f"{type(e).__name__}: {e}"
+        if out is not None:
+            out["c4"] = c4
+    if rank == 0:
+        print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

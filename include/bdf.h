@@ -56,6 +56,8 @@ typedef struct bdf_ctx   bdf_ctx;    /* device, stream, seed, sweep counter, scr
 typedef struct bdf_rel   bdf_rel;    /* Relation.data :: IndexedDF / FastIDF on the device  */
 typedef struct bdf_pairs bdf_pairs;  /* Relation.test_vec (+ running prediction state)      */
 typedef struct bdf_feat  bdf_feat;   /* Entity.F operator (dense / CSR / binary CSR / COO)  */
+typedef struct bdf_comm  bdf_comm;   /* the ranks (GPUs) that share the entities' rows       */
+typedef struct bdf_gibbs bdf_gibbs;  /* a whole Gibbs iteration enqueued from native code    */
 
 const char *bdf_last_error(void);
 int bdf_version(void);
@@ -69,22 +71,12 @@ int bdf_ctx_destroy(bdf_ctx *ctx);
  * the launches that follow by value. */
 int bdf_ctx_set_sweep(bdf_ctx *ctx, uint32_t sweep);
 int bdf_ctx_advance_sweep(bdf_ctx *ctx);
-/* Cross-stream hand-over of freshly sampled rows without an event: enqueues on `waiter`'s stream a one-wave kernel that
- * returns once every row-kernel launch (bdf_sample_rows) enqueued so far on `producer` has completed and its rows are
- * visible -- the ordering hipEventRecord(producer) + hipStreamWaitEvent(waiter) gives for those launches and everything
- * before them on producer's stream, at a quarter of the cost to the producer's stream.  Bounded wait (30 s, env
- * BDF_GATE_TIMEOUT_S): on time-out the waiter's next bdf_ctx_sync returns BDF_ERR_HIP.  Both contexts on one device.
- * bdf_rows_gate_selftest: *usable = 1 if the two streams really run side by side (a gate enqueued before the kernel
- * that satisfies it passes); callers fall back to events otherwise.  Synchronises both streams.  HIP multiplexes streams
- * onto a few hardware queues: two streams that fail this test share one, and work on them is serialised whatever the
- * hand-over mechanism (worth testing between any two streams that are meant to run side by side). */
-int bdf_rows_gate(bdf_ctx *waiter, const bdf_ctx *producer);
-int bdf_rows_gate_selftest(bdf_ctx *waiter, bdf_ctx *producer, int *usable);
-/* The gate at an earlier point of the producer's stream: bdf_gate_snapshot copies the producer's completion targets (64
- * counters) as they stand after the launches enqueued so far -- row kernels and hyperprior draws (bdf_hyper_sample) count
- * themselves -- and bdf_rows_gate_at waits for exactly those, whatever was enqueued on the producer since. */
-int bdf_gate_snapshot(const bdf_ctx *producer, uint32_t *targets);
-int bdf_rows_gate_at(bdf_ctx *waiter, const bdf_ctx *producer, const uint32_t *targets);
+/* A context on ANOTHER stream of main_ctx's device (created and owned by the library; bdf_ctx_destroy frees it), chosen so that
+ * kernels on it really run beside those of main_ctx and of the contexts in `apart`: HIP multiplexes streams onto a few
+ * hardware queues, and two streams that share one serialise each other (measured: 171 instead of 125 us per sweep).  A
+ * timing test (two 60 us spins, together) picks among a few candidate streams; with no passing candidate the last one is
+ * returned (correct, only slower).  The hyperprior of entity j is enqueued on such a context beside the rows of entity j+1. */
+int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, bdf_ctx **out);
 /* Measurement support: HIP events (timing enabled) and "attach this pair to the next bdf_sample_rows launch of ctx":
  * the events ride on the row kernel's own dispatch packet (hipExtLaunchKernelGGL), so start/stop are the kernel's begin and
  * end on its stream without marker packets around it (an event pair recorded around a launch costs the stream ~6 us and
@@ -96,9 +88,6 @@ int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
 /* the same for the hyperprior chain of ctx: `start` rides on the next bdf_hyper_sums' first kernel, `stop` on the next
  * bdf_hyper_sample's kernel */
 int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
-/* `stop` rides on the next bdf_rows_gate_at kernel enqueued on ctx: the moment the kernel behind the gate can begin (the
- * start event of a dispatch that waits behind a spinning gate is stamped while it waits) */
-int bdf_ctx_time_next_gate(bdf_ctx *ctx, void *stop);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
@@ -283,6 +272,82 @@ int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *f, int D, const double *sample
                     const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
                     int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
                     double *beta_out, double *rhs_out, int32_t *iters_out);
+
+/* ---- multi-GPU: rows of every entity shared out over the ranks, exchanged after sampling ---------------------------------
+ * The reference: sample_latent_all2! deals the rows i:P:N to P workers and ships every factor matrix to every worker in
+ * every call (src/sampling.jl:154-171, remotecall_fetch(sample_latent_range_ref, ...)).  Here: one process per GPU; every
+ * rank holds a replica of every factor matrix, the observations of ITS rows only, and after sampling its rows of an entity
+ * takes part in one in-place all-gather per chunk.
+ *
+ * bdf_layout_build (host-only): internal row positions of an entity.  Rows in falling order of `degree` (stable; the
+ * observations of the row over all the entity's relations) are dealt round-robin to the ranks, a rank's rows round-robin to
+ * `chunks` chunks; row i of chunk c of rank p sits at pos = (c * world + p) * cmax + i.  The factor matrix of the entity then
+ * has chunks * world * cmax rows (rows nobody owns stay zero), chunk c of it is one contiguous rank-major region.
+ * pos_out: N entries; *cmax_out = ceil(ceil(N / world) / chunks). */
+int bdf_layout_build(int64_t N, const int64_t *degree, int world, int chunks, int32_t *pos_out, int64_t *cmax_out);
+/* bdf_relation_create with a layout per mode (pos[m], cmax[m] from bdf_layout_build with the same world and chunks): the
+ * index is the full IndexedDF index as ever; the DEVICE holds only the observations of the rows `rank` owns, addressed by
+ * internal positions.  bdf_sample_rows on such a relation takes (shard, n_shards) = (chunk, chunks), N = chunks * world *
+ * cmax, writes the rows at their internal positions and keys every row's random stream by its ORIGINAL id, so that the
+ * chain does not depend on the number of GPUs (up to the summation order of the hyperprior's sums). */
+int bdf_relation_create_sharded(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz, const void *ids, int id_bytes,
+                                const double *values, const int32_t *const *pos, const int64_t *cmax, int rank, int world,
+                                int chunks, bdf_rel **out);
+/* The communicator.  RCCL transport: rank 0 calls bdf_comm_unique_id (128 bytes) and hands the id to the other ranks by
+ * whatever channel the host has (Julia: its cluster manager; Python: torch.distributed's store); librccl.so is resolved with
+ * dlopen at the first call.  Host transport (test rigs with several ranks on one GPU, where RCCL refuses to run): the block is
+ * staged through host memory and `fn` -- recv = world blocks of bytes_per_rank, rank-major -- does the exchange. */
+#define BDF_COMM_ID_BYTES 128
+int bdf_comm_unique_id(void *id_out);
+int bdf_comm_create(bdf_ctx *ctx, int rank, int world, const void *unique_id, bdf_comm **out);
+typedef int (*bdf_exchange_fn)(void *user, const void *send, void *recv, size_t bytes_per_rank);
+int bdf_comm_create_host(bdf_ctx *ctx, int rank, int world, bdf_exchange_fn fn, void *user, bdf_comm **out);
+int bdf_comm_destroy(bdf_comm *comm);
+int bdf_comm_size(const bdf_comm *comm, int *rank, int *world);
+/* Exchange of chunk `chunk` of the N x D factor matrix `sample` (dev; N = chunks * world * cmax rows, the layout above): an
+ * in-place all-gather of the ranks' blocks (ncclAllGather), ordered after the work enqueued so far on ctx's stream, run on
+ * the communicator's own stream -- the row kernel of the next chunk runs beside it.  bdf_allgather_join: ctx's stream waits
+ * for every exchange enqueued so far. */
+int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t N, double *sample, int chunk, int chunks);
+int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *comm);
+
+/* ---- a2: one Gibbs iteration enqueued from native code (src/macau.jl:80-203 without side information) ---------------------
+ * rows of every entity (+ exchange) -> hyperpriors -> test-set prediction update, on three streams (rows: ctx's; the other
+ * two are created here, chosen so that they really run beside it), hand-overs by events on the kernels' own dispatch
+ * packets.  The host pays one call per iteration. */
+typedef struct {
+    int64_t N;                    /* rows of the factor matrix (the entity's count; chunks * world * cmax with a layout)   */
+    int64_t n_real;               /* the entity's count (N of ConditionalNormalWishart, src/sampling.jl:117)             */
+    uint32_t tag;                 /* entity tag of the random streams (1-based entity number)                             */
+    int32_t n_terms;              /* relations the entity takes part in                                                    */
+    struct {
+        const bdf_rel *rel;
+        int32_t mode;             /* 0-based mode of this entity in rel                                                    */
+        int32_t entity_of_mode[BDF_MAX_MODES];   /* which entity (index into the array) every mode of rel is                */
+        double alpha, mean_value;
+    } terms[BDF_MAX_TERMS];
+    double *sample[3];            /* dev, D x N each: the rows rotate through three buffers; [0] holds the current rows      */
+    double *mu, *Lambda, *mu0, *WI, *sumU, *UUt, *params /*nullable*/, *prior_pack, *draws;   /* dev, as in bdf_hyper_sample */
+    double b0, nu0;
+} bdf_gibbs_entity;
+int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const bdf_gibbs_entity *entities, bdf_gibbs **out);
+int bdf_gibbs_destroy(bdf_gibbs *g);
+/* the contexts of the hyperprior and prediction streams (owned by g), e.g. to create the test pairs' running state there */
+int bdf_gibbs_contexts(bdf_gibbs *g, bdf_ctx **hyper, bdf_ctx **pred);
+int bdf_ctx_stream(const bdf_ctx *ctx, void **stream);
+/* test pairs updated at the end of every iteration (macau.jl:142-184); entity_of_mode: which entity every mode of the pairs is;
+ * the other arguments as bdf_predict_update's */
+int bdf_gibbs_set_test(bdf_gibbs *g, bdf_pairs *pairs, const int32_t *entity_of_mode, double mean_value, double clamp_lo,
+                       double clamp_hi, double class_cut, double *stats_dev);
+/* several ranks: exchange every entity's rows after sampling them (NULL: none) */
+int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm);
+/* one iteration.  predict_phase: bdf_predict_update's phase (0 burn-in, 1 first posterior sample, 2 later ones), -1: none */
+int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase);
+/* which of sample[0..2] holds entity's current rows */
+int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer);
+/* measurement: (start, stop) events ride on the dispatch of entity's next row kernel (bdf_ctx_time_next_rows) */
+int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop);
+int bdf_gibbs_sync(bdf_gibbs *g);     /* waits for the three streams; errors as bdf_ctx_sync */
 
 /* ---- synthetic sparse relation of configuration C4 (host-only, needs no GPU) ---------------------------------------
  * The reference's large-scale benchmark draws its relation with sprand (test/benchmark_parallel_latent.jl:8-12).

@@ -235,8 +235,7 @@ def test_c4_shaped_full_size_properties_and_quality(B):
     eng.ctx.set_gather(2)
     test = eng.test_pairs()
     for i in range(1, 21):
-        eng.sweep(i)
-        stats = test.update(D, eng.factors_of(rel), rel.model.mean_value, 0 if i <= 10 else (1 if i == 11 else 2), [1.0, 5.0], rel.class_cut)
+        stats = eng.step(i, 0 if i <= 10 else (1 if i == 11 else 2), [1.0, 5.0], rel.class_cut)
     eng.sync()
     rmse = float(np.sqrt(stats.cpu().numpy()[0] / test.n))
     tv = np.asarray(rel.test_vec.values)

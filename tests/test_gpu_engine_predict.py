@@ -9,6 +9,15 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=["native", "stepwise"])
+def mode(request, monkeypatch):
+    """the native iteration (bdf_gibbs_sweep; the pairs belong to the row context) and the step-by-step one (the pairs live on
+    the engine's prediction stream: the configuration of the round-1 race)"""
+    if request.param == "stepwise":
+        monkeypatch.setenv("BDF_NO_NATIVE", "1")
+    return request.param
+
+
 def _smoke_like(B, N1, N2, D, nnz, ntest, seed):
     rng = np.random.default_rng(seed)
     ids = np.stack([rng.integers(1, N1 + 1, nnz), rng.integers(1, N2 + 1, nnz)], axis=1)
@@ -21,15 +30,15 @@ def _smoke_like(B, N1, N2, D, nnz, ntest, seed):
 
 
 @pytest.mark.parametrize("N1,N2,D", [(300, 200, 16), (200, 300, 16), (257, 123, 32), (90, 140, 7)])
-def test_engine_test_pairs_predict_matches_oracle(B, O, N1, N2, D):
+def test_engine_test_pairs_predict_matches_oracle(B, O, mode, N1, N2, D):
     """two sweeps on a multi-stream engine, then predict() on the engine's pairs, repeatedly and without any host
     synchronisation in between: every call must see the rows of the sweep enqueued before it"""
     import torch
     rd, rel = _smoke_like(B, N1, N2, D, 6000, 500, seed=N1 + D)
     eng = B.GibbsEngine(rd, D, seed=42)
-    assert eng.ctx_p is not eng.ctx and eng.ctx_p.stream != eng.ctx.stream        # the hazardous configuration
+    assert eng.ctx_p is not eng.ctx and eng.ctx_p.stream != eng.ctx.stream        # rows and predictions on different streams
     tp = eng.test_pairs()
-    assert tp.ctx is eng.ctx_p
+    assert eng.native == (mode == "native") and (tp.ctx is eng.ctx_p) == (mode == "stepwise")
     for it in range(1, 6):
         eng.sweep(it)
         with torch.cuda.stream(eng.ctx.stream):

@@ -190,7 +190,8 @@ def test_whole_iterations_match_oracle(B, O, with_feat, use_ff):
 
 
 def test_determinism_and_stream_overlap(B, monkeypatch):
-    """same seed -> bit-identical chain; the two-stream schedule gives the same values as the single-stream one"""
+    """same seed -> bit-identical chain; the native three-stream iteration, the step-by-step one and the single-stream one
+    give the same values"""
     Y = _sprand(40, 30, 0.3, 9)
 
     def run(seed):
@@ -204,42 +205,12 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
     a3, _ = run(6)
     assert not np.array_equal(a1, a3)
-    monkeypatch.setenv("BDF_NO_GATE_BACK", "1")         # hyperprior -> rows by event instead of the draw kernel's completion count
-    a6, l6 = run(5)
-    assert np.array_equal(a1, a6) and np.array_equal(l1, l6)
-    monkeypatch.setenv("BDF_NO_GATE", "1")              # event hand-over instead of completion counters + gate kernel
+    monkeypatch.setenv("BDF_NO_NATIVE", "1")            # the iteration enqueued step by step from Python instead of bdf_gibbs_sweep
     a5, l5 = run(5)
     assert np.array_equal(a1, a5) and np.array_equal(l1, l5)
-    monkeypatch.setenv("BDF_NO_OVERLAP", "1")
+    monkeypatch.setenv("BDF_NO_OVERLAP", "1")           # ... and on one stream
     a4, l4 = run(5)
     assert np.array_equal(a1, a4) and np.array_equal(l1, l4)
-
-
-def test_rows_gate(B):
-    """bdf_rows_gate: the streams of the engine run side by side (self-test passes) and a consumer behind a gate on another
-    stream sees exactly the rows of the launch enqueued before the gate"""
-    import ctypes as C
-    import torch
-    from bdf_amd import _lib
-    from bdf_amd.engine import GibbsEngine
-    Y = _sprand(3000, 500, 0.05, 3)
-    rd = B.RelationData(Y, class_cut=0.5)
-    eng = GibbsEngine(rd, 16, seed=3)
-    assert eng.use_gate
-    L = _lib.lib()
-    for i in range(1, 6):
-        eng.ctx.set_sweep(i)
-        eng.ctx_h.set_sweep(i)
-        # consumer first: the gate must hold the copy back until the rows of THIS launch are there
-        before = eng.ent[0].sample_alt.clone()
-        torch.cuda.synchronize()
-        eng.sample_entity(0)                                  # writes sample_alt, then swaps
-        _lib.check(L.bdf_rows_gate(eng.ctx_h.handle, eng.ctx.handle))
-        with torch.cuda.stream(eng.ctx_h.stream):
-            seen = eng.ent[0].sample.clone()
-        eng.sync()
-        torch.cuda.synchronize()
-        assert torch.equal(seen, eng.ent[0].sample) and not torch.equal(seen, before)
 
 
 def test_argument_errors(B):
@@ -378,9 +349,10 @@ def test_movielens_d32_full_size_properties(B):
 
 
 def test_two_ranks_match_one(B):
-    """bench.py's N > 1 path (rows dealt over the ranks, all-gather of the sampled rows, test ratings split by user block,
-    RMSE all-reduced) gives the chain of the single-process run of the same 2-unit workload.  Two ranks on the one GPU of the
-    box: RCCL needs a GPU per rank, so the collectives are staged through the host by gloo (BDF_DIST_BACKEND=gloo)."""
+    """bench.py's N > 1 path (rows shared out by bdf_layout_build, every rank holding its rows' observations only, in-place
+    exchange of the sampled rows inside bdf_gibbs_sweep, test ratings split over the ranks, RMSE all-reduced) gives the chain
+    of the single-process run of the same workload.  Two ranks on the one GPU of the box: RCCL needs a GPU per rank, so the
+    exchange goes through the library's host transport with a gloo all-gather behind it (BDF_DIST_BACKEND=gloo)."""
     import json
     import subprocess
     import sys
@@ -388,16 +360,23 @@ def test_two_ranks_match_one(B):
     env = dict(os.environ, BDF_DIST_BACKEND="gloo")
     port = str(29600 + os.getpid() % 300)
     two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6"],
+                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6",
+                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline"],
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline",
+                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
     d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
     d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
     assert d2["n_gpus"] == 2 and d2["config"]["units_per_sweep"] == 2 and d2["scaling"] == "weak"
     assert abs(d2["test_rmse"] - d1["test_rmse"]) < 2e-5, (d2["test_rmse"], d1["test_rmse"])
+    # the strong-scaling block: the same C4-shaped relation on two ranks (rows at internal positions, sharded observations,
+    # in-place exchange) and on one: the chains agree up to the summation order of the hyperprior's sums
+    assert "error" not in d2["c4"] and "error" not in d1["c4"], (d2["c4"], d1["c4"])
+    assert d2["c4"]["n_gpus"] == 2 and d2["c4"]["scaling"] == "strong"
+    assert abs(d2["c4"]["test_rmse"] - d1["c4"]["test_rmse"]) < 1e-4, (d2["c4"], d1["c4"])
 
 
 def test_stream_schedule_soak(B):

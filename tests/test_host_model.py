@@ -184,59 +184,85 @@ def test_split_and_dataset_helpers(B):
         assert d["Fu"].shape == (6040, 29) and d["Fv"].shape == (3952, 18)
 
 
-_GLOO_WORKER = r'''
+_GLOO_WORKER = '''
 import os, sys
-sys.path.insert(0, sys.argv[1])
-import numpy as np, torch, torch.distributed as dist
-rank, world = int(sys.argv[2]), 2
-os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = sys.argv[3]
+import numpy as np
+import torch
+import torch.distributed as dist
+root, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+sys.path.insert(0, root)
+os.environ["MASTER_ADDR"] = "127.0.0.1"
+os.environ["MASTER_PORT"] = port
 dist.init_process_group("gloo", rank=rank, world_size=world)
-import bdf_amd as B
-from bdf_amd.engine import shard_rows, allgather_rows
-# a relation whose launch order the two ranks derive independently
-rng = np.random.default_rng(0)
-N, D = 37, 4
-ids = np.stack([rng.integers(1, N + 1, 300), rng.integers(1, 11, 300)], axis=1)
-idf = B.IndexedDF((ids, rng.standard_normal(300)), [N, 10])
-counts = np.diff(idf._rowptr[0])
-order = np.argsort(-counts, kind="stable").astype(np.int32)
-lists = shard_rows(order, world)
-assert sorted(np.concatenate(lists).tolist()) == list(range(N))
-# every rank "samples" its own rows (value = row id + 0.5 * column), then the all-gather must give everyone everything
-sample = torch.full((N, D), -1.0, dtype=torch.float64)
-mine = torch.as_tensor(lists[rank].astype(np.int64))
-sample[mine] = mine[:, None].double() + 0.5 * torch.arange(D, dtype=torch.float64)[None, :]
-allgather_rows(sample, [torch.as_tensor(l.astype(np.int64)) for l in lists], rank, world)
-expect = torch.arange(N, dtype=torch.float64)[:, None] + 0.5 * torch.arange(D, dtype=torch.float64)[None, :]
-assert torch.equal(sample, expect), (rank, sample)
-# the cached plan the engine reuses every half-sweep (the ranks' shards differ in length: 19 and 18 rows)
-from bdf_amd.engine import allgather_plan
-tl = [torch.as_tensor(l.astype(np.int64)) for l in lists]
-plan = allgather_plan(tl, rank, world)
-for rep in range(2):
-    sample.fill_(-1.0)
-    sample[mine] = (rep + 1) * expect[mine]
-    allgather_rows(sample, tl, rank, world, plan)
-    assert torch.equal(sample, (rep + 1) * expect), (rank, rep)
-# nnz balance of the strided deal
-load = [int(counts[l].sum()) for l in lists]
-assert max(load) - min(load) <= counts.max()
+import importlib.util
+import bdf_amd as B                                   # host-only pieces: no GPU in this test
+from bdf_amd import _lib
+import ctypes as C
+rng = np.random.default_rng(7)
+N, D = 1003, 6
+degree = rng.integers(0, 200, N).astype(np.int64)
+for chunks in (1, 3):
+    pos = np.zeros(N, dtype=np.int32)
+    cmax = C.c_int64(0)
+    _lib.check(_lib.lib().bdf_layout_build(N, degree.ctypes.data_as(_lib.c_i64p), world, chunks, pos.ctypes.data_as(_lib.c_i32p), C.byref(cmax)))
+    cmax = cmax.value
+    nint = chunks * world * cmax
+    assert cmax == -(-(-(-N // world)) // chunks) and len(set(pos.tolist())) == N and pos.max() < nint
+    owner = (pos // cmax) % world
+    chunk = (pos // cmax) // world
+    # balance: rows dealt in falling order of degree, round-robin over the ranks, then over a rank's chunks
+    load = [int(degree[owner == p].sum()) for p in range(world)]
+    assert max(load) - min(load) <= degree.max()
+    cl = [int(degree[(owner == rank) & (chunk == c)].sum()) for c in range(chunks)]
+    assert max(cl) - min(cl) <= degree.max() * 2
+    # the exchange: every rank "samples" its own rows (value = f(original id)), then one in-place all-gather per chunk
+    expect = torch.zeros(nint, D, dtype=torch.float64)
+    vals = torch.arange(N, dtype=torch.float64)[:, None] * 10.0 + torch.arange(D, dtype=torch.float64)[None, :] + 1.0
+    expect[torch.as_tensor(pos.astype(np.int64))] = vals
+    for rep in range(2):
+        sample = torch.zeros(nint, D, dtype=torch.float64)
+        mine = np.nonzero(owner == rank)[0]
+        sample[torch.as_tensor(pos[mine].astype(np.int64))] = (rep + 1) * vals[torch.as_tensor(mine)]
+        for c in range(chunks):
+            region = sample[c * world * cmax:(c + 1) * world * cmax]
+            dist.all_gather_into_tensor(region, region[rank * cmax:(rank + 1) * cmax].clone())       # bdf_allgather_rows: in place
+        assert torch.equal(sample, (rep + 1) * expect), (rank, chunks, rep)
 dist.destroy_process_group()
 print("ok", rank)
 '''
 
 
-def test_sharded_allgather_gloo_world2(tmp_path):
-    """the N>1 path: rows dealt rank::world over the degree order, all-gather of the sampled rows (torch.distributed,
-    gloo on CPU here, RCCL on the GPUs)"""
+@pytest.mark.parametrize("world", [2, 4])
+def test_layout_and_inplace_allgather_gloo(tmp_path, world):
+    """the N > 1 path on CPU: bdf_layout_build (rows dealt over the ranks in falling order of degree, a rank's rows over its
+    chunks; every chunk one contiguous rank-major region) and the exchange as an in-place all-gather per chunk --
+    torch.distributed gloo here, ncclAllGather through bdf_allgather_rows on the GPUs"""
     script = tmp_path / "worker.py"
     script.write_text(_GLOO_WORKER)
-    port = str(29500 + os.getpid() % 2000)
-    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), port], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
-                              text=True) for r in range(2)]
+    port = str(29500 + (os.getpid() + 7 * world) % 2000)
+    procs = [subprocess.Popen([sys.executable, str(script), ROOT, str(r), str(world), port], stdout=subprocess.PIPE,
+                              stderr=subprocess.STDOUT, text=True) for r in range(world)]
     outs = [p.communicate(timeout=240)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0 and f"ok {r}" in o, o
+
+
+def test_sharded_relation_needs_no_gpu_to_be_checked(B):
+    """bdf_layout_build on a relation's degrees: ranks and chunks partition the rows; positions are a bijection onto the
+    non-padding rows"""
+    import ctypes as C
+    from bdf_amd import _lib
+    deg = np.array([5, 0, 9, 9, 1, 3, 3, 2], dtype=np.int64)
+    pos = np.zeros(8, dtype=np.int32)
+    cmax = C.c_int64(0)
+    _lib.check(_lib.lib().bdf_layout_build(8, deg.ctypes.data_as(_lib.c_i64p), 2, 2, pos.ctypes.data_as(_lib.c_i32p), C.byref(cmax)))
+    assert cmax.value == 2
+    # sorted by falling degree (stable): rows 2,3,0,5,6,7,4,1 -> rank s%2, index s//2 -> chunk (s//2)%2, slot (s//2)//2
+    order = [2, 3, 0, 5, 6, 7, 4, 1]
+    for s_, row in enumerate(order):
+        p, r = s_ % 2, s_ // 2
+        c, i = r % 2, r // 2
+        assert pos[row] == (c * 2 + p) * 2 + i
 
 
 def test_data_reading_formats(tmp_path):

@@ -23,7 +23,7 @@ def run(label, n=400):
     ku = [t.elapsed_us() for (j, t) in eng.k1_events if j == 0]; km = [t.elapsed_us() for (j, t) in eng.k1_events if j == 1]
     ptrs = [hex(eng.ent[j].sample.data_ptr()) for j in (0, 1)] + [hex(eng.ent[j].sample_alt.data_ptr()) for j in (0, 1)]
     print(f"   K1 users {sum(ku)/len(ku):.1f} us, movies {sum(km)/len(km):.1f} us; sample buffers {ptrs}")
-    print(f"{label}: {1e6 * dt / n:.1f} us/sweep  use_gate={eng.use_gate} streams: main={eng.ctx.stream.cuda_stream:#x} side={eng.ctx_h.stream.cuda_stream:#x} pred={eng.ctx_p.stream.cuda_stream:#x}")
+    print(f"{label}: {1e6 * dt / n:.1f} us/sweep  native={eng.native} streams: main={eng.ctx.stream.cuda_stream:#x} side={eng.ctx_h.stream.cuda_stream:#x} pred={eng.ctx_p.stream.cuda_stream:#x}")
     eng.close()
 mode = sys.argv[1] if len(sys.argv) > 1 else ""
 if mode == "burn":

@@ -1,4 +1,4 @@
-"""Race soak: two runs of N sweeps of the bench workload (rows on three rotating buffers, gate hand-overs, three streams,
+"""Race soak: two runs of N sweeps of the bench workload (rows on three rotating buffers, event hand-overs, three streams,
 prediction updates beside the rows) must end bit-identical -- a missed dependency between the streams shows up as a
 difference sooner or later."""
 import os, sys
@@ -14,11 +14,10 @@ for rep in range(2):
     eng = B.GibbsEngine(rd, 32, seed=7, device=0)
     test = eng.test_pairs()
     for i in range(1, N + 1):
-        eng.sweep(i)
-        test.update(32, eng.factors_of(rel), rel.model.mean_value, 0 if i < 100 else (1 if i == 100 else 2), [1.0, 5.0], rel.class_cut)
+        eng.step(i, 0 if i < 100 else (1 if i == 100 else 2), [1.0, 5.0], rel.class_cut)
     eng.sync(); torch.cuda.synchronize()
     outs.append((eng.ent[0].sample.cpu().numpy().copy(), eng.ent[1].Lambda.cpu().numpy().copy(), test.stats.cpu().numpy().copy()))
-    print(f"run {rep}: use_gate={eng.use_gate} unfinished={eng.ctx.rows_unfinished()} rmse={np.sqrt(outs[-1][2][0] / 500000):.6f}")
+    print(f"run {rep}: native={eng.native} unfinished={eng.ctx.rows_unfinished()} rmse={np.sqrt(outs[-1][2][0] / 500000):.6f}")
     eng.close()
 same = all(np.array_equal(a, b) for a, b in zip(*outs))
 print("bit-identical:", same)
