@@ -138,7 +138,8 @@ _SIGS = {
     "bdf_sample_beta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
-    "bdf_ctx_create_side": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.POINTER(C.c_void_p)]),
+    "bdf_ctx_create_side": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
+    "bdf_ctx_create_rows": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "bdf_ctx_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "bdf_layout_build": (C.c_int, [C.c_int64, c_i64p, C.c_int, C.c_int, c_i32p, c_i64p]),
     "bdf_relation_create_sharded": (C.c_int, [C.c_void_p, C.c_int, c_i64p, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(c_i32p),

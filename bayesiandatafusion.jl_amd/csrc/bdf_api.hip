@@ -49,6 +49,9 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
+    c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr;
+    c->reserve_cus = 0;
+    c->on_reserved = 0;
     c->skip_flag = nullptr;
     c->cg_status = nullptr;
     c->cg_gen = 0;
@@ -587,6 +590,8 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     a.entity_tag = entity_tag;
     a.out = out;
     if (prior_pack && !mu_is_matrix) { a.prior_b = prior_pack; a.prior_c = prior_pack + D; }
+    if (ctx->rows_ready && prior_pack && !mu_is_matrix) { a.ready = ctx->rows_ready; a.ready_want = ctx->rows_ready_want; }
+    ctx->rows_ready = nullptr;
 #ifdef BDF_K1_STAMPS
     {   // diagnostic build only: per-wave phase stamps (16 x u64 per wave) readable through bdf_debug_stamps
         extern void *g_bdf_stamp_buf;

@@ -42,9 +42,16 @@ struct bdf_ctx {
     int piece_size;            // K1: ... into pieces of at most this many observations
     int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
+    const uint32_t *rows_ready;            // (library-internal) SampleArgs::ready of the next row launch, then cleared
+    uint32_t rows_ready_want;
+    uint32_t *hyper_ready;                 // (library-internal) flag the next bdf_hyper_sample sets to the sweep number, then cleared
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
     // batched CG (k_feat.hip): device flag that lets product kernels enqueued ahead return at once (NULL outside a solve),
     // and the host-mapped words through which the device reports (iteration, active columns)
+    // CU reservation (bdf_ctx_create_rows): the last... the first `reserve_cus` bits of the CU mask (one CU per XCD each 8)
+    // are kept free of this context's kernels, for the side context created with reserved = 1
+    int reserve_cus;           // CUs set aside by the row context this one belongs to (0: none)
+    int on_reserved;           // this context's stream runs on the reserved CUs only
     const int *skip_flag;
     volatile uint64_t *cg_status;
     uint32_t cg_gen;
@@ -274,6 +281,11 @@ struct SampleArgs {
     const double *prior_c;     // index-reversed Lambda in the accumulator layout, filled by the launch front-end
     double *P_dump, *b_dump;
     int *flag;
+    // nullable: the launch does not wait for the hyperprior draw that writes the prior pack; every wave polls *ready until
+    // it reaches ready_want right before it adds the prior (bdf_gibbs_sweep on reserved CUs), and reads the pack past
+    // the non-coherent caches
+    const uint32_t *ready;
+    uint32_t ready_want, _pad4;
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

@@ -11,6 +11,9 @@
 #include "bdf_common.h"
 #include <algorithm>
 #include <cstdlib>
+#include <map>
+#include <mutex>
+#include <tuple>
 
 struct bdf_gibbs {
     bdf_ctx *rows, *hyper, *pred;        // rows: the caller's context; hyper / pred: owned (own streams)
@@ -20,6 +23,7 @@ struct bdf_gibbs {
         int cur;                         // buffer holding the current rows
         hipEvent_t ev_rows, ev_hyper;    // rows of this sweep complete (and exchanged) | (mu, Lambda) of this sweep complete
         bool hyper_recorded;
+        uint32_t hyper_sweep;            // iteration number of the last hyperprior draw enqueued for this entity
         hipEvent_t t_start, t_stop;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
     };
     std::vector<Ent> ent;
@@ -27,10 +31,15 @@ struct bdf_gibbs {
     int32_t test_entity[BDF_MAX_MODES];
     double test_mean, clamp_lo, clamp_hi, class_cut;
     double *stats_dev;
-    hipEvent_t ev_pred[2];
-    int pred_flip;
-    bool pred_recorded;
+    hipEvent_t ev_pred[3];               // prediction update of iteration k complete: ev_pred[k % 3]
+    uint64_t n_pred;                     // prediction updates enqueued so far
     bdf_comm *comm;                      // nullable: exchange of the sampled rows between the ranks after every entity
+    // The row stream has NO wait for the hyperprior draws when they run on reserved CUs (bdf_ctx_create_rows): a draw there
+    // cannot be starved by the chip-filling row kernel, so the row kernel is enqueued right behind its predecessor (back-to-back
+    // row kernels start with no gap; a wait for another stream's event costs the row stream ~10 us even when long satisfied:
+    // profiles/r02_sweep_timeline_events.txt) and its waves poll ready[entity] where they first need the prior.
+    uint32_t *ready_dev;                 // per entity: iteration number of the last completed draw
+    bool polling;
 };
 
 namespace {
@@ -67,17 +76,57 @@ int streams_overlap(hipStream_t a, hipStream_t b, bool *yes)
     return BDF_OK;
 }
 
-int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bdf_ctx **out)
+// A non-blocking stream, optionally confined to a set of CUs.  CU mask bits are interleaved over the XCDs (bits 0..7 are CU 0
+// of shader engine 0 of XCD 0..7: tools/cu_mask_probe.hip), so `reserve` = 8 k bits set aside k CUs in every XCD -- a kernel's
+// workgroups are dealt over the XCDs, every XCD must have a CU of the mask.  reserved = true: the stream runs on those CUs
+// only; false: on all the others.
+// The streams live in a process-wide pool and are never destroyed: host frameworks keep references to a stream they have
+// used (torch: allocator pools per stream, events recorded on it) beyond the life of the context that ran on it, and
+// destroying it under them crashes at the framework's own teardown.  Slot k of (device, reserve, role) is always the same
+// stream, so later engines of a process pick the same streams as the first.
+int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t *out)
+{
+    static std::mutex mu;
+    static std::map<std::tuple<int, int, int, int>, hipStream_t> pool;
+    std::lock_guard<std::mutex> lock(mu);
+    const auto key = std::make_tuple(device, reserve, reserved ? 1 : 0, slot);
+    auto it = pool.find(key);
+    if (it != pool.end()) { *out = it->second; return BDF_OK; }
+    hipStream_t st;
+    if (reserve <= 0) {
+        BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    } else {
+        hipDeviceProp_t prop;
+        BDF_HIP(hipGetDeviceProperties(&prop, device));
+        const int ncu = prop.multiProcessorCount, words = (ncu + 31) / 32;
+        std::vector<uint32_t> mask((size_t)words, 0u);
+        for (int i = 0; i < ncu; i++)
+            if ((i < reserve) == reserved) mask[(size_t)(i / 32)] |= 1u << (i % 32);
+        BDF_HIP(hipExtStreamCreateWithCUMask(&st, (uint32_t)words, mask.data()));
+    }
+    pool[key] = st;
+    *out = st;
+    return BDF_OK;
+}
+
+int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bool reserved, bdf_ctx **out)
 {
     // a few candidate streams; the first that overlaps with the row stream and with every stream in `apart`
     bdf_ctx *fallback = nullptr;
     for (int attempt = 0; attempt < 8; attempt++) {
         hipStream_t st;
-        BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        // slot 0 of the unreserved role is the row stream itself
+        int rc = pooled_stream(main->device, main->reserve_cus, reserved, attempt + 1, &st);
+        if (rc) return rc;
+        if (st == main->stream) continue;
+        bool taken = false;
+        for (bdf_ctx *o : apart) taken = taken || o->stream == st;
+        if (taken) continue;
         bdf_ctx *c;
-        int rc = bdf_ctx_create(main->device, (void *)st, main->seed, &c);
-        if (rc) { (void)hipStreamDestroy(st); return rc; }
-        c->own_stream = true;
+        rc = bdf_ctx_create(main->device, (void *)st, main->seed, &c);
+        if (rc) return rc;
+        c->reserve_cus = main->reserve_cus;
+        c->on_reserved = (reserved && main->reserve_cus > 0) ? 1 : 0;
         bool ok = true;
         static const bool no_test = getenv("BDF_NO_STREAM_TEST") != nullptr;
         if (!no_test) {
@@ -98,11 +147,32 @@ int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bdf_ctx **
 
 }  // namespace
 
-extern "C" int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, bdf_ctx **out)
+extern "C" int bdf_ctx_create_rows(int device, uint64_t seed, int reserve_cus, bdf_ctx **out)
+{
+    BDF_REQUIRE(out && reserve_cus >= 0 && reserve_cus % 8 == 0 && reserve_cus <= 64, BDF_ERR_ARG,
+                "bdf_ctx_create_rows: reserve_cus must be 0, 8, 16, ... 64 (whole CUs per XCD)");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        bdf_set_error("bdf_ctx_create_rows: no HIP device visible (this library has no CPU path)");
+        return BDF_ERR_NOGPU;
+    }
+    BDF_REQUIRE(device >= 0 && device < ndev, BDF_ERR_ARG, "bdf_ctx_create_rows: device %d out of range", device);
+    BDF_HIP(hipSetDevice(device));
+    hipStream_t st;
+    int rc = pooled_stream(device, reserve_cus, false, 0, &st);
+    if (rc) return rc;
+    bdf_ctx *c;
+    if ((rc = bdf_ctx_create(device, (void *)st, seed, &c))) return rc;
+    c->reserve_cus = reserve_cus;
+    *out = c;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, int reserved, bdf_ctx **out)
 {
     BDF_REQUIRE(main_ctx && out && n_apart >= 0 && (n_apart == 0 || apart), BDF_ERR_ARG, "bdf_ctx_create_side: bad argument");
     std::vector<bdf_ctx *> ap(apart, apart + n_apart);
-    return make_side_ctx(main_ctx, ap, out);
+    return make_side_ctx(main_ctx, ap, reserved != 0, out);
 }
 
 extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const bdf_gibbs_entity *ents, bdf_gibbs **out)
@@ -125,18 +195,21 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     BDF_HIP(hipSetDevice(rows_ctx->device));
     bdf_gibbs *g = new bdf_gibbs();
     g->rows = rows_ctx; g->hyper = g->pred = nullptr; g->D = D; g->test = nullptr; g->stats_dev = nullptr;
-    g->pred_flip = 0; g->pred_recorded = false; g->comm = nullptr;
+    g->n_pred = 0; g->comm = nullptr; g->ready_dev = nullptr; g->polling = false;
     int rc;
-    if ((rc = make_side_ctx(rows_ctx, {}, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
+    if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
+    g->ready_dev = nullptr;
+    g->polling = rows_ctx->reserve_cus > 0 && g->hyper->on_reserved && !getenv("BDF_NO_POLL");
+    BDF_HIP(hipMalloc((void **)&g->ready_dev, (size_t)n_entities * sizeof(uint32_t)));
+    BDF_HIP(hipMemset(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t)));
     g->ent.resize((size_t)n_entities);
     for (int j = 0; j < n_entities; j++) {
         auto &E = g->ent[(size_t)j];
-        E.d = ents[j]; E.cur = 0; E.hyper_recorded = false; E.t_start = E.t_stop = nullptr;
+        E.d = ents[j]; E.cur = 0; E.hyper_recorded = false; E.hyper_sweep = 0; E.t_start = E.t_stop = nullptr;
         BDF_HIP(hipEventCreate(&E.ev_rows));          // (they ride on dispatch packets: plain events)
         BDF_HIP(hipEventCreate(&E.ev_hyper));
     }
-    BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[0], hipEventDisableTiming));
-    BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[1], hipEventDisableTiming));
+    for (int k = 0; k < 3; k++) BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[k], hipEventDisableTiming));
     *out = g;
     return BDF_OK;
 }
@@ -146,7 +219,8 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
     if (!g) return BDF_OK;
     if (g->rows) (void)hipStreamSynchronize(g->rows->stream);
     for (auto &E : g->ent) { (void)hipEventDestroy(E.ev_rows); (void)hipEventDestroy(E.ev_hyper); }
-    if (!g->ent.empty()) { (void)hipEventDestroy(g->ev_pred[0]); (void)hipEventDestroy(g->ev_pred[1]); }
+    if (!g->ent.empty()) for (int k = 0; k < 3; k++) (void)hipEventDestroy(g->ev_pred[k]);
+    if (g->ready_dev) (void)hipFree(g->ready_dev);
     if (g->pred) bdf_ctx_destroy(g->pred);
     if (g->hyper) bdf_ctx_destroy(g->hyper);
     delete g;
@@ -210,19 +284,18 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     const int D = g->D, n = (int)g->ent.size();
     int rc;
     R->sweep_host = H->sweep_host = P->sweep_host = sweep;
-    // The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep - 2; the prediction updates that
-    // read them were enqueued before the previous sweep began.  The hyperprior stream waits for them here (where it idles
-    // anyway); every row kernel of the next sweep waits for a hyperprior event recorded after this point.
-    if (g->test && predict_phase >= 0) {
-        if (g->pred_recorded) BDF_HIP(hipStreamWaitEvent(H->stream, g->ev_pred[g->pred_flip], 0));
-        g->pred_flip ^= 1;
-        BDF_HIP(hipEventRecord(g->ev_pred[g->pred_flip], P->stream));
-        g->pred_recorded = true;
-    }
+    // The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep - 2, which the prediction update of
+    // sweep - 2 reads.  The HOST waits here until the update of two sweeps ago has completed (normally it has, long ago): the
+    // device then needs no wait for the prediction stream anywhere, and the host never runs more than two prediction updates
+    // ahead.  (A device-side wait would let row kernels that poll for their prior fill the chip while the prediction kernel
+    // they transitively wait for still needs slots for its last workgroups.)
+    if (g->test && predict_phase >= 0 && g->n_pred >= 2) BDF_HIP(hipEventSynchronize(g->ev_pred[(g->n_pred - 2) % 3]));
     for (int j = 0; j < n; j++) {
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
-        if (E.hyper_recorded) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));      // (mu, Lambda) of the previous iteration
+        // (mu, Lambda) of the previous iteration: an event wait, or -- draws on reserved CUs -- the row kernel polls for it
+        const bool poll = g->polling && !g->comm && E.hyper_recorded;
+        if (E.hyper_recorded && !poll) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
         // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows
         if ((rc = bdf_hyper_draws(H, D, e.n_real, e.nu0, e.tag, e.draws))) return rc;
         bdf_term terms[BDF_MAX_TERMS];
@@ -242,6 +315,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         for (int c = 0; c < nch; c++) {
             R->time_start = (c == 0) ? E.t_start : nullptr;
             R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
+            if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.hyper_sweep; }
             if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
                                       E.hyper_recorded ? e.prior_pack : nullptr)))
                 return rc;
@@ -256,6 +330,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
         if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], nullptr, e.sumU, e.UUt))) return rc;
         H->time_h_stop = E.ev_hyper;
+        H->hyper_ready = g->ready_dev + j;
+        E.hyper_sweep = sweep;
         if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, e.WI, e.nu0, e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
             return rc;
         E.hyper_recorded = true;
@@ -269,6 +345,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         }
         if ((rc = bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
             return rc;
+        BDF_HIP(hipEventRecord(g->ev_pred[g->n_pred % 3], P->stream));
+        g->n_pred++;
     }
     return BDF_OK;
 }

@@ -32,6 +32,8 @@ struct NWArgs {
     const double *draws;       // Bartlett matrix (D x D row-major) + D mean normals, from k_hyper_draws
     double *pack_out;          // nullable: Lambda mu (D) then the accumulator-layout image of the reversed Lambda (K1)
     int *flag;
+    uint32_t *ready;           // nullable: set to `sweep` once the pack is written (row kernels that poll instead of waiting)
+    uint32_t sweep;
 };
 
 // ---- stage 1: partial sums of rows [r0, r0 + HS_ROWS) by NW waves; red: (NW-1) * PSZ doubles of LDS -----------------------
@@ -321,14 +323,15 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
         v += __shfl_xor(v, 4);
         v += __shfl_xor(v, 2);
         v += __shfl_xor(v, 1);
-        if (part == 0) a.pack_out[e] = v;
+        if (part == 0) __hip_atomic_store(a.pack_out + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     for (int e = wave; e < NB * 4; e += nthreads / 64) {
         const int b = e >> 2, r = e & 3;
         int I = 0;
         while ((I + 1) * (I + 2) / 2 <= b) I++;
         const int J = b - I * (I + 1) / 2;
-        a.pack_out[D + e * 64 + lane] = sL[(16 * I + (lane >> 4) + 4 * r) * LD + 16 * J + (lane & 15)];
+        __hip_atomic_store(a.pack_out + D + e * 64 + lane, sL[(16 * I + (lane >> 4) + 4 * r) * LD + 16 * J + (lane & 15)], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);      // write-through: a polling row kernel reads it past its L2
     }
     HSTAMP(6);
 }

@@ -78,6 +78,11 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
     __shared__ __attribute__((aligned(16))) double lds[HGeo<DP>::NW_LDS];
     __builtin_amdgcn_s_setprio(3);      // one workgroup beside a chip-filling K1 launch: take the issue slots when ready
     nw_draw<DP>(a, lds, threadIdx.x, 256);
+    if (a.ready) {                      // the pack (write-through stores) is complete: publish
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 }  // namespace
@@ -154,6 +159,8 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.D = D; a.N = (double)N; a.sumU = sumU; a.UUt = UUt; a.mu0 = mu0; a.Tinv = Tinv; a.b0 = b0; a.nu = nu;
     a.mu_out = mu_out; a.Lambda_out = Lambda_out; a.params_out = params_out; a.pack_out = prior_pack_out; a.draws = draws;
     a.flag = ctx->flag_dev;
+    a.ready = ctx->hyper_ready; a.sweep = ctx->sweep_host;
+    ctx->hyper_ready = nullptr;
     if (D <= 16) hipExtLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else hipExtLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);

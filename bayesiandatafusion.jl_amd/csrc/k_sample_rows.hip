@@ -502,14 +502,35 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
+    if (a.ready) {
+        // launched without waiting for the hyperprior draw (bdf_gibbs_sweep: the draw runs on CUs this kernel never uses, so
+        // it cannot be starved): poll its flag here, where the prior is first needed -- the gathers above have hidden most of
+        // the wait -- and read the pack with agent-scope loads (past the non-coherent L2 lines of the previous sweep's pack)
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 22)) { if (lane == 0) atomicOr(a.flag, 16); break; }      // bounded: ~seconds
+        }
 #pragma unroll
-    for (int b = 0; b < NB; b++)
+        for (int b = 0; b < NB; b++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) acc[b][r] += a.prior_c[(b * 4 + r) * 64 + lane];
+            for (int r = 0; r < 4; r++)
+                acc[b][r] += __hip_atomic_load(a.prior_c + (b * 4 + r) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-    for (int J = 0; J < DB; J++) {
-        const int ec = D - 1 - (16 * J + j);
-        if (ec >= 0) bv[J] += a.prior_b[(a.mu_is_matrix ? row * D : 0) + ec];
+        for (int J = 0; J < DB; J++) {
+            const int ec = D - 1 - (16 * J + j);
+            if (ec >= 0) bv[J] += __hip_atomic_load(a.prior_b + ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    } else {
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[b][r] += a.prior_c[(b * 4 + r) * 64 + lane];
+#pragma unroll
+        for (int J = 0; J < DB; J++) {
+            const int ec = D - 1 - (16 * J + j);
+            if (ec >= 0) bv[J] += a.prior_b[(a.mu_is_matrix ? row * D : 0) + ec];
+        }
     }
     STAMP(3);
 

@@ -112,13 +112,24 @@ class Context:
         return self
 
     @classmethod
-    def side(cls, main, apart=()):
+    def rows(cls, device, seed, reserve_cus=0):
+        """a row context on a library-owned stream that keeps `reserve_cus` CUs free for a side context (bdf_ctx_create_rows)"""
+        if not torch.cuda.is_available():
+            raise _lib.NoGpuError("no GPU visible: bayesiandatafusion.jl_amd has no CPU path (the reference is the CPU path)")
+        dev = torch.device("cuda", torch.cuda.current_device() if device is None else int(device))
+        torch.cuda.set_device(dev)
+        h = C.c_void_p()
+        check(lib().bdf_ctx_create_rows(dev.index, C.c_uint64(int(seed) & (2 ** 64 - 1)), int(reserve_cus), C.byref(h)))
+        return cls.wrap(h, dev, seed, owned=True)
+
+    @classmethod
+    def side(cls, main, apart=(), reserved=False):
         """a context on another stream of main's device, chosen by the library so that kernels on it really run beside those
         of `main` and of the contexts in `apart` (HIP multiplexes streams onto a few hardware queues; two streams on one
-        queue serialise each other: 171 instead of 125 us per sweep, tools/exp_stream_pairs.py)"""
+        queue serialise each other: 171 instead of 125 us per sweep); reserved: on the CUs main's stream leaves free"""
         h = C.c_void_p()
         arr = (C.c_void_p * max(len(apart), 1))(*[a.handle for a in apart])
-        check(lib().bdf_ctx_create_side(main.handle, arr, len(apart), C.byref(h)))
+        check(lib().bdf_ctx_create_side(main.handle, arr, len(apart), int(reserved), C.byref(h)))
         return cls.wrap(h, main.device, main.seed, owned=True)
 
     def adopt(self, child):
@@ -150,10 +161,12 @@ class Context:
         check(lib().bdf_ctx_sync(self.handle))
 
     def zeros(self, *shape, dtype=torch.float64):
-        return torch.zeros(*shape, dtype=dtype, device=self.device)
+        with torch.cuda.stream(self.stream):          # filled on the stream that will use it
+            return torch.zeros(*shape, dtype=dtype, device=self.device)
 
     def tensor(self, a, dtype=torch.float64):
-        return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
+        with torch.cuda.stream(self.stream):
+            return torch.as_tensor(np.ascontiguousarray(a), dtype=dtype).to(self.device)
 
     def close(self):
         if self.handle:
@@ -388,10 +401,10 @@ class EntityState:
         self.bufs = [ctx.zeros(self.N, D) for _ in range(3)]
         self.cur = 0
         self.mu = ctx.zeros(D)
-        self.Lambda = (5.0 * torch.eye(D, dtype=torch.float64)).to(ctx.device)
+        self.Lambda = ctx.tensor(5.0 * np.eye(D))
         self.mu0 = ctx.zeros(D)
         self.b0 = 2.0
-        self.WI = torch.eye(D, dtype=torch.float64).to(ctx.device)
+        self.WI = ctx.tensor(np.eye(D))
         self.nu0 = float(D)
         self.sumU = ctx.zeros(D)
         self.UUt = ctx.zeros(D, D)
@@ -420,7 +433,7 @@ class EntityState:
             self.mu_matrix = ctx.zeros(en.count, D)
             self.Tinv = ctx.zeros(D, D)
             self.lambda_beta = ctx.tensor([en.lambda_beta])
-            self.cg_iters = torch.zeros(D, dtype=torch.int32, device=ctx.device)
+            self.cg_iters = ctx.zeros(D, dtype=torch.int32)
 
     @property
     def sample(self):
@@ -452,7 +465,12 @@ class GibbsEngine:
         if not (1 <= num_latent <= _lib.BDF_MAX_D):
             raise ArgumentError(f"num_latent={num_latent} must be in 1..{_lib.BDF_MAX_D}")
         self.data, self.D = data, int(num_latent)
-        self.ctx = Context(device, seed)
+        # The row context runs on a stream of its own that leaves a few CUs (one or two per XCD) free for the hyperprior's
+        # small kernels, which otherwise wait for slots beside the chip-filling row kernel -- when the entities are small
+        # enough for those kernels to be small (the reductions of a 10M-row entity want the whole chip)
+        big = max((en.count for en in data.entities), default=0) * int(num_latent) * 8 > (32 << 20)
+        reserve = int(os.environ.get("BDF_RESERVE_CUS", "0" if big else "8"))
+        self.ctx = Context.rows(device, seed, reserve)
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))
         if os.environ.get("BDF_PIECE_SIZE"):
@@ -471,6 +489,10 @@ class GibbsEngine:
         # ---- row layouts (several ranks): degree of a row = its observations over all the entity's relations
         if chunks is None:
             chunks = int(os.environ.get("BDF_CHUNKS", "0"))
+        # one chunk count for the whole model (a relation's modes share it): the chunked exchange -- the row kernel of chunk
+        # c + 1 beside the all-gather of chunk c -- pays once an entity's share of rows is large
+        if chunks <= 0:
+            chunks = 4 if (self.world > 1 and max(-(-en.count // self.world) for en in data.entities) >= 200_000) else 1
         self.layouts = []
         for en in data.entities:
             if self.world == 1:
@@ -480,9 +502,7 @@ class GibbsEngine:
             for r in en.relations:
                 m = [e is en for e in r.entities].index(True)
                 deg += np.bincount(np.asarray(r.data.ids[:, m], dtype=np.int64) - 1, minlength=en.count)
-            per_rank = -(-en.count // self.world)
-            ch = chunks if chunks > 0 else (4 if per_rank >= 200_000 else 1)      # chunked exchange pays for large entities only
-            self.layouts.append(Layout(en.count, deg, self.world, ch))
+            self.layouts.append(Layout(en.count, deg, self.world, chunks))
         # ---- reset! (RelationData.jl:331-355)
         self.ent = []
         for j, en in enumerate(data.entities):
@@ -502,9 +522,6 @@ class GibbsEngine:
             if len(r.entities) != len(r.data.dims):
                 raise ArgumentError(f"Relation {r.name} has {len(r.entities)} entities but its data implies {r.data.size()}.")
             lays = [self.layouts[self._entity_index(e)] for e in r.entities]
-            if self.world > 1 and len({l.chunks for l in lays}) > 1:
-                # one chunk count per relation: take the entities' largest
-                raise ArgumentError("entities of one relation were given different chunk counts: pass chunks=")
             dr = DeviceRelation(self.ctx, r.data, lays if self.world > 1 else None, self.rank)
             r.model.mean_value = dr.value_mean()
             r._dev = dr
@@ -541,9 +558,10 @@ class GibbsEngine:
         else:
             self.ctx_h = self.ctx_p = self.ctx
             if not os.environ.get("BDF_NO_OVERLAP"):
-                self.ctx_h = Context.side(self.ctx)
+                self.ctx_h = Context.side(self.ctx, reserved=True)
                 if all(feat.isempty(r.F) for r in data.relations):
                     self.ctx_p = Context.side(self.ctx, [self.ctx_h])
+        torch.cuda.synchronize(self.ctx.device)      # everything set up above (on torch's streams too) is in place
 
     # ---- the native iteration (bdf_gibbs) -----------------------------------------------------------------------------
     def _create_native(self):

@@ -76,7 +76,14 @@ int bdf_ctx_advance_sweep(bdf_ctx *ctx);
  * hardware queues, and two streams that share one serialise each other (measured: 171 instead of 125 us per sweep).  A
  * timing test (two 60 us spins, together) picks among a few candidate streams; with no passing candidate the last one is
  * returned (correct, only slower).  The hyperprior of entity j is enqueued on such a context beside the rows of entity j+1. */
-int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, bdf_ctx **out);
+int bdf_ctx_create_side(bdf_ctx *main_ctx, bdf_ctx *const *apart, int n_apart, int reserved, bdf_ctx **out);
+/* A row context on a stream of its own that leaves `reserve_cus` CUs (0, 8, 16, ...: whole CUs per XCD) free of its kernels
+ * (hipExtStreamCreateWithCUMask); a side context created from it with reserved = 1 runs on exactly those CUs, with reserved =
+ * 0 on the others.  The row sampler fills every CU it may use for the whole launch (its waves hold 468 of a SIMD's 512
+ * registers): the hyperprior's small kernels, enqueued beside it, otherwise wait for slots -- measured, a one-workgroup kernel
+ * beside a chip-filling one: 194 us on plain streams, 6 - 11 us on its own 16 / 8 CUs (tools/cu_mask_probe.hip).  Worth it
+ * when the side work is small (MovieLens-sized entities); with reserve_cus = 0 all streams use the whole chip. */
+int bdf_ctx_create_rows(int device, uint64_t seed, int reserve_cus, bdf_ctx **out);
 /* Measurement support: HIP events (timing enabled) and "attach this pair to the next bdf_sample_rows launch of ctx":
  * the events ride on the row kernel's own dispatch packet (hipExtLaunchKernelGGL), so start/stop are the kernel's begin and
  * end on its stream without marker packets around it (an event pair recorded around a launch costs the stream ~6 us and
