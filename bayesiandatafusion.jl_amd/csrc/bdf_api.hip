@@ -38,6 +38,9 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
         return BDF_ERR_NOGPU;
     }
     bdf_ctx *c = new bdf_ctx();
+    c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr;
+    c->own_stream = false; c->stream = nullptr;
+    struct Guard { bdf_ctx *c; ~Guard() { if (c) bdf_ctx_destroy(c); } } guard{c};        // error paths free what was allocated
     c->device = device;
     c->seed = seed;
     c->own_stream = false;
@@ -65,6 +68,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
         const char *force = getenv("BDF_GATHER");
         c->gather_mode = force && !strcmp(force, "general") ? 1 : (force && !strcmp(force, "wide") ? 2 : 0);
     }
+    guard.c = nullptr;
     *out = c;
     return BDF_OK;
 }
@@ -76,8 +80,8 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     hipStreamSynchronize(ctx->stream);
     bdf_plans_release(ctx, 0);
     if (ctx->scratch) hipFree(ctx->scratch);
-    hipFree(ctx->sweep_dev);
-    hipFree(ctx->flag_dev);
+    if (ctx->sweep_dev) hipFree(ctx->sweep_dev);
+    if (ctx->flag_dev) hipFree(ctx->flag_dev);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);

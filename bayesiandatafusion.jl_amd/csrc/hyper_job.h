@@ -174,35 +174,6 @@ __device__ __forceinline__ void hyper_scatter(int D, int e, double s, double *su
 #define HSTAMP(k) do { } while (0)
 #endif
 
-template <int DP, int PARTS>
-__device__ __forceinline__ void nw_trsm_parts(const double *tri, double *sA, const double *s_sq, const double *s_rd, int D, int tid)
-{
-    using GG = Geo<DP>;
-    constexpr int LD = HGeo<DP>::LD;
-    const int c = tid / PARTS, part = tid % PARTS;
-    for (int i = DP - 1; i >= 0; i--) {
-        if (i >= D) {                                     // padding: identity
-            if (part == 0) sA[i * LD + c] = 0.0;
-            continue;
-        }
-        const typename GG::ColRT cr = GG::col_rt(i);      // column i of the packed factor: rows m > i
-        double s = 0.0;
-        for (int m = i + 1 + part; m < DP; m += PARTS)
-            s = fma(tri[cr.cbase + (m & 3) * cr.nr4 + (m >> 2) - cr.q], sA[m * LD + c], s);
-#pragma unroll
-        for (int off = PARTS >> 1; off >= 1; off >>= 1) s += __shfl_xor(s, off);      // compile-time offsets: DPP, not LDS permutes
-        if (part == 0) sA[i * LD + c] = (s_sq[i] * sA[i * LD + c] - s) * s_rd[i];
-        wave_sync();
-    }
-}
-
-template <int DP>
-__device__ __forceinline__ void nw_trsm(const double *tri, double *sA, const double *s_sq, const double *s_rd, int D, int tid, int nthreads)
-{
-    if (nthreads == 256) nw_trsm_parts<DP, 256 / DP>(tri, sA, s_sq, s_rd, D, tid);
-    else nw_trsm_parts<DP, 128 / DP>(tri, sA, s_sq, s_rd, D, tid);
-}
-
 template <int DP>
 __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, int nthreads)
 {
@@ -271,12 +242,23 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     __syncthreads();
     HSTAMP(2);
 
-    // ---- Z~ = L~^-T A~  <=>  Lt' Z~ = diag(sqrt(d)) A~ : backward substitution over the packed factor, PARTS threads per
-    // column of A~ (consecutive lanes of one wave): a thread adds the terms m = part (mod PARTS) of a row's sum, a butterfly
-    // over the parts completes it, and the column's solution replaces A~ in sA from the bottom up.  Only the column's own
-    // lanes read what they wrote: a wave-level LDS fence per row, no workgroup barrier.  (One thread per column with its 528
-    // dependent fmas took 12 us of the draw's 22 on its reserved CU.)
-    nw_trsm<DP>(tri, sA, s_sq, s_rd, D, tid, nthreads);
+    // ---- Z~ = L~^-T A~  <=>  Lt' Z~ = diag(sqrt(d)) A~ : one thread per column, backward substitution over the packed factor
+    if (tid < DP) {
+        double z[DP];
+#pragma unroll
+        for (int i = DP - 1; i >= 0; i--) {
+            if (i >= D) { z[i] = 0.0; continue; }            // padding: identity
+            constexpr int dummy = 0; (void)dummy;
+            // four interleaved partial sums (fixed assignment m % 4): four short dependency chains instead of one long one
+            double s4[4] = {s_sq[i] * sA[i * LD + tid], 0.0, 0.0, 0.0};
+            const int cb = GG::col_base(i), nr4 = GG::col_rows(i) / 4, r16 = GG::col_first(i);
+#pragma unroll
+            for (int m = i + 1; m < DP; m++) s4[m & 3] = fma(-tri[cb + (m & 3) * nr4 + (m - r16) / 4], z[m], s4[m & 3]);
+            z[i] = ((s4[0] + s4[1]) + (s4[2] + s4[3])) * s_rd[i];
+        }
+#pragma unroll
+        for (int i = 0; i < DP; i++) sA[i * LD + tid] = z[i];
+    }
     __syncthreads();
     HSTAMP(3);
 

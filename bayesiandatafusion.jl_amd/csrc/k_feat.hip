@@ -822,6 +822,7 @@ int create_sparse(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t
     };
     bdf_feat *f = new bdf_feat();
     memset(f, 0, sizeof(*f));
+    struct Guard { bdf_feat *f; ~Guard() { if (f) bdf_feat_destroy(f); } } guard{f};        // error paths free what was uploaded
     f->ctx = ctx; f->kind = vals ? 1 : 2; f->m = m; f->n = n; f->nnz = nnz;
     std::vector<int64_t> ptr; std::vector<int32_t> ind; std::vector<double> v;
     int rc;
@@ -831,6 +832,7 @@ int create_sparse(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t
     build(cols, rows, n, ptr, ind, v);
     if ((rc = upload_vec(ptr, &f->colptr_dev)) || (rc = upload_vec(ind, &f->rowind_dev))) return rc;
     if (vals && (rc = upload_vec(v, &f->cvals_dev))) return rc;
+    guard.f = nullptr;
     *out = f;
     return BDF_OK;
 }
@@ -844,8 +846,10 @@ extern "C" int bdf_feat_create_dense(bdf_ctx *ctx, int64_t m, int64_t n, const d
     bdf_feat *f = new bdf_feat();
     memset(f, 0, sizeof(*f));
     f->ctx = ctx; f->kind = 0; f->m = m; f->n = n; f->nnz = m * n;
+    struct Guard { bdf_feat *f; ~Guard() { if (f) bdf_feat_destroy(f); } } guard{f};
     BDF_HIP(hipMalloc((void **)&f->dense_dev, std::max<size_t>((size_t)m * n * sizeof(double), 8)));
     if (m * n) BDF_HIP(hipMemcpy(f->dense_dev, F, (size_t)m * n * sizeof(double), hipMemcpyHostToDevice));
+    guard.f = nullptr;
     *out = f;
     return BDF_OK;
 }

@@ -267,6 +267,8 @@ extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void
     }
     bdf_pairs *p = new bdf_pairs();
     p->ctx = ctx; p->n_modes = n_modes; p->n = n; p->count = 0.0; p->baseline_dev = nullptr; p->orig_dev = nullptr; p->sorted_mode = -1;
+    p->ids_dev = nullptr; p->values_dev = nullptr; p->avg_dev = nullptr; p->sq_dev = nullptr;
+    struct Guard { bdf_pairs *p; ~Guard() { if (p) bdf_pairs_destroy(p); } } guard{p};        // error paths free what was allocated
     p->ids_host = h;
     p->values_host.assign(values, values + (n ? n : 0));
     size_t nb = std::max<size_t>((size_t)n * sizeof(double), 8);
@@ -280,6 +282,7 @@ extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void
     }
     BDF_HIP(hipMemset(p->avg_dev, 0, nb));
     BDF_HIP(hipMemset(p->sq_dev, 0, nb));
+    guard.p = nullptr;
     *out = p;
     return BDF_OK;
 }

@@ -1,26 +1,34 @@
 #!/bin/bash
 # Round profile of the bench workload (run on the GPU box through gpurun):
-#   1. rocprofv3 --kernel-trace --stats            -> kernel_stats.csv
-#   2. separate --pmc passes FETCH_SIZE, WRITE_SIZE -> K1 HBM traffic per launch (gfx950: FETCH_SIZE counts half of a
-#      wide coalesced read, MI355X_MICROARCH.md "HBM"; the uncorrected and the doubled figure are both recorded)
+#   1. the bench line itself                       -> bench.json
+#   2. rocprofv3 --kernel-trace --stats            -> kernel_stats.csv
+#   3. separate --pmc passes (never with sys / runtime traces): FETCH_SIZE, WRITE_SIZE -> K1 HBM traffic per launch (gfx950:
+#      FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md "HBM"; the uncorrected and the doubled figure
+#      are both recorded, with the sha1 of the row kernel's source the passes ran on); two SQ counter sets -> pmc_k_rows.json
+#   4. micro-benchmarks behind DESIGN.md's bound analysis: fp64 pipe probe, CU mask probe, back-to-back row kernels
 # Output under gpurun_out/profile_<tag>/ ; copy what should be judged into profiles/.
-tag=${1:-r01}
+tag=${1:-r02}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
-(cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 300 --no-cpu-baseline > $out/bench_under_rocprof.log 2>&1)
+B="--no-cpu-baseline --no-c4"
+python3 bench.py > $out/bench.json 2> $out/bench.err
+(cd /tmp && rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 300 $B > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
-for c in FETCH_SIZE WRITE_SIZE; do
-  (cd /tmp && rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/prof_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --no-cpu-baseline > $out/pmc_$c.log 2>&1)
+i=0
+for set in "FETCH_SIZE" "WRITE_SIZE" \
+           "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM"; do
+  i=$((i+1))
+  (cd /tmp && rm -rf /tmp/prof_pmc$i && rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --k1-min-launches 0 $B > $out/pmc_pass$i.log 2>&1)
 done
 python3 - <<PY
-import csv, glob, json, collections
+import csv, glob, json, collections, hashlib
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
-for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob('/tmp/prof_%s/*/*counter_collection.csv' % c):
-        for r in csv.DictReader(open(f)):
-            agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
+for f in glob.glob('/tmp/prof_pmc*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 rows = []
 for k, d in agg.items():
     rows.append({"kernel": k[:90], "launches": len(d.get("FETCH_SIZE", [])),
@@ -28,12 +36,23 @@ for k, d in agg.items():
                  "WRITE_SIZE_KB_per_launch": sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [])), 1)})
 rows.sort(key=lambda r: -r["FETCH_SIZE_KB_per_launch"] - r["WRITE_SIZE_KB_per_launch"])
 k1 = [r for r in rows if "k_rows" in r["kernel"]]
-summary = {"rows": rows[:12]}
+summary = {"rows": rows[:12],
+           "k_sample_rows_sha1": hashlib.sha1(open('$GRAFT_REPO_ROOT/bayesiandatafusion.jl_amd/csrc/k_sample_rows.hip', 'rb').read()).hexdigest()}
 if k1:
     f, w = k1[0]["FETCH_SIZE_KB_per_launch"] * 1024, k1[0]["WRITE_SIZE_KB_per_launch"] * 1024
     summary["k1_traffic_bytes_per_launch"] = {"fetch_uncorrected": f, "write": w, "hbm_bytes_fetch_doubled": 2 * f + w,
                                                "hbm_bytes_fetch_as_counted": f + w}
 json.dump(summary, open('$out/hbm_traffic.json', 'w'), indent=1)
+pmc = {}
+for k, d in agg.items():
+    if 'k_rows' in k or 'k_hyper_sample' in k or 'k_predict_runs' in k:
+        pmc[k[:90]] = {c: {"n": len(v), "mean": sum(v) / len(v)} for c, v in sorted(d.items())}
+json.dump(pmc, open('$out/pmc_k_rows.json', 'w'), indent=1)
 print(json.dumps(summary.get("k1_traffic_bytes_per_launch")))
 PY
+tools/bin/fp64_pipe_probe > $out/fp64_pipe_probe.txt 2>&1
+timeout 120 tools/bin/cu_mask_probe 8 > $out/cu_mask_probe.txt 2>&1
+tools/k1_gap.sh > $out/k1_back_to_back.txt 2>&1
+tools/sweep_timeline.sh > $out/sweep_timeline.txt 2>&1
 head -12 $out/kernel_stats.csv | cut -c1-160
+tail -2 $out/bench.json | cut -c1-300
