@@ -29,6 +29,11 @@ mutable struct Context
         finalizer(x -> ccall((:bdf_ctx_destroy, lib), Cint, (Ptr{Cvoid},), x.h), c)
         c
     end
+    function Context(h::Ptr{Cvoid})                 # a context the library created (bdf_ctx_create_rows / _side)
+        c = new(h)
+        finalizer(x -> ccall((:bdf_ctx_destroy, lib), Cint, (Ptr{Cvoid},), x.h), c)
+        c
+    end
 end
 
 set_sweep!(c::Context, i) = check(ccall((:bdf_ctx_set_sweep, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, i))
@@ -36,15 +41,18 @@ sync(c::Context) = check(ccall((:bdf_ctx_sync, lib), Cint, (Ptr{Cvoid},), c.h))
 # K1 tuning: rows with more than `item` observations are split into pieces of at most `piece` (defaults 192 / 128)
 set_item_size!(c::Context, item) = check(ccall((:bdf_ctx_set_item_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, item))
 set_piece_size!(c::Context, piece) = check(ccall((:bdf_ctx_set_piece_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, piece))
-# a second context (own HIP stream) for the hyperprior / prediction work that runs beside the row kernels, and the hand-over
-# of fresh rows to it without an event: `rows_gate!(side, main)` holds `side`'s stream until every sample_rows! enqueued so
-# far on `main` has completed (use `gate_usable` once; fall back to events when the two streams share a hardware queue)
-rows_gate!(waiter::Context, producer::Context) =
-    check(ccall((:bdf_rows_gate, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), waiter.h, producer.h))
-function gate_usable(waiter::Context, producer::Context)
-    ok = Ref{Cint}(0)
-    check(ccall((:bdf_rows_gate_selftest, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ref{Cint}), waiter.h, producer.h, ok))
-    return ok[] != 0
+# a row context on a library-owned stream that leaves `reserve_cus` CUs (0, 8, 16, ...) free, and side contexts that really
+# run beside it -- on the reserved CUs (`reserved = true`: the hyperprior's small kernels) or on the others
+function rows_context(device::Integer=0; seed::Integer=0, reserve_cus::Integer=8)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    check(ccall((:bdf_ctx_create_rows, lib), Cint, (Cint, UInt64, Cint, Ref{Ptr{Cvoid}}), device, seed % UInt64, reserve_cus, out))
+    return Context(out[])
+end
+function side_context(main::Context; apart::Vector{Context}=Context[], reserved::Bool=false)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    hs = Ptr{Cvoid}[a.h for a in apart]
+    check(ccall((:bdf_ctx_create_side, lib), Cint, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Cint, Cint, Ref{Ptr{Cvoid}}), main.h, hs, length(hs), reserved, out))
+    return Context(out[])
 end
 
 "device copy of a Julia array (column-major as is)"
@@ -200,5 +208,78 @@ function sample_beta_rel!(c::Context, f::Ptr{Cvoid}, train::DevPairs, D, factors
                 (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Float64, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
                 c.h, f, train.h, D, fp, mean_value, alpha, lambda_beta, rel_tag, beta.p, linear_values.p, C_NULL))
 end
+
+# ---- the whole iteration (src/macau.jl:80-203 without side information) and the multi-GPU exchange ------------------------
+struct GibbsTerm
+    rel::Ptr{Cvoid}
+    mode::Int32
+    entity_of_mode::NTuple{4,Int32}
+    alpha::Float64
+    mean_value::Float64
+end
+
+struct GibbsEntity                                # bdf_gibbs_entity, field for field
+    N::Int64
+    n_real::Int64
+    tag::UInt32
+    n_terms::Int32
+    terms::NTuple{4,GibbsTerm}
+    sample::NTuple{3,Ptr{Cvoid}}
+    mu::Ptr{Cvoid}; Lambda::Ptr{Cvoid}; mu0::Ptr{Cvoid}; WI::Ptr{Cvoid}; sumU::Ptr{Cvoid}; UUt::Ptr{Cvoid}
+    params::Ptr{Cvoid}; prior_pack::Ptr{Cvoid}; draws::Ptr{Cvoid}
+    b0::Float64
+    nu0::Float64
+end
+
+mutable struct Gibbs
+    h::Ptr{Cvoid}
+    function Gibbs(rows::Context, num_latent::Integer, entities::Vector{GibbsEntity})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bdf_gibbs_create, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{GibbsEntity}, Ref{Ptr{Cvoid}}),
+                    rows.h, num_latent, length(entities), entities, out))
+        g = new(out[])
+        finalizer(x -> ccall((:bdf_gibbs_destroy, lib), Cint, (Ptr{Cvoid},), x.h), g)
+        g
+    end
+end
+
+"one Gibbs iteration; phase: 0 burn-in, 1 first posterior sample, 2 later ones, -1 no prediction update"
+sweep!(g::Gibbs, i::Integer, phase::Integer=-1) = check(ccall((:bdf_gibbs_sweep, lib), Cint, (Ptr{Cvoid}, UInt32, Cint), g.h, i, phase))
+sync(g::Gibbs) = check(ccall((:bdf_gibbs_sync, lib), Cint, (Ptr{Cvoid},), g.h))
+function current_buffer(g::Gibbs, entity::Integer)
+    b = Ref{Cint}(0)
+    check(ccall((:bdf_gibbs_current, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Cint}), g.h, entity - 1, b))
+    return b[] + 1
+end
+set_test!(g::Gibbs, pairs::Ptr{Cvoid}, entity_of_mode::Vector{Int32}, mean_value, clamp_lo, clamp_hi, class_cut, stats::DevArray) =
+    check(ccall((:bdf_gibbs_set_test, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Int32}, Float64, Float64, Float64, Float64, Ptr{Cvoid}),
+                g.h, pairs, entity_of_mode, mean_value, clamp_lo, clamp_hi, class_cut, stats.p))
+
+"internal row positions of an entity shared by `world` GPUs (bdf_layout_build): (pos::Vector{Int32} 0-based, cmax)"
+function layout(degree::Vector{Int64}, world::Integer, chunks::Integer)
+    pos = zeros(Int32, length(degree)); cmax = Ref{Int64}(0)
+    check(ccall((:bdf_layout_build, lib), Cint, (Int64, Ptr{Int64}, Cint, Cint, Ptr{Int32}, Ref{Int64}),
+                length(degree), degree, world, chunks, pos, cmax))
+    return pos, cmax[]
+end
+
+"rank 0: the 128-byte RCCL id to hand to the other workers (e.g. with remotecall_fetch)"
+function comm_unique_id()
+    id = zeros(UInt8, 128)
+    check(ccall((:bdf_comm_unique_id, lib), Cint, (Ptr{UInt8},), id))
+    return id
+end
+
+mutable struct Comm
+    h::Ptr{Cvoid}
+    function Comm(c::Context, rank::Integer, world::Integer, id::Vector{UInt8})
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        check(ccall((:bdf_comm_create, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), c.h, rank, world, id, out))
+        m = new(out[])
+        finalizer(x -> ccall((:bdf_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.h), m)
+        m
+    end
+end
+set_comm!(g::Gibbs, m::Comm) = check(ccall((:bdf_gibbs_set_comm, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), g.h, m.h))
 
 end # module

@@ -205,6 +205,14 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
     assert np.array_equal(a1, a2) and np.array_equal(l1, l2)
     a3, _ = run(6)
     assert not np.array_equal(a1, a3)
+    monkeypatch.setenv("BDF_NO_POLL", "1")              # row kernels wait for the hyperprior's event instead of polling its flag
+    a7, l7 = run(5)
+    assert np.array_equal(a1, a7) and np.array_equal(l1, l7)
+    monkeypatch.delenv("BDF_NO_POLL")
+    monkeypatch.setenv("BDF_RESERVE_CUS", "0")          # no CUs set aside for the hyperprior stream (events, whole chip)
+    a8, l8 = run(5)
+    assert np.array_equal(a1, a8) and np.array_equal(l1, l8)
+    monkeypatch.delenv("BDF_RESERVE_CUS")
     monkeypatch.setenv("BDF_NO_NATIVE", "1")            # the iteration enqueued step by step from Python instead of bdf_gibbs_sweep
     a5, l5 = run(5)
     assert np.array_equal(a1, a5) and np.array_equal(l1, l5)
