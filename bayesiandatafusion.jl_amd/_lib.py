@@ -130,6 +130,7 @@ _SIGS = {
     "bdf_feat_create_csr": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, c_dp, C.POINTER(C.c_void_p)]),
     "bdf_feat_create_bin": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, c_i32p, c_i32p, C.POINTER(C.c_void_p)]),
     "bdf_feat_destroy": (C.c_int, [C.c_void_p]),
+    "bdf_feat_set_row_ids": (C.c_int, [C.c_void_p, c_i32p]),
     "bdf_feat_size": (C.c_int, [C.c_void_p, c_i64p, c_i64p, c_i64p]),
     "bdf_feat_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int]),
     "bdf_feat_AtA_mul": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_double, C.c_void_p]),

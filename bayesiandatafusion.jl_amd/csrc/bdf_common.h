@@ -115,6 +115,7 @@ struct bdf_feat {
     int64_t *rowptr_dev; int32_t *colind_dev; double *rvals_dev;
     int64_t *colptr_dev; int32_t *rowind_dev; double *cvals_dev;
     double *FF_dev;       // n x n (F'F), built on first use_ff
+    int32_t *row_ids_dev; // nullable (bdf_feat_set_row_ids): original id of every row of F, keys the rows' noise streams
     double *chol_ws;      // workspace of the blocked direct solve (k_chol.hip), allocated on first use
     size_t chol_ws_doubles;
 };

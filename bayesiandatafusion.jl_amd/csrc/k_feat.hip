@@ -489,8 +489,11 @@ __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, 
 template <int DP>
 __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const double *Lr, const double *sample,
                                                      const double *mu, const double *scale_sq, uint64_t seed,
-                                                     uint32_t sweep, uint32_t purpose, uint32_t entity, double *T)
+                                                     uint32_t sweep, uint32_t purpose, uint32_t entity, double *T,
+                                                     const int32_t *__restrict__ row_ids)
 {
+    // row_ids (nullable): the row's ORIGINAL id, which keys its noise stream (rows stored at internal positions when several
+    // GPUs share the entity); negative = a row nobody owns: no noise (its feature row is zero)
     // 64 rows per workgroup.  Phase 1, all 256 threads: the rows' normals (a Philox block + log + sin/cos per pair is ~40x
     // the arithmetic of the solve), scaled by sqrt(p_j), into LDS.  Phase 2, one thread per row: the substitution.
     __shared__ double sL[DP * DP + 2 * DP];
@@ -505,7 +508,9 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
         const int lr = e / npairs, pr = e % npairs;
         const int64_t i = r0 + lr;
         if (i >= n) continue;
-        const u32x4 o = bdf_draw(seed, sweep, purpose, entity, (uint64_t)i, (uint32_t)pr);
+        const int64_t rid = row_ids ? (int64_t)row_ids[i] : i;
+        if (rid < 0) continue;
+        const u32x4 o = bdf_draw(seed, sweep, purpose, entity, (uint64_t)rid, (uint32_t)pr);
         const double u1 = bdf_u01(o.x, o.y), u2 = bdf_u01(o.z, o.w);
         const double r = sqrt(-2.0 * log(u1)), t = 6.283185307179586476925286766559 * u2;
         // normal number ej of the row belongs to reversed position j = D - 1 - ej
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
 
 template <int DP>
 int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr, const double *sample, const double *mu,
-               const double *scale_sq, uint32_t purpose, uint32_t entity, double *T, bool prep)
+               const double *scale_sq, uint32_t purpose, uint32_t entity, double *T, bool prep, const int32_t *row_ids = nullptr)
 {
     if (prep) {
         hipLaunchKernelGGL(k_noise_prep<DP>, dim3(1), dim3(64), 0, ctx->stream, D, Lambda, Lr, ctx->flag_dev);
@@ -543,7 +548,7 @@ int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr,
     }
     if (n > 0) {
         hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, D, n, Lr,
-                           sample, mu, scale_sq, ctx->seed, ctx->sweep_host, purpose, entity, T);
+                           sample, mu, scale_sq, ctx->seed, ctx->sweep_host, purpose, entity, T, row_ids);
         BDF_HIP(hipGetLastError());
     }
     return BDF_OK;
@@ -875,7 +880,19 @@ extern "C" int bdf_feat_destroy(bdf_feat *f)
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->dense_dev); hipFree(f->rowptr_dev); hipFree(f->colind_dev); hipFree(f->rvals_dev);
     hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev); hipFree(f->chol_ws);
+    hipFree(f->row_ids_dev);
     delete f;
+    return BDF_OK;
+}
+
+extern "C" int bdf_feat_set_row_ids(bdf_feat *f, const int32_t *row_ids_host)
+{
+    BDF_REQUIRE(f, BDF_ERR_ARG, "bdf_feat_set_row_ids: NULL argument");
+    if (f->row_ids_dev) { BDF_HIP(hipFree(f->row_ids_dev)); f->row_ids_dev = nullptr; }
+    if (row_ids_host && f->m > 0) {
+        BDF_HIP(hipMalloc((void **)&f->row_ids_dev, (size_t)f->m * sizeof(int32_t)));
+        BDF_HIP(hipMemcpy(f->row_ids_dev, row_ids_host, (size_t)f->m * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     return BDF_OK;
 }
 
@@ -1030,7 +1047,7 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
     // rhs = F'((sample - mu)' + E1) + sqrt(lb) E2
 #define NOISE(DPV)                                                                                                      \
     do {                                                                                                                \
-        if ((rc = noise_rows<DPV>(ctx, D, N, Lambda, Lr, sample, mu, nullptr, BDF_P_BETA_E1, entity_tag, T, true))) return rc; \
+        if ((rc = noise_rows<DPV>(ctx, D, N, Lambda, Lr, sample, mu, nullptr, BDF_P_BETA_E1, entity_tag, T, true, f->row_ids_dev))) return rc; \
         if ((rc = noise_rows<DPV>(ctx, D, numF, Lambda, Lr, nullptr, nullptr, lambda_beta_dev, BDF_P_BETA_E2, entity_tag, E2s, false))) return rc; \
     } while (0)
     if (DP == 16) NOISE(16); else if (DP == 32) NOISE(32); else NOISE(64);

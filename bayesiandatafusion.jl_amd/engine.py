@@ -331,10 +331,15 @@ class DevicePairs:
 class FeatOperator:
     """bdf_feat: the Entity.F operator on the device (dense / CSR / binary)."""
 
-    def __init__(self, ctx, F):
+    def __init__(self, ctx, F, layout=None):
+        """layout (several ranks): the rows of F move to the entity's internal positions (rows nobody owns are zero), and the
+        original ids key the rows' noise streams (bdf_feat_set_row_ids)"""
         self.ctx = ctx
         self.handle = C.c_void_p()
         L = lib()
+        self.m_orig = feat.feature_shape(F)[0]
+        if layout is not None and layout.pos is not None:
+            F = _rows_to_internal(F, layout)
         if isinstance(F, feat.SparseMatrixCSR):
             self.kind = "csr"
             check(L.bdf_feat_create_csr(ctx.handle, F.m, F.n, len(F.rows), F.rows.ctypes.data_as(_lib.c_i32p),
@@ -361,7 +366,10 @@ class FeatOperator:
             self.kind = "dense"
             check(L.bdf_feat_create_dense(ctx.handle, A.shape[0], A.shape[1], A.ctypes.data_as(_lib.c_dp), C.byref(self.handle)))
             self.m, self.n = int(A.shape[0]), int(A.shape[1])
-
+        if layout is not None and layout.pos is not None:
+            ids = np.full(layout.nint, -1, dtype=np.int32)
+            ids[layout.pos] = np.arange(layout.N, dtype=np.int32)
+            check(L.bdf_feat_set_row_ids(self.handle, ids.ctypes.data_as(_lib.c_i32p)))
         ctx.adopt(self)
 
     # B, out: torch tensors holding column-major matrices, i.e. shape (ncol, rows)
@@ -387,6 +395,23 @@ class FeatOperator:
             self.close()
         except Exception:
             pass
+
+
+def _rows_to_internal(F, layout):
+    """F with row i moved to row layout.pos[i] of a layout.nint-row matrix of the same kind"""
+    pos = layout.pos.astype(np.int64)
+    if isinstance(F, feat.SparseMatrixCSR):
+        return feat.SparseMatrixCSR(pos[F.rows - 1] + 1, F.cols, F.vals, layout.nint, F.n)
+    if isinstance(F, feat.SparseBinMatrix):
+        return feat.SparseBinMatrix(layout.nint, F.n, pos[F.rows - 1] + 1, F.cols)
+    if hasattr(F, "tocoo"):
+        import scipy.sparse as sp
+        coo = F.tocoo()
+        return sp.csr_matrix((coo.data, (pos[coo.row], coo.col)), shape=(layout.nint, coo.shape[1]))
+    A = np.asarray(F, dtype=np.float64)
+    out = np.zeros((layout.nint, A.shape[1]))
+    out[pos] = A
+    return out
 
 
 class EntityState:
@@ -424,13 +449,13 @@ class EntityState:
         self.lambda_beta = None
         self.cg_iters = None
         if not feat.isempty(en.F):
-            self.F = FeatOperator(ctx, en.F)
-            if self.F.m != en.count:
-                raise ArgumentError(f"Entity {en.name} has {en.count} instances but its feature matrix has {self.F.m} rows")
+            if feat.feature_shape(en.F)[0] != en.count:
+                raise ArgumentError(f"Entity {en.name} has {en.count} instances but its feature matrix has {feat.feature_shape(en.F)[0]} rows")
+            self.F = FeatOperator(ctx, en.F, layout)
             self.numF = self.F.n
             self.beta = ctx.zeros(D, self.numF)          # numF x D column-major
-            self.uhat = ctx.zeros(en.count, D)
-            self.mu_matrix = ctx.zeros(en.count, D)
+            self.uhat = ctx.zeros(self.N, D)
+            self.mu_matrix = ctx.zeros(self.N, D)
             self.Tinv = ctx.zeros(D, D)
             self.lambda_beta = ctx.tensor([en.lambda_beta])
             self.cg_iters = ctx.zeros(D, dtype=torch.int32)
@@ -452,7 +477,7 @@ class EntityState:
             return np.zeros((0, 0))
         torch.cuda.synchronize(t.device)      # the state is written on several streams (rows, hyperprior): wait for all of them
         a = t.detach().cpu().numpy()
-        if name == "sample" and self.layout.pos is not None:
+        if name in ("sample", "uhat", "mu_matrix") and self.layout.pos is not None:
             a = a[self.layout.pos]            # internal positions -> the reference's row order
         return a.T.copy() if a.ndim == 2 else a.copy()
 
@@ -480,12 +505,11 @@ class GibbsEngine:
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
         has_feat = any(not feat.isempty(en.F) for en in data.entities) or any(not feat.isempty(r.F) for r in data.relations)
-        if self.world > 1 and has_feat:
-            raise ArgumentError("side information with several GPUs is not implemented: the multi-GPU path is the BPMF iteration")
+        if self.world > 1 and (any(not feat.isempty(r.F) for r in data.relations) or any(r.model.alpha_sample for r in data.relations)):
+            raise ArgumentError("several GPUs: relation-level side information and alpha sampling are not implemented "
+                                "(entity side information is: F replicated, its rows at the entity's internal positions)")
         # the whole iteration in one native call unless something needs the step-by-step path
         self.native = not has_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
-        if self.world > 1 and not self.native:
-            raise ArgumentError("several GPUs: alpha sampling is not implemented on the multi-GPU path")
         # ---- row layouts (several ranks): degree of a row = its observations over all the entity's relations
         if chunks is None:
             chunks = int(os.environ.get("BDF_CHUNKS", "0"))
@@ -556,6 +580,8 @@ class GibbsEngine:
         if self.native:
             self._create_native()
         else:
+            if self.world > 1:
+                self.comm = make_comm(self.ctx, self.rank, self.world)
             self.ctx_h = self.ctx_p = self.ctx
             if not os.environ.get("BDF_NO_OVERLAP"):
                 self.ctx_h = Context.side(self.ctx, reserved=True)
@@ -664,9 +690,16 @@ class GibbsEngine:
             timer = KernelTimer()
             check(lib().bdf_ctx_time_next_rows(self.ctx.handle, timer.start, timer.stop))
         pack = st.prior_pack if (st.prior_pack_valid and not is_matrix) else None
-        # written into the entity's next buffer (nothing this launch reads), which then becomes the current one
-        check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
-                                    st.tag, 0, 1, _ptr(st.sample_next), _ptr(pack) if pack is not None else None))
+        # written into the entity's next buffer (nothing this launch reads), which then becomes the current one; several ranks:
+        # chunk after chunk, every chunk exchanged in place while the next one is sampled
+        nch = st.layout.chunks
+        for c in range(nch):
+            check(lib().bdf_sample_rows(self.ctx.handle, self.D, st.N, len(terms), terms, _ptr(mu), is_matrix, _ptr(st.Lambda),
+                                        st.tag, c, nch, _ptr(st.sample_next), _ptr(pack) if pack is not None else None))
+            if self.comm is not None:
+                check(lib().bdf_allgather_rows(self.ctx.handle, self.comm.handle, self.D, st.N, _ptr(st.sample_next), c, nch))
+        if self.comm is not None:
+            check(lib().bdf_allgather_join(self.ctx.handle, self.comm.handle))
         st.rotate()
         if timed:
             self.k1_events.append((j, timer))

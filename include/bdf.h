@@ -255,6 +255,10 @@ int bdf_feat_create_csr(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const i
 int bdf_feat_create_bin(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t *rows,
                         const int32_t *cols, bdf_feat **out);
 int bdf_feat_destroy(bdf_feat *f);
+/* Several GPUs store an entity's rows at internal positions (bdf_layout_build), and the rows of its F with them.
+ * row_ids_host (m entries, nullable to clear): the ORIGINAL id of every row of F (negative: a row nobody owns, all zero) --
+ * it keys the per-row noise of bdf_sample_beta (E1, src/sampling.jl:298-300), so that beta does not depend on the layout. */
+int bdf_feat_set_row_ids(bdf_feat *f, const int32_t *row_ids_host);
 int bdf_feat_size(const bdf_feat *f, int64_t *m, int64_t *n, int64_t *nnz);
 /* F*B (transpose=0: B n x ncol -> out m x ncol) or At_mul_B(F,B) (transpose=1: B m x ncol -> out
  * n x ncol); B, out dev column-major (RelationData.jl:314-329, parallel_matrix.jl:520-561) */

@@ -262,3 +262,29 @@ def test_c4_shaped_full_size_properties_and_quality(B):
     assert torch.equal(full, halves)
     assert ctx.rows_unfinished() == 0
     eng.close()
+
+
+def test_c5_two_ranks_match_one():
+    """C5's structure on two ranks -- a shared entity with two relations (3-mode + 2-mode) and binary sparse features, rows
+    at internal positions, F's rows with them, noise keyed by the original ids, in-place exchange after every entity -- gives
+    the chain of the single-process run (up to the summation order of the hyperprior's sums).  Two ranks on the box's one
+    GPU: the exchange goes through the library's host transport (BDF_DIST_BACKEND=gloo)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "c5_ranks.py")
+    one = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    port = str(29900 + os.getpid() % 90)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, tool], env=dict(os.environ, BDF_DIST_BACKEND="gloo", C5_CHUNKS="2"),
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["world"] == 2 and d1["world"] == 1
+    assert d1["rmse"] < 0.6 * d1["value_std"]
+    for k in ("rmse", "sample_norm", "beta_norm", "lambda_beta"):
+        assert abs(d2[k] - d1[k]) <= 1e-6 * max(1.0, abs(d1[k])), (k, d1, d2)
