@@ -104,6 +104,8 @@ _SIGS = {
     "bdf_sample_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
                                   C.c_uint32, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "bdf_prior_pack_doubles": (C.c_int, [C.c_int]),
+    "bdf_sample_block": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
+                                   C.c_void_p, C.c_uint32, C.c_void_p]),
     "bdf_row_system": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_int, C.POINTER(Term), C.c_void_p, C.c_int, C.c_void_p,
                                  C.c_void_p, C.c_void_p]),
     "bdf_normals": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),

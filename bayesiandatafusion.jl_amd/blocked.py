@@ -1,8 +1,9 @@
 """Block / sample_users_blocked (src/sampling.jl:236-249): the users of a block all observed the same items, so the
-reference shares one covariance between them.  On the device every row is a wavefront of the row kernel anyway (the
-shared covariance is recomputed per row from L2-resident operands); this mirror builds the block's dense relation and
-samples its users with bdf_sample_rows -- same value as the reference's expression for the same normals:
+reference shares one covariance between them:
     covar = inv(Lambda_u + alpha MM MM'),  mu = covar (alpha MM Yma + Lambda_u mu_u),  chol(covar)' z + mu.
+bdf_sample_block (csrc/k_block.hip) does the same on the device: the block's precision matrix is accumulated and factored
+ONCE, every user then costs its right-hand side and two triangular solves.  shared=False takes the row kernel instead (the
+block as a dense relation: one factorisation per user) -- same values, kept as the cross-check.
 (macau_blocked.jl, the only would-be caller, is an empty stub in the reference.)"""
 import ctypes as C
 
@@ -25,7 +26,7 @@ class Block:
             raise DimensionMismatch(f"Yma is {self.Yma.shape}, expected ({len(self.vx)}, {len(self.ux)})")
 
 
-def sample_users_blocked(block, sample_mt, alpha, mu_u, Lambda_u, ctx=None, entity_tag=1):
+def sample_users_blocked(block, sample_mt, alpha, mu_u, Lambda_u, ctx=None, entity_tag=1, shared=True):
     """sample_users_blocked(block, sample_mt, alpha, mu_u, Lambda_u) (sampling.jl:242-249) -> D x length(block.ux).
     sample_mt: D x M sample of the other side.  Column u of the result uses the normals of stream (row, entity_tag,
     u - 1) of the context's current sweep (column index within the block, not block.ux[u])."""
@@ -43,6 +44,17 @@ def sample_users_blocked(block, sample_mt, alpha, mu_u, Lambda_u, ctx=None, enti
         nu, nv = len(block.ux), len(block.vx)
         if nu == 0:
             return np.zeros((D, 0))
+        if shared:
+            import torch
+            fac = ctx.tensor(sample_mt.T)                        # M x D, a gathered column of sample_mt is contiguous
+            vx = ctx.tensor(block.vx - 1, dtype=torch.int32)
+            Y = ctx.tensor(np.asfortranarray(block.Yma).T)       # (nu, nv) C order == nv x nu column-major
+            mu_t, Lam_t = ctx.tensor(mu_u), ctx.tensor(Lambda_u)
+            out = ctx.zeros(nu, D)
+            check(lib().bdf_sample_block(ctx.handle, D, nu, nv, _ptr(vx), _ptr(Y), _ptr(fac), float(alpha), _ptr(mu_t), _ptr(Lam_t),
+                                         int(entity_tag), _ptr(out)))
+            ctx.sync()
+            return out.cpu().numpy().T.copy()
         ids = np.stack([np.repeat(np.arange(1, nu + 1), nv), np.tile(block.vx, nu)], axis=1)
         vals = block.Yma.T.reshape(-1)                       # user-major: all items of user 1, then user 2, ...
         dr = DeviceRelation(ctx, IndexedDF((ids, vals), [nu, M]))

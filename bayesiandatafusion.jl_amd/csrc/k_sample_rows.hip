@@ -804,6 +804,17 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
     if (rel_serial == 0) g_caches.erase(it);
 }
 
+// Lambda mu (D doubles) and the accumulator-layout image of the index-reversed Lambda (k_prior), for k_block.hip
+int bdf_prior_image(bdf_ctx *ctx, int D, const double *Lambda, const double *mu, double *out_b, double *out_c)
+{
+    const int DPp = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
+    const int nimg = (DPp / 16) * (DPp / 16 + 1) / 2 * 4;
+    const int64_t waves = ((int64_t)D + 7) / 8 + nimg;
+    hipLaunchKernelGGL(k_prior, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, D, DPp, (int64_t)1, Lambda, mu, 0, out_b, out_c);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump)
 {

@@ -158,6 +158,15 @@ typedef struct {
 int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, const bdf_term *terms,
                     const double *mu, int mu_is_matrix, const double *Lambda,
                     uint32_t entity_tag, int shard, int n_shards, double *out, const double *prior_pack);
+/* sample_users_blocked (src/sampling.jl:236-249): the nu users of a Block all observed the same nv items and share ONE
+ * covariance inv(Lambda + alpha MM MM'), MM = factor[:, vx]: it is accumulated and factored once for the block, every user
+ * then costs its right-hand side (alpha MM Yma[:, u] + Lambda mu) and two triangular solves.  vx_dev: dev nv item ids
+ * (0-based); Yma: dev nv x nu column-major (values without their mean, Block.Yma); factor: dev D x M sample of the other side;
+ * out: dev D x nu, column u drawn with the normals of stream (BDF_P_ROW, entity_tag, row u).  Same value as the reference's
+ * expression (and as bdf_sample_rows on the block as a dense relation) for the same normals. */
+int bdf_sample_block(bdf_ctx *ctx, int D, int64_t nu, int64_t nv, const int32_t *vx_dev, const double *Yma,
+                     const double *factor, double alpha, const double *mu, const double *Lambda, uint32_t entity_tag,
+                     double *out);
 /* doubles in a prior pack for num_latent = D */
 int bdf_prior_pack_doubles(int D);
 /* parity hook: the deterministic part only.  P_out: dev D x D x N, b_out: dev D x N */

@@ -526,6 +526,27 @@ def test_sample_users_blocked(B, O, ctx):
     covar = np.linalg.inv(Lam + alpha * (MM @ MM.T))
     mean = covar @ (alpha * MM @ Yma + (Lam @ mu)[:, None])
     np.testing.assert_allclose(got, np.linalg.cholesky(covar) @ z + mean, rtol=1e-8, atol=1e-9)
+    # the row kernel on the block as a dense relation (one factorisation per user) gives the same values
+    rows = B.sample_users_blocked(blk, sample_mt, alpha, mu, Lam, ctx=ctx, entity_tag=6, shared=False)
+    np.testing.assert_allclose(got, rows, rtol=1e-9, atol=1e-10)
+    # larger blocks at every kernel width: shared covariance == per-row factorisation == the reference's expression
+    for D2, M2, nv2, nu2 in ((5, 30, 7, 9), (32, 300, 150, 70), (64, 200, 90, 33)):
+        smt = rng.standard_normal((D2, M2))
+        vx2 = rng.choice(M2, nv2, replace=False) + 1
+        Y2 = rng.standard_normal((nv2, nu2))
+        A2 = rng.standard_normal((D2, D2))
+        Lam2, mu2 = A2 @ A2.T / D2 + np.eye(D2), rng.standard_normal(D2)
+        b2 = B.Block(np.arange(1, nu2 + 1), vx2, Y2)
+        g2 = B.sample_users_blocked(b2, smt, 0.9, mu2, Lam2, ctx=ctx, entity_tag=3)
+        r2 = B.sample_users_blocked(b2, smt, 0.9, mu2, Lam2, ctx=ctx, entity_tag=3, shared=False)
+        np.testing.assert_allclose(g2, r2, rtol=1e-8, atol=1e-9)
+        z2 = ctx.zeros(nu2, D2)
+        check(lib().bdf_normals(ctx.handle, 1, 3, 0, nu2, D2, _p(z2)))
+        ctx.sync()
+        MM2 = smt[:, vx2 - 1]
+        cov2 = np.linalg.inv(Lam2 + 0.9 * (MM2 @ MM2.T))
+        np.testing.assert_allclose(g2, np.linalg.cholesky(cov2) @ z2.cpu().numpy().T + cov2 @ (0.9 * MM2 @ Y2 + (Lam2 @ mu2)[:, None]),
+                                   rtol=1e-7, atol=1e-8)
     with pytest.raises(B.DimensionMismatch):
         B.Block(ux, vx, Yma.T)
     assert B.sample_users_blocked(B.Block([], vx, np.zeros((len(vx), 0))), sample_mt, alpha, mu, Lam, ctx=ctx).shape == (D, 0)
