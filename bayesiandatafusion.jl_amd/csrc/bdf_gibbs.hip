@@ -52,6 +52,35 @@ __global__ void k_spin(long long ticks)
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// Can a kernel on `b` run WHILE a kernel on `a` is running?  (Not under profilers that serialise kernels across queues --
+// rocprofv3 --pmc does -- nor if the two streams share a hardware queue.)  A kernel on `a` spins until a flag is set by a
+// kernel enqueued on `b` afterwards; bounded at 20 ms.  The row kernels poll for the hyperprior draw only if this holds.
+__global__ void k_wait_flag(const uint32_t *flag, long long max_ticks, uint32_t *timed_out)
+{
+    const long long t0 = wall_clock64();
+    while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > max_ticks) { *timed_out = 1; break; }
+    }
+}
+__global__ void k_set_flag(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
+
+int streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
+{
+    uint32_t *d;
+    BDF_HIP(hipMalloc((void **)&d, 2 * sizeof(uint32_t)));
+    BDF_HIP(hipMemset(d, 0, 2 * sizeof(uint32_t)));
+    BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
+    hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, a, (const uint32_t *)d, 2000000LL, d + 1);
+    hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, b, d);
+    BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
+    uint32_t h[2] = {0, 0};
+    BDF_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
+    BDF_HIP(hipFree(d));
+    *yes = h[1] == 0;
+    return BDF_OK;
+}
+
 int streams_overlap(hipStream_t a, hipStream_t b, bool *yes)
 {
     hipEvent_t e0, e1, e2;
@@ -200,6 +229,11 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
     g->ready_dev = nullptr;
     g->polling = rows_ctx->reserve_cus > 0 && g->hyper->on_reserved && !getenv("BDF_NO_POLL");
+    if (g->polling) {
+        bool conc = false;
+        if ((rc = streams_concurrent(rows_ctx->stream, g->hyper->stream, &conc))) { bdf_gibbs_destroy(g); return rc; }
+        g->polling = conc;              // kernels of the two streams do not run side by side here (a profiler serialising them): events
+    }
     BDF_HIP(hipMalloc((void **)&g->ready_dev, (size_t)n_entities * sizeof(uint32_t)));
     BDF_HIP(hipMemset(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t)));
     g->ent.resize((size_t)n_entities);
