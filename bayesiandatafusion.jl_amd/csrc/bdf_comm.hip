@@ -143,8 +143,8 @@ extern "C" int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *c, int D, int64_t N, d
     const int64_t cmax = N / ((int64_t)chunks * c->world);
     const size_t count = (size_t)cmax * (size_t)D;                         // doubles per rank
     double *region = sample + (size_t)chunk * (size_t)c->world * count;
-    if (c->world == 1 || count == 0) return BDF_OK;
-    if (c->nccl) {
+    if (count == 0 || (c->world == 1 && !c->nccl)) return BDF_OK;
+    if (c->nccl) {       // (a one-rank RCCL communicator still goes through ncclAllGather: the call path is exercised on one GPU)
         BDF_HIP(hipEventRecord(c->ev_rows, ctx->stream));
         BDF_HIP(hipStreamWaitEvent(c->stream, c->ev_rows, 0));
         BDF_NCCL(g_rccl.all_gather(region + (size_t)c->rank * count, region, count, 8 /* ncclFloat64 */, c->nccl, c->stream));
@@ -165,7 +165,7 @@ extern "C" int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *c, int D, int64_t N, d
 extern "C" int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *c)
 {
     BDF_REQUIRE(ctx && c, BDF_ERR_ARG, "bdf_allgather_join: NULL argument");
-    if (!c->nccl || c->world == 1) return BDF_OK;
+    if (!c->nccl) return BDF_OK;
     BDF_HIP(hipEventRecord(c->ev_done, c->stream));
     BDF_HIP(hipStreamWaitEvent(ctx->stream, c->ev_done, 0));
     return BDF_OK;

@@ -288,3 +288,33 @@ def test_c5_two_ranks_match_one():
     assert d1["rmse"] < 0.6 * d1["value_std"]
     for k in ("rmse", "sample_norm", "beta_norm", "lambda_beta"):
         assert abs(d2[k] - d1[k]) <= 1e-6 * max(1.0, abs(d1[k])), (k, d1, d2)
+
+
+def test_rccl_one_rank_allgather(B, ctx):
+    """librccl itself through bdf_comm (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the communicator's stream,
+    join): a ONE-rank communicator is all a 1-GPU box can hold, but it runs the whole call path; the N > 1 data movement is
+    covered by the host transport (test_two_ranks_match_one) and, on CPU, by the gloo tests of the layout."""
+    import ctypes as C
+    import torch
+    from bdf_amd import _lib
+    from bdf_amd._lib import check, lib
+    raw = (C.c_char * _lib.BDF_COMM_ID_BYTES)()
+    check(lib().bdf_comm_unique_id(raw))
+    assert any(b != b"\x00" for b in raw)
+    comm = C.c_void_p()
+    check(lib().bdf_comm_create(ctx.handle, 0, 1, raw.raw, C.byref(comm)))
+    rank, world = C.c_int(-1), C.c_int(-1)
+    check(lib().bdf_comm_size(comm, C.byref(rank), C.byref(world)))
+    assert (rank.value, world.value) == (0, 1)
+    D, chunks, cmax = 8, 3, 50
+    x = ctx.zeros(chunks * cmax, D)
+    with torch.cuda.stream(ctx.stream):
+        x.copy_(torch.arange(chunks * cmax * D, dtype=torch.float64, device=x.device).reshape(chunks * cmax, D))
+    ref = x.clone()
+    for c in range(chunks):
+        check(lib().bdf_allgather_rows(ctx.handle, comm, D, chunks * cmax, _p(x), c, chunks))
+    check(lib().bdf_allgather_join(ctx.handle, comm))
+    ctx.sync()
+    assert torch.equal(x, ref)
+    assert lib().bdf_allgather_rows(ctx.handle, comm, D, chunks * cmax + 1, _p(x), 0, chunks) == -1      # rows not chunks x ranks x cmax
+    check(lib().bdf_comm_destroy(comm))

@@ -1,0 +1,24 @@
+"""the row kernel alone: N back-to-back launches alternating the two entities on one stream, wall clock per launch (GPU box)"""
+import os, sys, time
+os.environ["BDF_NO_NATIVE"] = "1"; os.environ["BDF_NO_OVERLAP"] = "1"
+os.environ.setdefault("BDF_RESERVE_CUS", "0")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import bdf_amd as B
+from bdf_amd import datasets
+D = int(os.environ.get("D", "32"))
+rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
+eng = B.GibbsEngine(rd, D, seed=1, device=0)
+for i in range(1, 30):
+    eng.sweep(i)
+eng.sync()
+best = 1e9
+for rep in range(5):
+    n = 400
+    t0 = time.perf_counter()
+    for i in range(n):
+        eng.ctx.set_sweep(100 + i)
+        eng.sample_entity(i % 2)
+    eng.sync()
+    best = min(best, (time.perf_counter() - t0) / n)
+print(f"K1 alone: {best * 1e6:.2f} us per launch (mean of users' and movies', D={D}, reserve {os.environ['BDF_RESERVE_CUS']})")
+eng.close()
