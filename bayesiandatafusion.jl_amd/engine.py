@@ -516,7 +516,8 @@ class GibbsEngine:
         # one chunk count for the whole model (a relation's modes share it): the chunked exchange -- the row kernel of chunk
         # c + 1 beside the all-gather of chunk c -- pays once an entity's share of rows is large
         if chunks <= 0:
-            chunks = 4 if (self.world > 1 and max(-(-en.count // self.world) for en in data.entities) >= 200_000) else 1
+            share = max(-(-en.count // self.world) for en in data.entities) if self.world > 1 else 0
+            chunks = 8 if share >= 1_000_000 else (4 if share >= 200_000 else 1)      # the last chunk's exchange is what stays exposed
         self.layouts = []
         for en in data.entities:
             if self.world == 1:
