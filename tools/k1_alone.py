@@ -21,4 +21,15 @@ for rep in range(5):
     eng.sync()
     best = min(best, (time.perf_counter() - t0) / n)
 print(f"K1 alone: {best * 1e6:.2f} us per launch (mean of users' and movies', D={D}, reserve {os.environ['BDF_RESERVE_CUS']})")
+for j, name in enumerate(("users", "movies")):
+    bj = 1e9
+    for rep in range(5):
+        n = 300
+        t0 = time.perf_counter()
+        for i in range(n):
+            eng.ctx.set_sweep(1000 + i)
+            eng.sample_entity(j)
+        eng.sync()
+        bj = min(bj, (time.perf_counter() - t0) / n)
+    print(f"   {name}' launches only: {bj * 1e6:.2f} us")
 eng.close()
