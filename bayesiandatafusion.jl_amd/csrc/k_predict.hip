@@ -131,6 +131,11 @@ __global__ __launch_bounds__(256) void k_predict(PredArgs a)
 // consecutive pairs and keeps the factor row of the sorted mode in registers while its id does not change -- the update then
 // gathers one row per pair instead of two (MovieLens test set sorted by movie: 126 pairs per row; 136 MB instead of 256 MB
 // of L2 gathers per update, which is what the update and the row kernel running beside it compete for).
+// Everything per pair that is not the gather is done by the group's 8 lanes for 2 pairs each, not by one lane for all 16:
+// ids, values and the running state are read 8 consecutive pairs per group and instruction (a wave's 8 groups: 128
+// consecutive pairs in two instructions) before the first gather is issued, and written back the same way -- one lane per
+// group doing the 16 updates one after the other issued six times as many memory instructions as the gather itself, each
+// with 8 active lanes 128 B apart.
 constexpr int RUN = 16;
 __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
 {
@@ -142,24 +147,61 @@ __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
     const bool live = sub * 4 < a.D;                      // lanes beyond D / 4 hold zeros
     const int eoff = live ? sub * 4 : 0;
     const int64_t p0 = ((int64_t)blockIdx.x * 32 + tid / 8) * RUN;
+    // this lane's two pairs of the run: p0 + sub and p0 + 8 + sub
+    int64_t pm[2], po[2];
+    bool ok[2];
+    int32_t my_s[2], my_o[2];
+    double y[2] = {0.0, 0.0}, av[2] = {0.0, 0.0}, sv[2] = {0.0, 0.0}, base[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        pm[q] = p0 + 8 * q + sub;
+        ok[q] = pm[q] < a.n;
+        if (!ok[q]) pm[q] = a.n - 1;
+        my_s[q] = ids_s[pm[q]]; my_o[q] = ids_o[pm[q]];
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        po[q] = a.orig ? (int64_t)a.orig[pm[q]] : pm[q];
+        base[q] = a.linear ? a.linear[po[q]] : a.mean;
+        if (a.phase >= 0) y[q] = a.values[pm[q]];
+        if (a.phase == 2) { av[q] = a.avg[pm[q]]; sv[q] = a.sq[pm[q]]; }
+    }
     int32_t cur = -1;
     double4 srow = {0.0, 0.0, 0.0, 0.0};
-    for (int u0 = 0; u0 < RUN && p0 + u0 < a.n; u0 += 4) {
-        int32_t is[4], io[4];
-        double4 orow[4];
+    double keep[2] = {0.0, 0.0};
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-            const int64_t pu = (p0 + u0 + u < a.n) ? p0 + u0 + u : a.n - 1;
-            is[u] = ids_s[pu]; io[u] = ids_o[pu];
-        }
+    for (int q = 0; q < 2; q++) {
+        if (p0 + 8 * q >= a.n) break;                      // group-uniform
+        int32_t is[8], io[8];
+        double4 orow[8];
 #pragma unroll
-        for (int u = 0; u < 4; u++) orow[u] = *(const double4 *)(fo + (int64_t)io[u] * a.D + eoff);
+        for (int u = 0; u < 8; u++) { is[u] = __shfl(my_s[q], u, 8); io[u] = __shfl(my_o[q], u, 8); }
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
+        for (int u = 0; u < 8; u++) orow[u] = *(const double4 *)(fo + (int64_t)io[u] * a.D + eoff);
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
             if (is[u] != cur) { srow = *(const double4 *)(fs + (int64_t)is[u] * a.D + eoff); cur = is[u]; }
             double s = live ? (srow.x * orow[u].x + srow.y * orow[u].y) + (srow.z * orow[u].z + srow.w * orow[u].w) : 0.0;
             s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
-            if (sub == 0 && p0 + u0 + u < a.n) pair_update(a, p0 + u0 + u, s, st);
+            if (sub == u) keep[q] = s;
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        if (!ok[q]) continue;
+        const double p = keep[q] + base[q];
+        if (a.out) a.out[po[q]] = p;
+        if (a.phase >= 0) {                                // pair_update with the state read above
+            double avg;
+            if (a.phase == 0 || a.phase == 3) { avg = p; }
+            else if (a.phase == 1) { avg = p; a.sq[pm[q]] = p * p; }
+            else { avg = (a.count * av[q] + p) / (a.count + 1.0); a.sq[pm[q]] = sv[q] + p * p; }
+            if (a.phase != 3) a.avg[pm[q]] = avg;
+            const double ea = y[q] - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y[q] - clampv(p, a.clamp_lo, a.clamp_hi);
+            const bool label = y[q] < a.cut;
+            st[0] += ea * ea; st[1] += ep * ep;
+            st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
+            st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
         }
     }
     if (a.phase >= 0) {

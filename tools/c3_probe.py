@@ -7,7 +7,10 @@ import bdf_amd as B
 from bdf_amd import datasets
 
 F = np.random.default_rng(4242).standard_normal((6040, 500))
+which = sys.argv[1] if len(sys.argv) > 1 else "both"          # ff | cg | both
 for ff_size, label in ((6500, "FF path (numF=500 <= compute_ff_size)"), (0, "CG forced (compute_ff_size=0)")):
+    if which != "both" and (which == "ff") != (ff_size > 0):
+        continue
     rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
     rd.entities[0].F = F
     eng = B.GibbsEngine(rd, 32, seed=1, device=0, compute_ff_size=ff_size)
