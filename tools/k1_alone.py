@@ -32,4 +32,18 @@ for j, name in enumerate(("users", "movies")):
         eng.sync()
         bj = min(bj, (time.perf_counter() - t0) / n)
     print(f"   {name}' launches only: {bj * 1e6:.2f} us")
+# the test prediction update alone (two kernels: k_predict_runs + k_predict_final), back to back on its stream
+test = eng.test_pairs()
+r = rd.relations[0]
+facs = eng.factors_of(r)
+bp = 1e9
+for rep in range(5):
+    n = 300
+    eng.sync()
+    t0 = time.perf_counter()
+    for i in range(n):
+        test.update(D, facs, r.model.mean_value, 2, [1.0, 5.0], 2.5)
+    eng.sync()
+    bp = min(bp, (time.perf_counter() - t0) / n)
+print(f"prediction update alone: {bp * 1e6:.2f} us per update ({test.n} pairs)")
 eng.close()
