@@ -34,108 +34,142 @@ __device__ inline double clampv(double x, double lo, double hi)
     return x < lo ? lo : (x > hi ? hi : x);
 }
 
-// one test pair per group of LPP lanes; a group handles two pairs per trip so that their gathers overlap
-template <int LPP>
-__device__ inline double pair_dot(const PredArgs &a, int64_t pair, int sub)
+// ---- what a lane does for the pair it owns: everything of macau.jl:142-184 that is not the gather -----------------------
+// A group of 8 lanes computes the dot products of 8 consecutive pairs together (32 bytes of a factor row per lane) and then
+// lane `sub` owns pair p0 + sub: ids, value and running state are read 8 consecutive pairs per group and instruction before
+// the first gather is issued, and written back the same way.  (One lane per group doing the updates one after the other
+// issued six times as many memory instructions as the gather itself, each with 8 active lanes 128 B apart.)
+struct PairState {
+    int64_t pm, po;                // storage position; the caller's index (out, linear)
+    bool ok;
+    double y, av, sv, base;
+};
+
+__device__ inline void pair_load(const PredArgs &a, int64_t p, PairState &s)
 {
-    double s = 0.0;
-    if (LPP == 16 && (a.D & 1) == 0) {
-        for (int e = sub * 2; e < a.D; e += LPP * 2) {
-            double2 p = *(const double2 *)(a.fac[0] + (int64_t)a.ids[pair] * a.D + e);
-            for (int k = 1; k < a.n_modes; k++) {
-                const double2 q = *(const double2 *)(a.fac[k] + (int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e);
-                p.x *= q.x; p.y *= q.y;
-            }
-            s += p.x + p.y;
-        }
-    } else if ((a.D & 3) == 0) {
-        for (int e = sub * 4; e < a.D; e += LPP * 4) {
-            double4 p = *(const double4 *)(a.fac[0] + (int64_t)a.ids[pair] * a.D + e);
-            for (int k = 1; k < a.n_modes; k++) {
-                const double4 q = *(const double4 *)(a.fac[k] + (int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e);
-                p.x *= q.x; p.y *= q.y; p.z *= q.z; p.w *= q.w;
-            }
-            s += (p.x + p.y) + (p.z + p.w);
-        }
-    } else {
-        for (int e = sub; e < a.D; e += LPP) {
-            double p = 1.0;
-            for (int k = 0; k < a.n_modes; k++) p *= a.fac[k][(int64_t)a.ids[(int64_t)k * a.n + pair] * a.D + e];
-            s += p;
-        }
-    }
-#pragma unroll
-    for (int off = LPP / 2; off >= 1; off >>= 1) s += __shfl_xor(s, off);
-    return s;
+    s.ok = p < a.n;
+    s.pm = s.ok ? p : a.n - 1;
+    s.po = a.orig ? (int64_t)a.orig[s.pm] : s.pm;
+    s.base = a.linear ? a.linear[s.po] : a.mean;
+    s.y = a.phase >= 0 ? a.values[s.pm] : 0.0;
+    s.av = 0.0; s.sv = 0.0;
+    if (a.phase == 2) { s.av = a.avg[s.pm]; s.sv = a.sq[s.pm]; }
 }
 
-__device__ inline void pair_update(const PredArgs &a, int64_t pair, double s, double (&st)[4])
+__device__ inline void pair_finish(const PredArgs &a, const PairState &s, double dot, double (&st)[4])
 {
-    const int64_t o = a.orig ? a.orig[pair] : pair;
-    const double p = s + (a.linear ? a.linear[o] : a.mean);
-    if (a.out) a.out[o] = p;
+    if (!s.ok) return;
+    const double p = dot + s.base;
+    if (a.out) a.out[s.po] = p;
     if (a.phase >= 0) {
         double avg;
         if (a.phase == 0 || a.phase == 3) { avg = p; }
-        else if (a.phase == 1) { avg = p; a.sq[pair] = p * p; }
-        else { avg = (a.count * a.avg[pair] + p) / (a.count + 1.0); a.sq[pair] += p * p; }
-        if (a.phase != 3) a.avg[pair] = avg;           // phase 3: statistics of this sample only, no running state
-        const double y = a.values[pair];
-        const double ea = y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y - clampv(p, a.clamp_lo, a.clamp_hi);
-        const bool label = y < a.cut;
+        else if (a.phase == 1) { avg = p; a.sq[s.pm] = p * p; }
+        else { avg = (a.count * s.av + p) / (a.count + 1.0); a.sq[s.pm] = s.sv + p * p; }
+        if (a.phase != 3) a.avg[s.pm] = avg;           // phase 3: statistics of this sample only, no running state
+        const double ea = s.y - clampv(avg, a.clamp_lo, a.clamp_hi), ep = s.y - clampv(p, a.clamp_lo, a.clamp_hi);
+        const bool label = s.y < a.cut;
         st[0] += ea * ea; st[1] += ep * ep;
         st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
         st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
     }
 }
 
-template <int LPP, int PPT>
+__device__ inline void block_stats(const PredArgs &a, const double (&st)[4])
+{
+    __shared__ double red[4][256 / 64];
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double v = st[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        if ((tid & 63) == 0) red[q][tid >> 6] = v;
+    }
+    __syncthreads();
+    if (tid < 4) a.partial[blockIdx.x * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
+// General kernel: NM modes, any order of the pairs.  VEC = 4: D a multiple of 4, NC 32-byte pieces of a row per lane
+// (D <= 32: one, D <= 64: two); VEC = 1: any D, a lane takes elements sub, sub + 8, ...  A trip is 8 consecutive pairs, their
+// rows gathered BATCH pairs at a time.
+template <int NM, int VEC, int NC>
 __global__ __launch_bounds__(256) void k_predict(PredArgs a)
 {
-    const int tid = threadIdx.x;
-    const int sub = tid % LPP;
+    const int tid = threadIdx.x, sub = tid & 7;
     double st[4] = {0.0, 0.0, 0.0, 0.0};
-    const int64_t ngroups = (int64_t)gridDim.x * (256 / LPP);
-    // the lanes of a group share their pairs, so a group enters and leaves the loop together (the shuffles only cross
-    // lanes of one group); a group handles PPT pairs per trip so that their gathers overlap
-    for (int64_t p0 = (int64_t)blockIdx.x * (256 / LPP) + tid / LPP; p0 < a.n; p0 += PPT * ngroups) {
-        double s[PPT];
+    const int64_t ngroups = (int64_t)gridDim.x * 32, ntrips = (a.n + 7) / 8;
+    constexpr int BATCH = (VEC == 1) ? 2 : (NC * NM <= 3 ? 4 : 2);
+    for (int64_t trip = (int64_t)blockIdx.x * 32 + tid / 8; trip < ntrips; trip += ngroups) {
+        const int64_t p0 = trip * 8;
+        PairState ps;
+        pair_load(a, p0 + sub, ps);
+        int32_t my[NM];
 #pragma unroll
-        for (int u = 0; u < PPT; u++) {
-            const int64_t pu = p0 + u * ngroups;
-            s[u] = pair_dot<LPP>(a, pu < a.n ? pu : p0, sub);
-        }
-        if (sub == 0) {
+        for (int k = 0; k < NM; k++) my[k] = a.ids[(int64_t)k * a.n + ps.pm];
+        double keep = 0.0;
 #pragma unroll
-            for (int u = 0; u < PPT; u++) {
-                const int64_t pu = p0 + u * ngroups;
-                if (pu < a.n) pair_update(a, pu, s[u], st);
+        for (int u0 = 0; u0 < 8; u0 += BATCH) {
+            if (p0 + u0 >= a.n) break;                     // group-uniform
+            double s[BATCH];
+            if constexpr (VEC == 4) {
+                double4 f[BATCH][NM][NC];
+#pragma unroll
+                for (int u = 0; u < BATCH; u++)
+#pragma unroll
+                    for (int k = 0; k < NM; k++) {
+                        const double *row = a.fac[k] + (int64_t)__shfl(my[k], u0 + u, 8) * a.D;
+#pragma unroll
+                        for (int c = 0; c < NC; c++) {
+                            const int e = sub * 4 + 32 * c;
+                            f[u][k][c] = e < a.D ? *(const double4 *)(row + e) : double4{0.0, 0.0, 0.0, 0.0};
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < BATCH; u++) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int c = 0; c < NC; c++) {
+                        double4 p = f[u][0][c];
+#pragma unroll
+                        for (int k = 1; k < NM; k++) { p.x *= f[u][k][c].x; p.y *= f[u][k][c].y; p.z *= f[u][k][c].z; p.w *= f[u][k][c].w; }
+                        if (sub * 4 + 32 * c < a.D) acc += (p.x + p.y) + (p.z + p.w);
+                    }
+                    s[u] = acc;
+                }
+            } else {
+#pragma unroll
+                for (int u = 0; u < BATCH; u++) {
+                    const double *row[NM];
+#pragma unroll
+                    for (int k = 0; k < NM; k++) row[k] = a.fac[k] + (int64_t)__shfl(my[k], u0 + u, 8) * a.D;
+                    double acc = 0.0;
+                    for (int e = sub; e < a.D; e += 8) {
+                        double p = 1.0;
+#pragma unroll
+                        for (int k = 0; k < NM; k++) p *= row[k][e];
+                        acc += p;
+                    }
+                    s[u] = acc;
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                double v = s[u];
+                v += __shfl_xor(v, 4); v += __shfl_xor(v, 2); v += __shfl_xor(v, 1);
+                if (sub == u0 + u) keep = v;
             }
         }
+        pair_finish(a, ps, keep, st);
     }
-    if (a.phase >= 0) {
-        __shared__ double red[4][256 / 64];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            double v = st[q];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if ((tid & 63) == 0) red[q][tid >> 6] = v;
-        }
-        __syncthreads();
-        if (tid < 4) a.partial[blockIdx.x * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-    }
+    if (a.phase >= 0) block_stats(a, st);
 }
 
 // Pairs stored sorted by one mode (bdf_pairs_sort), two-mode relation, D a multiple of 4 up to 32: a group of 8 lanes walks RUN
 // consecutive pairs and keeps the factor row of the sorted mode in registers while its id does not change -- the update then
 // gathers one row per pair instead of two (MovieLens test set sorted by movie: 126 pairs per row; 136 MB instead of 256 MB
-// of L2 gathers per update, which is what the update and the row kernel running beside it compete for).
-// Everything per pair that is not the gather is done by the group's 8 lanes for 2 pairs each, not by one lane for all 16:
-// ids, values and the running state are read 8 consecutive pairs per group and instruction (a wave's 8 groups: 128
-// consecutive pairs in two instructions) before the first gather is issued, and written back the same way -- one lane per
-// group doing the 16 updates one after the other issued six times as many memory instructions as the gather itself, each
-// with 8 active lanes 128 B apart.
+// of L2 gathers per update, which is what the update and the row kernel running beside it compete for).  A lane owns two
+// pairs of the run (p0 + sub, p0 + 8 + sub), see PairState.
 constexpr int RUN = 16;
 __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
 {
@@ -147,24 +181,12 @@ __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
     const bool live = sub * 4 < a.D;                      // lanes beyond D / 4 hold zeros
     const int eoff = live ? sub * 4 : 0;
     const int64_t p0 = ((int64_t)blockIdx.x * 32 + tid / 8) * RUN;
-    // this lane's two pairs of the run: p0 + sub and p0 + 8 + sub
-    int64_t pm[2], po[2];
-    bool ok[2];
+    PairState ps[2];
     int32_t my_s[2], my_o[2];
-    double y[2] = {0.0, 0.0}, av[2] = {0.0, 0.0}, sv[2] = {0.0, 0.0}, base[2];
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        pm[q] = p0 + 8 * q + sub;
-        ok[q] = pm[q] < a.n;
-        if (!ok[q]) pm[q] = a.n - 1;
-        my_s[q] = ids_s[pm[q]]; my_o[q] = ids_o[pm[q]];
-    }
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        po[q] = a.orig ? (int64_t)a.orig[pm[q]] : pm[q];
-        base[q] = a.linear ? a.linear[po[q]] : a.mean;
-        if (a.phase >= 0) y[q] = a.values[pm[q]];
-        if (a.phase == 2) { av[q] = a.avg[pm[q]]; sv[q] = a.sq[pm[q]]; }
+        pair_load(a, p0 + 8 * q + sub, ps[q]);
+        my_s[q] = ids_s[ps[q].pm]; my_o[q] = ids_o[ps[q].pm];
     }
     int32_t cur = -1;
     double4 srow = {0.0, 0.0, 0.0, 0.0};
@@ -187,35 +209,8 @@ __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
         }
     }
 #pragma unroll
-    for (int q = 0; q < 2; q++) {
-        if (!ok[q]) continue;
-        const double p = keep[q] + base[q];
-        if (a.out) a.out[po[q]] = p;
-        if (a.phase >= 0) {                                // pair_update with the state read above
-            double avg;
-            if (a.phase == 0 || a.phase == 3) { avg = p; }
-            else if (a.phase == 1) { avg = p; a.sq[pm[q]] = p * p; }
-            else { avg = (a.count * av[q] + p) / (a.count + 1.0); a.sq[pm[q]] = sv[q] + p * p; }
-            if (a.phase != 3) a.avg[pm[q]] = avg;
-            const double ea = y[q] - clampv(avg, a.clamp_lo, a.clamp_hi), ep = y[q] - clampv(p, a.clamp_lo, a.clamp_hi);
-            const bool label = y[q] < a.cut;
-            st[0] += ea * ea; st[1] += ep * ep;
-            st[2] += (label == (avg < a.cut)) ? 1.0 : 0.0;
-            st[3] += (label == (p < a.cut)) ? 1.0 : 0.0;
-        }
-    }
-    if (a.phase >= 0) {
-        __shared__ double red[4][256 / 64];
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            double v = st[q];
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-            if ((tid & 63) == 0) red[q][tid >> 6] = v;
-        }
-        __syncthreads();
-        if (tid < 4) a.partial[blockIdx.x * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-    }
+    for (int q = 0; q < 2; q++) pair_finish(a, ps[q], keep[q], st);
+    if (a.phase >= 0) block_stats(a, st);
 }
 
 // fixed-order sum of the per-block statistics
@@ -255,20 +250,22 @@ int launch_predict(bdf_ctx *ctx, PredArgs &a)
         BDF_HIP(hipGetLastError());
         return BDF_OK;
     }
-    static const int variant = getenv("BDF_PREDICT_VARIANT") ? atoi(getenv("BDF_PREDICT_VARIANT")) : 0;
-    const int LPP = (variant == 1 || variant == 3) ? 16 : 8, PPT = (variant >= 2) ? 4 : 2;
-    const int64_t need = (a.n * LPP + 255) / 256;
-    const int nblocks = (int)std::min<int64_t>((need + PPT - 1) / PPT, 4096);
+    const int64_t ntrips = (a.n + 7) / 8;
+    const int nblocks = (int)std::min<int64_t>((ntrips + 31) / 32, 8192);
     if (a.phase >= 0) {
         void *sc;
         int rc = bdf_scratch(ctx, (size_t)nblocks * 4 * sizeof(double), &sc);
         if (rc) return rc;
         a.partial = (double *)sc;
     }
-    if (variant == 0) hipLaunchKernelGGL((k_predict<8, 2>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
-    else if (variant == 1) hipLaunchKernelGGL((k_predict<16, 2>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
-    else if (variant == 2) hipLaunchKernelGGL((k_predict<8, 4>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
-    else hipLaunchKernelGGL((k_predict<16, 4>), dim3(nblocks), dim3(256), 0, ctx->stream, a);
+#define PRED(NM, VEC, NC) hipLaunchKernelGGL((k_predict<NM, VEC, NC>), dim3(nblocks), dim3(256), 0, ctx->stream, a)
+#define PRED_NM(VEC, NC) do { if (a.n_modes == 2) PRED(2, VEC, NC); else if (a.n_modes == 3) PRED(3, VEC, NC); else PRED(4, VEC, NC); } while (0)
+    if ((a.D & 3) != 0 || a.n_modes < 2) {
+        if (a.n_modes == 1) PRED(1, 1, 1); else PRED_NM(1, 1);
+    } else if (a.D <= 32) PRED_NM(4, 1);
+    else PRED_NM(4, 2);
+#undef PRED_NM
+#undef PRED
     if (a.phase >= 0) hipLaunchKernelGGL(k_predict_final, dim3(1), dim3(256), 0, ctx->stream, nblocks, (const double *)a.partial, a.stats);
     BDF_HIP(hipGetLastError());
     return BDF_OK;

@@ -2,7 +2,7 @@
 // (factor_all<32>, the forward solve riding along) and runs the backward solve (backward_all<32>), with 1 .. 8 waves
 // resident per SIMD (LDS ballast).  w = 1 gives the length of one wave's dependent chain, large w the issue-bound rate:
 // what a launch of N rows can reach at w waves per SIMD is max(chain, w x issue) x N / (1024 w).
-//   hipcc --offload-arch=gfx950 -O3 -Ibayesiandatafusion.jl_amd/csrc -o factor_probe tools/factor_probe.hip && ./factor_probe
+//   hipcc --offload-arch=gfx950 -O3 -Ibayesiandatafusion.jl_amd/csrc [-DPROBE_DP=64] -o factor_probe tools/factor_probe.hip && ./factor_probe
 #include "c_layout_chol.h"
 #include <cstdio>
 #include <cstdlib>
@@ -59,7 +59,10 @@ int main()
     (void)hipMalloc(&out, 4096);
     hipEvent_t e0, e1;
     (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-    constexpr int DP = 32;
+#ifndef PROBE_DP
+#define PROBE_DP 32
+#endif
+    constexpr int DP = PROBE_DP;
     const int reps = 64;
     for (int bw = 0; bw < 2; bw++)
         for (int w : {1, 2, 3, 4, 5, 6, 7, 8}) {
@@ -81,8 +84,8 @@ int main()
             }
             const double per = best * 1e3 / reps;                 // us per system for one wave
             printf("%s  waves/SIMD %d: %8.1f us per launch, one system per wave in %6.2f us = %6.0f cycles at 2.4 GHz; per SIMD one system every %5.2f us;"
-                   " 6726 rows on 1024 SIMDs: %5.1f us\n", bw ? "factor+backward" : "factor only    ", w, best * 1e3, per, per * 2400.0, per / w,
-                   per / w * 6726.0 / 1024.0);
+                   " 6726 rows on 1024 SIMDs: %5.1f us (D = %d)\n", bw ? "factor+backward" : "factor only    ", w, best * 1e3, per, per * 2400.0, per / w,
+                   per / w * 6726.0 / 1024.0, DP);
         }
     return 0;
 }

@@ -5,7 +5,8 @@
 #   3. separate --pmc passes (never with sys / runtime traces): FETCH_SIZE, WRITE_SIZE -> K1 HBM traffic per launch (gfx950:
 #      FETCH_SIZE counts half of a wide coalesced read, MI355X_MICROARCH.md "HBM"; the uncorrected and the doubled figure
 #      are both recorded, with the sha1 of the row kernel's source the passes ran on); two SQ counter sets -> pmc_k_rows.json
-#   4. micro-benchmarks behind DESIGN.md's bound analysis: fp64 pipe probe, CU mask probe, back-to-back row kernels
+#   4. micro-benchmarks behind DESIGN.md's bound analysis: fp64 pipe probe, gather and finish-phase probes, the row kernel and
+#      the prediction update alone, CU mask probe, back-to-back row kernels
 # Output under gpurun_out/profile_<tag>/ ; copy what should be judged into profiles/.
 tag=${1:-r02}
 cd $GRAFT_REPO_ROOT
@@ -50,7 +51,12 @@ for k, d in agg.items():
 json.dump(pmc, open('$out/pmc_k_rows.json', 'w'), indent=1)
 print(json.dumps(summary.get("k1_traffic_bytes_per_launch")))
 PY
+# (tools/bin/* are built in the container before the call: tools/build_probes.sh)
 tools/bin/fp64_pipe_probe > $out/fp64_pipe_probe.txt 2>&1
+timeout 200 tools/bin/gather_probe 3952 > $out/gather_probe.txt 2>&1
+timeout 200 tools/bin/factor_probe > $out/factor_probe.txt 2>&1
+timeout 200 tools/bin/factor_probe64 >> $out/factor_probe.txt 2>&1
+python3 tools/k1_alone.py > $out/k1_alone.txt 2>&1
 timeout 120 tools/bin/cu_mask_probe 8 > $out/cu_mask_probe.txt 2>&1
 tools/k1_gap.sh > $out/k1_back_to_back.txt 2>&1
 tools/sweep_timeline.sh > $out/sweep_timeline.txt 2>&1
