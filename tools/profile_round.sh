@@ -18,6 +18,8 @@ python3 bench.py > $out/bench.json 2> $out/bench.err
 (cd /tmp && rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 300 $B > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
+# (the first --pmc invocation on a fresh box has returned a third of the dispatches with doubled values: one throw-away pass first)
+(cd /tmp && rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d /tmp/prof_warm -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 2 --k1-min-launches 0 $B > $out/pmc_pass0.log 2>&1)
 for set in "FETCH_SIZE" "WRITE_SIZE" \
            "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM"; do
@@ -32,7 +34,8 @@ for f in glob.glob('/tmp/prof_pmc*/*/*counter_collection.csv'):
         agg[r['Kernel_Name']][r['Counter_Name']].append(float(r['Counter_Value']))
 rows = []
 for k, d in agg.items():
-    rows.append({"kernel": k[:90], "launches": len(d.get("FETCH_SIZE", [])),
+    rows.append({"kernel": k[:90], "launches": len(d.get("FETCH_SIZE", [])), "launches_write_pass": len(d.get("WRITE_SIZE", [])),
+                 "FETCH_SIZE_KB_min_max": [min(d.get("FETCH_SIZE", [0])), max(d.get("FETCH_SIZE", [0]))],
                  "FETCH_SIZE_KB_per_launch": sum(d.get("FETCH_SIZE", [0])) / max(len(d.get("FETCH_SIZE", [])), 1),
                  "WRITE_SIZE_KB_per_launch": sum(d.get("WRITE_SIZE", [0])) / max(len(d.get("WRITE_SIZE", [])), 1)})
 rows.sort(key=lambda r: -r["FETCH_SIZE_KB_per_launch"] - r["WRITE_SIZE_KB_per_launch"])
