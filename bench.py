@@ -23,7 +23,8 @@ half-sweep (bdf_allgather_rows); the test ratings are split over the ranks.
 
 roofline: K1 (k_rows) algorithmic bytes per launch over its mean launch duration from HIP events attached to
 the kernel dispatches (on the launch stream), from the timed region and -- so that at least 200 launches are averaged --
-from further sweeps after it.  cpu_baseline: the CPU oracle (a C port of the reference algorithm, OpenMP over rows like
+from further sweeps after it; `avg_launch_us_alone` / `frac_alone`: the same kernel with nothing beside it (back-to-back
+launches on the row stream, wall clock).  cpu_baseline: the CPU oracle (a C port of the reference algorithm, OpenMP over rows like
 the reference's latent_pids workers) timed on this box.
 """
 import argparse
@@ -199,6 +200,23 @@ def main():
     achieved = (k1_bytes / 1e9) / (k1_ms / 1e3) if k1_ms > 0 else 0.0
     eng.k1_events = None
     traffic, traffic_source = recorded_traffic() if (world == 1 and replicas == 1 and D == 32) else (None, None)
+    # the same kernel with nothing beside it: back-to-back launches alternating the entities on the row stream, wall clock (one
+    # GPU only; in the sweep a launch also holds the wait for the prior inside the kernel and shares the CUs with the prediction
+    # update).  After the timed region: the chain's state is no longer used.
+    alone_us = None
+    if world == 1 and args.k1_min_launches > 0:
+        eng.sync()
+        torch.cuda.synchronize()
+        n_alone = 200
+        ta = time.perf_counter()
+        for i in range(n_alone):
+            eng.ctx.set_sweep(1_000_000 + i)
+            eng.sample_entity(i % len(eng.ent))
+        enq_us = 1e6 * (time.perf_counter() - ta) / n_alone
+        eng.sync()
+        alone_us = 1e6 * (time.perf_counter() - ta) / n_alone
+        if os.environ.get("BDF_BENCH_DEBUG"):
+            print(f"[bench] K1 alone: enqueue {enq_us:.1f} us per launch, total {alone_us:.1f} us", file=sys.stderr)
 
     out = None
     if rank == 0:
@@ -230,7 +248,9 @@ def main():
                          "launches_timed_in_region": in_region,
                          "avg_launch_us": round(1e3 * k1_ms / n_launch, 2),
                          "avg_launch_us_in_region": round(1e3 * k1_ms_region / max(in_region, 1), 2),
-                         "algorithmic_bytes_per_launch": int(k1_bytes / n_launch)},
+                         "algorithmic_bytes_per_launch": int(k1_bytes / n_launch),
+                         "avg_launch_us_alone": None if alone_us is None else round(alone_us, 2),
+                         "frac_alone": None if alone_us is None else round((k1_bytes / n_launch / 1e9) / (alone_us / 1e6) / HBM_PEAK_GBS, 4)},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(rd, D, args.seed)
