@@ -416,6 +416,35 @@ def test_predict_and_running_mean(B, O, ctx):
     pairs.close()
 
 
+@pytest.mark.parametrize("n_modes,D", [(2, 3), (2, 8), (2, 32), (2, 33), (2, 64), (3, 5), (3, 16), (3, 64), (4, 12), (4, 64), (4, 7)])
+def test_predict_every_kernel_variant_ragged_counts(B, O, ctx, n_modes, D):
+    """the prediction kernels by mode count and row width (scalar path for D not a multiple of 4, one or two 32-byte pieces per
+    lane otherwise; the run kernel for sorted two-mode pairs up to D = 32) at pair counts around the 8-pair trips and 16-pair runs"""
+    rng = np.random.default_rng(100 * n_modes + D)
+    dims = [13, 9, 4, 3][:n_modes]
+    facs = [rng.standard_normal((d, D)) * 0.6 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    clamp, cut = [2.0, 4.0], 3.0
+    for n in (1, 7, 8, 9, 15, 16, 17, 255, 257):
+        ids = np.stack([rng.integers(1, d + 1, n) for d in dims], axis=1)
+        y = rng.standard_normal(n) + 3
+        exp = O.predict(ids, facs, 2.5)
+        variants = [B.DevicePairs(ctx, ids, y)]
+        if n_modes == 2:
+            variants += [B.DevicePairs(ctx, ids, y).sort(0), B.DevicePairs(ctx, ids, y).sort(1)]
+        for pairs in variants:
+            np.testing.assert_allclose(pairs.predict(D, ft, 2.5).cpu().numpy(), exp, rtol=1e-12, atol=1e-12)
+            for phase in (0, 1, 2):
+                stats = pairs.update(D, ft, 2.5, phase, clamp, cut).cpu().numpy()
+            ca = np.clip(exp, *clamp)          # the same factors every time: running mean == the prediction
+            np.testing.assert_allclose(stats, [np.sum((y - ca) ** 2), np.sum((y - ca) ** 2), np.sum((y < cut) == (exp < cut)),
+                                               np.sum((y < cut) == (exp < cut))], rtol=1e-10, atol=1e-12)
+            a, sq = pairs.state()                 # in the caller's order
+            np.testing.assert_allclose(a, exp, rtol=1e-12, atol=1e-12)
+            np.testing.assert_allclose(sq, 2 * exp ** 2, rtol=1e-12, atol=1e-12)
+            pairs.close()
+
+
 def test_hyper_sums_large_entity(B, ctx):
     """more than 2048 x 128 rows: every workgroup of the sums kernel takes several 128-row chunks"""
     from bdf_amd._lib import check, lib
