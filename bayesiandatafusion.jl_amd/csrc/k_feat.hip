@@ -484,8 +484,9 @@ __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, 
     }
 }
 
-// step 2: T[:,i] = (sample[:,i] - mu) + e_i   (sample == NULL: T[:,i] = scale * e_i), one thread per row i;
+// step 2: T[:,i] = (sample[:,i] - mu) + e_i   (sample == NULL: T[:,i] = scale * e_i);
 // e solves U' e = z, i.e. L~' e~ = z~ in reversed coordinates:  e~_j = (sqrt(p_j) z~_j - sum_{m>j} Ah[m][j] e~_m) / p_j
+constexpr int NOISE_RPW = 16;       // rows per workgroup of k_noise_rows
 template <int DP>
 __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const double *Lr, const double *sample,
                                                      const double *mu, const double *scale_sq, uint64_t seed,
@@ -494,17 +495,18 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
 {
     // row_ids (nullable): the row's ORIGINAL id, which keys its noise stream (rows stored at internal positions when several
     // GPUs share the entity); negative = a row nobody owns: no noise (its feature row is zero)
-    // 64 rows per workgroup.  Phase 1, all 256 threads: the rows' normals (a Philox block + log + sin/cos per pair is ~40x
-    // the arithmetic of the solve), scaled by sqrt(p_j), into LDS.  Phase 2, one thread per row: the substitution.
+    // NOISE_RPW rows per workgroup.  Phase 1, all 256 threads: the rows' normals (a Philox block + log + sin/cos per pair is ~40x
+    // the arithmetic of the solve: one or two pairs per thread, so that 500 rows already fill 32 workgroups), scaled by
+    // sqrt(p_j), into LDS.  Phase 2, DP lanes per row: the substitution.
     __shared__ double sL[DP * DP + 2 * DP];
-    __shared__ double sz[64][DP + 1];
+    __shared__ double sz[NOISE_RPW][DP + 1];
     const int tid = threadIdx.x;
     for (int e = tid; e < DP * DP + 2 * DP; e += 256) sL[e] = Lr[e];
-    const int64_t r0 = (int64_t)blockIdx.x * 64;
+    const int64_t r0 = (int64_t)blockIdx.x * NOISE_RPW;
     const int npairs = (D + 1) / 2;
-    for (int e = tid; e < 64 * DP; e += 256) sz[e / DP][e % DP] = 0.0;
+    for (int e = tid; e < NOISE_RPW * DP; e += 256) sz[e / DP][e % DP] = 0.0;
     __syncthreads();
-    for (int e = tid; e < 64 * npairs; e += 256) {
+    for (int e = tid; e < NOISE_RPW * npairs; e += 256) {
         const int lr = e / npairs, pr = e % npairs;
         const int64_t i = r0 + lr;
         if (i >= n) continue;
@@ -519,21 +521,23 @@ __global__ __launch_bounds__(256) void k_noise_rows(int D, int64_t n, const doub
         if (e1 < D) sz[lr][D - 1 - e1] = r * sin(t) * sL[DP * DP + DP + (D - 1 - e1)];
     }
     __syncthreads();
-    const int64_t i = r0 + tid;
-    if (tid >= 64 || i >= n) return;
-    // in place in the row's LDS line (a register array of DP entries, fully unrolled, drags the whole factor into registers)
-    for (int j = DP - 1; j >= 0; j--) {
-        double s = sz[tid][j];
-#pragma unroll 4
-        for (int m = j + 1; m < DP; m++) s = fma(-sL[m * DP + j], sz[tid][m], s);
-        sz[tid][j] = s * sL[DP * DP + j];
-    }
+    // the substitution, DP lanes per row (lane = reversed position): as soon as e~_j is final every lane m < j takes its term
+    // Ah[j][m] e~_j -- one broadcast and one fma per step instead of a dot product walked by a single thread per row
+    const int sub = tid % DP, grp = tid / DP;
     const double scale = scale_sq ? sqrt(*scale_sq) : 1.0;
-    for (int j = 0; j < DP; j++) {
-        const int ej = D - 1 - j;
+    for (int lr = grp; lr < NOISE_RPW; lr += 256 / DP) {
+        const int64_t i = r0 + lr;
+        if (i >= n) break;
+        double sv = sz[lr][sub];
+        for (int j = DP - 1; j >= 0; j--) {
+            const double ej = __shfl(sv, j, DP) * sL[DP * DP + j];
+            if (sub == j) sv = ej;
+            else if (sub < j) sv = fma(-sL[j * DP + sub], ej, sv);
+        }
+        const int ej = D - 1 - sub;
         if (ej >= 0) {
             const int64_t off = i * D + ej;
-            T[off] = sample ? (sample[off] - mu[ej]) + sz[tid][j] : scale * sz[tid][j];
+            T[off] = sample ? (sample[off] - mu[ej]) + sv : scale * sv;
         }
     }
 }
@@ -547,7 +551,7 @@ int noise_rows(bdf_ctx *ctx, int D, int64_t n, const double *Lambda, double *Lr,
         BDF_HIP(hipGetLastError());
     }
     if (n > 0) {
-        hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, ctx->stream, D, n, Lr,
+        hipLaunchKernelGGL(k_noise_rows<DP>, dim3((unsigned)((n + NOISE_RPW - 1) / NOISE_RPW)), dim3(256), 0, ctx->stream, D, n, Lr,
                            sample, mu, scale_sq, ctx->seed, ctx->sweep_host, purpose, entity, T, row_ids);
         BDF_HIP(hipGetLastError());
     }
