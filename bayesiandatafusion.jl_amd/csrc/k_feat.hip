@@ -695,6 +695,90 @@ __global__ __launch_bounds__(1024) void k_cg_step(CgState s, const double *lambd
     }
 }
 
+// k_cg_step for short columns (n <= 256 EPT): the column's p, z, x, r are read ONCE into registers, both halves of the step
+// run on them, and what changed is written once -- the general kernel walks the column four times, each walk a global-memory
+// round trip (8.6 us per iteration at n = 500, where the arithmetic is nothing).  Same operations in the same order per element;
+// the dot products are summed thread-strided as in block_sum's callers.
+template <int EPT>
+__global__ __launch_bounds__(256) void k_cg_step_short(CgState s, const double *lambda_p, int iter, int maxiter)
+{
+    __shared__ double red[16];
+    __shared__ int go;
+    if (*s.nactive == 0) {
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            s.status[1] = 0;
+            __threadfence_system();
+            s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+        }
+        return;
+    }
+    const int d = blockIdx.x, tid = threadIdx.x;
+    const int64_t off = (int64_t)d * s.n;
+    const bool mine = s.active[d] && s.iters[d] == iter;
+    if (mine) {
+        const double lambda = *lambda_p;
+        double p[EPT], z[EPT], x[EPT], r[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int64_t i = tid + 256 * e;
+            const bool ok = i < s.n;
+            p[e] = ok ? s.P[off + i] : 0.0; z[e] = ok ? s.Z[off + i] : 0.0;
+            x[e] = ok ? s.X[off + i] : 0.0; r[e] = ok ? s.R[off + i] : 0.0;
+        }
+        double zp = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            z[e] = fma(lambda, p[e], z[e]);
+            zp = fma(z[e], p[e], zp);
+        }
+        zp = block_sum(zp, red);
+        const double ak = s.bknum[d] / zp;
+        double bknum = 0.0;
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            x[e] = fma(ak, p[e], x[e]);
+            r[e] = fma(-ak, z[e], r[e]);
+            bknum = fma(r[e], r[e], bknum);
+        }
+        bool proceed = false;
+        if (iter < maxiter) {                              // top of iteration iter + 1 (cg_pre)
+            bknum = block_sum(bknum, red);
+            if (tid == 0) {
+                go = !(sqrt(bknum) < s.tolb[d]);
+                if (!go) { s.active[d] = 0; atomicSub(s.nactive, 1); }
+            }
+            __syncthreads();
+            proceed = go != 0;
+            if (proceed) {
+                const double bk = bknum / s.bkden[d];
+#pragma unroll
+                for (int e = 0; e < EPT; e++) p[e] = fma(bk, p[e], r[e]);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int64_t i = tid + 256 * e;
+            if (i < s.n) {
+                s.X[off + i] = x[e]; s.R[off + i] = r[e];
+                if (proceed) s.P[off + i] = p[e];
+            }
+        }
+        __syncthreads();
+        if (proceed && tid == 0) { s.bkden[d] = bknum; s.bknum[d] = bknum; s.iters[d] = iter + 1; }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(s.done_blocks, 1) == s.D - 1) {
+            *s.done_blocks = 0;
+            const int na = __hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s.status[1] = (uint64_t)(iter < maxiter ? na : 0);
+            __threadfence_system();
+            s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+        }
+    }
+}
+
 // ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
 // G = beta' beta (D x D) by one block
 __global__ __launch_bounds__(256) void k_btb(int D, int64_t numF, const double *beta, double *G)
@@ -1017,7 +1101,10 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
             if ((rc = feat_apply(ctx, f, true, Tm, D, 1, D, Z, 1, numF))) return rc;
         }
         // bottom of this iteration and top of the next in one launch
-        hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        if (numF <= 512) hipLaunchKernelGGL(k_cg_step_short<2>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        else if (numF <= 1024) hipLaunchKernelGGL(k_cg_step_short<4>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        else if (numF <= 2048) hipLaunchKernelGGL(k_cg_step_short<8>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        else hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         BDF_HIP(hipGetLastError());
     }
     ctx->skip_flag = nullptr;
