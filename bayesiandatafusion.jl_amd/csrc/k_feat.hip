@@ -779,6 +779,98 @@ __global__ __launch_bounds__(256) void k_cg_step_short(CgState s, const double *
     }
 }
 
+// k_cg_step for long columns (n > 2048): one workgroup per column is one CU's bandwidth per column (82 us per iteration at
+// n = 50,000, D = 32: 32 CUs moving 100 MB).  Here a column is cut into G chunks, grid (D, G), and the step becomes three
+// launches with the two dot products summed over the chunks in chunk order by every workgroup that needs them:
+//   a: z = Z + lambda p, partial z.p          b: ak; x += ak p; r -= ak z; partial r.r          c: stop test; p = bk p + r
+// bkden is double-buffered by iteration parity (slot 1 = s.bkden, written by k_cg_pre at iteration 1; slot 0 = bkden0): in c
+// every workgroup of a column reads the old value while chunk 0 writes the new one.
+struct CgChunks { int G; int64_t len; double *partA, *partB, *bkden0; };
+
+__device__ __forceinline__ bool cg_all_stopped(const CgState &s, int iter)
+{
+    if (*s.nactive != 0) return false;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
+        s.status[1] = 0;
+        __threadfence_system();
+        s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+    }
+    return true;
+}
+
+__global__ __launch_bounds__(256) void k_cg_long_a(CgState s, CgChunks c, const double *lambda_p, int iter)
+{
+    __shared__ double red[16];
+    if (cg_all_stopped(s, iter)) return;
+    const int d = blockIdx.x, g = blockIdx.y;
+    if (!s.active[d] || s.iters[d] != iter) return;
+    const double lambda = *lambda_p;
+    const int64_t off = (int64_t)d * s.n, i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+    double zp = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        const double p = s.P[off + i];
+        const double z = fma(lambda, p, s.Z[off + i]);
+        s.Z[off + i] = z;
+        zp = fma(z, p, zp);
+    }
+    zp = block_sum(zp, red);
+    if (threadIdx.x == 0) c.partA[d * c.G + g] = zp;
+}
+
+__global__ __launch_bounds__(256) void k_cg_long_b(CgState s, CgChunks c, int iter)
+{
+    __shared__ double red[16];
+    if (*s.nactive == 0) return;
+    const int d = blockIdx.x, g = blockIdx.y;
+    if (!s.active[d] || s.iters[d] != iter) return;
+    double zp = 0.0;
+    for (int q = 0; q < c.G; q++) zp += c.partA[d * c.G + q];
+    const double ak = s.bknum[d] / zp;
+    const int64_t off = (int64_t)d * s.n, i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+    double rr = 0.0;
+    for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) {
+        s.X[off + i] = fma(ak, s.P[off + i], s.X[off + i]);
+        const double r = fma(-ak, s.Z[off + i], s.R[off + i]);
+        s.R[off + i] = r;
+        rr = fma(r, r, rr);
+    }
+    rr = block_sum(rr, red);
+    if (threadIdx.x == 0) c.partB[d * c.G + g] = rr;
+}
+
+__global__ __launch_bounds__(256) void k_cg_long_c(CgState s, CgChunks c, int iter, int maxiter)
+{
+    if (*s.nactive == 0) return;                          // (a) has reported
+    const int d = blockIdx.x, g = blockIdx.y;
+    if (s.active[d] && s.iters[d] == iter && iter < maxiter) {      // top of iteration iter + 1 (cg_pre)
+        double rr = 0.0;
+        for (int q = 0; q < c.G; q++) rr += c.partB[d * c.G + q];
+        const bool go = !(sqrt(rr) < s.tolb[d]);
+        double *bk_old = (iter & 1) ? s.bkden : c.bkden0, *bk_new = (iter & 1) ? c.bkden0 : s.bkden;
+        if (go) {
+            const double bk = rr / bk_old[d];
+            const int64_t off = (int64_t)d * s.n, i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+            for (int64_t i = i0 + threadIdx.x; i < i1; i += 256) s.P[off + i] = fma(bk, s.P[off + i], s.R[off + i]);
+        }
+        __syncthreads();                                  // every thread has read active / iters
+        if (g == 0 && threadIdx.x == 0) {
+            if (!go) { s.active[d] = 0; atomicSub(s.nactive, 1); }
+            else { bk_new[d] = rr; s.bknum[d] = rr; s.iters[d] = iter + 1; }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        if (atomicAdd(s.done_blocks, 1) == s.D * c.G - 1) {
+            *s.done_blocks = 0;
+            const int na = __hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s.status[1] = (uint64_t)(iter < maxiter ? na : 0);
+            __threadfence_system();
+            s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+        }
+    }
+}
+
 // ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
 // G = beta' beta (D x D) by one block
 __global__ __launch_bounds__(256) void k_btb(int D, int64_t numF, const double *beta, double *G)
@@ -1071,6 +1163,18 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     // iterations) and reads the (iteration, active columns) word the device writes to host-mapped memory after every
     // iteration.  Run-ahead is bounded to CG_AHEAD iterations; once every column has stopped, the launches already enqueued
     // return at once (product kernels through ctx->skip_flag, k_cg_step by itself).
+    // long columns: G chunks per column (k_cg_long_*); the partial dot products live behind the spare scalars
+    static const bool long_ok = !(getenv("BDF_CG_LONG") && atoi(getenv("BDF_CG_LONG")) == 0);
+    const bool long_cols = long_ok && numF > 2048;
+    CgChunks ch;
+    ch.G = (int)std::min<int64_t>(64, (numF + 4095) / 4096);
+    ch.len = (numF + ch.G - 1) / ch.G;
+    ch.partA = ch.partB = ch.bkden0 = nullptr;
+    if (long_cols) {
+        constexpr size_t PART = (size_t)2 * BDF_MAX_D * 64 + BDF_MAX_D;     // (the scratch buffers are reused by the products inside the loop)
+        if (!ctx->cg_part) BDF_HIP(hipMalloc((void **)&ctx->cg_part, PART * sizeof(double)));
+        ch.partA = ctx->cg_part; ch.partB = ch.partA + (size_t)BDF_MAX_D * 64; ch.bkden0 = ch.partB + (size_t)BDF_MAX_D * 64;
+    }
     constexpr int CG_AHEAD = 3;
     ctx->skip_flag = s.nactive;
     for (int iter = 1; iter <= maxiter; iter++) {
@@ -1104,7 +1208,11 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
         if (numF <= 512) hipLaunchKernelGGL(k_cg_step_short<2>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         else if (numF <= 1024) hipLaunchKernelGGL(k_cg_step_short<4>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         else if (numF <= 2048) hipLaunchKernelGGL(k_cg_step_short<8>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
-        else hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
+        else if (long_cols) {
+            hipLaunchKernelGGL(k_cg_long_a, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, (const double *)lambda_beta_dev, iter);
+            hipLaunchKernelGGL(k_cg_long_b, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, iter);
+            hipLaunchKernelGGL(k_cg_long_c, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, iter, maxiter);
+        } else hipLaunchKernelGGL(k_cg_step, dim3(D), cgb, 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         BDF_HIP(hipGetLastError());
     }
     ctx->skip_flag = nullptr;
