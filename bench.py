@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--num-latent", type=int, default=32)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--k1-event-every", type=int, default=8,
+    ap.add_argument("--k1-event-every", type=int, default=16,
                     help="time the K1 launches of every n-th step (HIP events attached to the kernel dispatch)")
     ap.add_argument("--k1-min-launches", type=int, default=200, help="K1 launches averaged for the roofline (further sweeps after the timed region)")
     ap.add_argument("--replicas", type=int, default=0, help="user blocks of the workload (default: one per GPU)")
