@@ -10,6 +10,8 @@
 // no marker packets on the row stream, no polling kernels.
 #include "bdf_common.h"
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -40,6 +42,11 @@ struct bdf_gibbs {
     // profiles/r02_sweep_timeline_events.txt) and its waves poll ready[entity] where they first need the prior.
     uint32_t *ready_dev;                 // per entity: iteration number of the last completed draw
     bool polling;
+    // BDF_DEBUG: where the host's time in bdf_gibbs_sweep goes (waiting for the prediction update of two sweeps ago = the device
+    // is the bottleneck; enqueueing = the host is)
+    bool debug;
+    double host_wait_us, host_enqueue_us;
+    uint64_t n_sweeps;
 };
 
 namespace {
@@ -225,6 +232,7 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     bdf_gibbs *g = new bdf_gibbs();
     g->rows = rows_ctx; g->hyper = g->pred = nullptr; g->D = D; g->test = nullptr; g->stats_dev = nullptr;
     g->n_pred = 0; g->comm = nullptr; g->ready_dev = nullptr; g->polling = false;
+    g->debug = false; g->host_wait_us = g->host_enqueue_us = 0.0; g->n_sweeps = 0;
     int rc;
     if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
     g->ready_dev = nullptr;
@@ -234,6 +242,10 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
         if ((rc = streams_concurrent(rows_ctx->stream, g->hyper->stream, &conc))) { bdf_gibbs_destroy(g); return rc; }
         g->polling = conc;              // kernels of the two streams do not run side by side here (a profiler serialising them): events
     }
+    g->debug = getenv("BDF_DEBUG") != nullptr;
+    if (g->debug)
+        fprintf(stderr, "[bdf_gibbs] reserve_cus=%d hyperprior stream on reserved CUs=%d polling=%d\n", rows_ctx->reserve_cus,
+                g->hyper->on_reserved, (int)g->polling);
     BDF_HIP(hipMalloc((void **)&g->ready_dev, (size_t)n_entities * sizeof(uint32_t)));
     BDF_HIP(hipMemset(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t)));
     g->ent.resize((size_t)n_entities);
@@ -252,6 +264,9 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
 {
     if (!g) return BDF_OK;
     if (g->rows) (void)hipStreamSynchronize(g->rows->stream);
+    if (g->debug && g->n_sweeps)
+        fprintf(stderr, "[bdf_gibbs] %llu sweeps: host enqueue %.1f us per sweep, host wait for the device %.1f us per sweep\n",
+                (unsigned long long)g->n_sweeps, g->host_enqueue_us / (double)g->n_sweeps, g->host_wait_us / (double)g->n_sweeps);
     for (auto &E : g->ent) { (void)hipEventDestroy(E.ev_rows); (void)hipEventDestroy(E.ev_hyper); }
     if (!g->ent.empty()) for (int k = 0; k < 3; k++) (void)hipEventDestroy(g->ev_pred[k]);
     if (g->ready_dev) (void)hipFree(g->ready_dev);
@@ -323,7 +338,9 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     // device then needs no wait for the prediction stream anywhere, and the host never runs more than two prediction updates
     // ahead.  (A device-side wait would let row kernels that poll for their prior fill the chip while the prediction kernel
     // they transitively wait for still needs slots for its last workgroups.)
+    const auto t_in = std::chrono::steady_clock::now();
     if (g->test && predict_phase >= 0 && g->n_pred >= 2) BDF_HIP(hipEventSynchronize(g->ev_pred[(g->n_pred - 2) % 3]));
+    const auto t_go = std::chrono::steady_clock::now();
     for (int j = 0; j < n; j++) {
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
@@ -381,6 +398,11 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             return rc;
         BDF_HIP(hipEventRecord(g->ev_pred[g->n_pred % 3], P->stream));
         g->n_pred++;
+    }
+    if (g->debug) {
+        g->host_wait_us += std::chrono::duration<double, std::micro>(t_go - t_in).count();
+        g->host_enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_go).count();
+        g->n_sweeps++;
     }
     return BDF_OK;
 }

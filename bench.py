@@ -77,6 +77,46 @@ def cpu_baseline(rd, D, seed, budget_s=12.0):
             "value_1thread": round(single, 4)}
 
 
+def pin_to_quiet_core(share, shares):
+    """The host thread that enqueues the sweeps runs ~15 HIP calls per 100 us sweep: 40 us when it stays on one quiet core, 60 us
+    when the scheduler moves it about, 80-90 us when it ends up away from the memory the runtime's queues live in -- and then the
+    sweep is host-bound (8.9k instead of 10k sweeps/s on the same GPU; tools/numa_probe.sh).  Pin the process to the core
+    that was idlest over the last 100 ms (its SMT sibling counted), among this rank's share of the allowed cores.
+    -> (core, previous affinity) or (None, None); BDF_BENCH_PIN=0 turns it off."""
+    if os.environ.get("BDF_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
+        return None, None
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        mine = [c for k, c in enumerate(allowed) if k % max(shares, 1) == share]
+        if len(allowed) < 4 or not mine:
+            return None, None
+
+        def snap():
+            out = {}
+            for line in open("/proc/stat"):
+                if line.startswith("cpu") and line[3].isdigit():
+                    f = line.split()
+                    v = [int(x) for x in f[1:9]]
+                    out[int(f[0][3:])] = (sum(v), v[3] + v[4])          # total, idle + iowait
+            return out
+
+        a = snap(); time.sleep(0.1); b = snap()
+        busy = {c: (b[c][0] - a[c][0]) - (b[c][1] - a[c][1]) for c in b if c in a}
+
+        def sibling(c):
+            try:
+                sib = open(f"/sys/devices/system/cpu/cpu{c}/topology/thread_siblings_list").read().strip().replace("-", ",").split(",")
+                return [int(x) for x in sib if int(x) != c]
+            except Exception:
+                return []
+
+        core = min(mine, key=lambda c: (busy.get(c, 0) + sum(busy.get(x, 0) for x in sibling(c)), c))
+        os.sched_setaffinity(0, {core})
+        return core, set(allowed)
+    except Exception:
+        return None, None
+
+
 def recorded_traffic():
     """HBM bytes of one K1 launch from the committed PMC passes (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured by this run: returned
@@ -112,14 +152,18 @@ def main():
     ap.add_argument("--c4-sweeps", type=int, default=5, help="warm-up and timed sweeps of the C4 measurement (5 + 5: SURVEY M-C4)")
     args = ap.parse_args()
 
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # before anything initialises the GPU runtime: its queues and signals are then allocated from the memory of the core the
+    # enqueueing thread stays on (a thread pinned later, away from where the runtime was initialised, enqueues at 80 us per sweep)
+    host_core, full_affinity = pin_to_quiet_core(rank % max(world, 1), world)
+
     import numpy as np
     import torch
     import bdf_amd as B
     from bdf_amd import datasets
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
@@ -218,6 +262,8 @@ def main():
         if os.environ.get("BDF_BENCH_DEBUG"):
             print(f"[bench] K1 alone: enqueue {enq_us:.1f} us per launch, total {alone_us:.1f} us", file=sys.stderr)
 
+    if full_affinity:
+        os.sched_setaffinity(0, full_affinity)            # the CPU baseline and the C4 generator use every core
     out = None
     if rank == 0:
         out = {
@@ -238,6 +284,7 @@ def main():
                                    + (f"; {replicas} such units: the ratings stacked over {replicas} disjoint user blocks, "
                                       f"value = {replicas} x sweeps/s" if replicas > 1 else ""),
                        "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
+                       "host_core": host_core,
                        "parallelism": (f"rows of each entity shared out over {world} GPUs (a rank holds its rows' observations only), "
                                        f"in-place RCCL all-gather of the sampled rows per half-sweep, test ratings split over the ranks")
                        if world > 1 else "1 GPU"},
