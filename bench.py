@@ -51,7 +51,8 @@ def cpu_baseline(rd, D, seed, budget_s=12.0):
     mu = [np.zeros(D), np.zeros(D)]
     Lam = [5.0 * np.eye(D), 5.0 * np.eye(D)]
     mean = r.data.valueMean()
-    nthreads = O.num_threads()
+    # (not omp_get_max_threads: the OpenMP runtime may have been loaded while the process was pinned to one core)
+    nthreads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else O.num_threads(), 1024))
 
     def sweep(it, nt):
         for j in (0, 1):
