@@ -158,7 +158,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     # before anything initialises the GPU runtime: its queues and signals are then allocated from the memory of the core the
     # enqueueing thread stays on (a thread pinned later, away from where the runtime was initialised, enqueues at 80 us per sweep)
-    host_core, full_affinity = pin_to_quiet_core(rank % max(world, 1), world)
+    # (one rank only: with several, RCCL's proxy threads would inherit the one-core mask and fight the enqueueing thread for it)
+    host_core, full_affinity = pin_to_quiet_core(0, 1) if world == 1 else (None, None)
 
     import numpy as np
     import torch
