@@ -54,6 +54,7 @@ struct bdf_ctx {
     int on_reserved;           // this context's stream runs on the reserved CUs only
     const int *skip_flag;
     volatile uint64_t *cg_status;
+    unsigned *pred_ticket;              // prediction kernels: workgroups finished (the last one adds the statistics), allocated at first use
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
 };
