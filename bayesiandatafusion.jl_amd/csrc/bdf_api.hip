@@ -39,6 +39,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     }
     bdf_ctx *c = new bdf_ctx();
     c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr; c->pred_ticket = nullptr;
+    c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->own_stream = false; c->stream = nullptr;
     struct Guard { bdf_ctx *c; ~Guard() { if (c) bdf_ctx_destroy(c); } } guard{c};        // error paths free what was allocated
     c->device = device;
@@ -57,6 +58,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->on_reserved = 0;
     c->skip_flag = nullptr;
     c->cg_status = nullptr; c->cg_part = nullptr; c->pred_ticket = nullptr;
+    c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->cg_gen = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;

@@ -54,6 +54,9 @@ struct bdf_ctx {
     int on_reserved;           // this context's stream runs on the reserved CUs only
     const int *skip_flag;
     volatile uint64_t *cg_status;
+    // bdf_gibbs_sweep: the next bdf_hyper_sums leaves its second stage to the bdf_hyper_sample that follows it on this context
+    bool hyper_fuse;
+    const double *hyper_partial; int hyper_nblocks; double *hyper_sumU, *hyper_UUt;
     unsigned *pred_ticket;              // prediction kernels: workgroups finished (the last one adds the statistics), allocated at first use
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;

@@ -379,6 +379,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         E.t_start = E.t_stop = nullptr;
         E.cur = nxt;
         BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
+        static const bool fuse_sums = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);
+        H->hyper_fuse = fuse_sums;        // small entities: the draw adds the sums' partials itself (one launch fewer)
         if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], nullptr, e.sumU, e.UUt))) return rc;
         H->time_h_stop = E.ev_hyper;
         H->hyper_ready = g->ready_dev + j;

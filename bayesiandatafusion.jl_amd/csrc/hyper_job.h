@@ -34,6 +34,11 @@ struct NWArgs {
     int *flag;
     uint32_t *ready;           // nullable: set to `sweep` once the pack is written (row kernels that poll instead of waiting)
     uint32_t sweep;
+    // nullable: the sums' partials (k_hyper_partial, at most 16 of them) -- the draw then adds them itself, in k_hyper_final's
+    // order, into sumU_w / UUt_w (== sumU / UUt) before it starts: one launch fewer per entity and sweep
+    const double *partial;
+    int nblocks;
+    double *sumU_w, *UUt_w;
 };
 
 // ---- stage 1: partial sums of rows [r0, r0 + HS_ROWS) by NW waves; red: (NW-1) * PSZ doubles of LDS -----------------------
@@ -186,6 +191,22 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     const int D = a.D;
     const double beta_N = a.b0 + a.N;
     HSTAMP(0);
+    if (a.partial) {
+        // stage 2 of the sums (k_hyper_final's order: chain q = partial q, then the butterfly 8, 4, 2, 1); all loads of an
+        // element in flight together
+        constexpr int PSZ = HGeo<DP>::PSZ;
+        for (int e = tid; e < PSZ; e += nthreads) {
+            double c[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) c[q] = q < a.nblocks ? a.partial[(int64_t)q * PSZ + e] : 0.0;
+#pragma unroll
+            for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+                for (int q = 0; q < off; q++) c[q] += c[q + off];
+            hyper_scatter<DP>(D, e, c[0], a.sumU_w, a.UUt_w);
+        }
+        __syncthreads();                            // (workgroup-scope release / acquire: the sums are read below)
+    }
     if (D < DP)                                     // the padding's entries of the packed factor are never stored: zero (backward_batch)
         for (int e = tid; e < GG::TRI_D; e += nthreads) tri[e] = 0.0;
     if (tid < 64) {

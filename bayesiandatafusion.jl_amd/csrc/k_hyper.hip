@@ -95,7 +95,11 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
     // HS_ROWS rows per workgroup, at most 2048 workgroups (a very large entity gives each several chunks)
     const int64_t chunks = std::max<int64_t>(1, (N + HS_ROWS - 1) / HS_ROWS);
-    const int64_t rpb = HS_ROWS * ((chunks + 2047) / 2048);
+    // the caller enqueues the draw next and lets it add the partials (bdf_gibbs_sweep): at most 16 of them, for entities small
+    // enough that 16 workgroups read them quickly
+    const bool fuse = ctx->hyper_fuse && N <= 16384;
+    ctx->hyper_fuse = false;
+    const int64_t rpb = HS_ROWS * ((chunks + (fuse ? 15 : 2047)) / (fuse ? 16 : 2048));
     const int nblocks = (int)std::max<int64_t>(1, (N + rpb - 1) / rpb);
     const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
     const int psz = DP == 16 ? HGeo<16>::PSZ : (DP == 32 ? HGeo<32>::PSZ : HGeo<64>::PSZ);
@@ -106,15 +110,18 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     const dim3 fgrid((psz + 15) / 16);
     if (DP == 16) {
         hipExtLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
-        hipLaunchKernelGGL(k_hyper_final<16>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
+        if (!fuse) hipLaunchKernelGGL(k_hyper_final<16>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else if (DP == 32) {
         hipExtLaunchKernelGGL(k_hyper_partial<32>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
-        hipLaunchKernelGGL(k_hyper_final<32>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
+        if (!fuse) hipLaunchKernelGGL(k_hyper_final<32>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     } else {
         hipExtLaunchKernelGGL(k_hyper_partial<64>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
-        hipLaunchKernelGGL(k_hyper_final<64>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
+        if (!fuse) hipLaunchKernelGGL(k_hyper_final<64>, fgrid, dim3(256), 0, ctx->stream, D, nblocks, (const double *)part, sumU, UUt);
     }
     ctx->time_h_start = nullptr;
+    ctx->hyper_partial = fuse ? part : nullptr;
+    ctx->hyper_nblocks = fuse ? nblocks : 0;
+    ctx->hyper_sumU = sumU; ctx->hyper_UUt = UUt;
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
@@ -161,6 +168,14 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.flag = ctx->flag_dev;
     a.ready = ctx->hyper_ready; a.sweep = ctx->sweep_host;
     ctx->hyper_ready = nullptr;
+    a.partial = nullptr; a.nblocks = 0; a.sumU_w = a.UUt_w = nullptr;
+    if (ctx->hyper_partial) {
+        // the partials of the bdf_hyper_sums call just before (same stream, fused mode): they live in the context's scratch
+        BDF_REQUIRE(draws != nullptr && sumU == ctx->hyper_sumU && UUt == ctx->hyper_UUt, BDF_ERR_ARG,
+                    "bdf_hyper_sample: fused sums need the draws made ahead and the sums' own output buffers");
+        a.partial = ctx->hyper_partial; a.nblocks = ctx->hyper_nblocks; a.sumU_w = ctx->hyper_sumU; a.UUt_w = ctx->hyper_UUt;
+        ctx->hyper_partial = nullptr;
+    }
     if (D <= 16) hipExtLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else hipExtLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
