@@ -64,6 +64,8 @@ struct bdf_ctx {
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
 int bdf_scratch2(bdf_ctx *ctx, size_t bytes, void **out);
+#define BDF_DRAWS_BATCH 8
+int bdf_hyper_draws_batch(bdf_ctx *ctx, int D, int n, const int64_t *N, const double *nu, const uint32_t *entity_tag, double *const *draws_out);
 
 struct bdf_mode_index {
     std::vector<int64_t> rowptr;   // host, dims+1

@@ -341,14 +341,23 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     const auto t_in = std::chrono::steady_clock::now();
     if (g->test && predict_phase >= 0 && g->n_pred >= 2) BDF_HIP(hipEventSynchronize(g->ev_pred[(g->n_pred - 2) % 3]));
     const auto t_go = std::chrono::steady_clock::now();
+    if (n <= BDF_DRAWS_BATCH) {
+        int64_t Ns[BDF_DRAWS_BATCH]; double nus[BDF_DRAWS_BATCH]; uint32_t tags[BDF_DRAWS_BATCH]; double *outs[BDF_DRAWS_BATCH];
+        for (int j = 0; j < n; j++) {
+            const bdf_gibbs_entity &e = g->ent[(size_t)j].d;
+            Ns[j] = e.n_real; nus[j] = e.nu0; tags[j] = e.tag; outs[j] = e.draws;
+        }
+        if ((rc = bdf_hyper_draws_batch(H, D, n, Ns, nus, tags, outs))) return rc;
+    }
     for (int j = 0; j < n; j++) {
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
         // (mu, Lambda) of the previous iteration: an event wait, or -- draws on reserved CUs -- the row kernel polls for it
         const bool poll = g->polling && !g->comm && E.hyper_recorded;
         if (E.hyper_recorded && !poll) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
-        // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows
-        if ((rc = bdf_hyper_draws(H, D, e.n_real, e.nu0, e.tag, e.draws))) return rc;
+        // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows -- for all entities
+        // in one launch at the head of the iteration when they are few
+        if (n > BDF_DRAWS_BATCH && (rc = bdf_hyper_draws(H, D, e.n_real, e.nu0, e.tag, e.draws))) return rc;
         bdf_term terms[BDF_MAX_TERMS];
         for (int t = 0; t < e.n_terms; t++) {
             terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;

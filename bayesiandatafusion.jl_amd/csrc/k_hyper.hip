@@ -71,6 +71,31 @@ __global__ __launch_bounds__(64) void k_hyper_draws(int D, double nu_N, uint64_t
     }
 }
 
+// the same for several entities in one launch (blockIdx.y = entity): bdf_gibbs_sweep makes every entity's draws at the head of
+// the iteration
+struct DrawsBatch {
+    int n;
+    double nu_N[BDF_DRAWS_BATCH];
+    uint32_t tag[BDF_DRAWS_BATCH];
+    double *out[BDF_DRAWS_BATCH];
+};
+__global__ __launch_bounds__(64) void k_hyper_draws_batch(int D, DrawsBatch b, uint64_t seed, uint32_t sweep)
+{
+    const int j = blockIdx.y;
+    const int e = blockIdx.x * 64 + threadIdx.x;
+    const uint32_t entity_tag = b.tag[j];
+    double *out = b.out[j];
+    if (e < D * D) {
+        const int arow = e / D, c = e % D;
+        double v = 0.0;
+        if (c < arow) v = bdf_normal(seed, sweep, BDF_P_NW_NORMAL, entity_tag, (uint64_t)arow, c);
+        else if (c == arow) v = sqrt(2.0 * bdf_gamma(seed, sweep, entity_tag, (uint64_t)arow, 0.5 * (b.nu_N[j] - (double)arow)));
+        out[e] = v;
+    } else if (e < D * D + D) {
+        out[e] = bdf_normal(seed, sweep, BDF_P_NW_MEAN, entity_tag, 0, e - D * D);
+    }
+}
+
 // One workgroup of 256 threads (hyper_job.h: nw_draw).
 template <int DP>
 __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
@@ -133,6 +158,20 @@ extern "C" int bdf_hyper_draws(bdf_ctx *ctx, int D, int64_t N, double nu, uint32
     const int total = D * D + D;
     hipLaunchKernelGGL(k_hyper_draws, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, D, nu + (double)N, ctx->seed,
                        ctx->sweep_host, entity_tag, draws_out);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+// bdf_hyper_draws for n <= BDF_DRAWS_BATCH entities in one launch (internal: bdf_gibbs_sweep)
+int bdf_hyper_draws_batch(bdf_ctx *ctx, int D, int n, const int64_t *N, const double *nu, const uint32_t *entity_tag, double *const *draws_out)
+{
+    BDF_REQUIRE(ctx && n >= 1 && n <= BDF_DRAWS_BATCH && N && nu && entity_tag && draws_out, BDF_ERR_ARG, "bdf_hyper_draws_batch: bad argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_draws_batch: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    DrawsBatch b;
+    b.n = n;
+    for (int j = 0; j < n; j++) { b.nu_N[j] = nu[j] + (double)N[j]; b.tag[j] = entity_tag[j]; b.out[j] = draws_out[j]; }
+    const int total = D * D + D;
+    hipLaunchKernelGGL(k_hyper_draws_batch, dim3((total + 63) / 64, n), dim3(64), 0, ctx->stream, D, b, ctx->seed, ctx->sweep_host);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
