@@ -38,7 +38,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
         return BDF_ERR_NOGPU;
     }
     bdf_ctx *c = new bdf_ctx();
-    c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr; c->pred_ticket = nullptr;
+    c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->own_stream = false; c->stream = nullptr;
     struct Guard { bdf_ctx *c; ~Guard() { if (c) bdf_ctx_destroy(c); } } guard{c};        // error paths free what was allocated
@@ -57,7 +57,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->reserve_cus = 0;
     c->on_reserved = 0;
     c->skip_flag = nullptr;
-    c->cg_status = nullptr; c->cg_part = nullptr; c->pred_ticket = nullptr;
+    c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->cg_gen = 0;
     c->scratch = nullptr;
@@ -87,7 +87,6 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
-    if (ctx->pred_ticket) hipFree(ctx->pred_ticket);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;

@@ -57,7 +57,6 @@ struct bdf_ctx {
     // bdf_gibbs_sweep: the next bdf_hyper_sums leaves its second stage to the bdf_hyper_sample that follows it on this context
     bool hyper_fuse;
     const double *hyper_partial; int hyper_nblocks; double *hyper_sumU, *hyper_UUt;
-    unsigned *pred_ticket;              // prediction kernels: workgroups finished (the last one adds the statistics), allocated at first use
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
 };

@@ -26,7 +26,6 @@ struct PredArgs {
     double count, clamp_lo, clamp_hi, cut;
     double *stats;
     double *partial;               // per-block statistics
-    unsigned *ticket;              // workgroups that have written theirs: the last one adds them up (left at zero)
 };
 
 __device__ inline double clampv(double x, double lo, double hi)
@@ -76,12 +75,9 @@ __device__ inline void pair_finish(const PredArgs &a, const PairState &s, double
     }
 }
 
-// per-workgroup statistics, then -- in the workgroup that finishes last -- their fixed-order sum: no second launch (a launch is
-// 4 us of the host's 40 per sweep).  Partials written through and read with agent-scope loads (the workgroups sit on all XCDs).
 __device__ inline void block_stats(const PredArgs &a, const double (&st)[4])
 {
     __shared__ double red[4][256 / 64];
-    __shared__ unsigned last;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -91,30 +87,7 @@ __device__ inline void block_stats(const PredArgs &a, const double (&st)[4])
         if ((tid & 63) == 0) red[q][tid >> 6] = v;
     }
     __syncthreads();
-    if (tid < 4) {
-        __hip_atomic_store(a.partial + blockIdx.x * 4 + tid, red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3], __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    __syncthreads();
-    if (tid == 0) last = __hip_atomic_fetch_add(a.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1;
-    __syncthreads();
-    if (!last) return;
-    const int nblocks = (int)gridDim.x;
-    double v[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int b = tid; b < nblocks; b += 256)
-#pragma unroll
-        for (int q = 0; q < 4; q++) v[q] += __hip_atomic_load(a.partial + b * 4 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        double x = v[q];
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
-        if ((tid & 63) == 0) red[q][tid >> 6] = x;
-    }
-    __syncthreads();
-    if (tid < 4) a.stats[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
-    if (tid == 0) __hip_atomic_store(a.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 4) a.partial[blockIdx.x * 4 + tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
 }
 
 // General kernel: NM modes, any order of the pairs.  VEC = 4: D a multiple of 4, NC 32-byte pieces of a row per lane
@@ -240,16 +213,29 @@ __global__ __launch_bounds__(256) void k_predict_runs(PredArgs a)
     if (a.phase >= 0) block_stats(a, st);
 }
 
+// fixed-order sum of the per-block statistics
+__global__ __launch_bounds__(256) void k_predict_final(int nblocks, const double *partial, double *stats)
+{
+    __shared__ double red[4][4];
+    const int tid = threadIdx.x;
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int b = tid; b < nblocks; b += 256)
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] += partial[b * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        double x = v[q];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) x += __shfl_xor(x, off);
+        if ((tid & 63) == 0) red[q][tid >> 6] = x;
+    }
+    __syncthreads();
+    if (tid < 4) stats[tid] = red[tid][0] + red[tid][1] + red[tid][2] + red[tid][3];
+}
+
 int launch_predict(bdf_ctx *ctx, PredArgs &a)
 {
     if (a.n == 0) return BDF_OK;
-    if (a.phase >= 0) {
-        if (!ctx->pred_ticket) {
-            BDF_HIP(hipMalloc((void **)&ctx->pred_ticket, sizeof(unsigned)));
-            BDF_HIP(hipMemsetAsync(ctx->pred_ticket, 0, sizeof(unsigned), ctx->stream));
-        }
-        a.ticket = ctx->pred_ticket;
-    }
     static const bool no_runs = getenv("BDF_PREDICT_NO_RUNS") != nullptr;       // test hook: the general kernel on sorted pairs
     if (!no_runs && a.sorted_mode >= 0 && a.n_modes == 2 && (a.D & 3) == 0 && a.D <= 32) {
         const int nblocks = (int)((a.n + 32 * RUN - 1) / (32 * RUN));
@@ -260,6 +246,7 @@ int launch_predict(bdf_ctx *ctx, PredArgs &a)
             a.partial = (double *)sc;
         }
         hipLaunchKernelGGL(k_predict_runs, dim3(nblocks), dim3(256), 0, ctx->stream, a);
+        if (a.phase >= 0) hipLaunchKernelGGL(k_predict_final, dim3(1), dim3(256), 0, ctx->stream, nblocks, (const double *)a.partial, a.stats);
         BDF_HIP(hipGetLastError());
         return BDF_OK;
     }
@@ -279,6 +266,7 @@ int launch_predict(bdf_ctx *ctx, PredArgs &a)
     else PRED_NM(4, 2);
 #undef PRED_NM
 #undef PRED
+    if (a.phase >= 0) hipLaunchKernelGGL(k_predict_final, dim3(1), dim3(256), 0, ctx->stream, nblocks, (const double *)a.partial, a.stats);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }

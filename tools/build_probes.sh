@@ -3,7 +3,7 @@
 cd $(dirname $0)/..
 mkdir -p tools/bin
 I=-Ibayesiandatafusion.jl_amd/csrc
-for p in fp64_pipe_probe cu_mask_probe gather_probe; do hipcc --offload-arch=gfx950 -O3 -w -o tools/bin/$p tools/$p.hip; done
+for p in fp64_pipe_probe cu_mask_probe gather_probe hip_call_cost; do hipcc --offload-arch=gfx950 -O3 -w -o tools/bin/$p tools/$p.hip; done
 hipcc --offload-arch=gfx950 -O3 -w $I -o tools/bin/factor_probe tools/factor_probe.hip
 hipcc --offload-arch=gfx950 -O3 -w $I -DPROBE_DP=64 -o tools/bin/factor_probe64 tools/factor_probe.hip
 ls -la tools/bin

@@ -60,6 +60,7 @@ timeout 200 tools/bin/gather_probe 3952 > $out/gather_probe.txt 2>&1
 timeout 200 tools/bin/factor_probe > $out/factor_probe.txt 2>&1
 timeout 200 tools/bin/factor_probe64 >> $out/factor_probe.txt 2>&1
 python3 tools/k1_alone.py > $out/k1_alone.txt 2>&1
+tools/bin/hip_call_cost > $out/hip_call_cost.txt 2>&1
 timeout 120 tools/bin/cu_mask_probe 8 > $out/cu_mask_probe.txt 2>&1
 tools/k1_gap.sh > $out/k1_back_to_back.txt 2>&1
 tools/sweep_timeline.sh > $out/sweep_timeline.txt 2>&1
