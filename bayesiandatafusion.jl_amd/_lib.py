@@ -82,6 +82,7 @@ _SIGS = {
     "bdf_ctx_set_sweep": (C.c_int, [C.c_void_p, C.c_uint32]),
     "bdf_ctx_advance_sweep": (C.c_int, [C.c_void_p]),
     "bdf_ctx_sync": (C.c_int, [C.c_void_p]),
+    "bdf_ctx_warnings": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32)]),
     "bdf_ctx_set_piece_size": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_ctx_set_gather": (C.c_int, [C.c_void_p, C.c_int]),
     "bdf_rows_unfinished": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64)]),

@@ -54,6 +54,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
     c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr;
+    c->warnings = 0;
     c->reserve_cus = 0;
     c->on_reserved = 0;
     c->skip_flag = nullptr;
@@ -169,6 +170,10 @@ extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
     BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
         BDF_HIP(hipMemset(ctx->flag_dev, 0, sizeof(int)));
+        ctx->warnings |= (uint32_t)flag & BDF_WARN_CG_MAXITER;
+        flag &= ~(int)BDF_WARN_CG_MAXITER;
+    }
+    if (flag) {
         if (flag & 16) {
             bdf_set_error("row sampler: a split row's pieces did not all arrive in time (flag %d)", flag);
             return BDF_ERR_HIP;
@@ -178,6 +183,14 @@ extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
                       flag & 2 ? "hyperprior " : "", flag & 4 ? "noise precision " : "", flag & 8 ? "FF + lambda I" : "");
         return BDF_ERR_NOTPD;
     }
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_warnings(bdf_ctx *ctx, uint32_t *bits_out)
+{
+    BDF_REQUIRE(ctx && bits_out, BDF_ERR_ARG, "bdf_ctx_warnings: NULL argument");
+    *bits_out = ctx->warnings;
+    ctx->warnings = 0;
     return BDF_OK;
 }
 

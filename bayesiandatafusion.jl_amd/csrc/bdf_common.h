@@ -37,7 +37,8 @@ struct bdf_ctx {
     size_t scratch_bytes;
     void *scratch2;            // second block: split-K partials of the dense products (used while `scratch` is held)
     size_t scratch2_bytes;
-    int *flag_dev;             // not-positive-definite flag
+    int *flag_dev;             // not-positive-definite flag (bits 1..32: errors; 64: BDF_WARN_CG_MAXITER)
+    uint32_t warnings;         // non-fatal bits seen by bdf_ctx_sync, until bdf_ctx_warnings takes them
     int item_size;             // K1: observations per work item (rows longer than this are split)
     int piece_size;            // K1: ... into pieces of at most this many observations
     int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)

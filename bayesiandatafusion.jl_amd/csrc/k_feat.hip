@@ -577,6 +577,7 @@ struct CgState {
     int *done_blocks;                    // columns (workgroups) that have finished the current k_cg_step
     volatile uint64_t *status;           // host-mapped: [0] = generation << 32 | last completed iteration, [1] = active columns
     uint32_t gen;
+    int *flag;                           // BDF_WARN_CG_MAXITER: a column still active after the last iteration
 };
 
 __device__ __forceinline__ double block_sum(double v, double *red)
@@ -680,6 +681,7 @@ __global__ __launch_bounds__(1024) void k_cg_step(CgState s, const double *lambd
     __threadfence_block();
     __syncthreads();
     if (iter < maxiter) cg_pre(s, iter + 1, red, go);
+    else if (threadIdx.x == 0 && s.active[blockIdx.x] && s.iters[blockIdx.x] == iter) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
     // the last column to finish reports (iteration, active columns) to the host, which enqueues ahead of the device and
     // stops when it reads 0 active columns: no stream synchronisation inside the solve
     __syncthreads();
@@ -741,6 +743,7 @@ __global__ __launch_bounds__(256) void k_cg_step_short(CgState s, const double *
             bknum = fma(r[e], r[e], bknum);
         }
         bool proceed = false;
+        if (iter >= maxiter && tid == 0) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
         if (iter < maxiter) {                              // top of iteration iter + 1 (cg_pre)
             bknum = block_sum(bknum, red);
             if (tid == 0) {
@@ -842,6 +845,7 @@ __global__ __launch_bounds__(256) void k_cg_long_c(CgState s, CgChunks c, int it
 {
     if (*s.nactive == 0) return;                          // (a) has reported
     const int d = blockIdx.x, g = blockIdx.y;
+    if (s.active[d] && s.iters[d] == iter && iter >= maxiter && g == 0 && threadIdx.x == 0) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
     if (s.active[d] && s.iters[d] == iter && iter < maxiter) {      // top of iteration iter + 1 (cg_pre)
         double rr = 0.0;
         for (int q = 0; q < c.G; q++) rr += c.partB[d * c.G + q];
@@ -1154,6 +1158,7 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     }
     struct SkipGuard { bdf_ctx *c; ~SkipGuard() { c->skip_flag = nullptr; } } guard{ctx};
     s.status = ctx->cg_status;
+    s.flag = ctx->flag_dev;
     s.gen = ++ctx->cg_gen;
     const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
     hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol);

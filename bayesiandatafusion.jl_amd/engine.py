@@ -159,6 +159,12 @@ class Context:
 
     def sync(self):
         check(lib().bdf_ctx_sync(self.handle))
+        bits = C.c_uint32(0)
+        check(lib().bdf_ctx_warnings(self.handle, C.byref(bits)))
+        if bits.value & 64:          # BDF_WARN_CG_MAXITER: the reference returns such a column silently (parallel_cg.jl:73-93)
+            import warnings
+            warnings.warn("beta update: a conjugate-gradient column was still above its tolerance after maxiter iterations",
+                          RuntimeWarning, stacklevel=2)
 
     def zeros(self, *shape, dtype=torch.float64):
         with torch.cuda.stream(self.stream):          # filled on the stream that will use it

@@ -96,6 +96,11 @@ int bdf_ctx_time_next_rows(bdf_ctx *ctx, void *start, void *stop);
  * bdf_hyper_sample's kernel */
 int bdf_ctx_time_next_hyper(bdf_ctx *ctx, void *start, void *stop);
 int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a kernel met a non-positive-definite matrix */
+/* Conditions that are not errors in the reference either, accumulated by bdf_ctx_sync and returned (and cleared) here:
+ * BDF_WARN_CG_MAXITER -- a conjugate-gradient column of the beta solve was still above its tolerance after maxiter iterations
+ * (cg_AtA, src/parallel_cg.jl:73-93, returns such a column as it stands, silently; hosts may want to say so). */
+#define BDF_WARN_CG_MAXITER 64u
+int bdf_ctx_warnings(bdf_ctx *ctx, uint32_t *bits_out);
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);

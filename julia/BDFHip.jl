@@ -37,7 +37,14 @@ mutable struct Context
 end
 
 set_sweep!(c::Context, i) = check(ccall((:bdf_ctx_set_sweep, lib), Cint, (Ptr{Cvoid}, UInt32), c.h, i))
-sync(c::Context) = check(ccall((:bdf_ctx_sync, lib), Cint, (Ptr{Cvoid},), c.h))
+function sync(c::Context)
+    check(ccall((:bdf_ctx_sync, lib), Cint, (Ptr{Cvoid},), c.h))
+    bits = Ref{UInt32}(0)
+    check(ccall((:bdf_ctx_warnings, lib), Cint, (Ptr{Cvoid}, Ref{UInt32}), c.h, bits))
+    # BDF_WARN_CG_MAXITER: cg_AtA (parallel_cg.jl:73-93) returns such a column silently
+    (bits[] & 0x40) != 0 && @warn "beta update: a conjugate-gradient column was still above its tolerance after maxiter iterations"
+    nothing
+end
 # K1 tuning: rows with more than `item` observations are split into pieces of at most `piece` (defaults 192 / 128)
 set_item_size!(c::Context, item) = check(ccall((:bdf_ctx_set_item_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, item))
 set_piece_size!(c::Context, piece) = check(ccall((:bdf_ctx_set_piece_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, piece))

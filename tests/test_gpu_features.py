@@ -120,6 +120,30 @@ def test_sample_beta_cg_and_direct_match_oracle(B, O, ctx, kind, D):
     op.close()
 
 
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+def test_cg_out_of_iterations_is_reported_not_raised(B, ctx, kind):
+    """cg_AtA (parallel_cg.jl:73-93) returns a column that ran out of iterations as it stands; the library does the same and
+    leaves BDF_WARN_CG_MAXITER for the host (Context.sync turns it into a RuntimeWarning); a solve that converges leaves none"""
+    import warnings
+    rng = np.random.default_rng(12)
+    op, A = _operators(B, ctx, rng)[kind]
+    N, numF = A.shape
+    D = 4
+    sample, mu, Lam = rng.standard_normal((N, D)), np.zeros(D), np.eye(D)
+    ctx.set_sweep(2)
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        _, _, it_ok, _ = _sample_beta(B, ctx, op, D, sample, mu, Lam, 0.5, False, None)       # converges well before numF iterations
+    assert it_ok.max() < numF
+    with pytest.warns(RuntimeWarning, match="conjugate-gradient"):
+        beta, _, it_cut, _ = _sample_beta(B, ctx, op, D, sample, mu, Lam, 0.5, False, None, maxiter=2)
+    assert np.all(it_cut == 2) and np.all(np.isfinite(beta))
+    with warnings.catch_warnings():                       # the condition was taken, not sticky
+        warnings.simplefilter("error")
+        ctx.sync()
+    op.close()
+
+
 def test_cg_reference_cases(B, O, ctx):
     """cg_AtA against the direct solve: lambda 0.5 (test/parallel_matrix.jl:107-109), 0.75 with tol 1e-6 and several
     right-hand sides (test/heavy_copyto.jl:28-50), driven through sample_beta with the noise switched off by a huge Lambda"""
