@@ -115,6 +115,8 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
 extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *sample, const double *uhat,
                               double *sumU, double *UUt)
 {
+    const bool fuse_asked = ctx && ctx->hyper_fuse;       // one call only, whatever happens below
+    if (ctx) { ctx->hyper_fuse = false; ctx->hyper_partial = nullptr; }
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
@@ -122,8 +124,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     const int64_t chunks = std::max<int64_t>(1, (N + HS_ROWS - 1) / HS_ROWS);
     // the caller enqueues the draw next and lets it add the partials (bdf_gibbs_sweep): at most 16 of them, for entities small
     // enough that 16 workgroups read them quickly
-    const bool fuse = ctx->hyper_fuse && N <= 16384;
-    ctx->hyper_fuse = false;
+    const bool fuse = fuse_asked && N <= 16384;
     const int64_t rpb = HS_ROWS * ((chunks + (fuse ? 15 : 2047)) / (fuse ? 16 : 2048));
     const int nblocks = (int)std::max<int64_t>(1, (N + rpb - 1) / rpb);
     const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
