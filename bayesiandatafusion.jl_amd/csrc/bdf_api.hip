@@ -374,11 +374,34 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         r->dims[m] = dims[m];
         r->nint[m] = sharded ? cmax[m] * world * chunks : dims[m];
         r->idx[m].rowptr_dev = nullptr; r->idx[m].colidx_dev = nullptr; r->idx[m].vals_dev = nullptr; r->idx[m].perm_dev = nullptr;
-        r->idx[m].order_dev = nullptr; r->idx[m].own_nnz = 0;
+        r->idx[m].order_dev = nullptr; r->idx[m].own_nnz = 0; r->idx[m].packed_dev = nullptr;
     }
+    r->n_codes = 0; r->table_dev = nullptr;
     double s = 0.0;
     for (int64_t i = 0; i < nnz; i++) s += values[i];
     r->value_mean = nnz ? s / (double)nnz : NAN;
+    // the distinct values, if there are at most 256 of them (two-mode relations: K1's coded variant)
+    std::vector<double> table;
+    static const bool no_codes = getenv("BDF_NO_CODES") != nullptr;
+    if (n_modes == 2 && nnz > 0 && !no_codes) {
+        bool ok = true;
+        for (int64_t i = 0; i < nnz && ok; i++) {
+            const double v = values[i];
+            auto it = std::lower_bound(table.begin(), table.end(), v);
+            if (it != table.end() && *it == v) continue;
+            if (!(v == v) || table.size() == 256) { ok = false; break; }       // NaN or too many
+            table.insert(it, v);
+        }
+        if (!ok) table.clear();
+    }
+    auto code_of = [&](double v) -> uint32_t { return (uint32_t)(std::lower_bound(table.begin(), table.end(), v) - table.begin()); };
+    if (!table.empty()) {
+        std::vector<double> t256(256, 0.0);
+        std::copy(table.begin(), table.end(), t256.begin());
+        int rct = upload(ctx, t256, &r->table_dev);
+        if (rct) return rct;
+        r->n_codes = (int)table.size();
+    }
 
     {
         int64_t *rps[BDF_MAX_MODES], *ris[BDF_MAX_MODES];
@@ -420,6 +443,11 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
             if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
             if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
             if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
+            if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
+                std::vector<uint32_t> packed((size_t)nnz);
+                for (int64_t q = 0; q < nnz; q++) packed[(size_t)q] = (code_of(vals[(size_t)q]) << 24) | (uint32_t)colidx[(size_t)q];
+                if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
+            }
             ix.own_nnz = nnz;
             continue;
         }
@@ -468,6 +496,11 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         if ((rc = upload(ctx, colidx, &ix.colidx_dev))) return rc;
         if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
         if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
+        if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
+            std::vector<uint32_t> packed((size_t)on);
+            for (int64_t q = 0; q < on; q++) packed[(size_t)q] = (code_of(vals[(size_t)q]) << 24) | (uint32_t)colidx[(size_t)q];
+            if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
+        }
     }
     guard.r = nullptr;
     *out = r;
@@ -497,7 +530,9 @@ extern "C" int bdf_relation_destroy(bdf_rel *rel)
     for (int m = 0; m < rel->n_modes; m++) {
         bdf_mode_index &ix = rel->idx[m];
         hipFree(ix.rowptr_dev); hipFree(ix.colidx_dev); hipFree(ix.vals_dev); hipFree(ix.perm_dev); hipFree(ix.order_dev);
+        hipFree(ix.packed_dev);
     }
+    hipFree(rel->table_dev);
     delete rel;
     return BDF_OK;
 }
@@ -568,6 +603,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         if (ctx->gather_mode == 2 && lean && D > 32) T.lean = 2;
         T.alpha = t.alpha;
         T.mean = t.mean_value;
+        if (T.lean == 1 && T.n_other == 1 && ix.packed_dev) { T.packed = ix.packed_dev; T.table = t.rel->table_dev; T.n_codes = t.rel->n_codes; }
     }
     a.n_terms = n_terms;
     a.D = D;

@@ -75,6 +75,7 @@ struct bdf_mode_index {
     int32_t *colidx_dev;           // (n_modes-1) planes of nnz: 0-based ids of the other modes, mode order
     double  *vals_dev;             // nnz values in mode order
     int32_t *perm_dev;             // nnz: 0-based COO row number in mode order
+    uint32_t *packed_dev;          // nullable, two-mode relations with <= 256 distinct values: (value code << 24) | other-mode id
     int32_t *order_dev;
     // relation created with a layout (bdf_relation_create_sharded): the device arrays hold only the observations of the rows
     // this rank owns, chunk after chunk in internal-position order, and colidx holds INTERNAL positions of the other modes
@@ -96,6 +97,10 @@ struct bdf_rel {
     int sharded;                       // created with a layout
     int rank, world, chunks;
     int64_t nint[BDF_MAX_MODES];       // rows of the factor matrix of every mode (== dims without a layout)
+    // ratings take few distinct values (MovieLens: 5): when there are at most 256 the relation also keeps them as 8-bit codes
+    // into this table, packed with the other mode's id (K1's coded two-mode variant: no value registers in its pipeline)
+    int n_codes;                       // 0: not coded
+    double *table_dev;                 // 256 doubles, ascending distinct values (the rest zero)
 };
 
 struct bdf_pairs {
@@ -261,6 +266,7 @@ __device__ __forceinline__ double readlane_f64(double v, int lane)   // lane mus
 }
 
 // kernel launch argument blocks ------------------------------------------------------------
+#define BDF_K1_CODES 32            // distinct values up to which K1's coded variant keeps a per-wave table
 struct TermDev {
     const int64_t *rowptr;
     const int32_t *colidx;
@@ -273,6 +279,9 @@ struct TermDev {
     int32_t lean;              // K1 lean gather: 1 = shared baseline, <= 2 other modes, factor matrices < 4 GiB with < 2^24
                                // rows (32-bit offsets); 2 = the same with 64-bit row offsets (D > 32 only); 0 = general path
     double alpha, mean;
+    const uint32_t *packed;    // nullable: (value code << 24) | other-mode id per observation, with
+    const double *table;       // the code -> value table (256 doubles)
+    int32_t n_codes, _padc;
 };
 
 struct SampleArgs {

@@ -17,6 +17,9 @@
 #ifndef BDF_K1_WAVES32
 #define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
 #endif
+#ifndef BDF_K1_WAVES32C
+#define BDF_K1_WAVES32C 7         // ... its variant for one two-mode relation with coded values (70 registers)
+#endif
 
 namespace {
 
@@ -31,6 +34,7 @@ struct Geo {
     static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
     static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
     static constexpr int WAVES_MATRIX = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
+    static constexpr int WAVES_CODED = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32C : 8);      // one two-mode relation, coded values
     __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
     // packed factor in LDS: column k keeps rows col_first(k) = RG * (k / RG) .. DP-1, by row class:
     // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - col_first(k)) / 4.  Columns are one double further apart

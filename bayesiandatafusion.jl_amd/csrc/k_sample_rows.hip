@@ -195,10 +195,15 @@ __device__ __forceinline__ void accumulate_reg(const SampleArgs &a, const Item &
 // Same pipeline as accumulate_reg, with what the general path pays per load taken out: wave-uniform (SGPR) bases with
 // 32-bit byte offsets, row offsets by one 24-bit mad, no predicated loads (indices are clamped to the item instead, and
 // only the item's last trip masks its operands).
-template <int DP, int NO, bool FULL, bool WIDE = false>
+// CODED (a launch with one two-mode relation whose values are at most BDF_K1_CODES distinct numbers -- ratings): the other-mode
+// id and the value's 8-bit code arrive as ONE 32-bit word per observation (TermDev::packed), the value minus the mean comes
+// from the wave's own table in LDS (the packed factor's space, idle until the factorisation) when it is used.  No value is held in registers two trips ahead: 70 instead of 80 VGPRs, SEVEN
+// resident waves per SIMD instead of six, and a third fewer memory instructions per trip.  Same arithmetic, same results.
+template <int DP, int NO, bool FULL, bool WIDE = false, bool CODED = false>
 __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
-                                       double (&bred)[Geo<DP>::DB])
+                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
+    static_assert(!CODED || (NO == 1 && !WIDE), "coded values: one two-mode relation, 32-bit row offsets");
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
     constexpr int KS = (NO == 1) ? BDF_K1_KS : 1;
     const TermDev &T = a.t[it.term];
@@ -221,11 +226,13 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     const char *ids[NO], *fac[NO];
 #pragma unroll
     for (int m = 0; m < NO; m++) {
-        ids[m] = (const char *)(T.colidx + (int64_t)m * T.nnz + it.q_begin);
+        ids[m] = CODED ? (const char *)(T.packed + it.q_begin) : (const char *)(T.colidx + (int64_t)m * T.nnz + it.q_begin);
         fac[m] = (const char *)T.fac[m];
     }
     const char *vals = (const char *)(T.vals + it.q_begin);
     const double mean = T.mean;
+    double tab_v = 0.0;
+    if (CODED && lane < BDF_K1_CODES) tab_v = T.table[lane] - mean;      // this wave's copy of the table: value - mean by code
 
     // two register sets, used alternately by even and odd trips (no rotation copies: a copy would have to wait for
     // the load it moves).  Trip t multiplies set t%2; the gathers of trip t+1 fill the other set; the ids and values of
@@ -238,7 +245,7 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
         uint32_t o = (t) * (4 * KS) + 4 * k + h;                                                \
         o = (o < n ? o : n - 1) * 4u;                                                           \
         _Pragma("unroll") for (int m = 0; m < NO; m++) ix[S][k][m] = *(const uint32_t *)(ids[m] + o); \
-        rr[S][k] = *(const double *)(vals + 2u * o);                                            \
+        if (!CODED) rr[S][k] = *(const double *)(vals + 2u * o);                                \
     }
 #define LOAD_DATA(S)                                                                            \
     _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
@@ -263,7 +270,8 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
             }                                                                                   \
         }                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KS; k++) {                                        \
-            const double r = rr[C][k] - mean;                                                   \
+            /* (__umul24 in LOAD_DATA takes the low 24 bits of the packed word: the id) */      \
+            const double r = CODED ? tab[ix[C][k][0] >> 24] : rr[C][k] - mean;                  \
             int b = 0;                                                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
                 _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
@@ -279,6 +287,9 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     LOAD_IDX(0u, 0)
     LOAD_IDX(1u, 1)
     LOAD_DATA(0)
+    // (its load was issued before the ids': it has arrived with them; a wave's LDS operations execute in order, so the reads
+    // below need no wait for this write, and the factorisation's writes none for those reads)
+    if (CODED && lane < BDF_K1_CODES) const_cast<double *>(tab)[lane] = tab_v;
     // trips go in pairs in one straight-line block (a branch between them lets the compiler sink the run-ahead loads to
     // their use); for an odd count the last one is empty: its operands are masked to zero
     for (uint32_t t = 0; t < ntrips; t += 2) {
@@ -303,10 +314,15 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
 // path and other-mode count are wave-uniform.  MATRIX: the kernel variant for launches whose terms are all two-mode
 // relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
 // 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
-template <int DP, bool MATRIX>
+template <int DP, bool MATRIX, bool CODED = false>
 __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
-                                      double (&bred)[Geo<DP>::DB])
+                                      double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
+    if constexpr (CODED) {                   // one two-mode relation, lean gather, coded values (checked by the host)
+        if (a.D == DP) accumulate_lean<DP, 1, true, false, true>(a, it, lane, acc, bred, tab);
+        else accumulate_lean<DP, 1, false, false, true>(a, it, lane, acc, bred, tab);
+        return;
+    }
     const int no = a.t[it.term].n_other;
     if constexpr (DP == 64) {
         if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
@@ -423,9 +439,10 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP, bool MATRIX>
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
 __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
+    double *const tab = tri;          // CODED: the wave's value table (BDF_K1_CODES doubles) sits in the packed factor's space until the factorisation
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, NB = GG::NB, PSZ = GG::PSZ;
     const int j = lane & 15, h = lane >> 4;
@@ -466,7 +483,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
-    } else if (it.count > 0) accumulate_any<DP, MATRIX>(a, it, lane, acc, bv);
+    } else if (it.count > 0) accumulate_any<DP, MATRIX, CODED>(a, it, lane, acc, bv, tab);
     else {
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
@@ -596,15 +613,17 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     STAMP(8);
 }
 
-template <int DP, bool DUMP, bool MATRIX>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES) void k_rows(SampleArgs a, PlanDev p)
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
+void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
     constexpr int WPB = GG::WPB;
     __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
-    if (w < (int64_t)p.n_split + p.n_direct) process_item<DP, DUMP, MATRIX>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+    if (w < (int64_t)p.n_split + p.n_direct)
+        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
 
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
@@ -750,8 +769,10 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
         for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
         static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
         matrix = matrix && !no_matrix;
+        static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
+        const bool coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
         auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
-                         : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>);
+                         : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves

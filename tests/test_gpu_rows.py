@@ -505,6 +505,68 @@ def test_gather_paths_agree(B, ctx, mode):
     np.testing.assert_allclose(outs[mode], outs[""], rtol=1e-12, atol=1e-13)
 
 
+@pytest.mark.parametrize("D,n_values", [(32, 5), (20, 10), (64, 5), (10, 32), (32, 33)])
+def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
+    """a two-mode relation whose values are a few distinct numbers (ratings) takes the row kernel's coded variant -- id and
+    8-bit value code in one word, the value from a table in LDS, seven resident waves at D <= 32; up to 32 distinct values,
+    33 fall back to the plain two-mode variant.  Same arithmetic: the rows equal the uncoded variant's (BDF_K1_NO_CODED, read
+    once per process: a child) to the last bit, and the oracle's to tolerance.  Rows of 0 .. 900 observations: whole rows,
+    ragged last trips, split rows."""
+    import subprocess, sys, textwrap, tempfile
+    code = textwrap.dedent('''
+        import ctypes as C, numpy as np, sys
+        sys.path.insert(0, %r)
+        import bdf_amd as B
+        from bdf_amd._lib import Term, check, lib
+        D, n_values = int(sys.argv[2]), int(sys.argv[3])
+        rng = np.random.default_rng(7 + D)
+        dims = [300, 120]
+        deg = np.minimum((rng.pareto(1.2, dims[0]) * 12).astype(int), 900)
+        deg[:3] = [0, 1, 900]
+        rows = np.repeat(np.arange(1, dims[0] + 1), deg)
+        ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
+        table = np.sort(rng.choice(np.arange(-20, 60) * 0.25, n_values, replace=False))
+        vals = table[rng.integers(0, n_values, len(rows))]
+        vals[:n_values] = table                              # every value occurs
+        ctx = B.Context(seed=11)
+        dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+        ft = [ctx.tensor(rng.standard_normal((d, D)) * 0.4) for d in dims]
+        A = rng.standard_normal((D, D)); Lam = ctx.tensor(A @ A.T / D + np.eye(D)); mu = ctx.tensor(rng.standard_normal(D))
+        outs = []
+        for mode in (0, 1):
+            terms = (Term * 1)()
+            terms[0].rel = dr.handle; terms[0].mode = mode; terms[0].alpha = 1.3; terms[0].mean_value = float(vals.mean())
+            terms[0].factors[1 - mode] = ft[1 - mode].data_ptr()
+            out = ctx.zeros(dims[mode], D)
+            ctx.set_sweep(2)
+            p = lambda t: C.c_void_p(t.data_ptr())
+            check(lib().bdf_sample_rows(ctx.handle, D, dims[mode], 1, terms, p(mu), 0, p(Lam), 1 + mode, 0, 1, p(out), None))
+            ctx.sync()
+            outs.append(out.cpu().numpy())
+        np.savez(sys.argv[1], u=outs[0], v=outs[1], ids=ids, vals=vals, f0=ft[0].cpu().numpy(), f1=ft[1].cpu().numpy(),
+                 Lam=Lam.cpu().numpy(), mu=mu.cpu().numpy())
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for no_coded in (False, True):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npz")
+            env = dict(os.environ)
+            env.pop("BDF_K1_NO_CODED", None); env.pop("BDF_NO_CODES", None)
+            if no_coded:
+                env["BDF_K1_NO_CODED"] = "1"
+            subprocess.run([sys.executable, "-c", code, f, str(D), str(n_values)], check=True, env=env, timeout=300)
+            got[no_coded] = dict(np.load(f))
+    for k in ("u", "v"):
+        assert np.array_equal(got[False][k], got[True][k]), k
+    g = got[False]
+    dims = [300, 120]
+    idx = O.index_build(g["ids"], dims)
+    for mode, key in ((0, "u"), (1, "v")):
+        t = O.Term(g["ids"], g["vals"], dims, mode, 1.3, float(g["vals"].mean()), [None if k == mode else g["f%d" % k] for k in (0, 1)], index=idx)
+        exp = O.sample_rows(D, dims[mode], [t], g["mu"], g["Lam"], 11, 2, 1 + mode)
+        np.testing.assert_allclose(g[key], exp, rtol=1e-7, atol=1e-9)
+
+
 @pytest.mark.parametrize("D,mode", [(12, 0), (32, 1), (32, 0), (10, 1), (4, 0)])
 def test_sorted_pairs_keep_the_callers_order(B, O, ctx, D, mode):
     """bdf_pairs_sort: same predictions, running means and statistics as the unsorted pairs, in the caller's order (D a

@@ -359,10 +359,12 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
     for k, v in hot.items():
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256 and v.get("VGPRs Spill".split(" ")[0], 0) >= 0, (k, v)
     occ = {k: v["Occupancy"] for k, v in hot.items()}
-    assert occ["_ZN12_GLOBAL__N_16k_rowsILi32ELb0ELb1EEEv10SampleArgsNS_7PlanDevE"] >= 6       # two-mode variant, D <= 32
-    assert occ["_ZN12_GLOBAL__N_16k_rowsILi32ELb0ELb0EEEv10SampleArgsNS_7PlanDevE"] >= 5
-    assert occ["_ZN12_GLOBAL__N_16k_rowsILi64ELb0ELb1EEEv10SampleArgsNS_7PlanDevE"] >= 2
-    assert occ["_ZN12_GLOBAL__N_16k_rowsILi16ELb0ELb1EEEv10SampleArgsNS_7PlanDevE"] >= 8
+    k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dEEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values>
+    assert occ[k % (32, 1, 1)] >= 7       # one two-mode relation with coded values (ratings), D <= 32: the bench's kernel
+    assert occ[k % (32, 1, 0)] >= 6       # two-mode variant, D <= 32
+    assert occ[k % (32, 0, 0)] >= 5
+    assert occ[k % (64, 1, 0)] >= 2
+    assert occ[k % (16, 1, 0)] >= 8
 
 
 def test_synth_ratings_is_counter_based(B):
