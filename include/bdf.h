@@ -125,6 +125,8 @@ int bdf_index_build(int n_modes, const int64_t *dims, int64_t nnz, const void *i
 /* ids: nnz x n_modes column-major, 1-based, id_bytes = 4 (Int32) or 8 (Int64); values: nnz.
  * Builds, per mode, the adjacency index in ORIGINAL COO order (bit-exact with
  * IndexedDF.index) and its device CSR.  Errors: BDF_ERR_BOUNDS for an id outside 1..dims. */
+/* (A two-mode relation whose values are at most 256 distinct numbers -- ratings -- is also kept as 8-bit value codes packed
+ * with the other mode's id, 4 bytes per observation and mode: the row kernel's coded variant, bit-identical results.) */
 int bdf_relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64_t nnz,
                         const void *ids, int id_bytes, const double *values, bdf_rel **out);
 int bdf_relation_destroy(bdf_rel *rel);
