@@ -394,8 +394,11 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         }
         if (!ok) table.clear();
     }
-    auto code_of = [&](double v) -> uint32_t { return (uint32_t)(std::lower_bound(table.begin(), table.end(), v) - table.begin()); };
+    std::vector<uint8_t> code_by_row;                                         // code of every observation, in table (COO) order
     if (!table.empty()) {
+        code_by_row.resize((size_t)nnz);
+        for (int64_t i = 0; i < nnz; i++)
+            code_by_row[(size_t)i] = (uint8_t)(std::lower_bound(table.begin(), table.end(), values[i]) - table.begin());
         std::vector<double> t256(256, 0.0);
         std::copy(table.begin(), table.end(), t256.begin());
         int rct = upload(ctx, t256, &r->table_dev);
@@ -445,7 +448,7 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
             if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
             if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
                 std::vector<uint32_t> packed((size_t)nnz);
-                for (int64_t q = 0; q < nnz; q++) packed[(size_t)q] = (code_of(vals[(size_t)q]) << 24) | (uint32_t)colidx[(size_t)q];
+                for (int64_t q = 0; q < nnz; q++) packed[(size_t)q] = ((uint32_t)code_by_row[(size_t)perm[(size_t)q]] << 24) | (uint32_t)colidx[(size_t)q];
                 if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
             }
             ix.own_nnz = nnz;
@@ -498,7 +501,7 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
         if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
             std::vector<uint32_t> packed((size_t)on);
-            for (int64_t q = 0; q < on; q++) packed[(size_t)q] = (code_of(vals[(size_t)q]) << 24) | (uint32_t)colidx[(size_t)q];
+            for (int64_t q = 0; q < on; q++) packed[(size_t)q] = ((uint32_t)code_by_row[(size_t)perm[(size_t)q]] << 24) | (uint32_t)colidx[(size_t)q];
             if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
         }
     }
