@@ -81,9 +81,11 @@ def cpu_baseline(rd, D, seed, budget_s=12.0):
 def pin_to_quiet_core(share, shares):
     """The host thread that enqueues the sweeps runs ~15 HIP calls per 100 us sweep: 40 us when it stays on one quiet core, 60 us
     when the scheduler moves it about, 80-90 us when it ends up away from the memory the runtime's queues live in -- and then the
-    sweep is host-bound (8.9k instead of 10k sweeps/s on the same GPU; tools/numa_probe.sh).  Pin the process to the core
-    that was idlest over the last 100 ms (its SMT sibling counted), among this rank's share of the allowed cores.
-    -> (core, previous affinity) or (None, None); BDF_BENCH_PIN=0 turns it off."""
+    sweep is host-bound (8.9k instead of 10k sweeps/s on the same GPU; tools/numa_probe.sh).  Pin the process to the block of
+    four neighbouring cores that was idlest over the last 100 ms (SMT siblings counted) -- one for the enqueueing thread, the
+    others for the runtime's own threads: pinned to ONE core they share it with the enqueueing thread and 4 runs in 10 are
+    host-bound; with four, none of 12 was.  -> (first core, previous affinity) or (None, None); BDF_BENCH_PIN=0 turns it off,
+    BDF_BENCH_PIN_CORES sets the width."""
     if os.environ.get("BDF_BENCH_PIN", "1") == "0" or not hasattr(os, "sched_setaffinity"):
         return None, None
     try:
@@ -111,8 +113,19 @@ def pin_to_quiet_core(share, shares):
             except Exception:
                 return []
 
-        core = min(mine, key=lambda c: (busy.get(c, 0) + sum(busy.get(x, 0) for x in sibling(c)), c))
-        os.sched_setaffinity(0, {core})
+        load = lambda c: busy.get(c, 0) + sum(busy.get(x, 0) for x in sibling(c))
+        width = int(os.environ.get("BDF_BENCH_PIN_CORES", "4"))
+        if width <= 1:
+            core = min(mine, key=lambda c: (load(c), c))
+            os.sched_setaffinity(0, {core})
+            return core, set(allowed)
+        # a block of `width` neighbouring cores (one for the enqueueing thread, the others for the runtime's own threads)
+        aset = set(allowed)
+        starts = [c for c in mine if all((c + k) in aset for k in range(width))]
+        if not starts:
+            return None, None
+        core = min(starts, key=lambda c: (sum(load(c + k) for k in range(width)), c))
+        os.sched_setaffinity(0, {core + k for k in range(width)})
         return core, set(allowed)
     except Exception:
         return None, None
