@@ -40,6 +40,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     bdf_ctx *c = new bdf_ctx();
     c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
+    c->hyper_chain = false; c->hyper_count = nullptr;
     c->own_stream = false; c->stream = nullptr;
     struct Guard { bdf_ctx *c; ~Guard() { if (c) bdf_ctx_destroy(c); } } guard{c};        // error paths free what was allocated
     c->device = device;
@@ -60,6 +61,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->skip_flag = nullptr;
     c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
+    c->hyper_chain = false; c->hyper_count = nullptr;
     c->cg_gen = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
@@ -88,6 +90,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
+    if (ctx->hyper_count) hipFree(ctx->hyper_count);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;

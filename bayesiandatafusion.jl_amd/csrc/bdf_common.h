@@ -58,6 +58,9 @@ struct bdf_ctx {
     // bdf_gibbs_sweep: the next bdf_hyper_sums leaves its second stage to the bdf_hyper_sample that follows it on this context
     bool hyper_fuse;
     const double *hyper_partial; int hyper_nblocks; double *hyper_sumU, *hyper_UUt;
+    bool hyper_chain;                   // ... and launches nothing itself: the draw's launch carries the sums' workgroups (k_hyper_chain)
+    int hyper_chain_D; int64_t hyper_chain_N, hyper_chain_rpb; const double *hyper_chain_sample, *hyper_chain_uhat;
+    unsigned *hyper_count;              // partial workgroups finished (k_hyper_chain), allocated at first use
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
 };

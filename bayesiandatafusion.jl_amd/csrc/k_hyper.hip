@@ -110,13 +110,52 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
     }
 }
 
+// The whole chain of a small entity in ONE launch: workgroups 0 .. nblocks-1 are k_hyper_partial's, the last one is
+// k_hyper_sample's -- dispatched after them (workgroups are dispatched in order), it waits for their count, adds the partials
+// and draws.  One launch and one kernel boundary fewer per entity and iteration than sums -> draw.
+struct ChainArgs {
+    int D; int64_t N, rows_per_block; const double *sample, *uhat; double *partial; unsigned *count; int nblocks;
+};
+template <int DP>
+__global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
+{
+    constexpr int LDS_D = (3 * HGeo<DP>::PSZ > HGeo<DP>::NW_LDS) ? 3 * HGeo<DP>::PSZ : HGeo<DP>::NW_LDS;
+    __shared__ __attribute__((aligned(16))) double lds[LDS_D];
+    __builtin_amdgcn_s_setprio(3);
+    if ((int)blockIdx.x < c.nblocks) {
+        const int64_t r0 = (int64_t)blockIdx.x * c.rows_per_block;
+        const int64_t r1 = r0 + c.rows_per_block < c.N ? r0 + c.rows_per_block : c.N;
+        hyper_partial<DP, 4>(c.D, c.N, c.sample, c.uhat, r0, r1, c.partial + (int64_t)blockIdx.x * HGeo<DP>::PSZ, lds, threadIdx.x);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's write-through stores of the partial have completed
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(c.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    if (threadIdx.x == 0) {
+        int spins = 0;
+        while (__hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c.nblocks) {
+            __builtin_amdgcn_s_sleep(4);
+            if (++spins > (1 << 24)) { atomicOr(a.flag, 16); break; }       // bounded: a bug must not hang the device
+        }
+        __hip_atomic_store(c.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    nw_draw<DP>(a, lds, threadIdx.x, 256);
+    if (a.ready) {
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace
 
 extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *sample, const double *uhat,
                               double *sumU, double *UUt)
 {
     const bool fuse_asked = ctx && ctx->hyper_fuse;       // one call only, whatever happens below
-    if (ctx) { ctx->hyper_fuse = false; ctx->hyper_partial = nullptr; }
+    if (ctx) { ctx->hyper_fuse = false; ctx->hyper_partial = nullptr; ctx->hyper_chain = false; }
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     BDF_REQUIRE(N >= 0, BDF_ERR_ARG, "bdf_hyper_sums: N < 0");
@@ -133,6 +172,14 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     int rc = bdf_scratch(ctx, (size_t)nblocks * psz * sizeof(double), &scratch);
     if (rc) return rc;
     double *part = (double *)scratch;
+    static const bool one_launch = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
+    if (fuse && one_launch) {
+        // left to the bdf_hyper_sample that follows: one launch for the whole chain (k_hyper_chain)
+        ctx->hyper_chain = true;
+        ctx->hyper_chain_D = D; ctx->hyper_chain_N = N; ctx->hyper_chain_rpb = rpb; ctx->hyper_chain_sample = sample; ctx->hyper_chain_uhat = uhat;
+        ctx->hyper_partial = part; ctx->hyper_nblocks = nblocks; ctx->hyper_sumU = sumU; ctx->hyper_UUt = UUt;
+        return BDF_OK;
+    }
     const dim3 fgrid((psz + 15) / 16);
     if (DP == 16) {
         hipExtLaunchKernelGGL(k_hyper_partial<16>, dim3(nblocks), dim3(HS_THREADS), 0, ctx->stream, ctx->time_h_start, nullptr, 0, D, N, rpb, sample, uhat, part);
@@ -215,6 +262,23 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
                     "bdf_hyper_sample: fused sums need the draws made ahead and the sums' own output buffers");
         a.partial = ctx->hyper_partial; a.nblocks = ctx->hyper_nblocks; a.sumU_w = ctx->hyper_sumU; a.UUt_w = ctx->hyper_UUt;
         ctx->hyper_partial = nullptr;
+    }
+    if (ctx->hyper_chain && a.partial) {
+        ctx->hyper_chain = false;
+        if (!ctx->hyper_count) {
+            BDF_HIP(hipMalloc((void **)&ctx->hyper_count, sizeof(unsigned)));
+            BDF_HIP(hipMemsetAsync(ctx->hyper_count, 0, sizeof(unsigned), ctx->stream));
+        }
+        ChainArgs c;
+        c.D = ctx->hyper_chain_D; c.N = ctx->hyper_chain_N; c.rows_per_block = ctx->hyper_chain_rpb; c.sample = ctx->hyper_chain_sample;
+        c.uhat = ctx->hyper_chain_uhat; c.partial = const_cast<double *>(a.partial); c.count = ctx->hyper_count; c.nblocks = a.nblocks;
+        const dim3 grid((unsigned)a.nblocks + 1);
+        if (D <= 16) hipExtLaunchKernelGGL(k_hyper_chain<16>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);
+        else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_chain<32>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);
+        else hipExtLaunchKernelGGL(k_hyper_chain<64>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);
+        ctx->time_h_start = ctx->time_h_stop = nullptr;
+        BDF_HIP(hipGetLastError());
+        return BDF_OK;
     }
     if (D <= 16) hipExtLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
