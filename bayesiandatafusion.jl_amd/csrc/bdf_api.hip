@@ -450,7 +450,7 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
             if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
             if ((rc = upload(ctx, ix.order, &ix.order_dev))) return rc;
             if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
-                std::vector<uint32_t> packed((size_t)nnz);
+                std::vector<uint32_t> packed((size_t)nnz + 1, 0u);          // (+1: the row kernel reads the words in pairs)
                 for (int64_t q = 0; q < nnz; q++) packed[(size_t)q] = ((uint32_t)code_by_row[(size_t)perm[(size_t)q]] << 24) | (uint32_t)colidx[(size_t)q];
                 if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
             }
@@ -503,7 +503,7 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         if ((rc = upload(ctx, vals, &ix.vals_dev))) return rc;
         if ((rc = upload(ctx, perm, &ix.perm_dev))) return rc;
         if (r->n_codes && r->nint[1 - m] < (1 << 24)) {
-            std::vector<uint32_t> packed((size_t)on);
+            std::vector<uint32_t> packed((size_t)on + 1, 0u);
             for (int64_t q = 0; q < on; q++) packed[(size_t)q] = ((uint32_t)code_by_row[(size_t)perm[(size_t)q]] << 24) | (uint32_t)colidx[(size_t)q];
             if ((rc = upload(ctx, packed, &ix.packed_dev))) return rc;
         }

@@ -240,12 +240,22 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     uint32_t ix[2][KS][NO];
     double rr[2][KS];
     double w[2][KS][NO][DB];
+// observation of (trip t, k-step k, lane group h): t * 4 KS + KS h + k -- a lane group's KS observations of a trip are
+// neighbours, so that the coded variant fetches their words with ONE load (the packed array carries a spare word at its end)
+#define OBS(t, k) ((t) * (4 * KS) + KS * h + (k))
 #define LOAD_IDX(t, S)                                                                          \
+    if (CODED && KS == 2) {                                                                     \
+        uint32_t o = OBS(t, 0);                                                                 \
+        o = (o < n ? o : n - 1) * 4u;                                                           \
+        const uint2 pw = *(const uint2 *)(ids[0] + o);                                          \
+        ix[S][0][0] = pw.x; ix[S][KS - 1][0] = pw.y;                                            \
+    } else {                                                                                    \
     _Pragma("unroll") for (int k = 0; k < KS; k++) {                                            \
-        uint32_t o = (t) * (4 * KS) + 4 * k + h;                                                \
+        uint32_t o = OBS(t, k);                                                                 \
         o = (o < n ? o : n - 1) * 4u;                                                           \
         _Pragma("unroll") for (int m = 0; m < NO; m++) ix[S][k][m] = *(const uint32_t *)(ids[m] + o); \
         if (!CODED) rr[S][k] = *(const double *)(vals + 2u * o);                                \
+    }                                                                                           \
     }
 #define LOAD_DATA(S)                                                                            \
     _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
@@ -265,7 +275,7 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
             }                                                                                   \
         if ((t) + 1 >= ntrips || !FULL) {     /* ragged last trip; padded elements when D < DP */ \
             _Pragma("unroll") for (int k = 0; k < KS; k++) {                                    \
-                const bool valid = (t) * (4 * KS) + 4 * k + h < n;                              \
+                const bool valid = OBS(t, k) < n;                                               \
                 _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = (valid && eok[I]) ? w_c[k][I] : 0.0; \
             }                                                                                   \
         }                                                                                       \
@@ -300,6 +310,7 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
 #undef LOAD_IDX
 #undef LOAD_DATA
 #undef TRIP
+#undef OBS
 #pragma unroll
     for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
 #pragma unroll
