@@ -311,6 +311,36 @@ extern "C" int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm)
     return BDF_OK;
 }
 
+// measurement: the rows of one entity and nothing else -- the launch bdf_gibbs_sweep makes for it (same kernel variant, same
+// inputs), without the hyperprior update, the exchange or the prediction update.  The chain's state is not kept consistent.
+extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
+{
+    BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_rows_only: bad argument");
+    bdf_ctx *R = g->rows;
+    auto &E = g->ent[(size_t)entity];
+    const bdf_gibbs_entity &e = E.d;
+    R->sweep_host = sweep;
+    bdf_term terms[BDF_MAX_TERMS];
+    for (int t = 0; t < e.n_terms; t++) {
+        terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
+        terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
+        for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
+        for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
+            const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
+            terms[t].factors[k] = O.d.sample[O.cur];
+        }
+    }
+    const int nxt = (E.cur + 1) % 3;
+    const int nch = e.terms[0].rel->chunks;
+    int rc;
+    for (int c = 0; c < nch; c++)
+        if ((rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
+                                  E.hyper_recorded ? e.prior_pack : nullptr)))
+            return rc;
+    E.cur = nxt;
+    return BDF_OK;
+}
+
 extern "C" int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop)
 {
     BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_time_rows: bad entity");

@@ -268,9 +268,13 @@ def main():
         torch.cuda.synchronize()
         n_alone = 200
         ta = time.perf_counter()
+        from bdf_amd._lib import check as _check, lib as _lib
         for i in range(n_alone):
-            eng.ctx.set_sweep(1_000_000 + i)
-            eng.sample_entity(i % len(eng.ent))
+            if eng.native:          # the launch the sweep makes (same kernel variant), alone
+                _check(_lib().bdf_gibbs_rows_only(eng.gibbs, i % len(eng.ent), 1_000_000 + i))
+            else:
+                eng.ctx.set_sweep(1_000_000 + i)
+                eng.sample_entity(i % len(eng.ent))
         enq_us = 1e6 * (time.perf_counter() - ta) / n_alone
         eng.sync()
         alone_us = 1e6 * (time.perf_counter() - ta) / n_alone

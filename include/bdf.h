@@ -372,6 +372,9 @@ int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm);
 int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase);
 /* which of sample[0..2] holds entity's current rows */
 int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer);
+/* measurement: the row launch of one entity as bdf_gibbs_sweep makes it, and nothing else (no hyperprior update, exchange or
+ * prediction update: the chain's state is not kept consistent) */
+int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep);
 /* measurement: (start, stop) events ride on the dispatch of entity's next row kernel (bdf_ctx_time_next_rows) */
 int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop);
 int bdf_gibbs_sync(bdf_gibbs *g);     /* waits for the three streams; errors as bdf_ctx_sync */

@@ -1,6 +1,8 @@
 """the row kernel alone: N back-to-back launches alternating the two entities on one stream, wall clock per launch (GPU box)"""
 import os, sys, time
-os.environ["BDF_NO_NATIVE"] = "1"; os.environ["BDF_NO_OVERLAP"] = "1"
+NATIVE = os.environ.get("K1_NATIVE", "1") != "0"       # the native engine's row launch (bdf_gibbs_rows_only) or the step-by-step one
+if not NATIVE:
+    os.environ["BDF_NO_NATIVE"] = "1"; os.environ["BDF_NO_OVERLAP"] = "1"
 os.environ.setdefault("BDF_RESERVE_CUS", "0")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import bdf_amd as B
@@ -15,13 +17,19 @@ if os.environ.get("PIECE"):
 for i in range(1, 30):
     eng.sweep(i)
 eng.sync()
+from bdf_amd._lib import check, lib
+def launch(j, sweep):
+    if eng.native:
+        check(lib().bdf_gibbs_rows_only(eng.gibbs, j, sweep))
+    else:
+        eng.ctx.set_sweep(sweep)
+        eng.sample_entity(j)
 best = 1e9
 for rep in range(5):
     n = 400
     t0 = time.perf_counter()
     for i in range(n):
-        eng.ctx.set_sweep(100 + i)
-        eng.sample_entity(i % 2)
+        launch(i % 2, 100 + i)
     eng.sync()
     best = min(best, (time.perf_counter() - t0) / n)
 print(f"K1 alone: {best * 1e6:.2f} us per launch (mean of users' and movies', D={D}, reserve {os.environ['BDF_RESERVE_CUS']})")
@@ -31,8 +39,7 @@ for j, name in enumerate(("users", "movies")):
         n = 300
         t0 = time.perf_counter()
         for i in range(n):
-            eng.ctx.set_sweep(1000 + i)
-            eng.sample_entity(j)
+            launch(j, 1000 + i)
         eng.sync()
         bj = min(bj, (time.perf_counter() - t0) / n)
     print(f"   {name}' launches only: {bj * 1e6:.2f} us")
