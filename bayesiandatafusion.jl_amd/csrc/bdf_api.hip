@@ -430,8 +430,8 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         });
         int rc;
         if (!sharded) {
-            std::vector<int32_t> colidx((size_t)nnz * (size_t)(n_modes - 1));
-            std::vector<double> vals((size_t)nnz);
+            std::vector<int32_t> colidx((size_t)nnz * (size_t)(n_modes - 1) + 1, 0);       // (+1: the row kernel reads ids and values in pairs)
+            std::vector<double> vals((size_t)nnz + 1, 0.0);
             std::vector<int32_t> perm((size_t)nnz);
             for (int64_t q = 0; q < nnz; q++) {
                 int64_t i = ix.rowids[(size_t)q] - 1;
@@ -481,8 +481,8 @@ static int relation_create(bdf_ctx *ctx, int n_modes, const int64_t *dims, int64
         ix.chunk_begin[(size_t)chunks] = (int64_t)ix.own_orig.size();
         const int64_t on = ix.own_q.back();
         ix.own_nnz = on;
-        std::vector<int32_t> colidx((size_t)on * (size_t)(n_modes - 1));
-        std::vector<double> vals((size_t)on);
+        std::vector<int32_t> colidx((size_t)on * (size_t)(n_modes - 1) + 1, 0);
+        std::vector<double> vals((size_t)on + 1, 0.0);
         std::vector<int32_t> perm((size_t)on);
         for (size_t o = 0; o < ix.own_orig.size(); o++) {
             const int64_t row = ix.own_orig[o];

@@ -249,6 +249,13 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
         o = (o < n ? o : n - 1) * 4u;                                                           \
         const uint2 pw = *(const uint2 *)(ids[0] + o);                                          \
         ix[S][0][0] = pw.x; ix[S][KS - 1][0] = pw.y;                                            \
+    } else if (KS == 2 && NO == 1) {          /* the pair's ids and values as one load each (the arrays carry a spare entry) */ \
+        uint32_t o = OBS(t, 0);                                                                 \
+        o = (o < n ? o : n - 1) * 4u;                                                           \
+        const uint2 pi = *(const uint2 *)(ids[0] + o);                                          \
+        const d2 pv = *(const d2 *)(vals + 2u * o);                                             \
+        ix[S][0][0] = pi.x; ix[S][KS - 1][0] = pi.y;                                            \
+        rr[S][0] = pv[0]; rr[S][KS - 1] = pv[1];                                                \
     } else {                                                                                    \
     _Pragma("unroll") for (int k = 0; k < KS; k++) {                                            \
         uint32_t o = OBS(t, k);                                                                 \
