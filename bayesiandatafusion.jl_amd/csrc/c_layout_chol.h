@@ -89,6 +89,35 @@ __device__ __forceinline__ void fm4_self(double &d0, double &d1, double &d2, dou
                  : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3)
                  : "v"(m), "n"(KJ));
 }
+// the last 4 - R0 of a block's four registers (the diagonal block of the step's own block column: register r holds rows
+// 4 r .. 4 r + 3 of the block, those at or above the pivot are finished -- nothing reads them again)
+template <int KJ, int R0>
+__device__ __forceinline__ void fm_self_from(double *t, double m)
+{
+    if constexpr (R0 <= 0) {
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %0, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %3, %3, %4 row_newbcast:%5 row_mask:0xf bank_mask:0xf"
+                     : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "v"(m), "n"(KJ));
+    } else if constexpr (R0 == 1) {
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %0, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %2, %2, %3 row_newbcast:%4 row_mask:0xf bank_mask:0xf"
+                     : "+v"(t[1]), "+v"(t[2]), "+v"(t[3]) : "v"(m), "n"(KJ));
+    } else if constexpr (R0 == 2) {
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %0, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf\n\t"
+                     "v_fmac_f64_dpp %1, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf"
+                     : "+v"(t[2]), "+v"(t[3]) : "v"(m), "n"(KJ));
+    } else {
+        asm volatile("s_nop 1\n\t"
+                     "v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf"
+                     : "+v"(t[3]) : "v"(m), "n"(KJ));
+    }
+}
 template <int KJ>
 __device__ __forceinline__ void fm1(double &d, double s, double m)
 {
@@ -218,7 +247,8 @@ __device__ __forceinline__ void factor_step(double (&A)[Geo<DP>::NB * 4], double
 #pragma unroll
         for (int I = K; I < DB; I++) {
             double *t = &A[GG::blk(I, K) * 4];
-            fm4_self<kj>(t[0], t[1], t[2], t[3], nm[K]);
+            if (I == K) fm_self_from<kj, (kj + 1) / 4>(t, nm[K]);      // the diagonal block: only the registers with rows below the pivot
+            else fm4_self<kj>(t[0], t[1], t[2], t[3], nm[K]);
         }
         fm1_self<kj>(bv[K], nm[K]);
     }
