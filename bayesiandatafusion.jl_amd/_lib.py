@@ -166,6 +166,7 @@ _SIGS = {
     "bdf_gibbs_time_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
     "bdf_gibbs_sync": (C.c_int, [C.c_void_p]),
     "bdf_gibbs_rows_only": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
+    "bdf_gibbs_warm_device": (C.c_int, [C.c_void_p, C.c_double]),
     "bdf_synth_ratings": (C.c_int, [C.c_uint64, C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.c_double, C.c_double, c_i32p, c_i32p,
                                     c_dp, C.c_void_p]),
 }

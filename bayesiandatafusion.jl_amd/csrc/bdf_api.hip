@@ -54,7 +54,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
-    c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr;
+    c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr; c->hyper_ready_value = 0;
     c->warnings = 0;
     c->reserve_cus = 0;
     c->on_reserved = 0;

@@ -76,9 +76,12 @@ static int comm_new(bdf_ctx *ctx, int rank, int world, bdf_comm **out)
     BDF_HIP(hipSetDevice(ctx->device));
     bdf_comm *c = new bdf_comm();
     c->ctx = ctx; c->rank = rank; c->world = world; c->nccl = nullptr; c->cb = nullptr; c->cb_user = nullptr;
+    c->stream = nullptr; c->ev_rows = c->ev_done = nullptr;
+    struct Guard { bdf_comm *c; ~Guard() { if (c) bdf_comm_destroy(c); } } guard{c};      // a failure below releases what exists so far
     BDF_HIP(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     BDF_HIP(hipEventCreateWithFlags(&c->ev_rows, hipEventDisableTiming));
     BDF_HIP(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
+    guard.c = nullptr;
     *out = c;
     return BDF_OK;
 }
@@ -117,10 +120,11 @@ extern "C" int bdf_comm_destroy(bdf_comm *c)
 {
     if (!c) return BDF_OK;
     (void)hipSetDevice(c->ctx->device);
-    (void)hipStreamSynchronize(c->stream);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && g_rccl.destroy) g_rccl.destroy(c->nccl);
-    (void)hipEventDestroy(c->ev_rows); (void)hipEventDestroy(c->ev_done);
-    (void)hipStreamDestroy(c->stream);
+    if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
+    if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
     return BDF_OK;
 }

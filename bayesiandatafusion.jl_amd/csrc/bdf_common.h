@@ -45,7 +45,8 @@ struct bdf_ctx {
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
     const uint32_t *rows_ready;            // (library-internal) SampleArgs::ready of the next row launch, then cleared
     uint32_t rows_ready_want;
-    uint32_t *hyper_ready;                 // (library-internal) flag the next bdf_hyper_sample sets to the sweep number, then cleared
+    uint32_t *hyper_ready;                 // (library-internal) word the next bdf_hyper_sample sets to hyper_ready_value once its pack is written, then cleared
+    uint32_t hyper_ready_value;
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
     // batched CG (k_feat.hip): device flag that lets product kernels enqueued ahead return at once (NULL outside a solve),
     // and the host-mapped words through which the device reports (iteration, active columns)

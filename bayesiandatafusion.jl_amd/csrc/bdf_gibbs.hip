@@ -6,8 +6,12 @@
 //
 // Three HIP streams: rows | hyperpriors | prediction updates.  The hyperprior of entity j runs beside the rows of entity
 // j+1, the prediction update of sweep t beside the rows of sweep t+1 (every entity's rows rotate through three buffers).
-// Hand-overs are HIP events that ride on the producing kernel's own dispatch packet (hipExtLaunchKernelGGL stop events):
-// no marker packets on the row stream, no polling kernels.
+// Hand-overs towards the hyperprior and prediction streams are HIP events that ride on the producing kernel's own dispatch
+// packet (hipExtLaunchKernelGGL stop events): no marker packets on the row stream.  The hand-over BACK to the row stream --
+// (mu, Lambda) of the draw, needed by the entity's next row launch -- is, by default, not an event: the draw runs on CUs
+// the row kernels never occupy (bdf_ctx_create_rows), publishes a per-entity epoch when its prior pack is written, and
+// the row kernel's waves poll that word where they first need the prior (BDF_NO_POLL=1, a profiler that serialises the
+// streams, or several ranks: event waits instead).
 #include "bdf_common.h"
 #include <algorithm>
 #include <chrono>
@@ -23,18 +27,23 @@ struct bdf_gibbs {
     struct Ent {
         bdf_gibbs_entity d;
         int cur;                         // buffer holding the current rows
-        hipEvent_t ev_rows, ev_hyper;    // rows of this sweep complete (and exchanged) | (mu, Lambda) of this sweep complete
-        bool hyper_recorded;
-        uint32_t hyper_sweep;            // iteration number of the last hyperprior draw enqueued for this entity
-        hipEvent_t t_start, t_stop;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
+        hipEvent_t ev_rows = nullptr, ev_hyper = nullptr;    // rows of this sweep complete (and exchanged) | (mu, Lambda) of this sweep complete
+        bool hyper_recorded = false;
+        // number of hyperprior draws enqueued for this entity so far: the value its next draw publishes in ready_dev and the
+        // entity's next row launch polls for.  Private and strictly increasing -- NOT the caller's sweep number, which may
+        // repeat or restart (a repeated number would let the poll pass while the draw is still writing the pack)
+        uint32_t epoch = 0;
+        hipEvent_t t_start = nullptr, t_stop = nullptr;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
     };
     std::vector<Ent> ent;
     bdf_pairs *test;
     int32_t test_entity[BDF_MAX_MODES];
     double test_mean, clamp_lo, clamp_hi, class_cut;
     double *stats_dev;
-    hipEvent_t ev_pred[3];               // prediction update of iteration k complete: ev_pred[k % 3]
+    hipEvent_t ev_pred[3] = {nullptr, nullptr, nullptr};   // prediction update number k complete: ev_pred[k % 3]
+    uint64_t pred_at[3] = {0, 0, 0};     // ... and the iteration count (n_iter) at which it was enqueued
     uint64_t n_pred;                     // prediction updates enqueued so far
+    uint64_t n_iter = 0;                 // iterations enqueued so far (with or without a prediction update)
     bdf_comm *comm;                      // nullable: exchange of the sampled rows between the ranks after every entity
     // The row stream has NO wait for the hyperprior draws when they run on reserved CUs (bdf_ctx_create_rows): a draw there
     // cannot be starved by the chip-filling row kernel, so the row kernel is enqueued right behind its predecessor (back-to-back
@@ -76,6 +85,7 @@ int streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
 {
     uint32_t *d;
     BDF_HIP(hipMalloc((void **)&d, 2 * sizeof(uint32_t)));
+    struct Free { uint32_t *p; ~Free() { (void)hipFree(p); } } guard{d};
     BDF_HIP(hipMemset(d, 0, 2 * sizeof(uint32_t)));
     BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
     hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, a, (const uint32_t *)d, 2000000LL, d + 1);
@@ -83,7 +93,6 @@ int streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
     BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
     uint32_t h[2] = {0, 0};
     BDF_HIP(hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost));
-    BDF_HIP(hipFree(d));
     *yes = h[1] == 0;
     return BDF_OK;
 }
@@ -246,16 +255,19 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     if (g->debug)
         fprintf(stderr, "[bdf_gibbs] reserve_cus=%d hyperprior stream on reserved CUs=%d polling=%d\n", rows_ctx->reserve_cus,
                 g->hyper->on_reserved, (int)g->polling);
+    // (every event starts out NULL and bdf_gibbs_destroy skips those: a failure below releases what exists so far)
+    struct Guard { bdf_gibbs *g; ~Guard() { if (g) bdf_gibbs_destroy(g); } } guard{g};
     BDF_HIP(hipMalloc((void **)&g->ready_dev, (size_t)n_entities * sizeof(uint32_t)));
     BDF_HIP(hipMemset(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t)));
     g->ent.resize((size_t)n_entities);
     for (int j = 0; j < n_entities; j++) {
         auto &E = g->ent[(size_t)j];
-        E.d = ents[j]; E.cur = 0; E.hyper_recorded = false; E.hyper_sweep = 0; E.t_start = E.t_stop = nullptr;
+        E.d = ents[j]; E.cur = 0;
         BDF_HIP(hipEventCreate(&E.ev_rows));          // (they ride on dispatch packets: plain events)
         BDF_HIP(hipEventCreate(&E.ev_hyper));
     }
     for (int k = 0; k < 3; k++) BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[k], hipEventDisableTiming));
+    guard.g = nullptr;
     *out = g;
     return BDF_OK;
 }
@@ -267,8 +279,12 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
     if (g->debug && g->n_sweeps)
         fprintf(stderr, "[bdf_gibbs] %llu sweeps: host enqueue %.1f us per sweep, host wait for the device %.1f us per sweep\n",
                 (unsigned long long)g->n_sweeps, g->host_enqueue_us / (double)g->n_sweeps, g->host_wait_us / (double)g->n_sweeps);
-    for (auto &E : g->ent) { (void)hipEventDestroy(E.ev_rows); (void)hipEventDestroy(E.ev_hyper); }
-    if (!g->ent.empty()) for (int k = 0; k < 3; k++) (void)hipEventDestroy(g->ev_pred[k]);
+    for (auto &E : g->ent) {
+        if (E.ev_rows) (void)hipEventDestroy(E.ev_rows);
+        if (E.ev_hyper) (void)hipEventDestroy(E.ev_hyper);
+    }
+    for (int k = 0; k < 3; k++)
+        if (g->ev_pred[k]) (void)hipEventDestroy(g->ev_pred[k]);
     if (g->ready_dev) (void)hipFree(g->ready_dev);
     if (g->pred) bdf_ctx_destroy(g->pred);
     if (g->hyper) bdf_ctx_destroy(g->hyper);
@@ -341,6 +357,44 @@ extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
     return BDF_OK;
 }
 
+// set-up: bring the device to its working state (clocks, power gating: a row launch right after idle time runs ~10 % slower
+// than the same launch 30 ms into sustained work) with untimed row launches that do NOT advance the chain -- every entity's
+// row kernel in turn, as bdf_gibbs_sweep makes it, written into the entity's NEXT buffer (which the next real iteration
+// overwrites in full) without rotating the buffers, random streams of iteration numbers no real iteration uses.
+extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
+{
+    BDF_REQUIRE(g && milliseconds >= 0.0 && milliseconds <= 10000.0, BDF_ERR_ARG, "bdf_gibbs_warm_device: bad argument");
+    bdf_ctx *R = g->rows;
+    const uint32_t keep = R->sweep_host;
+    const auto t0 = std::chrono::steady_clock::now();
+    int rc = BDF_OK;
+    uint32_t i = 0;
+    while (!rc && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < milliseconds) {
+        for (int batch = 0; batch < 8 && !rc; batch++, i++) {
+            auto &E = g->ent[(size_t)(i % g->ent.size())];
+            const bdf_gibbs_entity &e = E.d;
+            R->sweep_host = 0xffff0000u + (i & 0xffffu);
+            bdf_term terms[BDF_MAX_TERMS];
+            for (int t = 0; t < e.n_terms; t++) {
+                terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
+                terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
+                for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
+                for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
+                    const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
+                    terms[t].factors[k] = O.d.sample[O.cur];
+                }
+            }
+            const int nch = e.terms[0].rel->chunks;
+            for (int c = 0; c < nch && !rc; c++)
+                rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[(E.cur + 1) % 3],
+                                     E.hyper_recorded ? e.prior_pack : nullptr);
+        }
+        if (!rc && hipStreamSynchronize(R->stream) != hipSuccess) { bdf_set_error("bdf_gibbs_warm_device: stream synchronisation failed"); rc = BDF_ERR_HIP; }
+    }
+    R->sweep_host = keep;
+    return rc;
+}
+
 extern "C" int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop)
 {
     BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_time_rows: bad entity");
@@ -368,8 +422,13 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     // device then needs no wait for the prediction stream anywhere, and the host never runs more than two prediction updates
     // ahead.  (A device-side wait would let row kernels that poll for their prior fill the chip while the prediction kernel
     // they transitively wait for still needs slots for its last workgroups.)
+    // (Whether or not THIS iteration has a prediction update: an update enqueued two or more iterations ago must have
+    // completed -- iterations without one rotate the buffers all the same.)
     const auto t_in = std::chrono::steady_clock::now();
-    if (g->test && predict_phase >= 0 && g->n_pred >= 2) BDF_HIP(hipEventSynchronize(g->ev_pred[(g->n_pred - 2) % 3]));
+    for (uint64_t back = 1; back <= std::min<uint64_t>(g->n_pred, 3); back++) {
+        const uint64_t k = (g->n_pred - back) % 3;
+        if (g->pred_at[k] + 2 <= g->n_iter) { BDF_HIP(hipEventSynchronize(g->ev_pred[k])); break; }      // (and with it the earlier ones)
+    }
     const auto t_go = std::chrono::steady_clock::now();
     if (n <= BDF_DRAWS_BATCH) {
         int64_t Ns[BDF_DRAWS_BATCH]; double nus[BDF_DRAWS_BATCH]; uint32_t tags[BDF_DRAWS_BATCH]; double *outs[BDF_DRAWS_BATCH];
@@ -405,7 +464,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         for (int c = 0; c < nch; c++) {
             R->time_start = (c == 0) ? E.t_start : nullptr;
             R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
-            if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.hyper_sweep; }
+            if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.epoch; }
             if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
                                       E.hyper_recorded ? e.prior_pack : nullptr)))
                 return rc;
@@ -423,7 +482,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], nullptr, e.sumU, e.UUt))) return rc;
         H->time_h_stop = E.ev_hyper;
         H->hyper_ready = g->ready_dev + j;
-        E.hyper_sweep = sweep;
+        H->hyper_ready_value = ++E.epoch;
         if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, e.WI, e.nu0, e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
             return rc;
         E.hyper_recorded = true;
@@ -438,8 +497,10 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         if ((rc = bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
             return rc;
         BDF_HIP(hipEventRecord(g->ev_pred[g->n_pred % 3], P->stream));
+        g->pred_at[g->n_pred % 3] = g->n_iter;
         g->n_pred++;
     }
+    g->n_iter++;
     if (g->debug) {
         g->host_wait_us += std::chrono::duration<double, std::micro>(t_go - t_in).count();
         g->host_enqueue_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_go).count();

@@ -32,8 +32,8 @@ struct NWArgs {
     const double *draws;       // Bartlett matrix (D x D row-major) + D mean normals, from k_hyper_draws
     double *pack_out;          // nullable: Lambda mu (D) then the accumulator-layout image of the reversed Lambda (K1)
     int *flag;
-    uint32_t *ready;           // nullable: set to `sweep` once the pack is written (row kernels that poll instead of waiting)
-    uint32_t sweep;
+    uint32_t *ready;           // nullable: set to `ready_value` once the pack is written (row kernels that poll instead of waiting)
+    uint32_t ready_value;
     // nullable: the sums' partials (k_hyper_partial, at most 16 of them) -- the draw then adds them itself, in k_hyper_final's
     // order, into sumU_w / UUt_w (== sumU / UUt) before it starts: one launch fewer per entity and sweep
     const double *partial;

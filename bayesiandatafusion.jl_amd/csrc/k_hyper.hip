@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
     if (a.ready) {                      // the pack (write-through stores) is complete: publish
         __threadfence();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.ready_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     if (a.ready) {
         __threadfence();
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.sweep, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(a.ready, a.ready_value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -253,7 +253,7 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.D = D; a.N = (double)N; a.sumU = sumU; a.UUt = UUt; a.mu0 = mu0; a.Tinv = Tinv; a.b0 = b0; a.nu = nu;
     a.mu_out = mu_out; a.Lambda_out = Lambda_out; a.params_out = params_out; a.pack_out = prior_pack_out; a.draws = draws;
     a.flag = ctx->flag_dev;
-    a.ready = ctx->hyper_ready; a.sweep = ctx->sweep_host;
+    a.ready = ctx->hyper_ready; a.ready_value = ctx->hyper_ready_value;
     ctx->hyper_ready = nullptr;
     a.partial = nullptr; a.nblocks = 0; a.sumU_w = a.UUt_w = nullptr;
     if (ctx->hyper_partial) {

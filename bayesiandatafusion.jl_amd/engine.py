@@ -627,6 +627,12 @@ class GibbsEngine:
             self.comm = make_comm(self.ctx, self.rank, self.world)
             check(lib().bdf_gibbs_set_comm(self.gibbs, self.comm.handle))
 
+    def warm_device(self, milliseconds=50.0):
+        """set-up (native iteration): untimed row launches that do not advance the chain, to bring the device out of its idle
+        power state before the first iteration (bdf_gibbs_warm_device); a no-op on the step-by-step path"""
+        if self.gibbs and milliseconds > 0:
+            check(lib().bdf_gibbs_warm_device(self.gibbs, float(milliseconds)))
+
     def set_alpha(self):
         """(native iteration) the relations' precisions are launch arguments held by the bdf_gibbs object: rebuild it after
         setPrecision! on an initialised model"""

@@ -158,6 +158,9 @@ def main():
                     help="time the K1 launches of every n-th step (HIP events attached to the kernel dispatch)")
     ap.add_argument("--k1-min-launches", type=int, default=200, help="K1 launches averaged for the roofline (further sweeps after the timed region)")
     ap.add_argument("--replicas", type=int, default=0, help="user blocks of the workload (default: one per GPU)")
+    ap.add_argument("--device-warmup-ms", type=float, default=60.0,
+                    help="engine set-up: untimed row launches that do not advance the chain, before the first warm-up step "
+                         "(brings the device out of its idle power state; 0 = none)")
     ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
     ap.add_argument("--c4-rows", type=int, default=10_000_000)
     ap.add_argument("--c4-cols", type=int, default=1_000_000)
@@ -226,18 +229,29 @@ def main():
     test = eng.test_pairs(subset=my_share(n_test_total) if world > 1 else None)
     clamp = [1.0, 5.0]
 
+    # set-up, not a step: the device leaves its idle power state (a launch right after idle time runs ~10 % slower than the
+    # same launch 30 ms into sustained work, tools/region_pace.py); nothing of the chain advances
+    eng.warm_device(args.device_warmup_ms)
     for i in range(1, args.warmup + 1):
         eng.step(i, 0, clamp, rel.class_cut)
     eng.sync()
     fence()
-    eng.k1_events = []
-    eng.k1_event_every = max(1, min(args.k1_event_every, args.steps // 4))     # a short run still times a few launches
+    # the timed region: exactly --steps iterations, nothing else (the K1 launch timers are attached to sweeps AFTER it)
+    eng.k1_events = None
+    stamps = [] if os.environ.get("BDF_BENCH_DEBUG") else None
     t0 = time.perf_counter()
     for k in range(args.steps):
         eng.step(args.warmup + 1 + k, 1 if k == 0 else 2, clamp, rel.class_cut)
+        if stamps is not None:
+            stamps.append(time.perf_counter())
+    t_enq = time.perf_counter()
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
     eng.sync()
+    if stamps is not None:
+        per = [round(1e6 * (b - a), 1) for a, b in zip([t0] + stamps[:-1], stamps)]
+        print(f"[bench] timed region: enqueue per step (us) {per}; enqueue total {1e6 * (t_enq - t0):.0f} us, "
+              f"final wait {1e6 * (t0 + elapsed - t_enq):.0f} us", file=sys.stderr)
     rmse = None
     sse = test.stats[:1].clone().to(red_dev if dist is not None else "cuda")
     if dist is not None:
@@ -245,7 +259,7 @@ def main():
     rmse = float(np.sqrt(float(sse.item()) / n_test_total))
 
     # K1 roofline: the launches timed inside the timed region, then further sweeps (every launch timed) up to the minimum
-    in_region = len(eng.k1_events)
+    eng.k1_events = []
     eng.k1_event_every = 1
     it = args.warmup + args.steps
     while len(eng.k1_events) < args.k1_min_launches and it < args.warmup + args.steps + 2000:
@@ -255,7 +269,6 @@ def main():
     k1_ms = sum(t.elapsed_us() for (_, t) in eng.k1_events) / 1e3
     k1_bytes = sum(eng.k1_algorithmic_bytes(j) for (j, _) in eng.k1_events) / max(world, 1)
     n_launch = max(len(eng.k1_events), 1)
-    k1_ms_region = sum(t.elapsed_us() for (_, t) in eng.k1_events[:in_region]) / 1e3
     achieved = (k1_bytes / 1e9) / (k1_ms / 1e3) if k1_ms > 0 else 0.0
     eng.k1_events = None
     traffic, traffic_source = recorded_traffic() if (world == 1 and replicas == 1 and D == 32) else (None, None)
@@ -304,6 +317,7 @@ def main():
                                       f"value = {replicas} x sweeps/s" if replicas > 1 else ""),
                        "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
                        "host_core": host_core,
+                       "device_warmup_ms": args.device_warmup_ms if eng.gibbs else 0.0,
                        "parallelism": (f"rows of each entity shared out over {world} GPUs (a rank holds its rows' observations only), "
                                        f"in-place RCCL all-gather of the sampled rows per half-sweep, test ratings split over the ranks")
                        if world > 1 else "1 GPU"},
@@ -311,9 +325,7 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_rows (k_sample_rows.hip)", "launches_timed": n_launch,
-                         "launches_timed_in_region": in_region,
                          "avg_launch_us": round(1e3 * k1_ms / n_launch, 2),
-                         "avg_launch_us_in_region": round(1e3 * k1_ms_region / max(in_region, 1), 2),
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch),
                          "avg_launch_us_alone": None if alone_us is None else round(alone_us, 2),
                          "frac_alone": None if alone_us is None else round((k1_bytes / n_launch / 1e9) / (alone_us / 1e6) / HBM_PEAK_GBS, 4)},

@@ -340,8 +340,10 @@ int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *comm);
 
 /* ---- a2: one Gibbs iteration enqueued from native code (src/macau.jl:80-203 without side information) ---------------------
  * rows of every entity (+ exchange) -> hyperpriors -> test-set prediction update, on three streams (rows: ctx's; the other
- * two are created here, chosen so that they really run beside it), hand-overs by events on the kernels' own dispatch
- * packets.  The host pays one call per iteration. */
+ * two are created here, chosen so that they really run beside it).  Hand-overs: events on the kernels' own dispatch
+ * packets; and -- when ctx came from bdf_ctx_create_rows with CUs set aside, one rank, BDF_NO_POLL unset -- the row kernels
+ * poll a per-entity word the hyperprior draw publishes instead of the row stream waiting for the draw's event.
+ * The host pays one call per iteration.  `sweep` numbers key the random streams only: they need not increase. */
 typedef struct {
     int64_t N;                    /* rows of the factor matrix (the entity's count; chunks * world * cmax with a layout)   */
     int64_t n_real;               /* the entity's count (N of ConditionalNormalWishart, src/sampling.jl:117)             */
@@ -375,6 +377,9 @@ int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer);
 /* measurement: the row launch of one entity as bdf_gibbs_sweep makes it, and nothing else (no hyperprior update, exchange or
  * prediction update: the chain's state is not kept consistent) */
 int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep);
+/* set-up: untimed row launches for about `milliseconds` that do not advance the chain (written to every entity's next
+ * buffer, which the next iteration overwrites; buffers not rotated): brings the device out of its idle power state */
+int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds);
 /* measurement: (start, stop) events ride on the dispatch of entity's next row kernel (bdf_ctx_time_next_rows) */
 int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop);
 int bdf_gibbs_sync(bdf_gibbs *g);     /* waits for the three streams; errors as bdf_ctx_sync */
