@@ -167,7 +167,22 @@ def main():
     ap.add_argument("--c4-nnz", type=int, default=100_000_000)
     ap.add_argument("--c4-latent", type=int, default=64)
     ap.add_argument("--c4-sweeps", type=int, default=5, help="warm-up and timed sweeps of the C4 measurement (5 + 5: SURVEY M-C4)")
+    ap.add_argument("--rendezvous-only", action="store_true",
+                    help="test hook: every rank joins the process group, all-reduces its rank, rank 0 prints it; no GPU is touched")
     args = ap.parse_args()
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` as typed: start the N ranks ourselves -- one process per GPU through torch's launcher, as
+        # a CHILD process (nothing in this process has touched the GPU runtime yet, and nothing will) -- and relay its output
+        # and exit code.  The form `python -m torch.distributed.run ... bench.py --gpus N` keeps working: it sets WORLD_SIZE.
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -179,13 +194,21 @@ def main():
 
     import numpy as np
     import torch
-    import bdf_amd as B
-    from bdf_amd import datasets
 
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py --gpus N ...")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.rendezvous_only:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"rendezvous": world, "rank_sum": float(t.item())}), flush=True)
+        dist.destroy_process_group()
+        return
+    import bdf_amd as B
+    from bdf_amd import datasets
     # test rig: BDF_DIST_BACKEND=gloo runs all ranks on GPU 0 with the exchange staged through the host (RCCL needs one
     # GPU per rank); it checks the N > 1 logic on a 1-GPU box, its timings mean nothing
     backend = os.environ.get("BDF_DIST_BACKEND", "nccl")

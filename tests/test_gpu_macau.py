@@ -365,10 +365,10 @@ def test_two_ranks_match_one(B):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, BDF_DIST_BACKEND="gloo")
-    port = str(29600 + os.getpid() % 300)
-    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                          "--master-port", port, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BDF_DIST_BACKEND"] = "gloo"
+    # `python bench.py --gpus 2` as typed: bench.py starts its two ranks itself (torch's launcher, as a child process)
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6",
                           "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]

@@ -386,3 +386,19 @@ def test_synth_ratings_is_counter_based(B):
     rd = datasets.c4_relation_data(B, 5_000, 400, 40_000)
     rel = rd.relations[0]
     assert B.numData(rel) + B.numTest(rel) == 40_000 and rel.data.ids.dtype == np.int32 and rel.model.alpha == 2.0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (WORLD_SIZE unset) starts two ranks through torch's launcher before anything
+    touches the GPU runtime and relays rank 0's line (--rendezvous-only: the ranks meet over gloo and stop there)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["BDF_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--rendezvous-only"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d == {"rendezvous": 2, "rank_sum": 1.0}
