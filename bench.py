@@ -131,17 +131,42 @@ def pin_to_quiet_core(share, shares):
         return None, None
 
 
+TRAFFIC_JSON = "profiles/r03_hbm_traffic.json"
+
+
+def k1_source_sha1():
+    """sha1 over the row kernel's source AND every local header it includes, transitively (k_sample_rows.hip, bdf_common.h,
+    wave_linalg.h, c_layout_chol.h, include/bdf.h, ...): the identity of the code the PMC passes profiled"""
+    import re
+    csrc = os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc")
+    seen, todo = {}, [os.path.join(csrc, "k_sample_rows.hip")]
+    while todo:
+        f = os.path.normpath(todo.pop())
+        if f in seen:
+            continue
+        seen[f] = open(f, "rb").read()
+        for inc in re.findall(rb'^\s*#\s*include\s+"([^"]+)"', seen[f], flags=re.M):
+            for base in (os.path.dirname(f), csrc, os.path.join(ROOT, "include")):
+                cand = os.path.join(base, inc.decode())
+                if os.path.exists(cand):
+                    todo.append(cand)
+                    break
+    h = hashlib.sha1()
+    for f in sorted(seen):
+        h.update(os.path.relpath(f, ROOT).encode() + b"\0" + seen[f])
+    return h.hexdigest()
+
+
 def recorded_traffic():
     """HBM bytes of one K1 launch from the committed PMC passes (tools/profile_round.sh: FETCH_SIZE and WRITE_SIZE in
     separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950) -- NOT measured by this run: returned
-    only while the row kernel's source is the one the passes ran on, with the file named next to it."""
-    tj = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")
+    only while the row kernel's source (with every header it includes) is the one the passes ran on, with the file named
+    next to it."""
     try:
-        d = json.load(open(tj))
-        src = open(os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc", "k_sample_rows.hip"), "rb").read()
-        if d.get("k_sample_rows_sha1") != hashlib.sha1(src).hexdigest():
+        d = json.load(open(os.path.join(ROOT, TRAFFIC_JSON)))
+        if d.get("k1_source_sha1") != k1_source_sha1():
             return None, None
-        return d["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"], "profiles/r02_hbm_traffic.json (rocprofv3 --pmc passes of this workload on this kernel source; not measured by this run)"
+        return d["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"], TRAFFIC_JSON + " (rocprofv3 --pmc passes of this workload on this kernel source; not measured by this run)"
     except (OSError, KeyError, ValueError):
         return None, None
 

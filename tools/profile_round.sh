@@ -28,7 +28,8 @@ for set in "FETCH_SIZE" "WRITE_SIZE" \
   (cd /tmp && rm -rf /tmp/prof_pmc$i && BDF_NO_POLL=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 4 --k1-min-launches 0 $B > $out/pmc_pass$i.log 2>&1)
 done
 python3 - <<PY
-import csv, glob, json, collections, hashlib
+import csv, glob, json, collections, hashlib, sys
+sys.path.insert(0, '$GRAFT_REPO_ROOT')
 agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob('/tmp/prof_pmc*/*/*counter_collection.csv'):
     for r in csv.DictReader(open(f)):
@@ -42,7 +43,7 @@ for k, d in agg.items():
 rows.sort(key=lambda r: -r["FETCH_SIZE_KB_per_launch"] - r["WRITE_SIZE_KB_per_launch"])
 k1 = [r for r in rows if "k_rows" in r["kernel"]]
 summary = {"rows": rows[:12],
-           "k_sample_rows_sha1": hashlib.sha1(open('$GRAFT_REPO_ROOT/bayesiandatafusion.jl_amd/csrc/k_sample_rows.hip', 'rb').read()).hexdigest()}
+           "k1_source_sha1": __import__("bench").k1_source_sha1()}      # the kernel source and every header it includes
 if k1:
     f, w = k1[0]["FETCH_SIZE_KB_per_launch"] * 1024, k1[0]["WRITE_SIZE_KB_per_launch"] * 1024
     summary["k1_traffic_bytes_per_launch"] = {"fetch_uncorrected": f, "write": w, "hbm_bytes_fetch_doubled": 2 * f + w,
