@@ -61,7 +61,7 @@ struct Geo {
         r.cbase = RG * (r.q * (DP + 1) - RG * r.q * (r.q - 1) / 2) + (c % RG) * (DP - RG * r.q + 1);
         return r;
     }
-    static constexpr int WAVE_LDS = TRI_D;
+    static constexpr int WAVE_LDS = TRI_D + (DP == 64 ? 16 : 0);      // (DP = 64: + the extra row's entries of one panel, blocked variant)
 };
 
 // ---- DPP row-broadcast fma: d += (s of lane KJ of this lane's row of 16) * m.  Inline asm is opaque to the compiler's
@@ -276,6 +276,187 @@ __device__ __forceinline__ void factor_all(double (&A)[Geo<DP>::NB * 4], double 
     // step out of straight-line code (a skip-and-rejoin per step would make every step a merge point of the whole
     // register-resident matrix)
     (void)(... && ((Ks + 1 < D) && (factor_step<DP, Ks>(A, bv, ts, tri, fl, j, nm), true)));
+}
+
+// ======================================================================================================================
+// Blocked variant: 16-column panels, trailing update on the matrix cores (used for DP = 64).
+// Step k of the plain variant updates EVERY block column at and to the right of the pivot's (42 fp64 instructions per step
+// at D = 64) and needs a transposed multiplier per block column: the whole of column k goes to LDS under a four-lane EXEC
+// mask, 13 cycles of the CU's LDS store path per ds_write2_b64 whatever the number of active lanes (tools/valu_cost_probe.hip)
+// -- eight of them in front of every step of the first panel, and two resident waves per SIMD cannot hide that chain.
+// Here step k touches the pivot's own block column K only (the diagonal block and the panel below it: one multiplier, one
+// stored block per step); the block columns to the right get the panel's sixteen rank-1 updates at once when the panel is
+// complete:
+//     A(I,J) -= L(I,K) D_K^-1 L(J,K)'           I >= J > K         four v_mfma_f64_16x16x4_f64 per block
+// with the operands read back from the packed factor in the MFMA's operand layout -- lane (i = l & 15, kk = l >> 4) takes
+// row 16 I + i of column 16 K + 4 s + kk -- which the panel's blocks below the diagonal reach with two full-wave
+// ds_write2_b64 per block, once per panel.  The extra row b (the forward solve) follows the same way: its entries of the
+// later block columns take sum_c L(.,c) t_c / d_c from the same operands (4 fmas per block and panel + one reduction over
+// the four lane rows).  What the operand layout needs of the panel's columns besides -- 1 / d_c and t_c in the lanes of row
+// kk -- comes through LDS too: step c stores 1 / d_c in the spare entry at the end of column c (one lane), and the extra
+// row's panel entries, final once the panel is complete, are stored behind the packed factor.
+// (The f64 MFMA is no cheaper per flop than full-lane vector fmas -- they share a pipe and 64 cycles of it buy 2048 against
+// 14 x 128 flops -- so this is not about moving work to the matrix cores: it shortens what every step waits for.  One wave
+// alone factors and solves a 64 x 64 system in 11.9 us instead of 15.8, two per SIMD one system every 7.7 us instead of 10.4:
+// tools/factor_probe.hip.  At D = 32, seven waves per SIMD, the two variants measure the same and the plain one stays.)
+// v = 0 in the lanes whose position in their row of 16 is in M16
+template <int M16>
+__device__ __forceinline__ void zero_lanes(double &v)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %2\n\t"
+                 "s_mov_b32 exec_hi, %2\n\t"
+                 "v_mov_b64 %0, 0\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "+v"(v), "=&s"(save) : "n"(M16 | (M16 << 16)));
+}
+// lane 0 stores v (wave-uniform) at LDS byte address addr + 8 OFF (addr: lane 0's)
+template <int OFF>
+__device__ __forceinline__ void lane0_store(unsigned addr, double v)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %0, exec\n\t"
+                 "s_mov_b64 exec, 1\n\t"
+                 "ds_write_b64 %1, %2 offset:(%3)*8\n\t"
+                 "s_mov_b64 exec, %0"
+                 : "=&s"(save) : "v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+struct PanelLanes {             // per-lane LDS addressing of the blocked variant (opaque: stays in registers)
+    int kk, i3, i2;             // operand layout: lane row, (l & 15) & 3, (l & 15) >> 2
+};
+
+// doubles of LDS per wave: the packed factor + the extra row's entries of one panel
+template <int DP>
+struct GeoB { static constexpr int T_OFF = Geo<DP>::TRI_D, WAVE_LDS = Geo<DP>::TRI_D + 16; };
+
+// column k is final: its diagonal-block part to LDS (four owner lanes), 1 / d_k to the column's spare entry; the multiplier of
+// block column K for step k (when the block column has unfinished columns)
+template <int DP, int k>
+__device__ __forceinline__ void prep_b(const double (&A)[Geo<DP>::NB * 4], double *tri, const FactorLanes &fl, double &nmK)
+{
+    using GG = Geo<DP>;
+    constexpr int K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
+    constexpr int q = GG::col_first(k) / 4;
+    owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8 + cb * 8), std::make_integer_sequence<int, 1>{});      // block (K, K) only
+    const double rd = fast_rcp(readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh));
+    if constexpr (K + 1 < GG::DB) lane0_store<cb + GG::col_rows(k)>((unsigned)fl.wr0, rd);      // (lane 0: h = 0, wr0 = the factor's base)
+    if constexpr (kj < 15) {
+        wave_sync();
+        const double raw = tri[fl.rd0 - q * fl.j3 + (cb - q) + 4 * K];      // row 16 K + j of column k
+        nmK = -(raw * rd);
+        // The finished columns of the block column (lanes j <= kj) take no further updates: their registers in the blocks below
+        // the diagonal are stored only when the panel is complete, and their entries of the extra row ARE the forward solve
+        zero_lanes<(1 << (kj + 1)) - 1>(nmK);
+    }
+}
+
+// panel K is complete (every one of its columns final, diagonal block stored): the blocks below the diagonal to the packed
+// factor, then the trailing update of the block columns J > K and of the extra row's entries there
+template <int DP, int K>
+__device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, int j, int h,
+                                 const PanelLanes &pl)
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB;
+    static_assert(K + 1 < DB, "the last panel has nothing to its right");
+    // (a) blocks (I, K), I > K: lane (j, h) holds rows 16 I + h + 4 r of column 16 K + j -- consecutive entries of the column's
+    //     row class h in the packed factor; and the extra row's entries of the panel (lane j: t of column 16 K + j)
+    {
+        const typename GG::ColRT cr = GG::col_rt(16 * K + j);
+        double *dst = tri + cr.cbase + h * cr.nr4 - cr.q;
+#pragma unroll
+        for (int I = K + 1; I < DB; I++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[4 * I + r] = A[GG::blk(I, K) * 4 + r];
+        if (h == 0) tri[GeoB<DP>::T_OFF + j] = bv[K];
+    }
+    wave_sync();
+    // (b) operands: lane (i, kk), k-step s: row 16 I + i of column c = 16 K + 4 s + kk, at
+    //     col_base(c) + (i & 3) R / 4 + 4 (I - K) - s + (i >> 2),  R = DP - 16 K - 4 s rows stored, col_base(c) = col_base(c - kk) + kk (R + 1);
+    //     1 / d_c at col_base(c) + R
+    double pb[DB];
+#pragma unroll
+    for (int I = K + 1; I < DB; I++) pb[I] = 0.0;
+    asm volatile("s_nop 1" ::: "memory");        // (the accumulators were last written by inline-asm VALU instructions)
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+        const int R = DP - 16 * K - 4 * s;
+        const int base = GG::col_base(16 * K + 4 * s) - s;
+        const double *src = tri + base + pl.kk * (R + 1) + pl.i3 * (R / 4) + pl.i2;
+        double a[DB], as[DB];
+#pragma unroll
+        for (int I = K + 1; I < DB; I++) a[I] = src[4 * (I - K)];
+        const double nr = -tri[base + s + pl.kk * (R + 1) + R];
+        const double tc = tri[GeoB<DP>::T_OFF + 4 * s + pl.kk];
+#pragma unroll
+        for (int I = K + 1; I < DB; I++) as[I] = a[I] * nr;
+#pragma unroll
+        for (int J = K + 1; J < DB; J++)
+#pragma unroll
+            for (int I = J; I < DB; I++) {
+                d4 c = d4{A[GG::blk(I, J) * 4], A[GG::blk(I, J) * 4 + 1], A[GG::blk(I, J) * 4 + 2], A[GG::blk(I, J) * 4 + 3]};
+                c = __builtin_amdgcn_mfma_f64_16x16x4f64(as[I], a[J], c, 0, 0, 0);
+                A[GG::blk(I, J) * 4] = c[0]; A[GG::blk(I, J) * 4 + 1] = c[1]; A[GG::blk(I, J) * 4 + 2] = c[2]; A[GG::blk(I, J) * 4 + 3] = c[3];
+            }
+#pragma unroll
+        for (int I = K + 1; I < DB; I++) pb[I] = fma(as[I], tc, pb[I]);
+    }
+#pragma unroll
+    for (int I = K + 1; I < DB; I++) {
+        double v = pb[I];
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        bv[I] += v;
+    }
+    // the matrix instructions' results are read next by inline-asm VALU instructions, which the compiler's hazard
+    // recogniser cannot see into: wait out the last one's passes here (16 passes + 2)
+#pragma unroll
+    for (int b = 0; b < GG::NB * 4; b++) asm volatile("" : "+v"(A[b]));
+    asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
+}
+
+template <int DP, int k>
+__device__ __forceinline__ void factor_step_b(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, const FactorLanes &fl,
+                                     const PanelLanes &pl, int j, int h, double &nmK)
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB, K = k / 16, kj = k % 16;
+    if constexpr (kj < 15) {
+        // the diagonal block and the extra row first: the next column's part of them is what the next step waits for
+        fm_self_from<kj, (kj + 1) / 4>(&A[GG::blk(K, K) * 4], nmK);
+        fm1_self<kj>(bv[K], nmK);
+#pragma unroll
+        for (int I = K + 1; I < DB; I++) {
+            double *t = &A[GG::blk(I, K) * 4];
+            fm4_self<kj>(t[0], t[1], t[2], t[3], nmK);
+        }
+    } else if constexpr (K + 1 < DB) {
+        panel_end<DP, K>(A, bv, tri, j, h, pl);
+    }
+    prep_b<DP, k + 1>(A, tri, fl, nmK);
+}
+
+// (tri: GeoB<DP>::WAVE_LDS doubles)
+template <int DP, int... Ks>
+__device__ __forceinline__ void factor_all_blocked(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                          double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
+{
+    FactorLanes fl;
+    fl.wr0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * (DP / 4));   // LDS byte address
+    fl.h8 = 8 * h;
+    fl.rd0 = (j & 3) * (DP / 4) + (j >> 2);
+    fl.j3 = j & 3;
+    PanelLanes pl;
+    pl.kk = h; pl.i3 = j & 3; pl.i2 = j >> 2;
+    asm volatile("" : "+v"(fl.wr0), "+v"(fl.h8), "+v"(fl.rd0), "+v"(fl.j3), "+v"(pl.kk), "+v"(pl.i3), "+v"(pl.i2));
+    double nmK = 0.0;
+    prep_b<DP, 0>(A, tri, fl, nmK);
+    (void)(... && ((Ks + 1 < D) && (factor_step_b<DP, Ks>(A, bv, tri, fl, pl, j, h, nmK), true)));
+    // the extra row's entries stopped changing when their columns finished: they are the forward solve
+#pragma unroll
+    for (int J = 0; J < Geo<DP>::DB; J++) ts[J] = bv[J];
 }
 
 // ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----

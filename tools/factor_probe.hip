@@ -9,13 +9,13 @@
 void bdf_set_error(const char *, ...) {}
 
 template <int DP>
-__global__ __launch_bounds__(256) void k_factor(int reps, double *out, int with_backward)
+__global__ __launch_bounds__(256, (DP == 64 ? 2 : 8)) void k_factor(int reps, double *out, int with_backward)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, NB = GG::NB;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, h = lane >> 4;
-    double *tri = lds + wave * GG::TRI_D;
+    double *tri = lds + wave * GG::WAVE_LDS;
     double res = 0.0;
     for (int rep = 0; rep < reps; rep++) {
         double A[NB * 4], bv[DB], ts[DB];
@@ -30,7 +30,11 @@ __global__ __launch_bounds__(256) void k_factor(int reps, double *out, int with_
                 }
 #pragma unroll
         for (int J = 0; J < DB; J++) { bv[J] = 1.0 + 16 * J + j; ts[J] = 0.0; }
+#ifdef PROBE_BLOCKED
+        factor_all_blocked<DP>(A, bv, ts, tri, j, h, DP, std::make_integer_sequence<int, DP - 1>{});
+#else
         factor_all<DP>(A, bv, ts, tri, j, h, DP, std::make_integer_sequence<int, DP - 1>{});
+#endif
         wave_sync();
         double yh = 0.0;
         if (with_backward) {
@@ -67,7 +71,7 @@ int main()
     for (int bw = 0; bw < 2; bw++)
         for (int w : {1, 2, 3, 4, 5, 6, 7, 8}) {
             // workgroups of 4 waves (one per SIMD); w workgroups resident per CU through the LDS each one asks for
-            const size_t need = 4 * Geo<DP>::TRI_D * sizeof(double);
+            const size_t need = 4 * Geo<DP>::WAVE_LDS * sizeof(double);
             size_t lds = (size_t)(160 * 1024 / w) / 64 * 64;
             if (lds < need) { printf("w=%d does not fit\n", w); continue; }
             if (w == 8) lds = need;

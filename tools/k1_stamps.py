@@ -75,6 +75,16 @@ for j, name in enumerate(("users", "movies")):
         conc_max.append(mx); conc_avg.append(area / max(last - first, 1)); busy.append(last - first)
     print(f"   SIMDs seen {len(conc_max)}; waves live at once per SIMD: max {np.max(conc_max)} mean-of-max {np.mean(conc_max):.2f} "
           f"time-average {np.mean(conc_avg):.2f}; SIMD active span mean {np.mean(busy):.0f} max {np.max(busy)} ticks; items per SIMD {m.size / len(conc_max):.2f}")
+    # balance: when does each SIMD finish its last wave (relative to the launch's first start, in units of the span)?
+    fin_t, n_w = [], []
+    for kx in np.unique(key):
+        m = key == kx
+        fin_t.append((end[m].max() - t0) / span); n_w.append(int(m.sum()))
+    fin_t = np.array(fin_t); n_w = np.array(n_w)
+    print(f"   per-SIMD finish time / span: mean {fin_t.mean():.3f} p10 {np.quantile(fin_t, .1):.3f} p50 {np.median(fin_t):.3f} p90 {np.quantile(fin_t, .9):.3f} max {fin_t.max():.3f};"
+          f" waves per SIMD min {n_w.min()} mean {n_w.mean():.2f} max {n_w.max()}; corr(finish, waves) {np.corrcoef(fin_t, n_w)[0, 1]:.2f}")
+    # per CU
+    keyc = key >> 2 if False else (s[:, 10] & 0xf) * (1 << 20) + (hw & 0xff00)
     # the slowest waves
     tot = end - s[:, 0]
     worst = np.argsort(-tot)[:5]
