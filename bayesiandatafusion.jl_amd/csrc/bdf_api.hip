@@ -172,7 +172,7 @@ extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
     int flag = 0;
     BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
     if (flag) {
-        BDF_HIP(hipMemset(ctx->flag_dev, 0, sizeof(int)));
+        BDF_HIP(hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));      // (ordered before the context's next kernel)
         ctx->warnings |= (uint32_t)flag & BDF_WARN_CG_MAXITER;
         flag &= ~(int)BDF_WARN_CG_MAXITER;
     }

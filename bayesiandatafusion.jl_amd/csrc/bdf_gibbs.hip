@@ -86,7 +86,7 @@ int streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
     uint32_t *d;
     BDF_HIP(hipMalloc((void **)&d, 2 * sizeof(uint32_t)));
     struct Free { uint32_t *p; ~Free() { (void)hipFree(p); } } guard{d};
-    BDF_HIP(hipMemset(d, 0, 2 * sizeof(uint32_t)));
+    BDF_HIP(hipMemsetAsync(d, 0, 2 * sizeof(uint32_t), a));
     BDF_HIP(hipStreamSynchronize(a)); BDF_HIP(hipStreamSynchronize(b));
     hipLaunchKernelGGL(k_wait_flag, dim3(1), dim3(1), 0, a, (const uint32_t *)d, 2000000LL, d + 1);
     hipLaunchKernelGGL(k_set_flag, dim3(1), dim3(1), 0, b, d);
@@ -258,7 +258,8 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     // (every event starts out NULL and bdf_gibbs_destroy skips those: a failure below releases what exists so far)
     struct Guard { bdf_gibbs *g; ~Guard() { if (g) bdf_gibbs_destroy(g); } } guard{g};
     BDF_HIP(hipMalloc((void **)&g->ready_dev, (size_t)n_entities * sizeof(uint32_t)));
-    BDF_HIP(hipMemset(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t)));
+    BDF_HIP(hipMemsetAsync(g->ready_dev, 0, (size_t)n_entities * sizeof(uint32_t), rows_ctx->stream));
+    BDF_HIP(hipStreamSynchronize(rows_ctx->stream));
     g->ent.resize((size_t)n_entities);
     for (int j = 0; j < n_entities; j++) {
         auto &E = g->ent[(size_t)j];

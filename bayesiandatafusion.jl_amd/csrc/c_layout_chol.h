@@ -17,6 +17,9 @@
 #ifndef BDF_K1_WAVES32
 #define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
 #endif
+#ifndef BDF_K1_WAVES64
+#define BDF_K1_WAVES64 2          // waves per SIMD the D > 32 kernel is compiled for
+#endif
 #ifndef BDF_K1_WAVES32C
 #define BDF_K1_WAVES32C 7         // ... its variant for one two-mode relation with coded values (70 registers)
 #endif
@@ -32,9 +35,9 @@ struct Geo {
     static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
     static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
-    static constexpr int WAVES = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32 : 8);
-    static constexpr int WAVES_MATRIX = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
-    static constexpr int WAVES_CODED = (DP == 64) ? 2 : (DP == 32 ? BDF_K1_WAVES32C : 8);      // one two-mode relation, coded values
+    static constexpr int WAVES = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32 : 8);
+    static constexpr int WAVES_MATRIX = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
+    static constexpr int WAVES_CODED = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8);      // one two-mode relation, coded values
     __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
     // packed factor in LDS: column k keeps rows col_first(k) = RG * (k / RG) .. DP-1, by row class:
     // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - col_first(k)) / 4.  Columns are one double further apart
@@ -279,26 +282,29 @@ __device__ __forceinline__ void factor_all(double (&A)[Geo<DP>::NB * 4], double 
 }
 
 // ======================================================================================================================
-// Blocked variant: 16-column panels, trailing update on the matrix cores (used for DP = 64).
+// Blocked variant: 16-column panels, trailing update on the matrix cores, no LDS round trip inside a step (used for DP = 64).
+//
 // Step k of the plain variant updates EVERY block column at and to the right of the pivot's (42 fp64 instructions per step
 // at D = 64) and needs a transposed multiplier per block column: the whole of column k goes to LDS under a four-lane EXEC
-// mask, 13 cycles of the CU's LDS store path per ds_write2_b64 whatever the number of active lanes (tools/valu_cost_probe.hip)
-// -- eight of them in front of every step of the first panel, and two resident waves per SIMD cannot hide that chain.
-// Here step k touches the pivot's own block column K only (the diagonal block and the panel below it: one multiplier, one
-// stored block per step); the block columns to the right get the panel's sixteen rank-1 updates at once when the panel is
-// complete:
-//     A(I,J) -= L(I,K) D_K^-1 L(J,K)'           I >= J > K         four v_mfma_f64_16x16x4_f64 per block
-// with the operands read back from the packed factor in the MFMA's operand layout -- lane (i = l & 15, kk = l >> 4) takes
-// row 16 I + i of column 16 K + 4 s + kk -- which the panel's blocks below the diagonal reach with two full-wave
-// ds_write2_b64 per block, once per panel.  The extra row b (the forward solve) follows the same way: its entries of the
-// later block columns take sum_c L(.,c) t_c / d_c from the same operands (4 fmas per block and panel + one reduction over
-// the four lane rows).  What the operand layout needs of the panel's columns besides -- 1 / d_c and t_c in the lanes of row
-// kk -- comes through LDS too: step c stores 1 / d_c in the spare entry at the end of column c (one lane), and the extra
-// row's panel entries, final once the panel is complete, are stored behind the packed factor.
-// (The f64 MFMA is no cheaper per flop than full-lane vector fmas -- they share a pipe and 64 cycles of it buy 2048 against
-// 14 x 128 flops -- so this is not about moving work to the matrix cores: it shortens what every step waits for.  One wave
-// alone factors and solves a 64 x 64 system in 11.9 us instead of 15.8, two per SIMD one system every 7.7 us instead of 10.4:
-// tools/factor_probe.hip.  At D = 32, seven waves per SIMD, the two variants measure the same and the plain one stays.)
+// mask -- 13 cycles of the CU's LDS store path per ds_write2_b64 whatever the number of active lanes
+// (tools/valu_cost_probe.hip), eight of them in front of every step of the first panel -- and comes back through a read:
+// a dependent chain of ~600 cycles per step that the two waves a SIMD holds at D = 64 cannot hide.  Here:
+//  * step k touches the pivot's own block column K only: the diagonal block, the panel below it, the extra row;
+//  * its multipliers need no transposition through memory: the unfinished part of the diagonal block stays SYMMETRIC in the
+//    registers (the updates are symmetric and whole registers are updated), so the multiplier of column 16 K + j -- entry
+//    (16 K + j, k) -- is also entry (k, 16 K + j): register k / 4 of the block in the lanes of row k % 4, one ds_bpermute
+//    away from every lane row.  The lanes of the finished columns take a zero multiplier, so finished columns keep their
+//    final values in the registers and the whole panel is stored to the packed factor ONCE, when it is complete, with
+//    full-wave stores;
+//  * the block columns to the right get the panel's sixteen rank-1 updates at once when the panel is complete:
+//        A(I,J) -= L(I,K) D_K^-1 L(J,K)'           I >= J > K         four v_mfma_f64_16x16x4_f64 per block
+//    with the operands read back from the packed factor in the MFMA's operand layout -- lane (i = l & 15, kk = l >> 4)
+//    takes row 16 I + i of column c = 16 K + 4 s + kk, and 1 / d_c from the column's stored pivot.  The extra row b (the
+//    forward solve) follows the same way: its entries of the later block columns take sum_c L(.,c) t_c / d_c from the same
+//    operands (4 fmas per block and panel + one reduction over the four lane rows).
+// (The f64 MFMA is no cheaper per flop than full-lane vector fmas -- they share a pipe, and 64 cycles of it buy 2048 flops
+// against 14 x 128 -- so this is not about moving work to the matrix cores: it shortens what every step waits for.
+// tools/factor_probe.hip; at D = 32, seven waves per SIMD, the plain variant is already bound by the pipe and stays.)
 // v = 0 in the lanes whose position in their row of 16 is in M16
 template <int M16>
 __device__ __forceinline__ void zero_lanes(double &v)
@@ -311,49 +317,54 @@ __device__ __forceinline__ void zero_lanes(double &v)
                  "s_mov_b64 exec, %1"
                  : "+v"(v), "=&s"(save) : "n"(M16 | (M16 << 16)));
 }
-// lane 0 stores v (wave-uniform) at LDS byte address addr + 8 OFF (addr: lane 0's)
-template <int OFF>
-__device__ __forceinline__ void lane0_store(unsigned addr, double v)
-{
-    unsigned long long save;
-    asm volatile("s_mov_b64 %0, exec\n\t"
-                 "s_mov_b64 exec, 1\n\t"
-                 "ds_write_b64 %1, %2 offset:(%3)*8\n\t"
-                 "s_mov_b64 exec, %0"
-                 : "=&s"(save) : "v"(addr), "v"(v), "n"(OFF) : "memory");
-}
 
-struct PanelLanes {             // per-lane LDS addressing of the blocked variant (opaque: stays in registers)
+struct PanelLanes {             // per-lane constants of the blocked variant (opaque: they stay in registers)
     int kk, i3, i2;             // operand layout: lane row, (l & 15) & 3, (l & 15) >> 2
+    int j4;                     // 4 (l & 15): ds_bpermute address of the lane's own position in lane row 0
 };
 
-// doubles of LDS per wave: the packed factor + the extra row's entries of one panel
 template <int DP>
-struct GeoB { static constexpr int T_OFF = Geo<DP>::TRI_D, WAVE_LDS = Geo<DP>::TRI_D + 16; };
+struct GeoB { static constexpr int T_OFF = Geo<DP>::TRI_D; };       // the extra row's entries of one panel sit behind the packed factor
 
-// column k is final: its diagonal-block part to LDS (four owner lanes), 1 / d_k to the column's spare entry; the multiplier of
-// block column K for step k (when the block column has unfinished columns)
+// the multiplier of block column K for step k (column k is final; the block column has unfinished columns)
 template <int DP, int k>
-__device__ __forceinline__ void prep_b(const double (&A)[Geo<DP>::NB * 4], double *tri, const FactorLanes &fl, double &nmK)
+__device__ __forceinline__ void prep_b(const double (&A)[Geo<DP>::NB * 4], const PanelLanes &pl, double &nmK)
 {
     using GG = Geo<DP>;
-    constexpr int K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4, cb = GG::col_base(k);
-    constexpr int q = GG::col_first(k) / 4;
-    owner_store_all<DP, k>(A, (unsigned)(fl.wr0 - q * fl.h8 + cb * 8), std::make_integer_sequence<int, 1>{});      // block (K, K) only
-    const double rd = fast_rcp(readlane_f64(A[GG::blk(K, K) * 4 + kr], kj + 16 * kh));
-    if constexpr (K + 1 < GG::DB) lane0_store<cb + GG::col_rows(k)>((unsigned)fl.wr0, rd);      // (lane 0: h = 0, wr0 = the factor's base)
+    constexpr int K = k / 16, kj = k % 16, kh = kj % 4, kr = kj / 4;
     if constexpr (kj < 15) {
-        wave_sync();
-        const double raw = tri[fl.rd0 - q * fl.j3 + (cb - q) + 4 * K];      // row 16 K + j of column k
-        nmK = -(raw * rd);
-        // The finished columns of the block column (lanes j <= kj) take no further updates: their registers in the blocks below
-        // the diagonal are stored only when the panel is complete, and their entries of the extra row ARE the forward solve
+        const double row = A[GG::blk(K, K) * 4 + kr];           // lanes (j, kh): entry (k, 16 K + j) == entry (16 K + j, k)
+        const int lo = __builtin_amdgcn_ds_bpermute(pl.j4 + 64 * kh, __double2loint(row));
+        const int hi = __builtin_amdgcn_ds_bpermute(pl.j4 + 64 * kh, __double2hiint(row));
+        const double rd = fast_rcp(readlane_f64(row, kj + 16 * kh));
+        nmK = -(__hiloint2double(hi, lo) * rd);
+        // the finished columns (lanes j <= kj) take no further updates
         zero_lanes<(1 << (kj + 1)) - 1>(nmK);
     }
 }
 
-// panel K is complete (every one of its columns final, diagonal block stored): the blocks below the diagonal to the packed
-// factor, then the trailing update of the block columns J > K and of the extra row's entries there
+// panel K to the packed factor: the diagonal block (rows from each column's first stored row), the blocks below it, the
+// extra row's entries of the panel (lane j: t of column 16 K + j)
+template <int DP, int K>
+__device__ __forceinline__ void panel_store(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double *tri, int j, int h)
+{
+    using GG = Geo<DP>;
+    constexpr int DB = GG::DB;
+    const typename GG::ColRT cr = GG::col_rt(16 * K + j);
+    double *dst = tri + cr.cbase + h * cr.nr4 - cr.q;          // row 16 I + h + 4 r of column 16 K + j at dst[4 I + r]
+    const int r0 = j >> 2;                                      // the column stores rows 16 K + 4 (j >> 2) and on
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+        if (r >= r0) dst[4 * K + r] = A[GG::blk(K, K) * 4 + r];
+#pragma unroll
+    for (int I = K + 1; I < DB; I++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) dst[4 * I + r] = A[GG::blk(I, K) * 4 + r];
+    if (h == 0) tri[GeoB<DP>::T_OFF + j] = bv[K];
+}
+
+// panel K is complete: to the packed factor, then the trailing update of the block columns J > K and of the extra row's
+// entries there
 template <int DP, int K>
 __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, int j, int h,
                                  const PanelLanes &pl)
@@ -361,21 +372,11 @@ __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (
     using GG = Geo<DP>;
     constexpr int DB = GG::DB;
     static_assert(K + 1 < DB, "the last panel has nothing to its right");
-    // (a) blocks (I, K), I > K: lane (j, h) holds rows 16 I + h + 4 r of column 16 K + j -- consecutive entries of the column's
-    //     row class h in the packed factor; and the extra row's entries of the panel (lane j: t of column 16 K + j)
-    {
-        const typename GG::ColRT cr = GG::col_rt(16 * K + j);
-        double *dst = tri + cr.cbase + h * cr.nr4 - cr.q;
-#pragma unroll
-        for (int I = K + 1; I < DB; I++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[4 * I + r] = A[GG::blk(I, K) * 4 + r];
-        if (h == 0) tri[GeoB<DP>::T_OFF + j] = bv[K];
-    }
+    panel_store<DP, K>(A, bv, tri, j, h);
     wave_sync();
-    // (b) operands: lane (i, kk), k-step s: row 16 I + i of column c = 16 K + 4 s + kk, at
+    // operands: lane (i, kk), k-step s: row 16 I + i of column c = 16 K + 4 s + kk, at
     //     col_base(c) + (i & 3) R / 4 + 4 (I - K) - s + (i >> 2),  R = DP - 16 K - 4 s rows stored, col_base(c) = col_base(c - kk) + kk (R + 1);
-    //     1 / d_c at col_base(c) + R
+    // the column's pivot d_c: the first entry of its row class kk, at col_base(c) + kk R / 4
     double pb[DB];
 #pragma unroll
     for (int I = K + 1; I < DB; I++) pb[I] = 0.0;
@@ -383,12 +384,12 @@ __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int R = DP - 16 * K - 4 * s;
-        const int base = GG::col_base(16 * K + 4 * s) - s;
-        const double *src = tri + base + pl.kk * (R + 1) + pl.i3 * (R / 4) + pl.i2;
+        const int base = GG::col_base(16 * K + 4 * s);
+        const double *src = tri + (base - s) + pl.kk * (R + 1) + pl.i3 * (R / 4) + pl.i2;
         double a[DB], as[DB];
 #pragma unroll
         for (int I = K + 1; I < DB; I++) a[I] = src[4 * (I - K)];
-        const double nr = -tri[base + s + pl.kk * (R + 1) + R];
+        const double nr = -fast_rcp(tri[base + pl.kk * (R + 1 + R / 4)]);
         const double tc = tri[GeoB<DP>::T_OFF + 4 * s + pl.kk];
 #pragma unroll
         for (int I = K + 1; I < DB; I++) as[I] = a[I] * nr;
@@ -418,45 +419,50 @@ __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (
 }
 
 template <int DP, int k>
-__device__ __forceinline__ void factor_step_b(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, const FactorLanes &fl,
-                                     const PanelLanes &pl, int j, int h, double &nmK)
+__device__ __forceinline__ void factor_step_b(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, const PanelLanes &pl,
+                                     int j, int h, double &nmK)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, K = k / 16, kj = k % 16;
     if constexpr (kj < 15) {
-        // the diagonal block and the extra row first: the next column's part of them is what the next step waits for
+        // the diagonal block first: the next step's multipliers and pivot come from it
         fm_self_from<kj, (kj + 1) / 4>(&A[GG::blk(K, K) * 4], nmK);
+        double nm_next = 0.0;
+        prep_b<DP, k + 1>(A, pl, nm_next);
         fm1_self<kj>(bv[K], nmK);
 #pragma unroll
         for (int I = K + 1; I < DB; I++) {
             double *t = &A[GG::blk(I, K) * 4];
             fm4_self<kj>(t[0], t[1], t[2], t[3], nmK);
         }
-    } else if constexpr (K + 1 < DB) {
-        panel_end<DP, K>(A, bv, tri, j, h, pl);
+        nmK = nm_next;
+    } else {
+        if constexpr (K + 1 < DB) panel_end<DP, K>(A, bv, tri, j, h, pl);
+        prep_b<DP, k + 1>(A, pl, nmK);
     }
-    prep_b<DP, k + 1>(A, tri, fl, nmK);
 }
 
-// (tri: GeoB<DP>::WAVE_LDS doubles)
+// (tri: Geo<DP>::WAVE_LDS doubles)
 template <int DP, int... Ks>
 __device__ __forceinline__ void factor_all_blocked(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
                                           double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
 {
-    FactorLanes fl;
-    fl.wr0 = (int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + h * (DP / 4));   // LDS byte address
-    fl.h8 = 8 * h;
-    fl.rd0 = (j & 3) * (DP / 4) + (j >> 2);
-    fl.j3 = j & 3;
+    using GG = Geo<DP>;
     PanelLanes pl;
-    pl.kk = h; pl.i3 = j & 3; pl.i2 = j >> 2;
-    asm volatile("" : "+v"(fl.wr0), "+v"(fl.h8), "+v"(fl.rd0), "+v"(fl.j3), "+v"(pl.kk), "+v"(pl.i3), "+v"(pl.i2));
+    pl.kk = h; pl.i3 = j & 3; pl.i2 = j >> 2; pl.j4 = 4 * j;
+    asm volatile("" : "+v"(pl.kk), "+v"(pl.i3), "+v"(pl.i2), "+v"(pl.j4));
     double nmK = 0.0;
-    prep_b<DP, 0>(A, tri, fl, nmK);
-    (void)(... && ((Ks + 1 < D) && (factor_step_b<DP, Ks>(A, bv, tri, fl, pl, j, h, nmK), true)));
+    prep_b<DP, 0>(A, pl, nmK);
+    (void)(... && ((Ks + 1 < D) && (factor_step_b<DP, Ks>(A, bv, tri, pl, j, h, nmK), true)));
+    // the panel the factorisation ended in (the earlier ones were stored when they were complete)
+    const int Kf = (D - 1) >> 4;
+    if constexpr (GG::DB >= 1) { if (Kf == 0) panel_store<DP, 0>(A, bv, tri, j, h); }
+    if constexpr (GG::DB >= 2) { if (Kf == 1) panel_store<DP, 1>(A, bv, tri, j, h); }
+    if constexpr (GG::DB >= 3) { if (Kf == 2) panel_store<DP, 2>(A, bv, tri, j, h); }
+    if constexpr (GG::DB >= 4) { if (Kf == 3) panel_store<DP, 3>(A, bv, tri, j, h); }
     // the extra row's entries stopped changing when their columns finished: they are the forward solve
 #pragma unroll
-    for (int J = 0; J < Geo<DP>::DB; J++) ts[J] = bv[J];
+    for (int J = 0; J < GG::DB; J++) ts[J] = bv[J];
 }
 
 // ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----

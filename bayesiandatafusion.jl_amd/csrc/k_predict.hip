@@ -319,8 +319,11 @@ extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void
         BDF_HIP(hipMemcpy(p->ids_dev, h.data(), h.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         BDF_HIP(hipMemcpy(p->values_dev, values, (size_t)n * sizeof(double), hipMemcpyHostToDevice));
     }
-    BDF_HIP(hipMemset(p->avg_dev, 0, nb));
-    BDF_HIP(hipMemset(p->sq_dev, 0, nb));
+    // (on the context's stream and waited for: the pairs may be updated on another stream next, and a plain hipMemset may still
+    // be pending on the NULL stream when it returns)
+    BDF_HIP(hipMemsetAsync(p->avg_dev, 0, nb, ctx->stream));
+    BDF_HIP(hipMemsetAsync(p->sq_dev, 0, nb, ctx->stream));
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
     guard.p = nullptr;
     *out = p;
     return BDF_OK;

@@ -44,6 +44,7 @@
 #include "wave_linalg.h"
 #include "c_layout_chol.h"
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <map>
 #include <mutex>
@@ -771,7 +772,10 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         return rc;
     BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
     BDF_HIP(hipMalloc((void **)&plan.arrived_dev, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
-    BDF_HIP(hipMemset(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
+    // on the launch stream: hipMemset runs on the NULL stream and returns before the device has done it, and a kernel on a
+    // non-blocking stream does not wait for it -- the first launch of a new plan could have its counters zeroed under it
+    // (a split row then never finds its last piece: the row keeps its old content)
+    BDF_HIP(hipMemsetAsync(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8), ctx->stream));
     plan.dev.direct = plan.direct_dev; plan.dev.n_direct = (int32_t)direct.size();
     plan.dev.split = plan.split_dev;   plan.dev.n_split = (int32_t)split.size();
     plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
@@ -825,6 +829,13 @@ extern "C" int bdf_rows_unfinished(bdf_ctx *ctx, int64_t *count)
         std::vector<int32_t> h((size_t)n);
         BDF_HIP(hipMemcpy(h.data(), kv.second.arrived_dev, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
         for (int32_t v : h) *count += v != 0;
+        static const bool dbg = getenv("BDF_DEBUG_UNFINISHED") != nullptr;
+        if (dbg)
+            for (int i = 0; i < n; i++)
+                if (h[(size_t)i] != 0)
+                    fprintf(stderr, "[bdf] unfinished: plan DP=%d T=%d Tp=%d shard %d/%d terms %d, split row %d of %d: counter %d (array %p)\n",
+                            kv.first.DP, kv.first.T, kv.first.Tp, kv.first.shard, kv.first.n_shards, kv.first.n_terms, i, n, h[(size_t)i],
+                            (void *)kv.second.arrived_dev);
     }
     return BDF_OK;
 }
