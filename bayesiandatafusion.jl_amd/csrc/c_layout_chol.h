@@ -64,7 +64,7 @@ struct Geo {
         r.cbase = RG * (r.q * (DP + 1) - RG * r.q * (r.q - 1) / 2) + (c % RG) * (DP - RG * r.q + 1);
         return r;
     }
-    static constexpr int WAVE_LDS = TRI_D + (DP == 64 ? 16 : 0);      // (DP = 64: + the extra row's entries of one panel, blocked variant)
+    static constexpr int WAVE_LDS = TRI_D + 16;        // (+ the extra row's entries of one panel: factor_all_blocked)
 };
 
 // ---- DPP row-broadcast fma: d += (s of lane KJ of this lane's row of 16) * m.  Inline asm is opaque to the compiler's

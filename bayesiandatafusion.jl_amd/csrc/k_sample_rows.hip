@@ -51,7 +51,7 @@
 #include <utility>
 
 #ifndef BDF_CHOL_BLOCKED
-#define BDF_CHOL_BLOCKED 1        // D > 32: the row's factorisation in 16-column panels with the trailing update on the matrix cores (c_layout_chol.h)
+#define BDF_CHOL_BLOCKED 1        // the row's factorisation in 16-column panels: multipliers without an LDS round trip, trailing update on the matrix cores (c_layout_chol.h); 0: the plain right-looking variant
 #endif
 #ifndef BDF_K1_KS
 #define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
@@ -611,7 +611,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
 #pragma unroll                                    // (and any column's before its step) is still in bv
     for (int J = 0; J < DB; J++) ts[J] = 0.0;
     if (D < DP) zero_packed_factor<DP>(tri, lane);
-    if constexpr (DP == 64 && BDF_CHOL_BLOCKED)
+    if constexpr (BDF_CHOL_BLOCKED)
         factor_all_blocked<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
     else
         factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
