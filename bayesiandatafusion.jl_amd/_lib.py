@@ -68,7 +68,10 @@ class GibbsEntity(C.Structure):
                 ("terms", _GibbsTerm * BDF_MAX_TERMS), ("sample", C.c_void_p * 3),
                 ("mu", C.c_void_p), ("Lambda", C.c_void_p), ("mu0", C.c_void_p), ("WI", C.c_void_p), ("sumU", C.c_void_p),
                 ("UUt", C.c_void_p), ("params", C.c_void_p), ("prior_pack", C.c_void_p), ("draws", C.c_void_p),
-                ("b0", C.c_double), ("nu0", C.c_double)]
+                ("b0", C.c_double), ("nu0", C.c_double),
+                ("feat", C.c_void_p), ("beta", C.c_void_p), ("uhat", C.c_void_p), ("mu_matrix", C.c_void_p), ("Tinv", C.c_void_p),
+                ("lambda_beta", C.c_void_p), ("cg_iters", C.c_void_p), ("use_ff", C.c_int32), ("sample_lambda_beta", C.c_int32),
+                ("full_lambda_u", C.c_int32), ("_pad", C.c_int32), ("tol", C.c_double), ("lb_nu", C.c_double), ("lb_mu", C.c_double)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)

@@ -28,6 +28,8 @@ struct bdf_gibbs {
         bdf_gibbs_entity d;
         int cur;                         // buffer holding the current rows
         hipEvent_t ev_rows = nullptr, ev_hyper = nullptr;    // rows of this sweep complete (and exchanged) | (mu, Lambda) of this sweep complete
+        hipEvent_t ev_beta = nullptr;                        // side information: beta (and lambda_beta) of this sweep complete
+        bool beta_recorded = false;
         bool hyper_recorded = false;
         // number of hyperprior draws enqueued for this entity so far: the value its next draw publishes in ready_dev and the
         // entity's next row launch polls for.  Private and strictly increasing -- NOT the caller's sweep number, which may
@@ -230,6 +232,10 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
         BDF_REQUIRE(e.n_terms >= 1 && e.n_terms <= BDF_MAX_TERMS, BDF_ERR_ARG, "bdf_gibbs_create: entity %d takes part in %d relations (1..%d)", j, e.n_terms, BDF_MAX_TERMS);
         BDF_REQUIRE(e.sample[0] && e.sample[1] && e.sample[2] && e.mu && e.Lambda && e.mu0 && e.WI && e.sumU && e.UUt && e.prior_pack && e.draws,
                     BDF_ERR_ARG, "bdf_gibbs_create: entity %d has a NULL buffer", j);
+        BDF_REQUIRE(!e.feat || (e.beta && e.uhat && e.mu_matrix && e.Tinv && e.lambda_beta), BDF_ERR_ARG,
+                    "bdf_gibbs_create: entity %d has side information but a NULL beta / uhat / mu_matrix / Tinv / lambda_beta", j);
+        BDF_REQUIRE(!e.feat || e.feat->m == e.N, BDF_ERR_ARG, "bdf_gibbs_create: entity %d has %lld rows but its feature matrix %lld", j,
+                    (long long)e.N, e.feat ? (long long)e.feat->m : 0LL);
         for (int t = 0; t < e.n_terms; t++) {
             BDF_REQUIRE(e.terms[t].rel, BDF_ERR_ARG, "bdf_gibbs_create: entity %d term %d has no relation", j, t);
             for (int k = 0; k < e.terms[t].rel->n_modes; k++)
@@ -266,6 +272,7 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
         E.d = ents[j]; E.cur = 0;
         BDF_HIP(hipEventCreate(&E.ev_rows));          // (they ride on dispatch packets: plain events)
         BDF_HIP(hipEventCreate(&E.ev_hyper));
+        if (E.d.feat) BDF_HIP(hipEventCreateWithFlags(&E.ev_beta, hipEventDisableTiming));
     }
     for (int k = 0; k < 3; k++) BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[k], hipEventDisableTiming));
     guard.g = nullptr;
@@ -283,6 +290,7 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
     for (auto &E : g->ent) {
         if (E.ev_rows) (void)hipEventDestroy(E.ev_rows);
         if (E.ev_hyper) (void)hipEventDestroy(E.ev_hyper);
+        if (E.ev_beta) (void)hipEventDestroy(E.ev_beta);
     }
     for (int k = 0; k < 3; k++)
         if (g->ev_pred[k]) (void)hipEventDestroy(g->ev_pred[k]);
@@ -330,6 +338,11 @@ extern "C" int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm)
 
 // measurement: the rows of one entity and nothing else -- the launch bdf_gibbs_sweep makes for it (same kernel variant, same
 // inputs), without the hyperprior update, the exchange or the prediction update.  The chain's state is not kept consistent.
+namespace {
+// the hyperprior's degrees of freedom: nu0 (+ numF with side information and full_lambda_u, macau.jl:124-129)
+double hyper_nu(const bdf_gibbs_entity &e) { return e.nu0 + ((e.feat && e.full_lambda_u) ? (double)e.feat->n : 0.0); }
+}  // namespace
+
 extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
 {
     BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_rows_only: bad argument");
@@ -351,8 +364,8 @@ extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
     const int nch = e.terms[0].rel->chunks;
     int rc;
     for (int c = 0; c < nch; c++)
-        if ((rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
-                                  E.hyper_recorded ? e.prior_pack : nullptr)))
+        if ((rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
+                                  e.sample[nxt], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr)))
             return rc;
     E.cur = nxt;
     return BDF_OK;
@@ -387,8 +400,8 @@ extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
             }
             const int nch = e.terms[0].rel->chunks;
             for (int c = 0; c < nch && !rc; c++)
-                rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[(E.cur + 1) % 3],
-                                     E.hyper_recorded ? e.prior_pack : nullptr);
+                rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
+                                     e.sample[(E.cur + 1) % 3], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr);
         }
         if (!rc && hipStreamSynchronize(R->stream) != hipSuccess) { bdf_set_error("bdf_gibbs_warm_device: stream synchronisation failed"); rc = BDF_ERR_HIP; }
     }
@@ -435,7 +448,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         int64_t Ns[BDF_DRAWS_BATCH]; double nus[BDF_DRAWS_BATCH]; uint32_t tags[BDF_DRAWS_BATCH]; double *outs[BDF_DRAWS_BATCH];
         for (int j = 0; j < n; j++) {
             const bdf_gibbs_entity &e = g->ent[(size_t)j].d;
-            Ns[j] = e.n_real; nus[j] = e.nu0; tags[j] = e.tag; outs[j] = e.draws;
+            Ns[j] = e.n_real; nus[j] = hyper_nu(e); tags[j] = e.tag; outs[j] = e.draws;
         }
         if ((rc = bdf_hyper_draws_batch(H, D, n, Ns, nus, tags, outs))) return rc;
     }
@@ -443,11 +456,14 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
         // (mu, Lambda) of the previous iteration: an event wait, or -- draws on reserved CUs -- the row kernel polls for it
-        const bool poll = g->polling && !g->comm && E.hyper_recorded;
+        // (with side information the prior mean is a matrix, computed here from mu: nothing to poll for)
+        const bool poll = g->polling && !g->comm && E.hyper_recorded && !e.feat;
         if (E.hyper_recorded && !poll) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
+        // side information: uhat = (F beta)' with the beta of the previous iteration, per-row prior means mu + uhat (macau.jl:103-104)
+        if (e.feat && (rc = bdf_uhat(R, e.feat, D, e.beta, e.mu, e.uhat, e.mu_matrix))) return rc;
         // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows -- for all entities
         // in one launch at the head of the iteration when they are few
-        if (n > BDF_DRAWS_BATCH && (rc = bdf_hyper_draws(H, D, e.n_real, e.nu0, e.tag, e.draws))) return rc;
+        if (n > BDF_DRAWS_BATCH && (rc = bdf_hyper_draws(H, D, e.n_real, hyper_nu(e), e.tag, e.draws))) return rc;
         bdf_term terms[BDF_MAX_TERMS];
         for (int t = 0; t < e.n_terms; t++) {
             terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
@@ -466,8 +482,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             R->time_start = (c == 0) ? E.t_start : nullptr;
             R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
             if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.epoch; }
-            if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.mu, 0, e.Lambda, e.tag, c, nch, e.sample[nxt],
-                                      E.hyper_recorded ? e.prior_pack : nullptr)))
+            if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
+                                      e.sample[nxt], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr)))
                 return rc;
             if (g->comm && (rc = bdf_allgather_rows(R, g->comm, D, e.N, e.sample[nxt], c, nch))) return rc;
         }
@@ -480,14 +496,33 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
         static const bool fuse_sums = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);
         H->hyper_fuse = fuse_sums;        // small entities: the draw adds the sums' partials itself (one launch fewer)
-        if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], nullptr, e.sumU, e.UUt))) return rc;
+        // side information: U = sample - uhat, T^-1 = WI + beta' beta lambda_beta with the beta of the previous iteration
+        const double *Tinv = e.WI;
+        if (e.feat && e.full_lambda_u) {
+            if (E.beta_recorded) BDF_HIP(hipStreamWaitEvent(H->stream, E.ev_beta, 0));
+            if ((rc = bdf_hyper_feature_terms(H, D, e.feat->n, e.beta, e.WI, e.lambda_beta, e.Tinv))) return rc;
+            Tinv = e.Tinv;
+        }
+        if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], e.feat ? e.uhat : nullptr, e.sumU, e.UUt))) return rc;
         H->time_h_stop = E.ev_hyper;
         H->hyper_ready = g->ready_dev + j;
         H->hyper_ready_value = ++E.epoch;
-        if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, e.WI, e.nu0, e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
+        if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, Tinv, hyper_nu(e), e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
             return rc;
         E.hyper_recorded = true;
         if (j == n - 1 && g->test && predict_phase >= 0) BDF_HIP(hipStreamWaitEvent(P->stream, done, 0));
+    }
+    // side information: beta of every entity that has it, from this iteration's rows and (mu, Lambda) (macau.jl:138-140)
+    for (int j = 0; j < n; j++) {
+        auto &E = g->ent[(size_t)j];
+        const bdf_gibbs_entity &e = E.d;
+        if (!e.feat) continue;
+        BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
+        if ((rc = bdf_sample_beta(R, e.feat, D, e.sample[E.cur], e.mu, e.Lambda, e.lambda_beta, e.use_ff, e.tol, 0, e.sample_lambda_beta,
+                                  e.lb_nu, e.lb_mu, e.tag, e.beta, nullptr, e.cg_iters)))
+            return rc;
+        BDF_HIP(hipEventRecord(E.ev_beta, R->stream));
+        E.beta_recorded = true;
     }
     if (g->test && predict_phase >= 0) {
         const double *fac[BDF_MAX_MODES];

@@ -510,12 +510,13 @@ class GibbsEngine:
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
-        has_feat = any(not feat.isempty(en.F) for en in data.entities) or any(not feat.isempty(r.F) for r in data.relations)
+        rel_feat = any(not feat.isempty(r.F) for r in data.relations)
         if self.world > 1 and (any(not feat.isempty(r.F) for r in data.relations) or any(r.model.alpha_sample for r in data.relations)):
             raise ArgumentError("several GPUs: relation-level side information and alpha sampling are not implemented "
                                 "(entity side information is: F replicated, its rows at the entity's internal positions)")
-        # the whole iteration in one native call unless something needs the step-by-step path
-        self.native = not has_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
+        # the whole iteration in one native call (entity side information included) unless something needs the step-by-step
+        # path: relation-level side information, alpha sampling
+        self.native = not rel_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
         # ---- row layouts (several ranks): degree of a row = its observations over all the entity's relations
         if chunks is None:
             chunks = int(os.environ.get("BDF_CHUNKS", "0"))
@@ -617,6 +618,12 @@ class GibbsEngine:
             for name in ("mu", "Lambda", "mu0", "WI", "sumU", "UUt", "params", "prior_pack", "draws"):
                 setattr(g, name, getattr(st, name).data_ptr())
             g.b0, g.nu0 = st.b0, st.nu0
+            if st.F is not None:
+                g.feat = st.F.handle
+                for name in ("beta", "uhat", "mu_matrix", "Tinv", "lambda_beta", "cg_iters"):
+                    setattr(g, name, getattr(st, name).data_ptr())
+                g.use_ff, g.sample_lambda_beta, g.full_lambda_u = int(en.use_FF), int(en.lambda_beta_sample), int(self.full_lambda_u)
+                g.tol, g.lb_nu, g.lb_mu = self.tol, en.nu, en.mu
         self.gibbs = C.c_void_p()
         check(lib().bdf_gibbs_create(self.ctx.handle, self.D, len(self.ent), ents, C.byref(self.gibbs)))
         h, p = C.c_void_p(), C.c_void_p()

@@ -43,39 +43,171 @@ HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 def cpu_baseline(rd, D, seed, budget_s=12.0):
     """Sweeps/s of the CPU oracle on the same training set (rows of both entities + hyperprior draws)."""
     import numpy as np
-    from oracle import oracle as O
     r = rd.relations[0]
-    N = list(r.data.dims)
-    idx = O.index_build(r.data.ids, N)
+    nthreads = _host_threads()
+    multi, rows_only, n = cpu_rows_sweeps(r.data.ids, r.data.values, list(r.data.dims), r.model.alpha, D, seed, None, nthreads, budget_s, r.data.valueMean())
+    single, _, _ = cpu_rows_sweeps(r.data.ids, r.data.values, list(r.data.dims), r.model.alpha, D, seed, 2, 1, 0.0, r.data.valueMean())
+    return {"value": round(1.0 / multi, 4), "unit": "sweeps/s", "cores": nthreads, "kind": "port",
+            "sample": f"{n} full Gibbs sweeps (rows of both entities + hyperpriors) of the same MovieLens D={D} training set, "
+                      f"oracle/bdf_oracle.c with OpenMP over rows on {nthreads} threads (the row phase alone: {1.0 / rows_only:.1f} sweeps/s); "
+                      f"single thread: {1.0 / single:.4f} sweeps/s",
+            "value_1thread": round(1.0 / single, 4), "value_rows_only": round(1.0 / rows_only, 4)}
+
+
+def _host_threads():
+    # (not omp_get_max_threads: the OpenMP runtime may have been loaded while the process was pinned to one core)
+    return max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 1024))
+
+
+def cpu_rows_sweeps(ids, vals, dims, alpha, D, seed, n_sweeps, nthreads, budget_s=0.0, mean=None):
+    """(seconds per sweep, seconds of it in the row phase, sweeps timed) of the CPU oracle on a two-mode relation: rows of both
+    entities + hyperprior draws; one untimed sweep first; n_sweeps None: as many as fit budget_s (3 .. 200)"""
+    import numpy as np
+    from oracle import oracle as O
+    N = list(dims)
+    idx = O.index_build(ids, N)
     S = [np.zeros((N[0], D)), np.zeros((N[1], D))]
     mu = [np.zeros(D), np.zeros(D)]
     Lam = [5.0 * np.eye(D), 5.0 * np.eye(D)]
-    mean = r.data.valueMean()
-    # (not omp_get_max_threads: the OpenMP runtime may have been loaded while the process was pinned to one core)
-    nthreads = max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else O.num_threads(), 1024))
+    mean = float(np.mean(vals)) if mean is None else float(mean)
+    # the relation's view of each entity, built once: the rows are sampled in place (a term never reads its own entity's rows)
+    terms = [O.Term(ids, vals, N, j, alpha, mean, [None if k == j else S[k] for k in (0, 1)], index=idx) for j in (0, 1)]
+    t_rows = [0.0]
 
-    def sweep(it, nt):
+    def sweep(it):
         for j in (0, 1):
-            t = O.Term(r.data.ids, r.data.values, N, j, r.model.alpha, mean, [None if k == j else S[k] for k in (0, 1)], index=idx)
-            S[j] = O.sample_rows(D, N[j], [t], mu[j], Lam[j], seed, it, j + 1, nthreads=nt)
+            t0 = time.perf_counter()
+            O.sample_rows(D, N[j], [terms[j]], mu[j], Lam[j], seed, it, j + 1, out=S[j], nthreads=nthreads)
+            t_rows[0] += time.perf_counter() - t0
             mu_N, beta_N, T_N, nu_N = O.hyper_params(S[j], np.zeros(D), 2.0, np.eye(D), float(D))
             mu[j], Lam[j] = O.hyper_draw(mu_N, beta_N, T_N, nu_N, seed, it, j + 1)
 
-    sweep(1, nthreads)                      # untimed: first-touch, and a non-zero factor state
-    t0 = time.time()
+    sweep(1)                      # untimed: first touch, and a non-zero factor state
+    t_rows[0] = 0.0
+    t0 = time.perf_counter()
     n = 0
-    while n < 3 or (time.time() - t0 < budget_s and n < 200):
-        sweep(2 + n, nthreads)
+    while (n < n_sweeps) if n_sweeps is not None else (n < 3 or (time.perf_counter() - t0 < budget_s and n < 200)):
+        sweep(2 + n)
         n += 1
-    multi = n / (time.time() - t0)
-    t0 = time.time()
-    sweep(1000, 1)
-    sweep(1001, 1)
-    single = 2 / (time.time() - t0)
-    return {"value": round(multi, 4), "unit": "sweeps/s", "cores": nthreads, "kind": "port",
-            "sample": f"{n} full Gibbs sweeps (rows of both entities + hyperpriors) of the same MovieLens D={D} training set, "
-                      f"oracle/bdf_oracle.c with OpenMP over rows on {nthreads} threads; single thread: {single:.4f} sweeps/s",
-            "value_1thread": round(single, 4)}
+    return (time.perf_counter() - t0) / n, t_rows[0] / n, n
+
+
+def c4_cpu_baseline(rel4, D, budget_s=10.0):
+    """The CPU oracle beside configuration C4.  A full sweep of 11M rows at D = 64 takes the oracle minutes, so it is timed on
+    two samples of the SAME relation with every sampled row's complete observation list -- the first users (uniform rows,
+    ~10 observations each) and a block of mid-popularity items (hundreds to thousands each) -- and the sweep is extrapolated
+    with the cost model t = a rows + b observations fitted to the two (stated as such in `sample`)."""
+    import numpy as np
+    from oracle import oracle as O
+    ids, vals = np.asarray(rel4.data.ids), np.asarray(rel4.data.values, dtype=np.float64)
+    Nu, Ni = [int(x) for x in rel4.data.dims]
+    nnz = len(vals)
+    nthreads = _host_threads()
+    mean = float(vals.mean())
+    mu, Lam = np.zeros(D), 5.0 * np.eye(D)
+
+    def timed(mode, lo, hi):
+        """rows lo < id <= hi of `mode` with their complete observation lists (the other mode's ids compacted)"""
+        m = (ids[:, mode] > lo) & (ids[:, mode] <= hi)
+        sub = np.empty((int(m.sum()), 2), dtype=np.int64, order="F")
+        sub[:, mode] = ids[m, mode] - lo
+        other, inv = np.unique(ids[m, 1 - mode], return_inverse=True)
+        sub[:, 1 - mode] = inv + 1
+        dims = [0, 0]
+        dims[mode], dims[1 - mode] = hi - lo, len(other)
+        fac = [None, None]
+        fac[1 - mode] = np.full((len(other), D), 0.05)
+        t = O.Term(sub, vals[m], dims, mode, 2.0, mean, fac)
+        O.sample_rows(D, min(dims[mode], 256), [t], mu, Lam, 5, 1, mode + 1, row_end=min(dims[mode], 256), nthreads=nthreads)     # first touch
+        t0 = time.time()
+        O.sample_rows(D, dims[mode], [t], mu, Lam, 5, 2, mode + 1, nthreads=nthreads)
+        return time.time() - t0, dims[mode], int(m.sum())
+
+    # users: a probe sets the sample so that it takes about half the budget
+    tp, rp, _ = timed(0, 0, min(Nu, 20_000))
+    n1 = int(min(Nu, max(20_000, 0.5 * budget_s / max(tp, 1e-3) * rp)))
+    t1, r1, o1 = timed(0, 0, n1)
+    c0 = min(Ni // 2, 5000)
+    tp, rp, _ = timed(1, c0, min(Ni, c0 + 500))
+    n2 = int(min(Ni - c0, max(500, 0.5 * budget_s / max(tp, 1e-3) * rp)))
+    t2, r2, o2 = timed(1, c0, c0 + n2)
+    # t = a rows + b observations
+    det = r1 * o2 - r2 * o1
+    a = (t1 * o2 - t2 * o1) / det if det else t1 / max(r1, 1)
+    b = (r1 * t2 - r2 * t1) / det if det else 0.0
+    if a <= 0 or b <= 0:          # degenerate fit: rows only / observations only
+        a, b = t1 / max(r1, 1), t2 / max(o2, 1)
+    sweep_s = a * (Nu + Ni) + b * 2 * nnz
+    return {"value": round(1.0 / sweep_s, 5), "unit": "sweeps/s", "cores": nthreads, "kind": "port", "ms_per_sweep": round(1e3 * sweep_s, 1),
+            "sample": f"EXTRAPOLATED: oracle/bdf_oracle.c, OpenMP over rows on {nthreads} threads, timed on {r1} users ({o1} observations, {t1:.2f} s) "
+                      f"and {r2} items ({o2} observations, {t2:.2f} s) of this relation with their complete observation lists; cost model "
+                      f"t = {a * 1e6:.2f} us x rows + {b * 1e9:.1f} ns x observations applied to {Nu + Ni} rows and 2 x {nnz} observations "
+                      f"(row sampling only: the hyperprior draws are not in it)"}
+
+
+def c3_block(B, datasets, D, device, sweeps=20):
+    """Macau on MovieLens with the dense 6040 x 500 user features of configuration C3: one native call per iteration (uhat,
+    rows, hyperpriors with the feature terms, beta); the direct solve and the forced conjugate gradients"""
+    out = {"workload": f"Macau MovieLens-1M + dense user side information 6040 x 500 (iid N(0,1), seed 4242), D={D}, 5 + {sweeps} sweeps, "
+                       f"no prediction update; ms per sweep"}
+    for ff_size, key in ((6500, "ff"), (0, "cg")):
+        rd, _ = datasets.c3_relation_data(B, "iid")
+        eng = B.GibbsEngine(rd, D, seed=1, device=device, compute_ff_size=ff_size)
+        eng.warm_device(30.0)
+        for i in range(1, 6):
+            eng.sweep(i)
+        eng.sync()
+        t0 = time.perf_counter()
+        for i in range(6, 6 + sweeps):
+            eng.sweep(i)
+        eng.sync()
+        dt = (time.perf_counter() - t0) / sweeps
+        it = eng.ent[0].cg_iters.cpu().numpy()
+        out[key] = {"ms_per_sweep": round(1e3 * dt, 4), "sweeps_per_s": round(1.0 / dt, 1), "native_iteration": bool(eng.native),
+                    "solver": "direct (blocked Cholesky of F'F + lambda I)" if ff_size else "conjugate gradients (compute_ff_size=0)",
+                    "cg_iterations_last_sweep": [int(it.min()), int(it.max())]}
+        eng.close()
+    return out
+
+
+def mref_block(B, device, cpu):
+    """The reference's own benchmark shape (test/benchmark_parallel_latent.jl:8-61): sprand(1_500_000, 1000, 0.01)-like
+    relation (uniform positions, U(0,1) values, seed 1500), BPMF with D = 10 and 30, 2 + 2 iterations, 50 test entries"""
+    import numpy as np
+    rng = np.random.default_rng(1500)
+    N, M = 1_500_000, 1000
+    nnz = int(N * M * 0.01)
+    key = np.unique(rng.integers(0, N * M, size=int(nnz * 1.01)))[:nnz]
+    ids = np.stack([key // M + 1, key % M + 1], axis=1)
+    vals = rng.random(len(key))
+    out = {"workload": f"uniform {N} x {M}, {len(key)} observations U(0,1) (seed 1500), BPMF, 2 burn-in + 2 timed iterations, 50 test entries"}
+    for D in (10, 30):
+        rel = B.Relation((ids, vals), "r", [B.Entity("rows"), B.Entity("cols")], dims=[N, M])
+        B.assignToTest(rel, np.arange(1, 51))
+        rd = B.RelationData(rel)
+        eng = B.GibbsEngine(rd, D, seed=1, device=device)
+        test = eng.test_pairs()
+        for i in (1, 2):
+            eng.step(i, 0, [], rel.class_cut)
+        eng.sync()
+        t0 = time.perf_counter()
+        for i in (3, 4):
+            eng.step(i, 1 if i == 3 else 2, [], rel.class_cut)
+        eng.sync()
+        dt = (time.perf_counter() - t0) / 2
+        bytes_sweep = sum(eng.k1_algorithmic_bytes(j) for j in (0, 1))
+        blk = {"ms_per_sweep": round(1e3 * dt, 3), "sweeps_per_s": round(1.0 / dt, 2), "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
+               "algorithmic_tb_per_s": round(bytes_sweep / dt / 1e12, 3)}
+        train_ids, train_vals = np.asarray(rel.data.ids), np.asarray(rel.data.values, dtype=np.float64)
+        eng.close()
+        if cpu:
+            nt = _host_threads()
+            s_all, s_rows, _ = cpu_rows_sweeps(train_ids, train_vals, [N, M], rel.model.alpha, D, 1, 2, nt)
+            blk["cpu_baseline"] = {"value": round(1.0 / s_all, 4), "unit": "sweeps/s", "cores": nt, "kind": "port",
+                                   "sample": f"2 full sweeps (rows of both entities + hyperpriors) of the same relation after one untimed, "
+                                             f"oracle/bdf_oracle.c with OpenMP over rows on {nt} threads (the row phase alone: {1.0 / s_rows:.3f} sweeps/s)"}
+        out[f"d{D}"] = blk
+    return out
 
 
 def pin_to_quiet_core(share, shares):
@@ -187,6 +319,8 @@ def main():
                     help="engine set-up: untimed row launches that do not advance the chain, before the first warm-up step "
                          "(brings the device out of its idle power state; 0 = none)")
     ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
+    ap.add_argument("--no-c3", action="store_true", help="skip the C3 block (Macau with dense side information; one GPU only)")
+    ap.add_argument("--no-mref", action="store_true", help="skip the block on the reference's own benchmark shape (one GPU only)")
     ap.add_argument("--c4-rows", type=int, default=10_000_000)
     ap.add_argument("--c4-cols", type=int, default=1_000_000)
     ap.add_argument("--c4-nnz", type=int, default=100_000_000)
@@ -421,10 +555,23 @@ def main():
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
             eng4.close()
+            if not args.no_cpu_baseline and rank == 0:
+                del eng4, test4
+                c4["cpu_baseline"] = c4_cpu_baseline(rel4, args.c4_latent)
         except Exception as e:      # noqa: BLE001 -- the BASELINE metric above must still be reported
             c4["error"] = f"{type(e).__name__}: {e}"
         if out is not None:
             out["c4"] = c4
+    # ---- configuration C3 and the reference's own benchmark shape (one GPU) ------------------------------------------------
+    if world == 1 and out is not None:
+        for name, skip, fn in (("c3", args.no_c3, lambda: c3_block(B, datasets, D, local_rank)),
+                               ("mref", args.no_mref, lambda: mref_block(B, local_rank, not args.no_cpu_baseline))):
+            if skip:
+                continue
+            try:
+                out[name] = fn()
+            except Exception as e:      # noqa: BLE001
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

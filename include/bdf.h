@@ -338,7 +338,8 @@ int bdf_comm_size(const bdf_comm *comm, int *rank, int *world);
 int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t N, double *sample, int chunk, int chunks);
 int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *comm);
 
-/* ---- a2: one Gibbs iteration enqueued from native code (src/macau.jl:80-203 without side information) ---------------------
+/* ---- a2: one Gibbs iteration enqueued from native code (src/macau.jl:80-203; relation-level side information and alpha
+ * sampling excepted: those iterations are enqueued step by step through the entry points above) ------------------------
  * rows of every entity (+ exchange) -> hyperpriors -> test-set prediction update, on three streams (rows: ctx's; the other
  * two are created here, chosen so that they really run beside it).  Hand-overs: events on the kernels' own dispatch
  * packets; and -- when ctx came from bdf_ctx_create_rows with CUs set aside, one rank, BDF_NO_POLL unset -- the row kernels
@@ -358,6 +359,20 @@ typedef struct {
     double *sample[3];            /* dev, D x N each: the rows rotate through three buffers; [0] holds the current rows      */
     double *mu, *Lambda, *mu0, *WI, *sumU, *UUt, *params /*nullable*/, *prior_pack, *draws;   /* dev, as in bdf_hyper_sample */
     double b0, nu0;
+    /* side information of the entity (Entity.F; NULL: none -- a zeroed tail of the struct is "no features").  With it the
+     * iteration runs uhat = (F beta)' and the per-row prior means before the entity's rows (macau.jl:103-104), the feature
+     * terms in its hyperprior (macau.jl:124-129) and update_beta! after the rows of every entity (macau.jl:138-140) */
+    const bdf_feat *feat;
+    double *beta;                 /* dev, numF x D                                                                          */
+    double *uhat, *mu_matrix;     /* dev, D x N each                                                                        */
+    double *Tinv;                 /* dev, D x D: WI + beta' beta lambda_beta                                                */
+    double *lambda_beta;          /* dev, 1                                                                                 */
+    int32_t *cg_iters;            /* dev, D (nullable)                                                                      */
+    int32_t use_ff;               /* (F'F + lambda I) \ rhs directly (numF <= compute_ff_size) or by conjugate gradients    */
+    int32_t sample_lambda_beta, full_lambda_u;
+    int32_t _pad;
+    double tol;                   /* NaN: eps() * numF                                                                      */
+    double lb_nu, lb_mu;          /* hyper-parameters of sample_lambda_beta (Entity.nu, Entity.mu)                          */
 } bdf_gibbs_entity;
 int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const bdf_gibbs_entity *entities, bdf_gibbs **out);
 int bdf_gibbs_destroy(bdf_gibbs *g);

@@ -179,9 +179,11 @@ double orc_gamma(uint64_t seed, uint32_t sweep, uint32_t entity, uint64_t g, dou
 /* ------------------------------------------------------------------------------------ */
 /* general inverse by LU with partial pivoting -- what Julia's inv(::Matrix) does through
  * LAPACK getrf+getri (src/sampling.jl:207,229,284). returns 0 on success */
-static int inv_lu(int n, const double *A, double *Ainv)
+/* `work`: n * n + n doubles of scratch (NULL: allocated here) */
+static int inv_lu_ws(int n, const double *A, double *Ainv, double *work)
 {
-    double *M = (double *)malloc(sizeof(double) * (size_t)n * n);
+    double *M = work ? work : (double *)malloc(sizeof(double) * ((size_t)n * n + n));
+    double *colk = M + (size_t)n * n;
     memcpy(M, A, sizeof(double) * (size_t)n * n);
     for (int j = 0; j < n; j++)
         for (int i = 0; i < n; i++) Ainv[i + (size_t)j * n] = (i == j) ? 1.0 : 0.0;
@@ -191,7 +193,7 @@ static int inv_lu(int n, const double *A, double *Ainv)
             double v = fabs(M[i + (size_t)k * n]);
             if (v > best) { best = v; p = i; }
         }
-        if (best == 0.0) { free(M); return -1; }
+        if (best == 0.0) { if (!work) free(M); return -1; }
         if (p != k)
             for (int j = 0; j < n; j++) {
                 double t = M[k + (size_t)j * n]; M[k + (size_t)j * n] = M[p + (size_t)j * n]; M[p + (size_t)j * n] = t;
@@ -199,19 +201,23 @@ static int inv_lu(int n, const double *A, double *Ainv)
             }
         double piv = 1.0 / M[k + (size_t)k * n];
         for (int j = 0; j < n; j++) { M[k + (size_t)j * n] *= piv; Ainv[k + (size_t)j * n] *= piv; }
-        for (int i = 0; i < n; i++) {
-            if (i == k) continue;
-            double f = M[i + (size_t)k * n];
-            if (f == 0.0) continue;
-            for (int j = 0; j < n; j++) {
-                M[i + (size_t)j * n] -= f * M[k + (size_t)j * n];
-                Ainv[i + (size_t)j * n] -= f * Ainv[k + (size_t)j * n];
+        /* row i -= f_i * row k for every i != k with f_i = M[i][k]: the same products and differences as the row-by-row form,
+         * taken column by column so that the inner loop runs along the (column-major) storage */
+        for (int i = 0; i < n; i++) colk[i] = (i == k) ? 0.0 : M[i + (size_t)k * n];
+        for (int j = 0; j < n; j++) {
+            const double mk = M[k + (size_t)j * n], ak = Ainv[k + (size_t)j * n];
+            double *Mj = M + (size_t)j * n, *Aj = Ainv + (size_t)j * n;
+            for (int i = 0; i < n; i++) {
+                if (colk[i] == 0.0) continue;
+                Mj[i] -= colk[i] * mk;
+                Aj[i] -= colk[i] * ak;
             }
         }
     }
-    free(M);
+    if (!work) free(M);
     return 0;
 }
+static int inv_lu(int n, const double *A, double *Ainv) { return inv_lu_ws(n, A, Ainv, NULL); }
 
 /* lower Cholesky factor L (L L' = A) reading the UPPER triangle of A, as
  * chol(Hermitian(covar))' does (src/sampling.jl:211). returns 0 on success */
@@ -286,14 +292,15 @@ void orc_row_system(int D, int n_terms, const orc_term *terms, int64_t row,
 /* sample_user_basic / sample_user2 (src/sampling.jl:200-212, 215-234, 266-289), literally:
  * covar = inv(P); mu = covar*b; x = chol(Hermitian(covar))' * z + mu.
  * mean_out (nullable) receives covar*b. returns 0 on success */
-int orc_sample_row(int D, int n_terms, const orc_term *terms, int64_t row, const double *mu_i,
-                   const double *Lambda, const double *z, double *x, double *mean_out)
+/* work: 4 D^2 + D doubles of scratch (NULL: allocated here) */
+static int orc_sample_row_ws(int D, int n_terms, const orc_term *terms, int64_t row, const double *mu_i,
+                             const double *Lambda, const double *z, double *x, double *mean_out, double *work)
 {
-    double *P = (double *)malloc(sizeof(double) * (size_t)D * D * 3);
+    double *P = work ? work : (double *)malloc(sizeof(double) * ((size_t)D * D * 4 + D));
     double *covar = P + (size_t)D * D, *L = covar + (size_t)D * D;
     double b[ORC_MAX_D], m[ORC_MAX_D];
     orc_row_system(D, n_terms, terms, row, mu_i, Lambda, P, b);
-    int rc = inv_lu(D, P, covar);
+    int rc = inv_lu_ws(D, P, covar, L + (size_t)D * D);
     if (!rc) {
         for (int i = 0; i < D; i++) {
             double s = 0.0;
@@ -310,8 +317,13 @@ int orc_sample_row(int D, int n_terms, const orc_term *terms, int64_t row, const
             if (mean_out) mean_out[i] = m[i];
         }
     }
-    free(P);
+    if (!work) free(P);
     return rc;
+}
+int orc_sample_row(int D, int n_terms, const orc_term *terms, int64_t row, const double *mu_i,
+                   const double *Lambda, const double *z, double *x, double *mean_out)
+{
+    return orc_sample_row_ws(D, n_terms, terms, row, mu_i, Lambda, z, x, mean_out, NULL);
 }
 
 /* sample_latent_range / sample_user2_all! (src/sampling.jl:181-198, 251-264): every row in
@@ -324,14 +336,22 @@ int orc_sample_rows(int D, int64_t row_begin, int64_t row_end, int n_terms, cons
                     uint64_t seed, uint32_t sweep, uint32_t entity_tag, double *out, int nthreads)
 {
     int fail = 0;
+    /* (one scratch block per thread: a malloc per row serialises 256 threads on the allocator) */
 #ifdef _OPENMP
-#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads > 0 ? nthreads : 1)
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
 #endif
-    for (int64_t i = row_begin; i < row_end; i++) {
-        double z[ORC_MAX_D + 1];
-        orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D, z);
-        const double *mu_i = mu_is_matrix ? mu + (size_t)i * D : mu;
-        if (orc_sample_row(D, n_terms, terms, i, mu_i, Lambda, z, out + (size_t)i * D, NULL)) fail = 1;
+    {
+        double *work = (double *)malloc(sizeof(double) * ((size_t)D * D * 4 + D));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+        for (int64_t i = row_begin; i < row_end; i++) {
+            double z[ORC_MAX_D + 1];
+            orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D, z);
+            const double *mu_i = mu_is_matrix ? mu + (size_t)i * D : mu;
+            if (orc_sample_row_ws(D, n_terms, terms, i, mu_i, Lambda, z, out + (size_t)i * D, NULL, work)) fail = 1;
+        }
+        free(work);
     }
     (void)nthreads;
     return fail ? -1 : 0;
@@ -351,12 +371,21 @@ int orc_hyper_params(int D, int64_t N, const double *U, const double *mu0, doubl
     double *NS = (double *)calloc((size_t)D * D, sizeof(double));
     double NU[ORC_MAX_D];
     for (int i = 0; i < D; i++) NU[i] = 0.0;
-    for (int64_t n = 0; n < N; n++) {
-        const double *u = U + (size_t)n * D;
-        for (int j = 0; j < D; j++) {
-            NU[j] += u[j];
-            for (int i = 0; i < D; i++) NS[i + (size_t)j * D] += u[i] * u[j];
+    /* one column of N S per task: every element is still the sum over the rows in their order (the same bits as a serial
+     * pass), and a 1.5M-row entity no longer costs a second of one core per draw */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static, 1) if (N * (int64_t)D * D > 4000000)
+#endif
+    for (int j = 0; j < D; j++) {
+        double nu_j = 0.0;
+        double *col = NS + (size_t)j * D;
+        for (int64_t n = 0; n < N; n++) {
+            const double *u = U + (size_t)n * D;
+            const double uj = u[j];
+            nu_j += uj;
+            for (int i = 0; i < D; i++) col[i] += u[i] * uj;
         }
+        NU[j] = nu_j;
     }
     *nu_N = nu + (double)N;
     *beta_N = b0 + (double)N;

@@ -128,6 +128,7 @@ def test_c3_reduced_whole_iterations_match_oracle(B, O, use_ff):
     B.setPrecision(rel, 1.5)
     rd = B.RelationData(rel)
     B.macau(rd, burnin=2, psamples=0, num_latent=D, verbose=False, seed=21, compute_ff_size=6500 if use_ff else 0)
+    assert rd._engine.native          # entity side information runs inside the native iteration (bdf_gibbs_sweep)
     _compare(rd, *oracle_macau(O, rd, D, 21, 2, use_ff))
 
 
@@ -187,6 +188,7 @@ def test_c5_reduced_whole_iterations_match_oracle(B, O, use_ff):
     D = 32
     B.macau(rd, burnin=2, psamples=0, num_latent=D, verbose=False, seed=31, compute_ff_size=6500 if use_ff else 0)
     assert len(rd.entities) == 4 and len(rd.entities[0].relations) == 2 and rd.entities[0].use_FF is use_ff
+    assert rd._engine.native
     _compare(rd, *oracle_macau(O, rd, D, 31, 2, use_ff))
 
 

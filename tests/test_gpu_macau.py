@@ -372,7 +372,7 @@ def test_two_ranks_match_one(B):
                           "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
-    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline",
+    one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline", "--no-c3", "--no-mref",
                           "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]

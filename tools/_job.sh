@@ -1,7 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 1500 python -m pytest tests/ -q -m gpu 2>&1 | grep -E "passed|failed|^E " | tail -5 > gpurun_out/suite.txt
-for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-c4 --no-cpu-baseline 2>/dev/null | tail -1 | cut -c1-140 >> gpurun_out/suite.txt; done
-python3 bench.py --no-c4 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+SECONDS=0; python3 bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/bench_full.json 2> gpurun_out/bench_full.err
+tail -1 gpurun_out/bench_full.json | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('long', d['value'], d['ms_per_step'], d['roofline'])" >> gpurun_out/suite.txt
-cat gpurun_out/suite.txt
+d=json.loads(sys.stdin.readline())
+print('value', d['value'], d['ms_per_step'], 'rmse', d['test_rmse'])
+print('roofline', d['roofline'])
+print('cpu', d.get('cpu_baseline'))
+print('c4', d.get('c4'))
+print('c3', d.get('c3'))
+print('mref', d.get('mref'))
+"
+echo "wall ${SECONDS}s"; tail -3 gpurun_out/bench_full.err | cut -c1-300

@@ -13,7 +13,7 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
-B="--no-cpu-baseline --no-c4"
+B="--no-cpu-baseline --no-c4 --no-c3 --no-mref"
 python3 bench.py > $out/bench.json 2> $out/bench.err
 (cd /tmp && rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 300 $B > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
