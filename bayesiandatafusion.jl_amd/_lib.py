@@ -145,6 +145,10 @@ _SIGS = {
     "bdf_sample_beta": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
                                   C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
                                   C.c_void_p]),
+    "bdf_sample_beta_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                        C.c_double, C.c_int, C.c_int, C.c_double, C.c_double, C.c_uint32, C.c_void_p, C.c_void_p,
+                                        C.c_void_p]),
+    "bdf_allgather_block": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bdf_ctx_create_side": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.c_int, C.c_int, C.POINTER(C.c_void_p)]),
     "bdf_ctx_create_rows": (C.c_int, [C.c_int, C.c_uint64, C.c_int, C.POINTER(C.c_void_p)]),
     "bdf_ctx_stream": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -166,6 +166,29 @@ extern "C" int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *c, int D, int64_t N, d
     return BDF_OK;
 }
 
+// in-place all-gather of `bytes` bytes per rank: rank r's block sits at buf + r * bytes.  Ordered after the work enqueued so far on
+// ctx's stream, runs on the communicator's stream (bdf_allgather_join: ctx's stream waits for it); host transport: synchronous.
+extern "C" int bdf_allgather_block(bdf_ctx *ctx, bdf_comm *c, void *buf, size_t bytes)
+{
+    BDF_REQUIRE(ctx && c && buf, BDF_ERR_ARG, "bdf_allgather_block: NULL argument");
+    if (bytes == 0 || (c->world == 1 && !c->nccl)) return BDF_OK;
+    char *b = (char *)buf;
+    if (c->nccl) {
+        BDF_HIP(hipEventRecord(c->ev_rows, ctx->stream));
+        BDF_HIP(hipStreamWaitEvent(c->stream, c->ev_rows, 0));
+        BDF_NCCL(g_rccl.all_gather(b + (size_t)c->rank * bytes, b, bytes, 1 /* ncclUint8 */, c->nccl, c->stream));
+        return BDF_OK;
+    }
+    c->hsend.resize(bytes); c->hrecv.resize(bytes * (size_t)c->world);
+    BDF_HIP(hipMemcpyAsync(c->hsend.data(), b + (size_t)c->rank * bytes, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    int rc = c->cb(c->cb_user, c->hsend.data(), c->hrecv.data(), bytes);
+    BDF_REQUIRE(rc == 0, BDF_ERR_HIP, "bdf_allgather_block: the host exchange function returned %d", rc);
+    BDF_HIP(hipMemcpyAsync(b, c->hrecv.data(), bytes * (size_t)c->world, hipMemcpyHostToDevice, ctx->stream));
+    BDF_HIP(hipStreamSynchronize(ctx->stream));
+    return BDF_OK;
+}
+
 extern "C" int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *c)
 {
     BDF_REQUIRE(ctx && c, BDF_ERR_ARG, "bdf_allgather_join: NULL argument");

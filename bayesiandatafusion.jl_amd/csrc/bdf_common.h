@@ -134,6 +134,8 @@ struct bdf_feat {
     int32_t *row_ids_dev; // nullable (bdf_feat_set_row_ids): original id of every row of F, keys the rows' noise streams
     double *chol_ws;      // workspace of the blocked direct solve (k_chol.hip), allocated on first use
     size_t chol_ws_doubles;
+    void *gather_dev;     // several ranks: the blocks of beta columns the ranks exchange (bdf_sample_beta_ranks), on first use
+    size_t gather_bytes;
 };
 
 // (FF + lambda I) \ rhs for all D right-hand sides by blocked Cholesky (solve_full, src/sampling.jl:314-320)

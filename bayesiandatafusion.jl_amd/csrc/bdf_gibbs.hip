@@ -518,8 +518,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         const bdf_gibbs_entity &e = E.d;
         if (!e.feat) continue;
         BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
-        if ((rc = bdf_sample_beta(R, e.feat, D, e.sample[E.cur], e.mu, e.Lambda, e.lambda_beta, e.use_ff, e.tol, 0, e.sample_lambda_beta,
-                                  e.lb_nu, e.lb_mu, e.tag, e.beta, nullptr, e.cg_iters)))
+        if ((rc = bdf_sample_beta_ranks(R, g->comm, e.feat, D, e.sample[E.cur], e.mu, e.Lambda, e.lambda_beta, e.use_ff, e.tol, 0,
+                                        e.sample_lambda_beta, e.lb_nu, e.lb_mu, e.tag, e.beta, nullptr, e.cg_iters)))
             return rc;
         BDF_HIP(hipEventRecord(E.ev_beta, R->stream));
         E.beta_recorded = true;

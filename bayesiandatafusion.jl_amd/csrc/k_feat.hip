@@ -1064,7 +1064,7 @@ extern "C" int bdf_feat_destroy(bdf_feat *f)
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->dense_dev); hipFree(f->rowptr_dev); hipFree(f->colind_dev); hipFree(f->rvals_dev);
     hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev); hipFree(f->chol_ws);
-    hipFree(f->row_ids_dev);
+    hipFree(f->row_ids_dev); hipFree(f->gather_dev);
     delete f;
     return BDF_OK;
 }
@@ -1230,6 +1230,20 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
                                int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
                                double *beta_out, double *rhs_out, int32_t *iters_out)
 {
+    return bdf_sample_beta_ranks(ctx, nullptr, fc, D, sample, mu, Lambda, lambda_beta_dev, use_ff, tol, maxiter, sample_lambda, lb_nu,
+                                 lb_mu, entity_tag, beta_out, rhs_out, iters_out);
+}
+
+// Several ranks (comm != NULL, conjugate gradients): the D solves are shared out as solve_cg2 shares them over its workers
+// (src/parallel_matrix.jl:488-507): every rank forms the whole right-hand side (the same noise streams on every rank: one
+// product with F'), solves a contiguous block of ceil(D / P) columns and the blocks are all-gathered.  A column's iterates do
+// not depend on which other columns are solved beside it, so beta is the one a single rank computes.  The direct solve
+// handles all D right-hand sides in one factorisation and stays whole.
+extern "C" int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *fc, int D, const double *sample, const double *mu,
+                                     const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
+                                     int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
+                                     double *beta_out, double *rhs_out, int32_t *iters_out)
+{
     BDF_REQUIRE(ctx && fc && sample && mu && Lambda && lambda_beta_dev && beta_out, BDF_ERR_ARG, "bdf_sample_beta: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_sample_beta: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
     bdf_feat *f = const_cast<bdf_feat *>(fc);
@@ -1281,8 +1295,41 @@ extern "C" int bdf_sample_beta(bdf_ctx *ctx, const bdf_feat *fc, int D, const do
         const bool ff_op = cg_ff && numF > 0 && numF <= 1024 && numF * numF <= f->nnz;
         if (ff_op && (rc = ensure_FF(f))) return rc;
         int *cg_iters = nullptr;
-        if ((rc = cg_solve(ctx, f, ff_op, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
-        if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        int rank = 0, world = 1;
+        if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
+        if (world <= 1) {
+            if ((rc = cg_solve(ctx, f, ff_op, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+            if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+        } else {
+            // this rank's block of columns, solved into its place of a gather buffer of world blocks (>= D columns), then the
+            // exchange; the iteration counts travel behind each block's columns
+            const int nc = (D + world - 1) / world, c0 = rank * nc, mine = std::max(0, std::min(nc, D - c0));
+            const size_t blk = (size_t)nc * numF * sizeof(double) + (size_t)nc * sizeof(int32_t);
+            if (f->gather_bytes < blk * (size_t)world) {
+                BDF_HIP(hipStreamSynchronize(ctx->stream));
+                if (f->gather_dev) BDF_HIP(hipFree(f->gather_dev));
+                f->gather_dev = nullptr; f->gather_bytes = 0;
+                BDF_HIP(hipMalloc((void **)&f->gather_dev, blk * (size_t)world));
+                f->gather_bytes = blk * (size_t)world;
+            }
+            char *gb = (char *)f->gather_dev;
+            double *my_beta = (double *)(gb + (size_t)rank * blk);
+            int32_t *my_iters = (int32_t *)(gb + (size_t)rank * blk + (size_t)nc * numF * sizeof(double));
+            BDF_HIP(hipMemsetAsync(my_beta, 0, blk, ctx->stream));
+            if (mine > 0) {
+                if ((rc = cg_solve(ctx, f, ff_op, mine, lambda_beta_dev, rhs + (size_t)c0 * numF, my_beta, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+                BDF_HIP(hipMemcpyAsync(my_iters, cg_iters, (size_t)mine * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            if ((rc = bdf_allgather_block(ctx, comm, gb, blk)) || (rc = bdf_allgather_join(ctx, comm))) return rc;
+            for (int r = 0; r < world; r++) {
+                const int rc0 = r * nc, rn = std::max(0, std::min(nc, D - rc0));
+                if (rn <= 0) break;
+                BDF_HIP(hipMemcpyAsync(beta_out + (size_t)rc0 * numF, gb + (size_t)r * blk, (size_t)rn * numF * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                if (iters_out)
+                    BDF_HIP(hipMemcpyAsync(iters_out + rc0, gb + (size_t)r * blk + (size_t)nc * numF * sizeof(double), (size_t)rn * sizeof(int32_t),
+                                           hipMemcpyDeviceToDevice, ctx->stream));
+            }
+        }
     }
     if (sample_lambda) {
         {

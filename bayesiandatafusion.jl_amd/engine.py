@@ -757,9 +757,10 @@ class GibbsEngine:
         en, st = self.data.entities[j], self.ent[j]
         if st.F is None:
             return
-        check(lib().bdf_sample_beta(self.ctx.handle, st.F.handle, self.D, _ptr(st.sample), _ptr(st.mu), _ptr(st.Lambda),
-                                    _ptr(st.lambda_beta), int(en.use_FF), self.tol, 0, int(en.lambda_beta_sample),
-                                    en.nu, en.mu, st.tag, _ptr(st.beta), None, _ptr(st.cg_iters)))
+        # (several ranks: the conjugate-gradient columns are shared out over them and all-gathered, parallel_matrix.jl:488-507)
+        check(lib().bdf_sample_beta_ranks(self.ctx.handle, self.comm.handle if self.comm is not None else None, st.F.handle, self.D,
+                                          _ptr(st.sample), _ptr(st.mu), _ptr(st.Lambda), _ptr(st.lambda_beta), int(en.use_FF), self.tol, 0,
+                                          int(en.lambda_beta_sample), en.nu, en.mu, st.tag, _ptr(st.beta), None, _ptr(st.cg_iters)))
 
     def sync_host_scalars(self):
         for en, st in zip(self.data.entities, self.ent):

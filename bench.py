@@ -49,14 +49,39 @@ def cpu_baseline(rd, D, seed, budget_s=12.0):
     single, _, _ = cpu_rows_sweeps(r.data.ids, r.data.values, list(r.data.dims), r.model.alpha, D, seed, 2, 1, 0.0, r.data.valueMean())
     return {"value": round(1.0 / multi, 4), "unit": "sweeps/s", "cores": nthreads, "kind": "port",
             "sample": f"{n} full Gibbs sweeps (rows of both entities + hyperpriors) of the same MovieLens D={D} training set, "
-                      f"oracle/bdf_oracle.c with OpenMP over rows on {nthreads} threads (the row phase alone: {1.0 / rows_only:.1f} sweeps/s); "
+                      f"oracle/bdf_oracle.c with OpenMP over rows on {_threads_note(nthreads)} (the row phase alone: {1.0 / rows_only:.1f} sweeps/s); "
                       f"single thread: {1.0 / single:.4f} sweeps/s",
             "value_1thread": round(1.0 / single, 4), "value_rows_only": round(1.0 / rows_only, 4)}
 
 
+def _cpu_quota():
+    """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), or None"""
+    for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
+                        ("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", lambda t: (t.strip(), open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().strip()))):
+        try:
+            q, per = parse(open(path).read())
+            if q != "max" and int(q) > 0:
+                return int(q) / int(per)
+        except (OSError, ValueError, IndexError):
+            pass
+    return None
+
+
 def _host_threads():
-    # (not omp_get_max_threads: the OpenMP runtime may have been loaded while the process was pinned to one core)
-    return max(1, min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 1024))
+    """threads for the CPU baseline: the hardware threads the process may run on, capped by the container's CPU quota (more
+    threads than the quota only get throttled: 256 threads on a 16-CPU quota ran the row phase 15 x slower than 16 did)
+    (not omp_get_max_threads: the OpenMP runtime may have been loaded while the process was pinned to one core)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = _cpu_quota()
+    if q is not None:
+        n = min(n, max(1, int(q + 0.5)))
+    return max(1, min(n, 1024))
+
+
+def _threads_note(nthreads):
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    q = _cpu_quota()
+    return f"{nthreads} threads" + (f" (the container's CPU quota, cpu.max = {q:g} CPUs, of the box's {n} hardware threads)" if q is not None and q < n else "")
 
 
 def cpu_rows_sweeps(ids, vals, dims, alpha, D, seed, n_sweeps, nthreads, budget_s=0.0, mean=None):
@@ -139,7 +164,7 @@ def c4_cpu_baseline(rel4, D, budget_s=10.0):
         a, b = t1 / max(r1, 1), t2 / max(o2, 1)
     sweep_s = a * (Nu + Ni) + b * 2 * nnz
     return {"value": round(1.0 / sweep_s, 5), "unit": "sweeps/s", "cores": nthreads, "kind": "port", "ms_per_sweep": round(1e3 * sweep_s, 1),
-            "sample": f"EXTRAPOLATED: oracle/bdf_oracle.c, OpenMP over rows on {nthreads} threads, timed on {r1} users ({o1} observations, {t1:.2f} s) "
+            "sample": f"EXTRAPOLATED: oracle/bdf_oracle.c, OpenMP over rows on {_threads_note(nthreads)}, timed on {r1} users ({o1} observations, {t1:.2f} s) "
                       f"and {r2} items ({o2} observations, {t2:.2f} s) of this relation with their complete observation lists; cost model "
                       f"t = {a * 1e6:.2f} us x rows + {b * 1e9:.1f} ns x observations applied to {Nu + Ni} rows and 2 x {nnz} observations "
                       f"(row sampling only: the hyperprior draws are not in it)"}
@@ -205,7 +230,7 @@ def mref_block(B, device, cpu):
             s_all, s_rows, _ = cpu_rows_sweeps(train_ids, train_vals, [N, M], rel.model.alpha, D, 1, 2, nt)
             blk["cpu_baseline"] = {"value": round(1.0 / s_all, 4), "unit": "sweeps/s", "cores": nt, "kind": "port",
                                    "sample": f"2 full sweeps (rows of both entities + hyperpriors) of the same relation after one untimed, "
-                                             f"oracle/bdf_oracle.c with OpenMP over rows on {nt} threads (the row phase alone: {1.0 / s_rows:.3f} sweeps/s)"}
+                                             f"oracle/bdf_oracle.c with OpenMP over rows on {_threads_note(nt)} (the row phase alone: {1.0 / s_rows:.3f} sweeps/s)"}
         out[f"d{D}"] = blk
     return out
 

@@ -337,6 +337,16 @@ int bdf_comm_size(const bdf_comm *comm, int *rank, int *world);
  * for every exchange enqueued so far. */
 int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t N, double *sample, int chunk, int chunks);
 int bdf_allgather_join(bdf_ctx *ctx, bdf_comm *comm);
+/* the same for any buffer of world equal blocks (dev; rank r's block at buf + r * bytes_per_rank) */
+int bdf_allgather_block(bdf_ctx *ctx, bdf_comm *comm, void *buf, size_t bytes_per_rank);
+/* bdf_sample_beta on several ranks: solve_cg2 shares the D conjugate-gradient solves out over its workers
+ * (src/parallel_matrix.jl:488-507); here every rank forms the right-hand side, solves a contiguous block of ceil(D / world)
+ * columns and the blocks (with their iteration counts) are all-gathered: beta, lambda_beta and iters_out end up identical on
+ * every rank and equal to the single-rank result.  comm NULL or one rank, or use_ff: exactly bdf_sample_beta. */
+int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *f, int D, const double *sample, const double *mu,
+                          const double *Lambda, double *lambda_beta_dev, int use_ff, double tol, int maxiter,
+                          int sample_lambda, double lb_nu, double lb_mu, uint32_t entity_tag,
+                          double *beta_out, double *rhs_out, int32_t *iters_out);
 
 /* ---- a2: one Gibbs iteration enqueued from native code (src/macau.jl:80-203; relation-level side information and alpha
  * sampling excepted: those iterations are enqueued step by step through the entry points above) ------------------------

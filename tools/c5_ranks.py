@@ -35,6 +35,27 @@ A = rd.entities[0]
 out = {"world": world, "rmse": float(np.sqrt(sse.item() / n_test)), "sample_norm": float(np.linalg.norm(A.model.sample)),
        "beta_norm": float(np.linalg.norm(A.model.beta)), "lambda_beta": float(eng.ent[0].lambda_beta.item()),
        "cg_iters": int(eng.ent[0].cg_iters.max().item()), "value_std": info["value_std"]}
+# the beta update by itself, after the chain: with several ranks every rank solves ceil(D / world) of the D conjugate-gradient
+# columns (bdf_sample_beta_ranks) -- its time per call, the slowest rank's
+import time
+from bdf_amd._lib import check, lib
+from bdf_amd.engine import _ptr
+st, en = eng.ent[0], A
+eng.sync(); torch.cuda.synchronize()
+if dist is not None:
+    dist.barrier()
+t0 = time.perf_counter()
+for k in range(3):
+    eng.ctx.set_sweep(1000 + k)
+    check(lib().bdf_sample_beta_ranks(eng.ctx.handle, eng.comm.handle if eng.comm is not None else None, st.F.handle, D, _ptr(st.sample),
+                                      _ptr(st.mu), _ptr(st.Lambda), _ptr(st.lambda_beta), 0, float("nan"), 0, 1, en.nu, en.mu, st.tag,
+                                      _ptr(st.beta), None, _ptr(st.cg_iters)))
+eng.ctx.sync()
+tb = torch.tensor([(time.perf_counter() - t0) / 3 * 1e3], dtype=torch.float64)
+if dist is not None:
+    dist.all_reduce(tb, op=dist.ReduceOp.MAX)
+out["beta_update_ms"] = round(float(tb.item()), 3)
+out["beta_columns_per_rank"] = -(-D // world)
 if rank == 0:
     print(json.dumps(out), flush=True)
 eng.close()
