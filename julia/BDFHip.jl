@@ -85,12 +85,28 @@ end
 "Relation.data (IndexedDF / FastIDF) on the device: replaces FastIDF(rel.data) + @spawnat (src/macau.jl:50-52)"
 mutable struct DevRelation
     h::Ptr{Cvoid}
+    ctx::Context                      # keeps the context alive for as long as the relation (the library frees through it)
     function DevRelation(c::Context, ids::Matrix{Int64}, values::Vector{Float64}, dims::Vector{Int64})
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:bdf_relation_create, lib), Cint,
                     (Ptr{Cvoid}, Cint, Ptr{Int64}, Int64, Ptr{Cvoid}, Cint, Ptr{Float64}, Ref{Ptr{Cvoid}}),
                     c.h, size(ids, 2), dims, size(ids, 1), ids, 8, values, out))
-        r = new(out[])
+        r = new(out[], c)
+        finalizer(x -> ccall((:bdf_relation_destroy, lib), Cint, (Ptr{Cvoid},), x.h), r)
+        r
+    end
+    """
+    Several GPUs: the relation of rank `rank` of `world` -- the full IndexedDF index, but on the device only the observations
+    of the rows this rank owns, at the internal positions `pos[m]` (0-based, from `layout`) of every mode (bdf_relation_create_sharded).
+    """
+    function DevRelation(c::Context, ids::Matrix{Int64}, values::Vector{Float64}, dims::Vector{Int64},
+                         pos::Vector{Vector{Int32}}, cmax::Vector{Int64}, rank::Integer, world::Integer, chunks::Integer)
+        out = Ref{Ptr{Cvoid}}(C_NULL)
+        pp = Ptr{Int32}[pointer(p) for p in pos]
+        GC.@preserve pos check(ccall((:bdf_relation_create_sharded, lib), Cint,
+                    (Ptr{Cvoid}, Cint, Ptr{Int64}, Int64, Ptr{Cvoid}, Cint, Ptr{Float64}, Ptr{Ptr{Int32}}, Ptr{Int64}, Cint, Cint, Cint, Ref{Ptr{Cvoid}}),
+                    c.h, size(ids, 2), dims, size(ids, 1), ids, 8, values, pp, cmax, rank, world, chunks, out))
+        r = new(out[], c)
         finalizer(x -> ccall((:bdf_relation_destroy, lib), Cint, (Ptr{Cvoid},), x.h), r)
         r
     end
@@ -236,19 +252,32 @@ struct GibbsEntity                                # bdf_gibbs_entity, field for 
     params::Ptr{Cvoid}; prior_pack::Ptr{Cvoid}; draws::Ptr{Cvoid}
     b0::Float64
     nu0::Float64
+    # side information of the entity (Entity.F): C_NULL / zeros = none.  With it the iteration runs F_mul_beta and the per-row
+    # prior means before the rows (macau.jl:103-104), the feature terms of the hyperprior (:124-129) and update_beta! (:138-140)
+    feat::Ptr{Cvoid}
+    beta::Ptr{Cvoid}; uhat::Ptr{Cvoid}; mu_matrix::Ptr{Cvoid}; Tinv::Ptr{Cvoid}; lambda_beta::Ptr{Cvoid}; cg_iters::Ptr{Cvoid}
+    use_ff::Int32; sample_lambda_beta::Int32; full_lambda_u::Int32; _pad::Int32
+    tol::Float64; lb_nu::Float64; lb_mu::Float64
 end
 
 mutable struct Gibbs
     h::Ptr{Cvoid}
-    function Gibbs(rows::Context, num_latent::Integer, entities::Vector{GibbsEntity})
+    # what the native object dereferences for as long as it lives: its row context (bdf_gibbs_sweep / _destroy synchronise
+    # its stream) and, once set, the communicator -- held here so that the GC cannot finalize them first
+    rows::Context
+    comm::Any
+    keep::Vector{Any}                 # device arrays and relations the entity descriptions point into
+    function Gibbs(rows::Context, num_latent::Integer, entities::Vector{GibbsEntity}; keep::Vector=Any[])
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:bdf_gibbs_create, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{GibbsEntity}, Ref{Ptr{Cvoid}}),
                     rows.h, num_latent, length(entities), entities, out))
-        g = new(out[])
+        g = new(out[], rows, nothing, collect(Any, keep))
         finalizer(x -> ccall((:bdf_gibbs_destroy, lib), Cint, (Ptr{Cvoid},), x.h), g)
         g
     end
 end
+"set-up: untimed row launches for about `ms` milliseconds that do not advance the chain (bdf_gibbs_warm_device)"
+warm_device!(g::Gibbs, ms::Real) = check(ccall((:bdf_gibbs_warm_device, lib), Cint, (Ptr{Cvoid}, Float64), g.h, ms))
 
 "one Gibbs iteration; phase: 0 burn-in, 1 first posterior sample, 2 later ones, -1 no prediction update"
 sweep!(g::Gibbs, i::Integer, phase::Integer=-1) = check(ccall((:bdf_gibbs_sweep, lib), Cint, (Ptr{Cvoid}, UInt32, Cint), g.h, i, phase))
@@ -279,14 +308,32 @@ end
 
 mutable struct Comm
     h::Ptr{Cvoid}
+    ctx::Context                      # bdf_comm_destroy uses the context's device
     function Comm(c::Context, rank::Integer, world::Integer, id::Vector{UInt8})
         out = Ref{Ptr{Cvoid}}(C_NULL)
         check(ccall((:bdf_comm_create, lib), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{UInt8}, Ref{Ptr{Cvoid}}), c.h, rank, world, id, out))
-        m = new(out[])
+        m = new(out[], c)
         finalizer(x -> ccall((:bdf_comm_destroy, lib), Cint, (Ptr{Cvoid},), x.h), m)
         m
     end
 end
-set_comm!(g::Gibbs, m::Comm) = check(ccall((:bdf_gibbs_set_comm, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), g.h, m.h))
+function set_comm!(g::Gibbs, m::Comm)
+    check(ccall((:bdf_gibbs_set_comm, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), g.h, m.h))
+    g.comm = m                        # the native object keeps the pointer: keep the communicator alive with it
+    nothing
+end
+"in-place exchange of chunk `chunk` (0-based) of the D x N sample matrix between the ranks, then `allgather_join!` (bdf_allgather_rows / _join)"
+allgather_rows!(c::Context, m::Comm, D, N, sample::DevArray, chunk::Integer, chunks::Integer) =
+    check(ccall((:bdf_allgather_rows, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Cint, Cint), c.h, m.h, D, N, sample.p, chunk, chunks))
+allgather_join!(c::Context, m::Comm) = check(ccall((:bdf_allgather_join, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), c.h, m.h))
+"update_beta! on several ranks: the conjugate-gradient columns shared out and all-gathered (parallel_matrix.jl:488-507; bdf_sample_beta_ranks)"
+function update_beta!(c::Context, m::Comm, feat::Ptr{Cvoid}, D, sample, mu, Lambda, lambda_beta_dev, use_ff::Bool, tol, sample_lambda::Bool,
+                      nu, mu_h, entity_tag, beta)
+    check(ccall((:bdf_sample_beta_ranks, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Cint, Float64, Cint, Cint, Float64, Float64,
+                 UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, m.h, feat, D, sample.p, mu.p, Lambda.p, lambda_beta_dev.p, use_ff, tol, 0, sample_lambda, nu, mu_h, entity_tag,
+                beta.p, C_NULL, C_NULL))
+end
 
 end # module
