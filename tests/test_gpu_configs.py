@@ -236,13 +236,14 @@ def test_c4_shaped_full_size_properties_and_quality(B):
     eng = GibbsEngine(rd, D, seed=5)
     eng.ctx.set_gather(2)
     test = eng.test_pairs()
-    for i in range(1, 21):
-        stats = eng.step(i, 0 if i <= 10 else (1 if i == 11 else 2), [1.0, 5.0], rel.class_cut)
+    for i in range(1, 61):
+        stats = eng.step(i, 0 if i <= 30 else (1 if i == 31 else 2), [1.0, 5.0], rel.class_cut)
     eng.sync()
     rmse = float(np.sqrt(stats.cpu().numpy()[0] / test.n))
     tv = np.asarray(rel.test_vec.values)
-    # 10 + 10 sweeps on ~20 ratings per user beat the mean predictor (0.88); the generator's floor is sqrt(0.25 + 1/12) = 0.58
-    assert 0.55 < rmse < 0.965 * tv.std(), (rmse, tv.std())
+    # 30 + 30 sweeps on ~20 ratings per user at D = 64: 0.72 (0.745 after 10 + 10, 0.714 after 60 + 60; tools/c4_quality_probe.py)
+    # against 0.88 for the mean predictor; the generator's floor is sqrt(0.25 + 1/12) = 0.58
+    assert 0.55 < rmse < 0.75 and tv.std() > 0.85, (rmse, tv.std())
     # items (100k rows, Zipf-like: the head rows are split into the maximum number of pieces), wide gather
     a = _shards_items_map(eng, 1, D, (0, 1, 99, 5000, 99999))
     # the same launch with 32-bit offsets (the factor matrices of this size allow both): identical arithmetic
