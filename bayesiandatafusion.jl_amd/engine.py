@@ -500,7 +500,11 @@ class GibbsEngine:
         # small kernels, which otherwise wait for slots beside the chip-filling row kernel -- when the entities are small
         # enough for those kernels to be small (the reductions of a 10M-row entity want the whole chip)
         big = max((en.count for en in data.entities), default=0) * int(num_latent) * 8 > (32 << 20)
-        reserve = int(os.environ.get("BDF_RESERVE_CUS", "0" if big else "8"))
+        # (the test rig that runs several ranks on ONE GPU, BDF_DIST_BACKEND=gloo, reserves none: two processes' kernels on the
+        # same eight masked CUs stalled each other for seconds once in ten runs -- k_hyper_chain's last workgroup ran into its spin
+        # bound; one process per GPU, the deployment, has the reserved CUs to itself)
+        rig = shard is not None and shard[1] > 1 and os.environ.get("BDF_DIST_BACKEND") == "gloo"
+        reserve = int(os.environ.get("BDF_RESERVE_CUS", "0" if (big or rig) else "8"))
         self.ctx = Context.rows(device, seed, reserve)
         if os.environ.get("BDF_ITEM_SIZE"):
             self.ctx.set_item_size(int(os.environ["BDF_ITEM_SIZE"]))

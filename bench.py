@@ -585,6 +585,7 @@ def main():
                 c4["cpu_baseline"] = c4_cpu_baseline(rel4, args.c4_latent)
         except Exception as e:      # noqa: BLE001 -- the BASELINE metric above must still be reported
             c4["error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: the C4 block failed: {c4['error']}", file=sys.stderr, flush=True)
         if out is not None:
             out["c4"] = c4
     # ---- configuration C3 and the reference's own benchmark shape (one GPU) ------------------------------------------------
