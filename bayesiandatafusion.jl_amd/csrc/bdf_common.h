@@ -136,7 +136,14 @@ struct bdf_feat {
     size_t chol_ws_doubles;
     void *gather_dev;     // several ranks: the blocks of beta columns the ranks exchange (bdf_sample_beta_ranks), on first use
     size_t gather_bytes;
+    // direct solve of a mid-sized feature set (64 < n <= BDF_EIG_MAX): F'F = Q diag(s) Q' once (host, first use), then
+    // (F'F + lambda I) \ rhs = Q ((Q' rhs) ./ (s + lambda)) per iteration -- lambda changes every iteration, Q and s do not
+    bdf_feat *eig_Q;      // Q as a dense n x n operator (eigenvectors in columns)
+    double *eig_s;        // n eigenvalues (dev)
+    double *eig_y;        // n x D workspace (dev), eig_y_cols columns
+    int eig_y_cols;
 };
+#define BDF_EIG_MAX 640
 
 // (FF + lambda I) \ rhs for all D right-hand sides by blocked Cholesky (solve_full, src/sampling.jl:314-320)
 int bdf_chol_solve(bdf_ctx *ctx, bdf_feat *f, int D, const double *lambda_dev, const double *rhs, double *beta);

@@ -189,7 +189,7 @@ def c3_block(B, datasets, D, device, sweeps=20):
         dt = (time.perf_counter() - t0) / sweeps
         it = eng.ent[0].cg_iters.cpu().numpy()
         out[key] = {"ms_per_sweep": round(1e3 * dt, 4), "sweeps_per_s": round(1.0 / dt, 1), "native_iteration": bool(eng.native),
-                    "solver": "direct (blocked Cholesky of F'F + lambda I)" if ff_size else "conjugate gradients (compute_ff_size=0)",
+                    "solver": "direct: F'F = Q diag(s) Q' once, beta = Q ((Q' rhs) ./ (s + lambda)) per iteration" if ff_size else "conjugate gradients (compute_ff_size=0)",
                     "cg_iterations_last_sweep": [int(it.min()), int(it.max())]}
         eng.close()
     return out

@@ -10,6 +10,8 @@ recomputed in numpy from the row-system hook, the beta update solves the referen
 """
 import ctypes as C
 
+import os
+
 import numpy as np
 import pytest
 
@@ -157,8 +159,20 @@ def test_c3_full_size_properties(B, kind, use_ff):
     res = (Ab - rhs).norm(dim=1) / rhs.norm(dim=1)
     its = its.cpu().numpy()
     if use_ff:
-        assert float(res.max()) < 1e-10, float(res.max())          # direct solve
+        assert float(res.max()) < 1e-10, float(res.max())          # direct solve (numF <= 640: through F'F = Q diag(s) Q')
         assert its.max() == 0
+        # the same solve by the blocked Cholesky factorisation (what larger feature sets take; BDF_NO_EIG forces it here)
+        beta2 = eng.ctx.zeros(D, st.numF)
+        os.environ["BDF_NO_EIG"] = "1"
+        try:
+            check(lib().bdf_sample_beta(eng.ctx.handle, st.F.handle, D, _p(st.sample), _p(st.mu), _p(st.Lambda), _p(lb), 1,
+                                        float("nan"), 0, 0, 1e-3, 1.0, st.tag, _p(beta2), _p(rhs), _p(its_t := torch.zeros(D, dtype=torch.int32, device=eng.ctx.device))))
+        finally:
+            del os.environ["BDF_NO_EIG"]
+        Ab2 = st.F.AtA_mul(beta2, lam0)
+        eng.ctx.sync()
+        assert float(((Ab2 - rhs).norm(dim=1) / rhs.norm(dim=1)).max()) < 1e-10
+        assert float((beta2 - beta).abs().max()) <= 1e-8 * max(1.0, float(beta.abs().max()))
     else:
         # cg_AtA stops when ||r|| < eps * numF * ||b|| or after numF iterations (parallel_cg.jl:65-75)
         assert float(res.max()) < (1e-9 if kind == "iid" else 1e-6), float(res.max())
