@@ -580,7 +580,7 @@ def main():
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
             eng4.close()
-            if not args.no_cpu_baseline and rank == 0:
+            if not args.no_cpu_baseline and world == 1:         # (the CPU figures: one process only, as the main line's)
                 del eng4, test4
                 c4["cpu_baseline"] = c4_cpu_baseline(rel4, args.c4_latent)
         except Exception as e:      # noqa: BLE001 -- the BASELINE metric above must still be reported

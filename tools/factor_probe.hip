@@ -8,14 +8,22 @@
 #include <cstdlib>
 void bdf_set_error(const char *, ...) {}
 
+#ifndef PROBE_MINWAVES
+#define PROBE_MINWAVES (DP == 64 ? 2 : 8)
+#endif
 template <int DP>
-__global__ __launch_bounds__(256, (DP == 64 ? 2 : 8)) void k_factor(int reps, double *out, int with_backward)
+__global__ __launch_bounds__(256, PROBE_MINWAVES) void k_factor(int reps, double *out, int with_backward)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB, NB = GG::NB;
     extern __shared__ __attribute__((aligned(16))) double lds[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, h = lane >> 4;
+    #ifdef PROBE_ALIAS     // timing experiment: the workgroup's four waves share ONE factor region (results are garbage) so that more
+                       // waves per SIMD fit than the real kernel's LDS allows -- what would 3 or 4 waves per SIMD buy at D = 64?
+    double *tri = lds;
+#else
     double *tri = lds + wave * GG::WAVE_LDS;
+#endif
     double res = 0.0;
     for (int rep = 0; rep < reps; rep++) {
         double A[NB * 4], bv[DB], ts[DB];
@@ -71,7 +79,11 @@ int main()
     for (int bw = 0; bw < 2; bw++)
         for (int w : {1, 2, 3, 4, 5, 6, 7, 8}) {
             // workgroups of 4 waves (one per SIMD); w workgroups resident per CU through the LDS each one asks for
+            #ifdef PROBE_ALIAS
+            const size_t need = 1 * Geo<DP>::WAVE_LDS * sizeof(double);
+#else
             const size_t need = 4 * Geo<DP>::WAVE_LDS * sizeof(double);
+#endif
             size_t lds = (size_t)(160 * 1024 / w) / 64 * 64;
             if (lds < need) { printf("w=%d does not fit\n", w); continue; }
             if (w == 8) lds = need;
