@@ -8,13 +8,15 @@
 #   4. micro-benchmarks behind DESIGN.md's bound analysis: fp64 pipe probe, gather and finish-phase probes, the row kernel and
 #      the prediction update alone, CU mask probe, back-to-back row kernels
 # Output under gpurun_out/profile_<tag>/ ; copy what should be judged into profiles/.
-tag=${1:-r02}
+tag=${1:-r03}
 cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
 B="--no-cpu-baseline --no-c4 --no-c3 --no-mref"
-python3 bench.py > $out/bench.json 2> $out/bench.err
+# the driver's command first (fresh process, 5 warm-up + 20 timed steps), three times; then the default long form
+for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd_$i.json 2> $out/bench_driver_cmd_$i.err; done
+python3 bench.py --no-c4 --no-c3 --no-mref --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 (cd /tmp && rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 300 $B > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
@@ -56,7 +58,38 @@ for k, d in agg.items():
 json.dump(pmc, open('$out/pmc_k_rows.json', 'w'), indent=1)
 print(json.dumps(summary.get("k1_traffic_bytes_per_launch")))
 PY
+# the D = 64 row kernel on a C4-shaped relation (2M x 200k, 20M observations): kernel statistics and SQ counters
+bash tools/c4_profile.sh 2000000 200000 20000000 > $out/c4_shaped_kernel_stats.txt 2>&1
+C4="--steps 2 --warmup 2 --no-cpu-baseline --no-c3 --no-mref --k1-min-launches 0 --c4-rows 2000000 --c4-cols 200000 --c4-nnz 20000000 --c4-sweeps 3"
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
+           "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM" \
+           "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1))
+  (cd /tmp && rm -rf /tmp/prof_c4pmc$i && BDF_NO_POLL=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/prof_c4pmc$i -- python3 $GRAFT_REPO_ROOT/bench.py $C4 > $out/c4_pmc_pass$i.log 2>&1)
+done
+python3 - <<PY
+import csv, glob, json, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob('/tmp/prof_c4pmc*/*/*counter_collection.csv'):
+    for r in csv.DictReader(open(f)):
+        if 'k_rows<64' in r['Kernel_Name']:
+            agg[r['Kernel_Name'][:90]][r['Counter_Name']].append(float(r['Counter_Value']))
+out = {k: {c: {"n": len(v), "mean": sum(v) / len(v), "min": min(v), "max": max(v)} for c, v in sorted(d.items())} for k, d in agg.items()}
+json.dump(out, open('$out/pmc_k_rows64_c4_shaped.json', 'w'), indent=1)
+PY
+# schedule switches under the driver's command, interleaved (polling on reserved CUs | events on reserved CUs | events on all CUs)
+for i in 1 2 3 4 5; do for cfg in "default" "BDF_NO_POLL=1" "BDF_RESERVE_CUS=0"; do
+  if [ "$cfg" = default ]; then v=$(python3 bench.py --gpus 1 --steps 20 --warmup 5 $B 2>/dev/null | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.readline())['value'])")
+  else v=$(env $cfg python3 bench.py --gpus 1 --steps 20 --warmup 5 $B 2>/dev/null | tail -1 | python3 -c "import json,sys; print(json.loads(sys.stdin.readline())['value'])"); fi
+  echo "$cfg run $i: $v sweeps/s (driver form)"
+done; done > $out/schedule_ab_driver_form.txt
 # (tools/bin/* are built in the container before the call: tools/build_probes.sh)
+timeout 120 tools/bin/valu_cost_probe > $out/valu_cost_probe.txt 2>&1
+for p in factor_probe_b factor_probe64_b; do echo "== $p (blocked variant)"; timeout 200 tools/bin/$p; done > $out/factor_probe_blocked.txt 2>&1
+python3 tools/region_pace.py 5 12 20 > $out/region_pace.txt 2>&1
+python3 tools/c3_probe.py > $out/c3.txt 2>&1
+python3 tools/c5_probe.py > $out/c5.txt 2>&1
 tools/bin/fp64_pipe_probe > $out/fp64_pipe_probe.txt 2>&1
 timeout 200 tools/bin/gather_probe 3952 > $out/gather_probe.txt 2>&1
 timeout 200 tools/bin/factor_probe > $out/factor_probe.txt 2>&1
