@@ -221,6 +221,64 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
     assert np.array_equal(a1, a4) and np.array_equal(l1, l4)
 
 
+def test_warm_device_and_repeated_sweep_numbers(B, monkeypatch):
+    """(i) bdf_gibbs_warm_device (untimed row launches into the entities' next buffers, set-up of the bench) does not advance
+    the chain; (ii) the hand-over between a draw and the next row launch is keyed on a private epoch, not on the caller's
+    sweep number: a number that repeats (same random streams, evolving state) gives the same chain whether the row kernels
+    poll for the draw or the row stream waits for its event"""
+    from bdf_amd import datasets
+    from bdf_amd.engine import GibbsEngine
+
+    def run(warm_ms, numbers):
+        rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
+        eng = GibbsEngine(rd, 32, seed=11)
+        assert eng.native
+        if warm_ms:
+            eng.warm_device(warm_ms)
+        for i in numbers:
+            eng.sweep(i)
+            if warm_ms and i == numbers[1]:
+                eng.warm_device(5.0)                  # in the middle of a chain too
+        eng.sync()
+        out = [e.model.sample.copy() for e in rd.entities] + [rd.entities[0].model.Lambda.copy()]
+        eng.close()
+        return out
+
+    same = lambda a, b: all(np.array_equal(x, y) for x, y in zip(a, b))
+    base = run(0.0, [1, 2, 3, 4])
+    assert same(base, run(15.0, [1, 2, 3, 4]))
+    rep = run(0.0, [7, 7, 7, 3, 3, 7])
+    assert not same(base, rep)
+    monkeypatch.setenv("BDF_NO_POLL", "1")
+    assert same(rep, run(0.0, [7, 7, 7, 3, 3, 7]))
+
+
+def test_native_iteration_with_side_information_equals_step_by_step(B, monkeypatch):
+    """entity side information inside bdf_gibbs_sweep (uhat, per-row prior means, feature terms, beta: macau.jl:96-140 in one
+    native call) gives bit for bit the chain of the iteration enqueued step by step from the host"""
+    rng = np.random.default_rng(3)
+    N1, N2, nnz, numF, D = 300, 120, 6000, 40, 16
+    ids = np.stack([rng.integers(1, N1 + 1, nnz), rng.integers(1, N2 + 1, nnz)], axis=1)
+    vals = np.clip(np.round(3.5 + rng.standard_normal(nnz)), 1, 5)
+    F = rng.standard_normal((N1, numF))
+
+    def run(ff):
+        rel = B.Relation({"u": ids[:, 0], "v": ids[:, 1], "y": vals}, "r", [B.Entity("u", F=F), B.Entity("v")], dims=[N1, N2])
+        B.setPrecision(rel, 1.5)
+        rd = B.RelationData(rel)
+        B.macau(rd, burnin=3, psamples=2, num_latent=D, verbose=False, seed=4, compute_ff_size=6500 if ff else 0)
+        en = rd.entities[0]
+        return rd._engine.native, en.model.sample.copy(), en.model.beta.copy(), float(en.lambda_beta), rd.entities[1].model.sample.copy()
+
+    for ff in (True, False):
+        n1 = run(ff)
+        monkeypatch.setenv("BDF_NO_NATIVE", "1")
+        n0 = run(ff)
+        monkeypatch.delenv("BDF_NO_NATIVE")
+        assert n1[0] is True and n0[0] is False
+        assert np.array_equal(n1[1], n0[1]) and np.array_equal(n1[2], n0[2]) and n1[3] == n0[3] and np.array_equal(n1[4], n0[4])
+
+
 def test_argument_errors(B):
     Y = _sprand(15, 10, 0.3, 1)
     rd = B.RelationData(Y)
