@@ -346,6 +346,10 @@ def main():
     ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 block (Macau with dense side information; one GPU only)")
     ap.add_argument("--no-mref", action="store_true", help="skip the block on the reference's own benchmark shape (one GPU only)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the C5 block (3-mode tensor + matrix sharing an entity with binary sparse "
+                                                          "features; strong scaling over the ranks)")
+    ap.add_argument("--c5-sizes", default="", help="C5 (tests): nA,nB,nC,nT,n1,n2,n_feat,feat_per_row instead of the configuration's sizes")
+    ap.add_argument("--c5-sweeps", type=int, default=10, help="C5: burn-in sweeps, then as many timed sweeps with the prediction update")
     ap.add_argument("--c4-rows", type=int, default=10_000_000)
     ap.add_argument("--c4-cols", type=int, default=1_000_000)
     ap.add_argument("--c4-nnz", type=int, default=100_000_000)
@@ -588,6 +592,46 @@ def main():
             print(f"[bench] rank {rank}: the C4 block failed: {c4['error']}", file=sys.stderr, flush=True)
         if out is not None:
             out["c4"] = c4
+    # ---- configuration C5: tensor + matrix sharing an entity with binary sparse features (strong scaling) -------------------
+    if not args.no_c5:
+        z5 = dict(zip(("nA", "nB", "nC", "nT", "n1", "n2", "n_feat", "feat_per_row"),
+                      [int(x) for x in (args.c5_sizes or "100000,64,1000,500,5000000,1000000,50000,50").split(",")]))
+        c5 = {"workload": f"entity A ({z5['nA']} rows, binary sparse features {z5['nA']} x {z5['n_feat']}, {z5['feat_per_row']} per row) shared by a "
+                          f"3-mode relation A x B x C ({z5['nB']} x {z5['nC']}; {z5['n1']} cells of a planted rank-8 model, noise 0.1, 1% held out) and a "
+                          f"2-mode relation A x T ({z5['nT']}; {z5['n2']} cells); Macau D=32, alpha 5 / 2, beta by conjugate gradients; "
+                          f"{args.c5_sweeps}+{args.c5_sweeps} sweeps (SURVEY M-C5)",
+              "n_gpus": world, "scaling": "strong"}
+        try:
+            rd5, info5 = datasets.c5_relation_data(B, **z5)
+            rel5 = rd5.relations[0]
+            eng5 = B.GibbsEngine(rd5, 32, seed=3, device=local_rank, compute_ff_size=0, shard=(rank, world))
+            n5 = len(np.asarray(rel5.test_vec.values))
+            test5 = eng5.test_pairs(subset=my_share(n5) if world > 1 else None)
+            for i in range(1, args.c5_sweeps + 1):
+                eng5.step(i, 0, [], rel5.class_cut)
+            eng5.sync()
+            fence()
+            t0 = time.perf_counter()
+            for k in range(args.c5_sweeps):
+                eng5.step(args.c5_sweeps + 1 + k, 1 if k == 0 else 2, [], rel5.class_cut)
+            fence()
+            el5 = max_over_ranks(time.perf_counter() - t0)
+            eng5.sync()
+            sse5 = test5.stats[:1].clone().to(red_dev if dist is not None else "cuda")
+            if dist is not None:
+                dist.all_reduce(sse5)
+            it5 = eng5.ent[0].cg_iters.cpu().numpy()
+            c5.update({"sweeps_per_s": round(args.c5_sweeps / el5, 2), "ms_per_sweep": round(1e3 * el5 / args.c5_sweeps, 3),
+                       "test_rmse": round(float(np.sqrt(float(sse5.item()) / max(n5, 1))), 5), "value_std": round(info5["value_std"], 4),
+                       "noise": info5["noise"], "native_iteration": bool(eng5.native),
+                       "cg_iterations_last_sweep": [int(it5.min()), int(it5.max())], "beta_columns_per_rank": -(-32 // world)})
+            eng5.close()
+            del eng5, test5, rd5, rel5
+        except Exception as e:      # noqa: BLE001
+            c5["error"] = f"{type(e).__name__}: {e}"
+            print(f"[bench] rank {rank}: the C5 block failed: {c5['error']}", file=sys.stderr, flush=True)
+        if out is not None:
+            out["c5"] = c5
     # ---- configuration C3 and the reference's own benchmark shape (one GPU) ------------------------------------------------
     if world == 1 and out is not None:
         for name, skip, fn in (("c3", args.no_c3, lambda: c3_block(B, datasets, D, local_rank)),

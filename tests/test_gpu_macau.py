@@ -425,13 +425,14 @@ def test_two_ranks_match_one(B):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BDF_DIST_BACKEND"] = "gloo"
+    c5_sizes = "3000,16,60,40,120000,30000,400,8"
     # `python bench.py --gpus 2` as typed: bench.py starts its two ranks itself (torch's launcher, as a child process)
     two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6",
-                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
+                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64", "--c5-sizes", c5_sizes, "--c5-sweeps", "6"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline", "--no-c3", "--no-mref",
-                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
+                          "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64", "--c5-sizes", c5_sizes, "--c5-sweeps", "6"],
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
     d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
@@ -443,6 +444,10 @@ def test_two_ranks_match_one(B):
     assert "error" not in d2["c4"] and "error" not in d1["c4"], (d2["c4"], d1["c4"])
     assert d2["c4"]["n_gpus"] == 2 and d2["c4"]["scaling"] == "strong"
     assert abs(d2["c4"]["test_rmse"] - d1["c4"]["test_rmse"]) < 1e-4, (d2["c4"], d1["c4"])
+    # and the C5-shaped block (a shared entity with two relations and binary sparse features, beta's columns split over the ranks)
+    assert "error" not in d2["c5"] and "error" not in d1["c5"], (d2["c5"], d1["c5"])
+    assert d2["c5"]["n_gpus"] == 2 and d2["c5"]["beta_columns_per_rank"] == 16 and d2["c5"]["native_iteration"] and d1["c5"]["native_iteration"]
+    assert abs(d2["c5"]["test_rmse"] - d1["c5"]["test_rmse"]) < 1e-5, (d2["c5"], d1["c5"])
 
 
 def test_stream_schedule_soak(B):

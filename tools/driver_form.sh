@@ -7,7 +7,7 @@ run() { # label, env..., -- args
   label=$1; shift
   ( for kv in "$@"; do [ "$kv" = "--" ] && break; export "$kv"; done
     args=(); seen=0; for a in "$@"; do if [ $seen = 1 ]; then args+=("$a"); fi; [ "$a" = "--" ] && seen=1; done
-    BDF_DEBUG=1 BDF_BENCH_DEBUG=1 python3 $root/bench.py --gpus 1 --no-c4 --no-c3 --no-mref --no-cpu-baseline "${args[@]}" 2> /tmp/err.txt | tail -1 | python3 -c "
+    BDF_DEBUG=1 BDF_BENCH_DEBUG=1 python3 $root/bench.py --gpus 1 --no-c4 --no-c3 --no-c5 --no-mref --no-cpu-baseline "${args[@]}" 2> /tmp/err.txt | tail -1 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.readline()); r=d['roofline']; print('$label', d['value'], 'sweeps/s', d['ms_per_step'], 'ms  K1', r['avg_launch_us'], 'alone', r['avg_launch_us_alone'], 'rmse', d['test_rmse'])" >> $out
     grep -E "^\[b" /tmp/err.txt | cut -c1-700 >> $out )

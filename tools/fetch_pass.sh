@@ -5,8 +5,8 @@ R=$GRAFT_REPO_ROOT
 for cfg in "default" "BDF_NO_POLL=1" "BDF_RESERVE_CUS=0" "BDF_NO_NATIVE=1 BDF_NO_OVERLAP=1"; do
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf /tmp/fp
-    if [ "$cfg" = default ]; then rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/fp -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-mref > /tmp/fp.log 2>&1
-    else env $cfg $(which rocprofv3) --pmc $c --kernel-trace --output-format csv -d /tmp/fp -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-mref > /tmp/fp.log 2>&1; fi
+    if [ "$cfg" = default ]; then rocprofv3 --pmc $c --kernel-trace --output-format csv -d /tmp/fp -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref > /tmp/fp.log 2>&1
+    else env $cfg $(which rocprofv3) --pmc $c --kernel-trace --output-format csv -d /tmp/fp -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref > /tmp/fp.log 2>&1; fi
     python3 - "$cfg" $c <<'PY'
 import csv, glob, sys, collections
 v = collections.defaultdict(list)

@@ -13,10 +13,10 @@ cd $GRAFT_REPO_ROOT
 export TMPDIR=/tmp
 out=$GRAFT_REPO_ROOT/gpurun_out/profile_$tag
 mkdir -p $out
-B="--no-cpu-baseline --no-c4 --no-c3 --no-mref"
+B="--no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref"
 # the driver's command first (fresh process, 5 warm-up + 20 timed steps), three times; then the default long form
 for i in 1 2 3; do python3 bench.py --gpus 1 --steps 20 --warmup 5 > $out/bench_driver_cmd_$i.json 2> $out/bench_driver_cmd_$i.err; done
-python3 bench.py --no-c4 --no-c3 --no-mref --no-cpu-baseline > $out/bench.json 2> $out/bench.err
+python3 bench.py --no-c4 --no-c3 --no-c5 --no-mref --no-cpu-baseline > $out/bench.json 2> $out/bench.err
 (cd /tmp && rm -rf /tmp/prof_stats && rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_stats -- python3 $GRAFT_REPO_ROOT/bench.py --steps 200 --warmup 300 $B > $out/bench_under_rocprof.log 2>&1)
 cp /tmp/prof_stats/*/*kernel_stats.csv $out/kernel_stats.csv
 i=0
@@ -60,7 +60,7 @@ print(json.dumps(summary.get("k1_traffic_bytes_per_launch")))
 PY
 # the D = 64 row kernel on a C4-shaped relation (2M x 200k, 20M observations): kernel statistics and SQ counters
 bash tools/c4_profile.sh 2000000 200000 20000000 > $out/c4_shaped_kernel_stats.txt 2>&1
-C4="--steps 2 --warmup 2 --no-cpu-baseline --no-c3 --no-mref --k1-min-launches 0 --c4-rows 2000000 --c4-cols 200000 --c4-nnz 20000000 --c4-sweeps 3"
+C4="--steps 2 --warmup 2 --no-cpu-baseline --no-c3 --no-c5 --no-mref --k1-min-launches 0 --c4-rows 2000000 --c4-cols 200000 --c4-nnz 20000000 --c4-sweeps 3"
 i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM" \

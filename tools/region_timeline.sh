@@ -3,7 +3,7 @@
 # the region is the group of 40 row launches between two idle gaps of the row stream
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-c3 --no-mref --k1-min-launches 0 > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref --k1-min-launches 0 > /tmp/tl.log 2>&1
 tail -2 /tmp/tl.log | cut -c1-300
 python3 - <<'PY'
 import csv, glob

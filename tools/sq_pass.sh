@@ -8,7 +8,7 @@ i=0
 for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_INSTS_VMEM"; do
   i=$((i+1)); rm -rf /tmp/sq$i
-  BDF_NO_POLL=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq$i -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-mref > $R/gpurun_out/sq/pass$i.log 2>&1
+  BDF_NO_POLL=1 rocprofv3 --pmc $set --kernel-trace --output-format csv -d /tmp/sq$i -- python3 $R/bench.py --steps 8 --warmup 4 --k1-min-launches 0 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref > $R/gpurun_out/sq/pass$i.log 2>&1
 done
 python3 - <<PY
 import csv, glob, json, collections

@@ -3,7 +3,7 @@
 # relative to the first row kernel of a late sweep
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/tl
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 100 --no-cpu-baseline --no-c4 --no-c3 --no-mref --k1-min-launches 0 > /tmp/tl.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $GRAFT_REPO_ROOT/bench.py --steps 40 --warmup 100 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref --k1-min-launches 0 > /tmp/tl.log 2>&1
 python3 - <<'PY'
 import csv, glob
 f = glob.glob('/tmp/tl/*/*kernel_trace.csv')[0]
