@@ -1523,12 +1523,12 @@ extern "C" int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_fea
 }
 
 // ---- relation-level side information (sample_beta_rel, src/sampling.jl:322-337) and alpha (sample_alpha, :129-134) -----
-__global__ void k_rel_target(int64_t N, const double *values, const double *pred, double inv_sqrt_alpha, uint64_t seed,
-                             uint32_t sweep, uint32_t tag, double *v)
+__global__ void k_rel_target(int64_t N, int64_t first_obs, const double *values, const double *pred, double inv_sqrt_alpha,
+                             uint64_t seed, uint32_t sweep, uint32_t tag, double *v)
 {
-    // v = (values - udot - mean) + alpha^-1/2 z,  pred = udot + mean
+    // v = (values - udot - mean) + alpha^-1/2 z,  pred = udot + mean; the noise is keyed by the observation's place in the relation
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < N) v[i] = (values[i] - pred[i]) + inv_sqrt_alpha * bdf_normal(seed, sweep, BDF_P_BETA_REL1, tag, (uint64_t)i, 0);
+    if (i < N) v[i] = (values[i] - pred[i]) + inv_sqrt_alpha * bdf_normal(seed, sweep, BDF_P_BETA_REL1, tag, (uint64_t)(first_obs + i), 0);
 }
 
 __global__ void k_rel_rhs(int64_t numF, double alpha, double lambda, uint64_t seed, uint32_t sweep, uint32_t tag,
@@ -1581,12 +1581,56 @@ extern "C" int bdf_sample_alpha(bdf_ctx *ctx, double alpha_lambda0, double alpha
     return BDF_OK;
 }
 
+// several ranks: x (n doubles) := the sum of the ranks' x, block after block in rank order (every rank ends with the same
+// bits); gb: world * n doubles of scratch
+__global__ void k_sum_blocks(int64_t n, int world, const double *gb, double *x)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double s = 0.0;
+    for (int r = 0; r < world; r++) s += gb[(size_t)r * n + i];
+    x[i] = s;
+}
+
+static int sum_ranks_in(bdf_ctx *ctx, bdf_comm *comm, int rank, int world, double *x, int64_t n, double *gb)
+{
+    if (world <= 1 || n <= 0) return BDF_OK;
+    int rc;
+    BDF_HIP(hipMemcpyAsync(gb + (size_t)rank * n, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    if ((rc = bdf_allgather_block(ctx, comm, gb, (size_t)n * sizeof(double))) || (rc = bdf_allgather_join(ctx, comm))) return rc;
+    hipLaunchKernelGGL(k_sum_blocks, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, n, world, (const double *)gb, x);
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
+extern "C" int bdf_sum_ranks(bdf_ctx *ctx, bdf_comm *comm, double *x, int64_t n)
+{
+    BDF_REQUIRE(ctx && x && n >= 0, BDF_ERR_ARG, "bdf_sum_ranks: NULL argument or negative length");
+    int rank = 0, world = 1, rc;
+    if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
+    if (world <= 1) return BDF_OK;
+    void *sv;
+    if ((rc = bdf_scratch(ctx, (size_t)world * (size_t)n * sizeof(double), &sv))) return rc;
+    return sum_ranks_in(ctx, comm, rank, world, x, n, (double *)sv);
+}
+
 extern "C" int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *fc, const bdf_pairs *train, int D,
                                    const double *const *factors, double mean_value, double alpha, double lambda_beta,
                                    uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out)
 {
+    return bdf_sample_beta_rel_ranks(ctx, nullptr, fc, train, 0, D, factors, mean_value, alpha, lambda_beta, rel_tag, beta_out,
+                                     linear_out, rhs_out);
+}
+
+extern "C" int bdf_sample_beta_rel_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *fc, const bdf_pairs *train,
+                                         int64_t first_obs, int D, const double *const *factors, double mean_value, double alpha,
+                                         double lambda_beta, uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out)
+{
     BDF_REQUIRE(ctx && fc && train && factors && beta_out && linear_out, BDF_ERR_ARG, "bdf_sample_beta_rel: NULL argument");
     BDF_REQUIRE(alpha > 0.0 && lambda_beta >= 0.0, BDF_ERR_ARG, "bdf_sample_beta_rel: alpha must be positive, lambda_beta >= 0");
+    BDF_REQUIRE(first_obs >= 0, BDF_ERR_ARG, "bdf_sample_beta_rel: first_obs must not be negative");
+    int rank = 0, world = 1;
+    if (comm) { int rcw = bdf_comm_size(comm, &rank, &world); if (rcw) return rcw; }
     bdf_feat *f = const_cast<bdf_feat *>(fc);
     const int64_t N = f->m, numF = f->n;
     BDF_REQUIRE(train->n == N, BDF_ERR_ARG,
@@ -1594,26 +1638,35 @@ extern "C" int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *fc, const bdf_p
                 (long long)train->n, (long long)N);
     const uint32_t tag = 0x800000u | rel_tag;
     // scratch (doubles): pred N | v N | t numF | rs numF | R P Z (numF each) | Tm N | scal 4 | lam 1, then ints
-    const size_t total = 3 * (size_t)N + 5 * (size_t)numF + 16;
+    // several ranks: this rank holds the rows [first_obs, first_obs + N) of the relation's feature matrix and the same
+    // observations as pairs; F'v and (once) F'F are summed over the ranks in rank order, the solve is repeated on every rank
+    const bool sum_ff = world > 1 && !f->FF_summed;
+    const size_t gsz = world > 1 ? (size_t)world * (size_t)(sum_ff ? numF * numF : numF) : 0;
+    const size_t total = 3 * (size_t)N + 5 * (size_t)numF + 16 + gsz;
     void *sv;
     int rc = bdf_scratch(ctx, total * sizeof(double) + 16 * sizeof(int), &sv);
     if (rc) return rc;
     double *pred = (double *)sv, *v = pred + N, *t = v + N, *rs = t + numF, *R = rs + numF, *P = R + numF, *Z = P + numF,
-           *Tm = Z + numF, *scal = Tm + N, *lam = scal + 8;
-    int *ints = (int *)(lam + 8);
+           *Tm = Z + numF, *scal = Tm + N, *lam = scal + 8, *gb = lam + 8;
+    (void)R; (void)P; (void)Z; (void)Tm;
     if ((rc = bdf_predict_plain(ctx, train, D, factors, mean_value, pred))) return rc;
     if (N > 0) {
-        hipLaunchKernelGGL(k_rel_target, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N,
+        hipLaunchKernelGGL(k_rel_target, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N, first_obs,
                            (const double *)train->values_dev, (const double *)pred, 1.0 / sqrt(alpha), ctx->seed,
                            ctx->sweep_host, tag, v);
         BDF_HIP(hipGetLastError());
     }
     if ((rc = feat_apply(ctx, f, true, v, 1, N, 1, t, 1, numF))) return rc;
+    if ((rc = sum_ranks_in(ctx, comm, rank, world, t, numF, gb))) return rc;
     hipLaunchKernelGGL(k_rel_rhs, dim3((unsigned)((numF + 255) / 256)), dim3(256), 0, ctx->stream, numF, alpha, lambda_beta,
                        ctx->seed, ctx->sweep_host, tag, t, rs, lam);
     BDF_HIP(hipGetLastError());
     if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, t, numF * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if ((rc = ensure_FF(f))) return rc;
+    if (sum_ff) {
+        if ((rc = sum_ranks_in(ctx, comm, rank, world, f->FF_dev, numF * numF, gb))) return rc;
+        f->FF_summed = true;
+    }
     if (numF <= 16) hipLaunchKernelGGL(k_solve_small<16>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
     else if (numF <= 32) hipLaunchKernelGGL(k_solve_small<32>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);
     else if (numF <= 64) hipLaunchKernelGGL(k_solve_small<64>, dim3(1), dim3(64), 0, ctx->stream, (int)numF, 1, f->FF_dev, lam, rs, beta_out, ctx->flag_dev);

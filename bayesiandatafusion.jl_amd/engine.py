@@ -420,6 +420,24 @@ def _rows_to_internal(F, layout):
     return out
 
 
+def _take_rows(F, rows0):
+    """the rows rows0 (0-based, in that order) of F as a matrix of the same kind"""
+    rows0 = np.asarray(rows0, dtype=np.int64)
+    m = feat.feature_shape(F)[0]
+    if isinstance(F, (feat.SparseMatrixCSR, feat.SparseBinMatrix)):
+        new = np.full(m, -1, dtype=np.int64)
+        new[rows0] = np.arange(len(rows0))                    # (rows0 holds no row twice: blocks and test subsets)
+        to = new[np.asarray(F.rows, dtype=np.int64) - 1]
+        keep = to >= 0
+        rr = (to[keep] + 1).astype(np.int32)
+        if isinstance(F, feat.SparseMatrixCSR):
+            return feat.SparseMatrixCSR(rr, F.cols[keep], F.vals[keep], len(rows0), F.n)
+        return feat.SparseBinMatrix(len(rows0), F.n, rr, F.cols[keep])
+    if hasattr(F, "tocsr"):
+        return F.tocsr()[rows0]
+    return np.asarray(F, dtype=np.float64)[rows0]
+
+
 class EntityState:
     """Device-resident EntityModel (RelationData.jl:14-40, initModel! :66-90)."""
 
@@ -515,9 +533,6 @@ class GibbsEngine:
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
         rel_feat = any(not feat.isempty(r.F) for r in data.relations)
-        if self.world > 1 and (any(not feat.isempty(r.F) for r in data.relations) or any(r.model.alpha_sample for r in data.relations)):
-            raise ArgumentError("several GPUs: relation-level side information and alpha sampling are not implemented "
-                                "(entity side information is: F replicated, its rows at the entity's internal positions)")
         # the whole iteration in one native call (entity side information included) unless something needs the step-by-step
         # path: relation-level side information, alpha sampling
         self.native = not rel_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
@@ -564,19 +579,28 @@ class GibbsEngine:
             self.rel.append(dr)
             # relation-level side information (RelationData.jl:348-353): FF path only, as in the reference
             dr.F = dr.beta = dr.linear = dr.train = None
+            # several ranks: the relation's observations (COO order) in world blocks of obs_block; this rank's block is
+            # [obs_lo, obs_hi): its rows of the relation's feature matrix, its observations as pairs (the squared-error sum
+            # of sample_alpha and F'v of sample_beta_rel are summed over the ranks in rank order, bdf_sum_ranks)
+            nn = r.data.nnz()
+            dr.obs_block = -(-nn // self.world)
+            dr.obs_lo = min(nn, self.rank * dr.obs_block)
+            dr.obs_hi = min(nn, dr.obs_lo + dr.obs_block)
+            if self.world > 1 and (not feat.isempty(r.F) or r.model.alpha_sample) and dr.obs_hi - dr.obs_lo < 1:
+                raise ArgumentError(f"Relation {r.name} has fewer observations ({nn}) than a block per rank needs")
             if not feat.isempty(r.F):
-                dr.F = FeatOperator(self.ctx, r.F)
-                if dr.F.m != r.data.nnz():
-                    raise ArgumentError(f"Relation {r.name} has {r.data.nnz()} observations but its feature matrix has {dr.F.m} rows")
+                if feat.feature_shape(r.F)[0] != nn:
+                    raise ArgumentError(f"Relation {r.name} has {nn} observations but its feature matrix has {feat.feature_shape(r.F)[0]} rows")
+                dr.F = FeatOperator(self.ctx, r.F if self.world == 1 else _take_rows(r.F, np.arange(dr.obs_lo, dr.obs_hi)))
                 if dr.F.n > compute_ff_size:
                     raise ArgumentError("conjugate gradient unimplemented for sampling relation beta")      # sampling.jl:335
                 dr.beta = self.ctx.zeros(dr.F.n)
-                dr.linear = self.ctx.tensor(np.full(r.data.nnz(), r.model.mean_value))
+                dr.linear = self.ctx.tensor(np.full(dr.obs_block * self.world, r.model.mean_value))     # K1 reads [0, nnz)
                 r.model.beta = np.zeros(dr.F.n)
             if dr.F is not None or r.model.alpha_sample:
-                dr.train = DevicePairs(self.ctx, r.data.ids, r.data.values)
+                dr.train = self._pairs(self.ctx, r, np.asarray(r.data.ids)[dr.obs_lo:dr.obs_hi], np.asarray(r.data.values)[dr.obs_lo:dr.obs_hi])
                 if dr.F is not None:         # pred(r) = udot + linear_values on the training table (sampling.jl:16-18)
-                    check(lib().bdf_pairs_set_baseline(dr.train.handle, _ptr(dr.linear)))
+                    check(lib().bdf_pairs_set_baseline(dr.train.handle, C.c_void_p(dr.linear.data_ptr() + 8 * dr.obs_lo)))
             dr.alpha_dev = self.ctx.zeros(1)
         self._test_pairs = None
         self._train_pairs = None
@@ -687,16 +711,23 @@ class GibbsEngine:
             if not (r.model.alpha_sample or dr.F is not None):
                 continue
             facs = self.factors_of(r)
+            comm = self.comm.handle if (self.world > 1 and self.comm is not None) else None
             if r.model.alpha_sample:
                 sse = dr.train.sse(self.D, facs, r.model.mean_value)          # the pairs carry linear_values as baseline
+                if comm is not None:
+                    check(lib().bdf_sum_ranks(self.ctx.handle, comm, C.c_void_p(sse.data_ptr() + 8), 1))
                 check(lib().bdf_sample_alpha(self.ctx.handle, r.model.alpha_lambda0, r.model.alpha_nu0, r.data.nnz(),
                                              C.c_void_p(sse.data_ptr() + 8), ri + 1, _ptr(dr.alpha_dev)))
                 self.ctx.sync()
                 r.model.alpha = float(dr.alpha_dev.item())
             if dr.F is not None:
                 fp = (C.c_void_p * len(facs))(*[f.data_ptr() for f in facs])
-                check(lib().bdf_sample_beta_rel(self.ctx.handle, dr.F.handle, dr.train.handle, self.D, fp, r.model.mean_value,
-                                                r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta), _ptr(dr.linear), None))
+                check(lib().bdf_sample_beta_rel_ranks(self.ctx.handle, comm, dr.F.handle, dr.train.handle, dr.obs_lo, self.D, fp,
+                                                      r.model.mean_value, r.model.alpha, r.model.lambda_beta, ri + 1, _ptr(dr.beta),
+                                                      C.c_void_p(dr.linear.data_ptr() + 8 * dr.obs_lo), None))
+                if comm is not None:         # every rank's row kernels read linear_values of their own rows' observations
+                    check(lib().bdf_allgather_block(self.ctx.handle, comm, _ptr(dr.linear), 8 * dr.obs_block))
+                    check(lib().bdf_allgather_join(self.ctx.handle, comm))
         self.refresh_baselines()
 
     # ---- macau.jl:96-117: latent rows of entity j --------------------------------------------------------------
@@ -904,7 +935,7 @@ class GibbsEngine:
             if dr.F is not None:             # pred(r, probe_vec, F) = udot + F_test beta + mean_value (sampling.jl:9-14)
                 if feat.isempty(r.test_F):
                     raise ArgumentError(f"Relation {r.name} has features but its test set has no feature rows (test_F)")
-                dr.F_test = FeatOperator(self.ctx, r.test_F)
+                dr.F_test = FeatOperator(self.ctx, r.test_F if subset is None else _take_rows(r.test_F, np.asarray(subset)))
                 dr.test_baseline = self.ctx.zeros(self._test_pairs.n)
                 check(lib().bdf_pairs_set_baseline(self._test_pairs.handle, _ptr(dr.test_baseline)))
         return self._test_pairs

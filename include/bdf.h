@@ -241,6 +241,19 @@ int bdf_sample_alpha(bdf_ctx *ctx, double alpha_lambda0, double alpha_nu0, int64
 int bdf_sample_beta_rel(bdf_ctx *ctx, const bdf_feat *F, const bdf_pairs *train, int D, const double *const *factors,
                         double mean_value, double alpha, double lambda_beta, uint32_t rel_tag,
                         double *beta_out, double *linear_out, double *rhs_out);
+/* The same over several ranks (the reference computes err and F'v on the master, macau.jl:83-92): rank r holds a
+ * block of consecutive observations [first_obs, first_obs + n) -- F is that block of the feature matrix's rows, train the same
+ * observations as pairs.  F'v and, once, F'F are summed over the ranks in rank order (bdf_sum_ranks), every rank solves the
+ * numF x numF system and ends with the same beta; z1 is keyed by the observation's place in the whole relation, so the chain
+ * does not depend on the number of ranks up to the summation order.  linear_out: this rank's n values (the host gathers the
+ * blocks with bdf_allgather_block).  comm NULL or one rank: bdf_sample_beta_rel. */
+int bdf_sample_beta_rel_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *F, const bdf_pairs *train, int64_t first_obs, int D,
+                              const double *const *factors, double mean_value, double alpha, double lambda_beta, uint32_t rel_tag,
+                              double *beta_out, double *linear_out, double *rhs_out);
+/* x (dev, n doubles) := sum over the ranks of x, added block after block in rank order: every rank ends with the same bits
+ * (the squared-error sum of sample_alpha over the ranks' blocks of observations; F'v above).  comm NULL or one rank: no-op. */
+int bdf_sum_ranks(bdf_ctx *ctx, bdf_comm *comm, double *x, int64_t n);
+
 
 /* ---- f2: test-set prediction (src/sampling.jl:9-45, macau.jl:142-203, 231-241) -------- */
 /* ids: n x n_modes column-major 1-based (test_vec[:,1:end-1]); values: n (test_vec[:,end]) */

@@ -336,4 +336,28 @@ function update_beta!(c::Context, m::Comm, feat::Ptr{Cvoid}, D, sample, mu, Lamb
                 beta.p, C_NULL, C_NULL))
 end
 
+"the relation model on several ranks (rank r holds the block of observations first_obs+1 : first_obs+train.n -- f: those rows of the
+relation's feature matrix, train: the same observations as pairs): the squared-error sum is added up over the ranks in rank order
+(bdf_sum_ranks) before sample_alpha; n_total: the relation's observations"
+function sample_alpha!(c::Context, m::Comm, p::DevPairs, n_total::Integer, D, factors::Vector{<:DevArray}, mean_value, lambda0, nu0, rel_tag,
+                       stats::DevArray, alpha_out::DevArray)
+    fp = Ptr{Cvoid}[f.p for f in factors]
+    check(ccall((:bdf_predict_sse, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, p.h, D, fp, mean_value, C_NULL, stats.p))
+    check(ccall((:bdf_sum_ranks, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64), c.h, m.h, stats.p + 8, 1))
+    check(ccall((:bdf_sample_alpha, lib), Cint, (Ptr{Cvoid}, Float64, Float64, Int64, Ptr{Cvoid}, UInt32, Ptr{Cvoid}),
+                c.h, lambda0, nu0, n_total, stats.p + 8, rel_tag, alpha_out.p))
+end
+"sample_beta_rel on several ranks (bdf_sample_beta_rel_ranks): F'v and, once, F'F summed over the ranks, the same beta on every rank;
+linear_values: world blocks of `block` values, this rank's block written, then gathered in place (bdf_allgather_block)"
+function sample_beta_rel!(c::Context, m::Comm, f::Ptr{Cvoid}, train::DevPairs, first_obs::Integer, block::Integer, D, factors::Vector{<:DevArray},
+                          mean_value, alpha, lambda_beta, rel_tag, beta::DevArray, linear_values::DevArray)
+    fp = Ptr{Cvoid}[x.p for x in factors]
+    check(ccall((:bdf_sample_beta_rel_ranks, lib), Cint,
+                (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Int64, Cint, Ptr{Ptr{Cvoid}}, Float64, Float64, Float64, UInt32, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, m.h, f, train.h, first_obs, D, fp, mean_value, alpha, lambda_beta, rel_tag, beta.p, linear_values.p + 8 * first_obs, C_NULL))
+    check(ccall((:bdf_allgather_block, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, m.h, linear_values.p, 8 * block))
+    allgather_join!(c, m)
+end
+
 end # module

@@ -311,6 +311,35 @@ def test_c5_two_ranks_match_one():
     print("beta update: one rank %.3f ms, two ranks (same GPU, host transport) %.3f ms per call" % (d1["beta_update_ms"], d2["beta_update_ms"]))
 
 
+@pytest.mark.parametrize("kind", ["dense", "csr"])
+def test_relation_side_information_and_alpha_two_ranks_match_one(kind):
+    """relation-level side information (sample_beta_rel) and alpha sampling with the rows shared out over two ranks: every rank
+    holds one block of the observations (its rows of the relation's feature matrix, its observations as pairs); the squared
+    errors, F'v and F'F are summed over the ranks in rank order (bdf_sum_ranks, bdf_sample_beta_rel_ranks), linear_values are
+    gathered block by block.  Same chain as one process up to the summation order; the planted relation beta is recovered."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tool = os.path.join(root, "tools", "relfeat_ranks.py")
+    one = subprocess.run([sys.executable, tool, kind], capture_output=True, text=True, timeout=600)
+    assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
+    port = str(29800 + os.getpid() % 90)
+    two = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", port, tool, kind], env=dict(os.environ, BDF_DIST_BACKEND="gloo", RELFEAT_CHUNKS="2"),
+                         capture_output=True, text=True, timeout=600)
+    assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
+    d1 = json.loads([l for l in one.stdout.splitlines() if l.startswith("{")][-1])
+    d2 = json.loads([l for l in two.stdout.splitlines() if l.startswith("{")][-1])
+    assert d2["world"] == 2 and d1["world"] == 1
+    assert np.allclose(d1["beta_rel"], [1.0, -0.5, 2.0], atol=0.05), d1
+    assert d1["rmse"] < 0.35 * d1["value_std"] and d1["alpha"] > 5.0, d1         # noise 0.2 -> precision ~ 25
+    for k in ("rmse", "alpha", "alpha_5", "sample_norm", "linear_norm"):
+        assert abs(d2[k] - d1[k]) <= 1e-6 * max(1.0, abs(d1[k])), (k, d1, d2)
+    assert np.allclose(d2["beta_rel"], d1["beta_rel"], rtol=0, atol=1e-7), (d1, d2)
+
+
 def test_rccl_one_rank_allgather(B, ctx):
     """librccl itself through bdf_comm (dlopen, ncclGetUniqueId, ncclCommInitRank, ncclAllGather on the communicator's stream,
     join): a ONE-rank communicator is all a 1-GPU box can hold, but it runs the whole call path; the N > 1 data movement is
