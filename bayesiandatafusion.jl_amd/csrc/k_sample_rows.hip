@@ -541,6 +541,19 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
+#ifdef BDF_EXP_NO_PRIOR       // experiment: what the prior's loads cost (wrong results: 5 I instead of the prior's image)
+    if (true) {
+        int b = 0;
+#pragma unroll
+        for (int I = 0; I < DB; I++)
+#pragma unroll
+            for (int J = 0; J <= I; J++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[b][r] += (I == J && h + 4 * r == j) ? 5.0 : 0.0;
+                b++;
+            }
+    } else
+#endif
     if (a.ready) {
         // launched without waiting for the hyperprior draw (bdf_gibbs_sweep: the draw runs on CUs this kernel never uses, so
         // it cannot be starved): poll its flag here, where the prior is first needed -- the gathers above have hidden most of

@@ -17,6 +17,7 @@ Layout: an entity's sample is the reference's D x N column-major matrix == a con
 """
 import ctypes as C
 import os
+import sys
 import weakref
 
 import numpy as np
@@ -994,6 +995,7 @@ class Comm:
         import torch.distributed as dist
         self.handle = C.c_void_p()
         self._cb = None
+        self.transport = "RCCL (ncclAllGather in place, librccl resolved by the library)"
         if dist.get_backend() == "nccl":
             buf = torch.zeros(_lib.BDF_COMM_ID_BYTES, dtype=torch.uint8)
             if rank == 0:
@@ -1003,18 +1005,48 @@ class Comm:
             dev = buf.to(ctx.device)
             dist.broadcast(dev, src=0)
             raw = bytes(dev.cpu().numpy().tobytes())
-            check(lib().bdf_comm_create(ctx.handle, rank, world, raw, C.byref(self.handle)))
+            # every rank must end up on the same transport: the outcome of the library's own communicator is agreed on over
+            # torch's process group; if any rank could not create it, all of them exchange through torch.distributed instead
+            # (the library's host transport: staged through host memory -- slower, and said so in `transport`)
+            err = ""
+            try:
+                if os.environ.get("BDF_COMM_FORCE_STAGED"):
+                    raise _lib.HipError("BDF_COMM_FORCE_STAGED is set")
+                check(lib().bdf_comm_create(ctx.handle, rank, world, raw, C.byref(self.handle)))
+            except Exception as e:          # noqa: BLE001 -- agreed on below, then reported
+                err = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctx.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if self.handle:
+                    lib().bdf_comm_destroy(self.handle)
+                    self.handle = C.c_void_p()
+                self.transport = ("torch.distributed all-gather behind the library's host transport (a rank could not create the "
+                                  "library's RCCL communicator" + (f": {err}" if err else "") + ")")
+                print(f"[bdf] rank {rank}: {self.transport}", file=sys.stderr, flush=True)
+                self._host_transport(ctx, rank, world, on_device=True)
         else:
-            def exchange(user, send, recv, nbytes):
-                try:
-                    s = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8)
-                    r = torch.frombuffer((C.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+            self.transport = "host transport with a gloo all-gather behind it (test rig: several ranks on one GPU)"
+            self._host_transport(ctx, rank, world, on_device=False)
+
+    def _host_transport(self, ctx, rank, world, on_device):
+        import torch.distributed as dist
+
+        def exchange(user, send, recv, nbytes):
+            try:
+                s = torch.frombuffer((C.c_char * nbytes).from_address(send), dtype=torch.uint8)
+                r = torch.frombuffer((C.c_char * (nbytes * world)).from_address(recv), dtype=torch.uint8)
+                if on_device:               # torch's own RCCL process group: through device tensors
+                    rd = torch.empty(nbytes * world, dtype=torch.uint8, device=ctx.device)
+                    dist.all_gather_into_tensor(rd, s.to(ctx.device))
+                    r.copy_(rd.cpu())
+                else:
                     dist.all_gather_into_tensor(r, s)
-                    return 0
-                except Exception:        # noqa: BLE001 -- reported through the library's error code
-                    return 1
-            self._cb = _lib.EXCHANGE_FN(exchange)
-            check(lib().bdf_comm_create_host(ctx.handle, rank, world, self._cb, None, C.byref(self.handle)))
+                return 0
+            except Exception:        # noqa: BLE001 -- reported through the library's error code
+                return 1
+        self._cb = _lib.EXCHANGE_FN(exchange)
+        check(lib().bdf_comm_create_host(ctx.handle, rank, world, self._cb, None, C.byref(self.handle)))
 
     def close(self):
         if self.handle:

@@ -530,7 +530,8 @@ def main():
                        "host_core": host_core,
                        "device_warmup_ms": args.device_warmup_ms if eng.gibbs else 0.0,
                        "parallelism": (f"rows of each entity shared out over {world} GPUs (a rank holds its rows' observations only), "
-                                       f"in-place RCCL all-gather of the sampled rows per half-sweep, test ratings split over the ranks")
+                                       f"in-place all-gather of the sampled rows per half-sweep, test ratings split over the ranks; "
+                                       f"transport: {eng.comm.transport if eng.comm is not None else 'none'}")
                        if world > 1 else "1 GPU"},
             "test_rmse": None if rmse is None else round(rmse, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

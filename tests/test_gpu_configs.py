@@ -368,3 +368,21 @@ def test_rccl_one_rank_allgather(B, ctx):
     assert torch.equal(x, ref)
     assert lib().bdf_allgather_rows(ctx.handle, comm, D, chunks * cmax + 1, _p(x), 0, chunks) == -1      # rows not chunks x ranks x cmax
     check(lib().bdf_comm_destroy(comm))
+
+
+@pytest.mark.parametrize("staged", [False, True])
+def test_engine_communicator_transports(staged):
+    """the engine's communicator over torch's RCCL process group (one rank: all a 1-GPU box holds): the library's own RCCL
+    communicator, and the fall-back every rank agrees on when one of them cannot create it -- torch.distributed's all-gather
+    behind the library's host transport (forced here with BDF_COMM_FORCE_STAGED)"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BDF_DIST_BACKEND")}
+    if staged:
+        env["BDF_COMM_FORCE_STAGED"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "comm_transport_check.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("transport:")][-1]
+    assert ("torch.distributed all-gather" in line) if staged else ("RCCL (ncclAllGather in place" in line), line
