@@ -89,6 +89,7 @@ timeout 120 tools/bin/valu_cost_probe > $out/valu_cost_probe.txt 2>&1
 for p in factor_probe_b factor_probe64_b; do echo "== $p (blocked variant)"; timeout 200 tools/bin/$p; done > $out/factor_probe_blocked.txt 2>&1
 python3 tools/region_pace.py 5 12 20 > $out/region_pace.txt 2>&1
 python3 tools/c3_probe.py > $out/c3.txt 2>&1
+python3 tools/setup_cost.py > $out/setup_cost.txt 2>&1
 python3 tools/c5_probe.py > $out/c5.txt 2>&1
 tools/bin/fp64_pipe_probe > $out/fp64_pipe_probe.txt 2>&1
 timeout 200 tools/bin/gather_probe 3952 > $out/gather_probe.txt 2>&1
