@@ -40,7 +40,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     bdf_ctx *c = new bdf_ctx();
     c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
-    c->hyper_chain = false; c->hyper_count = nullptr;
+    c->hyper_chain = false; c->hyper_count = nullptr; c->hyper_chain_draws = nullptr;
     c->own_stream = false; c->stream = nullptr;
     struct Guard { bdf_ctx *c; ~Guard() { if (c) bdf_ctx_destroy(c); } } guard{c};        // error paths free what was allocated
     c->device = device;
@@ -61,7 +61,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->skip_flag = nullptr;
     c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
-    c->hyper_chain = false; c->hyper_count = nullptr;
+    c->hyper_chain = false; c->hyper_count = nullptr; c->hyper_chain_draws = nullptr;
     c->cg_gen = 0;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
@@ -654,6 +654,18 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     if (prior_pack && !mu_is_matrix) { a.prior_b = prior_pack; a.prior_c = prior_pack + D; }
     if (ctx->rows_ready && prior_pack && !mu_is_matrix) { a.ready = ctx->rows_ready; a.ready_want = ctx->rows_ready_want; }
     ctx->rows_ready = nullptr;
+#ifdef BDF_K1_SPANS
+    {   // diagnostic build only: a ring of 1024 launches x 8192 waves x {start, end, wait} (bdf_debug_spans)
+        extern unsigned long long *g_bdf_span_buf;
+        extern unsigned long long g_bdf_span_count;
+        if (!g_bdf_span_buf) {
+            BDF_HIP(hipMalloc((void **)&g_bdf_span_buf, (size_t)1024 * 8192 * 3 * 8));
+            BDF_HIP(hipMemset(g_bdf_span_buf, 0, (size_t)1024 * 8192 * 3 * 8));
+            BDF_HIP(hipDeviceSynchronize());
+        }
+        a.b_dump = (double *)(g_bdf_span_buf + (size_t)8192 * 3 * (g_bdf_span_count++ % 1024));
+    }
+#endif
 #ifdef BDF_K1_STAMPS
     {   // diagnostic build only: per-wave phase stamps (16 x u64 per wave) readable through bdf_debug_stamps
         extern void *g_bdf_stamp_buf;
@@ -665,6 +677,17 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     return bdf_launch_sample_rows(ctx, a, rels, modes, shard, n_shards, false);
 }
 
+#ifdef BDF_K1_SPANS
+unsigned long long *g_bdf_span_buf = nullptr;
+unsigned long long g_bdf_span_count = 0;
+extern "C" int bdf_debug_spans(unsigned long long *host, unsigned long long *count)
+{
+    BDF_HIP(hipDeviceSynchronize());
+    if (g_bdf_span_buf) BDF_HIP(hipMemcpy(host, g_bdf_span_buf, (size_t)1024 * 8192 * 3 * 8, hipMemcpyDeviceToHost));
+    *count = g_bdf_span_count;
+    return BDF_OK;
+}
+#endif
 #ifdef BDF_K1_STAMPS
 void *g_bdf_stamp_buf = nullptr;
 extern "C" int bdf_debug_stamps(bdf_ctx *ctx, unsigned long long *host, int nwaves)

@@ -62,6 +62,7 @@ struct bdf_ctx {
     bool hyper_chain;                   // ... and launches nothing itself: the draw's launch carries the sums' workgroups (k_hyper_chain)
     int hyper_chain_D; int64_t hyper_chain_N, hyper_chain_rpb; const double *hyper_chain_sample, *hyper_chain_uhat;
     unsigned *hyper_count;              // partial workgroups finished (k_hyper_chain), allocated at first use
+    double *hyper_chain_draws;          // (bdf_gibbs_sweep) the chain's launch also makes the entity's random part (k_hyper_draws' values) into this buffer
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
 };

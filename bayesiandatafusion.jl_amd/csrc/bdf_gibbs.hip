@@ -444,7 +444,15 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         if (g->pred_at[k] + 2 <= g->n_iter) { BDF_HIP(hipEventSynchronize(g->ev_pred[k])); break; }      // (and with it the earlier ones)
     }
     const auto t_go = std::chrono::steady_clock::now();
-    if (n <= BDF_DRAWS_BATCH) {
+    // the data-independent part of every entity's hyperprior draw (Bartlett matrix, mean normals): inside the entity's chain
+    // launch, beside its partial sums, when every entity is small enough for the one-launch chain (the hyperprior stream is
+    // busy ~85 of an iteration's 90 us: a launch of its own at the head of the iteration is 7 us of that); else ahead of the rows
+    static const bool fuse_sums_ = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);
+    static const bool one_launch_ = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
+    static const bool draws_ahead_ = getenv("BDF_DRAWS_AHEAD") != nullptr;
+    bool draws_in_chain = fuse_sums_ && one_launch_ && !draws_ahead_;
+    for (int j = 0; j < n; j++) draws_in_chain = draws_in_chain && g->ent[(size_t)j].d.N <= 16384;
+    if (!draws_in_chain && n <= BDF_DRAWS_BATCH) {
         int64_t Ns[BDF_DRAWS_BATCH]; double nus[BDF_DRAWS_BATCH]; uint32_t tags[BDF_DRAWS_BATCH]; double *outs[BDF_DRAWS_BATCH];
         for (int j = 0; j < n; j++) {
             const bdf_gibbs_entity &e = g->ent[(size_t)j].d;
@@ -463,7 +471,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         if (e.feat && (rc = bdf_uhat(R, e.feat, D, e.beta, e.mu, e.uhat, e.mu_matrix))) return rc;
         // the data-independent part of the hyperprior draw (Bartlett matrix, mean normals): beside the rows -- for all entities
         // in one launch at the head of the iteration when they are few
-        if (n > BDF_DRAWS_BATCH && (rc = bdf_hyper_draws(H, D, e.n_real, hyper_nu(e), e.tag, e.draws))) return rc;
+        if (!draws_in_chain && n > BDF_DRAWS_BATCH && (rc = bdf_hyper_draws(H, D, e.n_real, hyper_nu(e), e.tag, e.draws))) return rc;
         bdf_term terms[BDF_MAX_TERMS];
         for (int t = 0; t < e.n_terms; t++) {
             terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
@@ -504,6 +512,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             Tinv = e.Tinv;
         }
         if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], e.feat ? e.uhat : nullptr, e.sumU, e.UUt))) return rc;
+        H->hyper_chain_draws = draws_in_chain ? e.draws : nullptr;
         H->time_h_stop = E.ev_hyper;
         H->hyper_ready = g->ready_dev + j;
         H->hyper_ready_value = ++E.epoch;

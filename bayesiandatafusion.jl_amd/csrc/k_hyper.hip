@@ -115,6 +115,9 @@ __global__ __launch_bounds__(256) void k_hyper_sample(NWArgs a)
 // and draws.  One launch and one kernel boundary fewer per entity and iteration than sums -> draw.
 struct ChainArgs {
     int D; int64_t N, rows_per_block; const double *sample, *uhat; double *partial; unsigned *count; int nblocks;
+    // ndraw > 0: the first ndraw workgroups make the data-independent random part (k_hyper_draws' entries, 256 per workgroup)
+    // into draws_out -- beside the partial sums instead of in a launch of their own on the same stream
+    int ndraw; double nu_N; uint64_t seed; uint32_t sweep, tag; double *draws_out;
 };
 template <int DP>
 __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
@@ -122,10 +125,27 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     constexpr int LDS_D = (3 * HGeo<DP>::PSZ > HGeo<DP>::NW_LDS) ? 3 * HGeo<DP>::PSZ : HGeo<DP>::NW_LDS;
     __shared__ __attribute__((aligned(16))) double lds[LDS_D];
     __builtin_amdgcn_s_setprio(3);
-    if ((int)blockIdx.x < c.nblocks) {
-        const int64_t r0 = (int64_t)blockIdx.x * c.rows_per_block;
+    if ((int)blockIdx.x < c.ndraw) {
+        const int D = c.D, e = blockIdx.x * 256 + threadIdx.x;
+        if (e < D * D + D) {
+            double v = 0.0;
+            if (e < D * D) {
+                const int arow = e / D, col = e % D;
+                if (col < arow) v = bdf_normal(c.seed, c.sweep, BDF_P_NW_NORMAL, c.tag, (uint64_t)arow, col);
+                else if (col == arow) v = sqrt(2.0 * bdf_gamma(c.seed, c.sweep, c.tag, (uint64_t)arow, 0.5 * (c.nu_N - (double)arow)));
+            } else v = bdf_normal(c.seed, c.sweep, BDF_P_NW_MEAN, c.tag, 0, e - D * D);
+            __hip_atomic_store(c.draws_out + e, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);        // write-through
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(c.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    const int pb = (int)blockIdx.x - c.ndraw;
+    if (pb < c.nblocks) {
+        const int64_t r0 = (int64_t)pb * c.rows_per_block;
         const int64_t r1 = r0 + c.rows_per_block < c.N ? r0 + c.rows_per_block : c.N;
-        hyper_partial<DP, 4>(c.D, c.N, c.sample, c.uhat, r0, r1, c.partial + (int64_t)blockIdx.x * HGeo<DP>::PSZ, lds, threadIdx.x);
+        hyper_partial<DP, 4>(c.D, c.N, c.sample, c.uhat, r0, r1, c.partial + (int64_t)pb * HGeo<DP>::PSZ, lds, threadIdx.x);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's write-through stores of the partial have completed
         __syncthreads();
         if (threadIdx.x == 0) __hip_atomic_fetch_add(c.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -133,7 +153,7 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     }
     if (threadIdx.x == 0) {
         int spins = 0;
-        while (__hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)c.nblocks) {
+        while (__hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(c.nblocks + c.ndraw)) {
             __builtin_amdgcn_s_sleep(4);
             if (++spins > (1 << 24)) { atomicOr(a.flag, 16); break; }       // bounded: a bug must not hang the device
         }
@@ -238,6 +258,14 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
 {
     BDF_REQUIRE(ctx && sumU && UUt && mu0 && Tinv && mu_out && Lambda_out, BDF_ERR_ARG, "bdf_hyper_sample: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sample: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    if (ctx->hyper_chain_draws && !(ctx->hyper_chain && ctx->hyper_partial)) {
+        // the caller left the random part to the chain's launch, and there is no chain after all: make it now, same stream
+        const int total = D * D + D;
+        hipLaunchKernelGGL(k_hyper_draws, dim3((total + 63) / 64), dim3(64), 0, ctx->stream, D, nu + (double)N, ctx->seed,
+                           ctx->sweep_host, entity_tag, ctx->hyper_chain_draws);
+        BDF_HIP(hipGetLastError());
+        ctx->hyper_chain_draws = nullptr;
+    }
     if (draws == nullptr) {
         // no draws made ahead (bdf_hyper_draws): make them now, same stream, into the context's scratch
         void *sc;
@@ -272,7 +300,14 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
         ChainArgs c;
         c.D = ctx->hyper_chain_D; c.N = ctx->hyper_chain_N; c.rows_per_block = ctx->hyper_chain_rpb; c.sample = ctx->hyper_chain_sample;
         c.uhat = ctx->hyper_chain_uhat; c.partial = const_cast<double *>(a.partial); c.count = ctx->hyper_count; c.nblocks = a.nblocks;
-        const dim3 grid((unsigned)a.nblocks + 1);
+        c.ndraw = 0; c.nu_N = 0.0; c.seed = 0; c.sweep = 0; c.tag = 0; c.draws_out = nullptr;
+        if (ctx->hyper_chain_draws) {
+            BDF_REQUIRE(ctx->hyper_chain_draws == draws, BDF_ERR_ARG, "bdf_hyper_sample: the chain's draws go to another buffer than the one the draw reads");
+            c.ndraw = (D * D + D + 255) / 256; c.nu_N = nu + (double)N; c.seed = ctx->seed; c.sweep = ctx->sweep_host; c.tag = entity_tag;
+            c.draws_out = ctx->hyper_chain_draws;
+            ctx->hyper_chain_draws = nullptr;
+        }
+        const dim3 grid((unsigned)(a.nblocks + c.ndraw) + 1);
         if (D <= 16) hipExtLaunchKernelGGL(k_hyper_chain<16>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);
         else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_chain<32>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);
         else hipExtLaunchKernelGGL(k_hyper_chain<64>, grid, dim3(256), 0, ctx->stream, ctx->time_h_start, ctx->time_h_stop, 0, c, a);

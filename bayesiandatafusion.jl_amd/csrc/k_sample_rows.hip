@@ -57,6 +57,15 @@
 #define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
 #endif
 
+#ifdef BDF_K1_SPANS      // diagnostic build: per wave of every launch {start, end, wait for the prior} (s_memrealtime: the 100 MHz clock all XCDs share -- s_memtime is per XCD; plain stores)
+#define SPAN_BEGIN() do { if (lane == 0 && a.b_dump && wid < 8192) ((unsigned long long *)a.b_dump)[wid * 3] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SPAN_END() do { if (lane == 0 && a.b_dump && wid < 8192) ((unsigned long long *)a.b_dump)[wid * 3 + 1] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SPAN_WAIT(t0) do { if (lane == 0 && a.b_dump && wid < 8192) ((unsigned long long *)a.b_dump)[wid * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_memrealtime() - (t0); } while (0)
+#else
+#define SPAN_BEGIN() do { } while (0)
+#define SPAN_END() do { } while (0)
+#define SPAN_WAIT(t0) do { } while (0)
+#endif
 #ifdef BDF_K1_STAMPS
 #define STAMP(slot) do { if (lane == 0 && a.b_dump) ((unsigned long long *)a.b_dump)[wid * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -473,6 +482,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     double bv[DB];
     int64_t row;
     STAMP(0);
+    SPAN_BEGIN();
 #ifdef BDF_K1_STAMPS
     if (lane == 0 && a.b_dump) {           // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID
         ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
@@ -532,7 +542,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (p.decoupled || old != sr.n_slots - 1) return;       // not the last item of the row (decoupled: never finishes)
+        if (p.decoupled || old != sr.n_slots - 1) { SPAN_END(); return; }       // not the last item of the row (decoupled: never finishes)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
@@ -559,10 +569,14 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         // it cannot be starved): poll its flag here, where the prior is first needed -- the gathers above have hidden most of
         // the wait -- and read the pack with agent-scope loads (past the non-coherent L2 lines of the previous sweep's pack)
         int spins = 0;
+#ifdef BDF_K1_SPANS
+        const unsigned long long t_poll = __builtin_amdgcn_s_memrealtime();
+#endif
         while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
             __builtin_amdgcn_s_sleep(16);
             if (++spins > (1 << 22)) { if (lane == 0) atomicOr(a.flag, 16); break; }      // bounded: ~seconds
         }
+        SPAN_WAIT(t_poll);
 #pragma unroll
         for (int b = 0; b < NB; b++)
 #pragma unroll
@@ -649,6 +663,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
     if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
     STAMP(8);
+    SPAN_END();
 }
 
 template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
@@ -771,13 +786,36 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         while (next_f < srows.size()) order[pos++] = (int32_t)(nP + (int64_t)next_f++);
     } else {
         static const int mode = getenv("BDF_K1_ORDER") ? atoi(getenv("BDF_K1_ORDER")) : 1;
-        int64_t stride = 1;
-        if (mode == 1 && total > 2) {
-            stride = (int64_t)(0.6180339887 * (double)total) | 1;
-            auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
-            while (gcd(stride, total) != 1) stride += 2;
+        auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
+        auto stride_of = [&](int64_t n) {
+            int64_t st = 1;
+            if (n > 2) {
+                st = (int64_t)(0.6180339887 * (double)n) | 1;
+                while (gcd(st, n) != 1) st += 2;
+            }
+            return st;
+        };
+        // mode 2 (experiment, BDF_K1_ORDER=2): a launch with more waves than the device holds at once starts its last waves
+        // only when slots come free, a third to a half into the launch; make those the LIGHTEST rows -- the `slots` heaviest
+        // items in the stride order, then the rest by falling length.  (Alone: the pair of launches 86.0 -> 83.4 us; inside
+        // the iteration: no change -- the iteration is not paced by the launches' tails.)
+        int64_t head = total;
+        if (mode == 2) {
+            static const int64_t slots_env = getenv("BDF_K1_SLOTS") ? atoll(getenv("BDF_K1_SLOTS")) : 0;
+            int64_t slots = slots_env;
+            if (slots <= 0) {
+                hipDeviceProp_t prop;
+                int dev = 0;
+                BDF_HIP(hipGetDevice(&dev));
+                BDF_HIP(hipGetDeviceProperties(&prop, dev));
+                const int per_simd = key.DP == 64 ? BDF_K1_WAVES64 : (key.DP == 32 ? BDF_K1_WAVES32C : 8);
+                slots = (int64_t)(prop.multiProcessorCount - ctx->reserve_cus) * 4 * per_simd;
+            }
+            if (total > slots && total < 2 * slots) head = slots;
         }
-        for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i * stride) % total);
+        const int64_t stride = (mode >= 1) ? stride_of(head) : 1;
+        for (int64_t i = 0; i < head; i++) order[(size_t)i] = (int32_t)((i * stride) % head);
+        for (int64_t i = head; i < total; i++) order[(size_t)i] = (int32_t)i;
     }
     int rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||

@@ -1,8 +1,9 @@
 #!/bin/bash
-root=$GRAFT_REPO_ROOT
-for rep in 1 2; do
-for so in base noprior; do
-BDF_LIB_PATH=$root/bayesiandatafusion.jl_amd/csrc/variants/libbdf_$so.so python3 $root/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-c3 --no-c5 --no-mref --k1-min-launches 0 --c4-rows 2000000 --c4-cols 200000 --c4-nnz 20000000 --c4-sweeps 5 2>/dev/null | tail -1 | python3 -c "
+cd $GRAFT_REPO_ROOT
+for cfg in "BDF_X=1" "BDF_ITEM_SIZE=224 BDF_PIECE_SIZE=160" "BDF_ITEM_SIZE=256 BDF_PIECE_SIZE=176" "BDF_ITEM_SIZE=192 BDF_PIECE_SIZE=160" "BDF_ITEM_SIZE=160 BDF_PIECE_SIZE=112" "BDF_X=1"; do
+echo "== $cfg"
+env $cfg python3 tools/sweep_pace_parts.py 2>&1 | grep -a "^iteration"
+env $cfg python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-c4 --no-c3 --no-c5 --no-mref 2>/dev/null | tail -1 | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('$so', d['c4'].get('ms_per_sweep'), 'ms/sweep', d['c4'].get('error'))"
-done; done
+d=json.loads(sys.stdin.readline()); print('driver form', d['value'], 'K1 in region', d['roofline']['avg_launch_us'], 'alone', d['roofline']['avg_launch_us_alone'], 'rmse', d['test_rmse'])"
+done

@@ -30,6 +30,14 @@ def rows_only(i):
     check(lib().bdf_gibbs_rows_only(eng.gibbs, 0, 1_000_000 + 2 * i))
     check(lib().bdf_gibbs_rows_only(eng.gibbs, 1, 1_000_001 + 2 * i))
 c = pace(rows_only)
+from bdf_amd.engine import KernelTimer
+ts = [KernelTimer(), KernelTimer()]
+def rows_with_events(i):        # ... each with a completion event on its dispatch, as the iteration attaches one
+    for j in (0, 1):
+        check(lib().bdf_ctx_time_next_rows(eng.ctx.handle, None, ts[j].stop))
+        check(lib().bdf_gibbs_rows_only(eng.gibbs, j, 2_000_000 + 2 * i + j))
+d = pace(rows_with_events)
+print(f"the two row launches alone with a completion event riding on each dispatch: {d:.1f} us")
 print(f"iteration with the prediction update {a:.1f} us; without it {b:.1f} us; the two row launches alone {c:.1f} us "
       f"(hand-overs {b - c:.1f} us, prediction update beside the rows {a - b:.1f} us)")
 eng.close()
