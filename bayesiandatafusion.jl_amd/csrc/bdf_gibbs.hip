@@ -432,16 +432,31 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     int rc;
     R->sweep_host = H->sweep_host = P->sweep_host = sweep;
     // The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep - 2, which the prediction update of
-    // sweep - 2 reads.  The HOST waits here until the update of two sweeps ago has completed (normally it has, long ago): the
-    // device then needs no wait for the prediction stream anywhere, and the host never runs more than two prediction updates
+    // sweep - 2 reads.  The HOST waits here until an update of some sweeps ago has completed (normally it has, long ago): the
+    // device then needs no wait for the prediction stream anywhere, and the host never runs more than a few prediction updates
     // ahead.  (A device-side wait would let row kernels that poll for their prior fill the chip while the prediction kernel
     // they transitively wait for still needs slots for its last workgroups.)
     // (Whether or not THIS iteration has a prediction update: an update enqueued two or more iterations ago must have
     // completed -- iterations without one rotate the buffers all the same.)
+    // How many iterations back: 3 (BDF_PRED_LAG, 1..3) -- the most the three buffers allow: iteration s overwrites the rows of
+    // iteration s - 3, which the prediction update of s - 3 read.  (Until round 3: 2.  On a quiet host there is no difference;
+    // with 3 an enqueue that takes 50 us instead of 23, or a late wake-up, no longer leaves the row stream dry.)
+    static const int pred_lag = getenv("BDF_PRED_LAG") ? std::max(1, std::min(3, atoi(getenv("BDF_PRED_LAG")))) : 3;
     const auto t_in = std::chrono::steady_clock::now();
     for (uint64_t back = 1; back <= std::min<uint64_t>(g->n_pred, 3); back++) {
         const uint64_t k = (g->n_pred - back) % 3;
-        if (g->pred_at[k] + 2 <= g->n_iter) { BDF_HIP(hipEventSynchronize(g->ev_pred[k])); break; }      // (and with it the earlier ones)
+        if (g->pred_at[k] + (uint64_t)pred_lag <= g->n_iter) {          // (and with it the earlier ones)
+            // a short spin on the event before the blocking wait: a thread put to sleep here wakes 10-40 us after the event,
+            // and with the host one iteration ahead of the device at that moment a late wake-up plus a slow enqueue (50 us on
+            // a busy host) leaves the row stream dry
+            hipError_t st = hipErrorNotReady;
+            const auto t_spin = std::chrono::steady_clock::now();
+            while ((st = hipEventQuery(g->ev_pred[k])) == hipErrorNotReady &&
+                   std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() < 400.0) { }
+            if (st == hipErrorNotReady) st = hipEventSynchronize(g->ev_pred[k]);
+            BDF_HIP(st);
+            break;
+        }
     }
     const auto t_go = std::chrono::steady_clock::now();
     // the data-independent part of every entity's hyperprior draw (Bartlett matrix, mean normals): inside the entity's chain
