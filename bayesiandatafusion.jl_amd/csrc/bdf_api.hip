@@ -1,4 +1,5 @@
 // bdf_api.hip -- C-ABI entry points: context, device memory, IndexedDF -> device CSR, row sampling front-end
+#include <chrono>
 #include "bdf_common.h"
 #include <cstdlib>
 #include <cstring>
@@ -38,7 +39,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
         return BDF_ERR_NOGPU;
     }
     bdf_ctx *c = new bdf_ctx();
-    c->sweep_dev = nullptr; c->flag_dev = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr;
+    c->sweep_dev = nullptr; c->flag_dev = nullptr; c->flag_host = nullptr; c->scratch = nullptr; c->scratch2 = nullptr; c->cg_status = nullptr; c->cg_part = nullptr;
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->hyper_chain = false; c->hyper_count = nullptr; c->hyper_chain_draws = nullptr;
     c->own_stream = false; c->stream = nullptr;
@@ -48,9 +49,10 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->own_stream = false;
     c->stream = (hipStream_t)stream;          // NULL is the device's default stream
     BDF_HIP(hipMalloc((void **)&c->sweep_dev, sizeof(uint32_t)));
-    BDF_HIP(hipMalloc((void **)&c->flag_dev, 16 * sizeof(int)));      // [0] error flag, [1..] self-resetting arrival counters
+    BDF_HIP(hipHostMalloc((void **)&c->flag_host, 16 * sizeof(int), hipHostMallocMapped | hipHostMallocCoherent));
+    memset(c->flag_host, 0, 16 * sizeof(int));
+    BDF_HIP(hipHostGetDevicePointer((void **)&c->flag_dev, c->flag_host, 0));
     BDF_HIP(hipMemsetAsync(c->sweep_dev, 0, sizeof(uint32_t), c->stream));
-    BDF_HIP(hipMemsetAsync(c->flag_dev, 0, 16 * sizeof(int), c->stream));
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
@@ -86,7 +88,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     bdf_plans_release(ctx, 0);
     if (ctx->scratch) hipFree(ctx->scratch);
     if (ctx->sweep_dev) hipFree(ctx->sweep_dev);
-    if (ctx->flag_dev) hipFree(ctx->flag_dev);
+    if (ctx->flag_host) hipHostFree(ctx->flag_host);
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
@@ -168,11 +170,16 @@ extern "C" int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations)
 extern "C" int bdf_ctx_sync(bdf_ctx *ctx)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_sync: ctx is NULL");
-    BDF_HIP(hipStreamSynchronize(ctx->stream));
-    int flag = 0;
-    BDF_HIP(hipMemcpy(&flag, ctx->flag_dev, sizeof(int), hipMemcpyDeviceToHost));
+    // a short spin before the blocking wait (a sleeping thread wakes 10-40 us after the stream has drained)
+    hipError_t st = hipErrorNotReady;
+    const auto t_spin = std::chrono::steady_clock::now();
+    while ((st = hipStreamQuery(ctx->stream)) == hipErrorNotReady &&
+           std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_spin).count() < 300.0) { }
+    if (st == hipErrorNotReady) st = hipStreamSynchronize(ctx->stream);
+    BDF_HIP(st);
+    int flag = __atomic_load_n(ctx->flag_host, __ATOMIC_ACQUIRE);
     if (flag) {
-        BDF_HIP(hipMemsetAsync(ctx->flag_dev, 0, sizeof(int), ctx->stream));      // (ordered before the context's next kernel)
+        __atomic_store_n(ctx->flag_host, 0, __ATOMIC_RELEASE);      // (the stream is idle: nothing of this context is in flight)
         ctx->warnings |= (uint32_t)flag & BDF_WARN_CG_MAXITER;
         flag &= ~(int)BDF_WARN_CG_MAXITER;
     }

@@ -37,7 +37,9 @@ struct bdf_ctx {
     size_t scratch_bytes;
     void *scratch2;            // second block: split-K partials of the dense products (used while `scratch` is held)
     size_t scratch2_bytes;
-    int *flag_dev;             // not-positive-definite flag (bits 1..32: errors; 64: BDF_WARN_CG_MAXITER)
+    int *flag_dev;             // not-positive-definite flag (bits 1..32: errors; 64: BDF_WARN_CG_MAXITER): the device address of
+    int *flag_host;            // ... a word of mapped, coherent HOST memory (kernels atomicOr into it on their error paths only;
+                               // bdf_ctx_sync reads it without a copy -- a 4-byte blocking device-to-host copy is ~10 us)
     uint32_t warnings;         // non-fatal bits seen by bdf_ctx_sync, until bdf_ctx_warnings takes them
     int item_size;             // K1: observations per work item (rows longer than this are split)
     int piece_size;            // K1: ... into pieces of at most this many observations
