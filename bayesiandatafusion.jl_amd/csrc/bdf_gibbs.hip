@@ -378,35 +378,93 @@ extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
 extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
 {
     BDF_REQUIRE(g && milliseconds >= 0.0 && milliseconds <= 10000.0, BDF_ERR_ARG, "bdf_gibbs_warm_device: bad argument");
+    if (milliseconds <= 0.0) return BDF_OK;
     bdf_ctx *R = g->rows;
-    const uint32_t keep = R->sweep_host;
-    const auto t0 = std::chrono::steady_clock::now();
-    int rc = BDF_OK;
-    uint32_t i = 0;
-    while (!rc && std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() < milliseconds) {
-        for (int batch = 0; batch < 8 && !rc; batch++, i++) {
-            auto &E = g->ent[(size_t)(i % g->ent.size())];
-            const bdf_gibbs_entity &e = E.d;
-            R->sweep_host = 0xffff0000u + (i & 0xffffu);
-            bdf_term terms[BDF_MAX_TERMS];
-            for (int t = 0; t < e.n_terms; t++) {
-                terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
-                terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
-                for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
-                for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
-                    const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
-                    terms[t].factors[k] = O.d.sample[O.cur];
-                }
-            }
-            const int nch = e.terms[0].rel->chunks;
-            for (int c = 0; c < nch && !rc; c++)
-                rc = bdf_sample_rows(R, g->D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
-                                     e.sample[(E.cur + 1) % 3], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr);
+    const int D = g->D, n = (int)g->ent.size();
+    int rc;
+    if ((rc = bdf_gibbs_sync(g))) return rc;
+    // the chain's state: every entity's current sample, (mu, Lambda), sums, posterior parameters, prior pack, draws, and with
+    // side information beta, uhat, the per-row prior means, Tinv, lambda_beta, the iteration counts
+    struct Piece { void *p; size_t bytes; bool sample; int ent; };
+    std::vector<Piece> pieces;
+    std::vector<char> flags;
+    const size_t DD = (size_t)D * D * sizeof(double), Dv = (size_t)D * sizeof(double);
+    for (int j = 0; j < n; j++) {
+        auto &E = g->ent[(size_t)j];
+        const bdf_gibbs_entity &e = E.d;
+        pieces.push_back({e.sample[E.cur], (size_t)e.N * Dv, true, j});
+        pieces.push_back({e.mu, Dv, false, j}); pieces.push_back({e.Lambda, DD, false, j});
+        pieces.push_back({e.sumU, Dv, false, j}); pieces.push_back({e.UUt, DD, false, j});
+        if (e.params) pieces.push_back({e.params, Dv + DD, false, j});
+        pieces.push_back({e.prior_pack, (size_t)bdf_prior_pack_doubles(D) * sizeof(double), false, j});
+        pieces.push_back({e.draws, DD + Dv, false, j});
+        if (e.feat) {
+            pieces.push_back({e.beta, (size_t)e.feat->n * Dv, false, j});
+            pieces.push_back({e.uhat, (size_t)e.N * Dv, false, j});
+            pieces.push_back({e.mu_matrix, (size_t)e.N * Dv, false, j});
+            pieces.push_back({e.Tinv, DD, false, j});
+            pieces.push_back({e.lambda_beta, sizeof(double), false, j});
+            if (e.cg_iters) pieces.push_back({e.cg_iters, (size_t)D * sizeof(int32_t), false, j});
         }
-        if (!rc && hipStreamSynchronize(R->stream) != hipSuccess) { bdf_set_error("bdf_gibbs_warm_device: stream synchronisation failed"); rc = BDF_ERR_HIP; }
+        flags.push_back(E.hyper_recorded ? 1 : 0); flags.push_back(E.beta_recorded ? 1 : 0);
     }
-    R->sweep_host = keep;
+    size_t total = 0;
+    for (auto &pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
+    char *snap = nullptr;
+    BDF_HIP(hipMalloc((void **)&snap, std::max<size_t>(total, 256)));
+    struct Free { char *p; ~Free() { if (p) (void)hipFree(p); } } guard{snap};
+    size_t off = 0;
+    for (auto &pc : pieces) {
+        BDF_HIP(hipMemcpyAsync(snap + off, pc.p, pc.bytes, hipMemcpyDeviceToDevice, R->stream));
+        off += (pc.bytes + 255) & ~(size_t)255;
+    }
+    BDF_HIP(hipStreamSynchronize(R->stream));
+    // full iterations with numbers no real iteration uses; the prediction kernel without running state.  One rank: for the
+    // time asked for; several ranks: a fixed count (every rank must make the same number of exchanges)
+    const uint32_t keep = R->sweep_host;
+    const int64_t fixed = g->comm ? std::max<int64_t>(1, (int64_t)(milliseconds / 0.1)) : 0;
+    const auto t0 = std::chrono::steady_clock::now();
+    int64_t k = 0;
+    rc = BDF_OK;
+    while (!rc) {
+        for (int b = 0; b < 8 && !rc; b++, k++) rc = bdf_gibbs_sweep(g, 0xfffe0000u + (uint32_t)(k & 0xffff), g->test ? 3 : -1);
+        if (fixed ? k >= fixed : std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= milliseconds) break;
+    }
+    const int rc_sync = bdf_gibbs_sync(g);
+    if (!rc) rc = rc_sync;
+    // put the state back: the saved sample into whichever buffer is current now, everything else where it was
+    off = 0;
+    for (auto &pc : pieces) {
+        void *dst = pc.sample ? (void *)g->ent[(size_t)pc.ent].d.sample[g->ent[(size_t)pc.ent].cur] : pc.p;
+        BDF_HIP(hipMemcpyAsync(dst, snap + off, pc.bytes, hipMemcpyDeviceToDevice, R->stream));
+        off += (pc.bytes + 255) & ~(size_t)255;
+    }
+    for (int j = 0; j < n; j++) {
+        g->ent[(size_t)j].hyper_recorded = flags[(size_t)2 * j] != 0;
+        g->ent[(size_t)j].beta_recorded = flags[(size_t)2 * j + 1] != 0;
+    }
+    BDF_HIP(hipStreamSynchronize(R->stream));
+    R->sweep_host = g->hyper->sweep_host = g->pred->sweep_host = keep;
     return rc;
+}
+
+// (set-up) whether the entity's hyperprior draw / beta of an earlier iteration exist -- what the next iteration's row launch
+// takes its prior pack from and waits for; a caller that runs iterations and then puts the chain's state back (the engine's
+// device warm-up) puts these back with it
+extern "C" int bdf_gibbs_recorded(const bdf_gibbs *g, int entity, int *hyper, int *beta)
+{
+    BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size() && hyper && beta, BDF_ERR_ARG, "bdf_gibbs_recorded: bad argument");
+    *hyper = g->ent[(size_t)entity].hyper_recorded ? 1 : 0;
+    *beta = g->ent[(size_t)entity].beta_recorded ? 1 : 0;
+    return BDF_OK;
+}
+
+extern "C" int bdf_gibbs_set_recorded(bdf_gibbs *g, int entity, int hyper, int beta)
+{
+    BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_set_recorded: bad argument");
+    g->ent[(size_t)entity].hyper_recorded = hyper != 0;
+    g->ent[(size_t)entity].beta_recorded = beta != 0;
+    return BDF_OK;
 }
 
 extern "C" int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop)
@@ -554,7 +612,9 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             const auto &O = g->ent[(size_t)g->test_entity[k]];
             fac[k] = O.d.sample[O.cur];
         }
-        if ((rc = bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
+        // (phase 3, set-up only: the same kernel on the same pairs, statistics of this sample into stats_dev, no running state)
+        if ((rc = predict_phase == 3 ? bdf_predict_sse(P, g->test, D, fac, g->test_mean, nullptr, g->stats_dev)
+                                     : bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
             return rc;
         BDF_HIP(hipEventRecord(g->ev_pred[g->n_pred % 3], P->stream));
         g->pred_at[g->n_pred % 3] = g->n_iter;

@@ -664,10 +664,19 @@ class GibbsEngine:
             check(lib().bdf_gibbs_set_comm(self.gibbs, self.comm.handle))
 
     def warm_device(self, milliseconds=50.0):
-        """set-up (native iteration): untimed row launches that do not advance the chain, to bring the device out of its idle
-        power state before the first iteration (bdf_gibbs_warm_device); a no-op on the step-by-step path"""
+        """set-up (native iteration): bring the device to its working state before the first iteration
+        (bdf_gibbs_warm_device).  Full iterations -- rows of every entity, hyperprior chains, beta, the prediction kernel on
+        the registered test pairs without running state -- with iteration numbers no real iteration uses, for `milliseconds`
+        (several ranks: a fixed count, the same on every rank), then the chain's state is put back bit for bit.  Nothing of
+        the chain advances.  (Row launches alone do not do it: a 20-iteration region behind 60 ms of them runs at 96-98 us
+        per iteration, behind full iterations at 92-93: tools/region_idle_probe.py)  A no-op on the
+        step-by-step path."""
         if self.gibbs and milliseconds > 0:
             check(lib().bdf_gibbs_warm_device(self.gibbs, float(milliseconds)))
+            for j, st in enumerate(self.ent):          # the library's buffer rotation went on: follow it
+                cur = C.c_int(0)
+                check(lib().bdf_gibbs_current(self.gibbs, j, C.byref(cur)))
+                st.cur = cur.value
 
     def set_alpha(self):
         """(native iteration) the relations' precisions are launch arguments held by the bdf_gibbs object: rebuild it after
@@ -812,18 +821,26 @@ class GibbsEngine:
         sample, 2 later ones); returns the pairs' device stats"""
         test = self.test_pairs()
         if self.native:
-            opts = (tuple(clamp), float(class_cut))
-            if self._test_opts != opts:
-                lo, hi = (clamp[0], clamp[1]) if len(clamp) else (1.0, -1.0)
-                r = self.data.relations[0]
-                eom = (C.c_int32 * len(r.entities))(*[self._entity_index(e) for e in r.entities])
-                check(lib().bdf_gibbs_set_test(self.gibbs, test.handle, eom, r.model.mean_value, lo, hi, class_cut, _ptr(test.stats)))
-                self._test_opts = opts
+            self.register_test(clamp, class_cut)
             self.sweep(i, phase)
             return test.stats
         self.sweep(i)
         r = self.data.relations[0]
         return test.update(self.D, self.factors_of(r), r.model.mean_value, phase, list(clamp), class_cut)
+
+    def register_test(self, clamp=(), class_cut=0.0):
+        """(native iteration) the test pairs and reporting options the library's prediction update runs with; step() does it,
+        a caller that warms the device before its first step does it first so that the warm-up runs the prediction kernel too"""
+        if not self.native:
+            return
+        test = self.test_pairs()
+        opts = (tuple(clamp), float(class_cut))
+        if self._test_opts != opts:
+            lo, hi = (clamp[0], clamp[1]) if len(clamp) else (1.0, -1.0)
+            r = self.data.relations[0]
+            eom = (C.c_int32 * len(r.entities))(*[self._entity_index(e) for e in r.entities])
+            check(lib().bdf_gibbs_set_test(self.gibbs, test.handle, eom, r.model.mean_value, lo, hi, class_cut, _ptr(test.stats)))
+            self._test_opts = opts
 
     def sweep(self, i, predict_phase=None):
         """iteration i without reporting (native: with the prediction update of `predict_phase` on the registered test pairs)"""

@@ -341,8 +341,8 @@ def main():
     ap.add_argument("--k1-min-launches", type=int, default=200, help="K1 launches averaged for the roofline (further sweeps after the timed region)")
     ap.add_argument("--replicas", type=int, default=0, help="user blocks of the workload (default: one per GPU)")
     ap.add_argument("--device-warmup-ms", type=float, default=60.0,
-                    help="engine set-up: untimed row launches that do not advance the chain, before the first warm-up step "
-                         "(brings the device out of its idle power state; 0 = none)")
+                    help="engine set-up before the first warm-up step: full iterations whose results are discarded (the chain's state is "
+                         "put back bit for bit), for this long; brings the device to its working state; 0 = none")
     ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 block (Macau with dense side information; one GPU only)")
     ap.add_argument("--no-mref", action="store_true", help="skip the block on the reference's own benchmark shape (one GPU only)")
@@ -440,8 +440,10 @@ def main():
     test = eng.test_pairs(subset=my_share(n_test_total) if world > 1 else None)
     clamp = [1.0, 5.0]
 
-    # set-up, not a step: the device leaves its idle power state (a launch right after idle time runs ~10 % slower than the
-    # same launch 30 ms into sustained work, tools/region_pace.py); nothing of the chain advances
+    # set-up, not a step: the device is brought to its working state by full iterations whose results are discarded -- the
+    # chain's state is put back bit for bit, nothing of it advances (engine.warm_device; tools/region_idle_probe.py: a
+    # 20-iteration region right after idle time or after row launches alone runs 5-10 % slower than in sustained work)
+    eng.register_test(clamp, rel.class_cut)
     eng.warm_device(args.device_warmup_ms)
     for i in range(1, args.warmup + 1):
         eng.step(i, 0, clamp, rel.class_cut)
@@ -529,6 +531,7 @@ def main():
                        "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
                        "host_core": host_core,
                        "device_warmup_ms": args.device_warmup_ms if eng.gibbs else 0.0,
+                       "device_warmup": "set-up: full iterations for that long, results discarded, the chain's state put back bit for bit",
                        "parallelism": (f"rows of each entity shared out over {world} GPUs (a rank holds its rows' observations only), "
                                        f"in-place all-gather of the sampled rows per half-sweep, test ratings split over the ranks; "
                                        f"transport: {eng.comm.transport if eng.comm is not None else 'none'}")

@@ -409,15 +409,24 @@ int bdf_gibbs_set_test(bdf_gibbs *g, bdf_pairs *pairs, const int32_t *entity_of_
 /* several ranks: exchange every entity's rows after sampling them (NULL: none) */
 int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm);
 /* one iteration.  predict_phase: bdf_predict_update's phase (0 burn-in, 1 first posterior sample, 2 later ones), -1: none */
-int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase);
+int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase);      /* predict_phase 3 (set-up): this sample's statistics only, no running state */
 /* which of sample[0..2] holds entity's current rows */
 int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer);
 /* measurement: the row launch of one entity as bdf_gibbs_sweep makes it, and nothing else (no hyperprior update, exchange or
  * prediction update: the chain's state is not kept consistent) */
 int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep);
-/* set-up: untimed row launches for about `milliseconds` that do not advance the chain (written to every entity's next
- * buffer, which the next iteration overwrites; buffers not rotated): brings the device out of its idle power state */
+/* set-up: brings the device to its working state without advancing the chain.  Full iterations (rows of every entity,
+ * hyperprior chains, beta, the prediction kernel on the registered test pairs WITHOUT running state) with iteration numbers
+ * no real iteration uses, for about `milliseconds` (with a communicator: milliseconds / 0.1 iterations, the same count on
+ * every rank), then the chain's state -- every entity's current sample, (mu, Lambda), sums, prior pack, draws, beta, uhat,
+ * lambda_beta, and whether a draw of an earlier iteration exists -- is put back bit for bit.  The buffers rotate meanwhile:
+ * ask bdf_gibbs_current afterwards.  (Row launches alone leave a short run of iterations 5 % slower than this does.) */
 int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds);
+/* (set-up) does the entity's hyperprior draw / beta of an earlier iteration exist (bdf_gibbs_sweep takes the next row launch's
+ * prior pack from it and waits for it)?  A host that runs iterations whose results it then discards -- the engine's device
+ * warm-up: full iterations, then every buffer put back -- puts these two flags back as well. */
+int bdf_gibbs_recorded(const bdf_gibbs *g, int entity, int *hyper, int *beta);
+int bdf_gibbs_set_recorded(bdf_gibbs *g, int entity, int hyper, int beta);
 /* measurement: (start, stop) events ride on the dispatch of entity's next row kernel (bdf_ctx_time_next_rows) */
 int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop);
 int bdf_gibbs_sync(bdf_gibbs *g);     /* waits for the three streams; errors as bdf_ctx_sync */

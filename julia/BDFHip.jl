@@ -276,7 +276,8 @@ mutable struct Gibbs
         g
     end
 end
-"set-up: untimed row launches for about `ms` milliseconds that do not advance the chain (bdf_gibbs_warm_device)"
+"set-up: full iterations for about `ms` milliseconds whose results are discarded -- the chain's state is put back bit for bit, only the
+buffers have rotated (ask `current_buffer`) -- to bring the device to its working state (bdf_gibbs_warm_device)"
 warm_device!(g::Gibbs, ms::Real) = check(ccall((:bdf_gibbs_warm_device, lib), Cint, (Ptr{Cvoid}, Float64), g.h, ms))
 
 "one Gibbs iteration; phase: 0 burn-in, 1 first posterior sample, 2 later ones, -1 no prediction update"
