@@ -443,6 +443,9 @@ def main():
     # set-up, not a step: the device is brought to its working state by full iterations whose results are discarded -- the
     # chain's state is put back bit for bit, nothing of it advances (engine.warm_device; tools/region_idle_probe.py: a
     # 20-iteration region right after idle time or after row launches alone runs 5-10 % slower than in sustained work)
+    import gc
+    gc.collect()          # (as timeit does: no collector pause inside the 2 ms timed region -- a collection here, before the
+    gc.disable()          #  device warm-up, not between the warm-up steps and the region, where it would be idle time)
     eng.register_test(clamp, rel.class_cut)
     eng.warm_device(args.device_warmup_ms)
     for i in range(1, args.warmup + 1):
@@ -460,6 +463,7 @@ def main():
     t_enq = time.perf_counter()
     fence()
     elapsed = max_over_ranks(time.perf_counter() - t0)
+    gc.enable()
     eng.sync()
     if stamps is not None:
         per = [round(1e6 * (b - a), 1) for a, b in zip([t0] + stamps[:-1], stamps)]
