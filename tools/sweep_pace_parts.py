@@ -30,6 +30,23 @@ def rows_only(i):
     check(lib().bdf_gibbs_rows_only(eng.gibbs, 0, 1_000_000 + 2 * i))
     check(lib().bdf_gibbs_rows_only(eng.gibbs, 1, 1_000_001 + 2 * i))
 c = pace(rows_only)
+from bdf_amd.engine import _ptr
+eng.sync()
+side = []
+for st in eng.ent:               # a frozen copy of every entity's rows and outputs of their own: nothing of the chain is touched
+    side.append(dict(S=st.sample.clone(), sumU=st.sumU.clone(), UUt=st.UUt.clone(), mu=st.mu.clone(), Lam=st.Lambda.clone(),
+                     par=st.params.clone(), pack=st.prior_pack.clone()))
+eng.sync()
+def rows_beside_hyper(i):        # ... with the hyperprior kernels of both entities on the reserved CUs beside them, no dependence
+    rows_only(i)
+    eng.ctx_h.set_sweep(3_000_000 + i)
+    h = eng.ctx_h.handle
+    for st, b in zip(eng.ent, side):
+        check(lib().bdf_hyper_sums(h, 32, st.N, _ptr(b["S"]), None, _ptr(b["sumU"]), _ptr(b["UUt"])))
+        check(lib().bdf_hyper_sample(h, 32, st.n_real, _ptr(b["sumU"]), _ptr(b["UUt"]), _ptr(st.mu0), st.b0, _ptr(st.WI), st.nu0, st.tag,
+                                     _ptr(b["mu"]), _ptr(b["Lam"]), _ptr(b["par"]), _ptr(b["pack"]), None))
+e = pace(rows_beside_hyper)
+print(f"the two row launches with independent hyperprior kernels beside them on the reserved CUs: {e:.1f} us")
 from bdf_amd.engine import KernelTimer
 ts = [KernelTimer(), KernelTimer()]
 def rows_with_events(i):        # ... each with a completion event on its dispatch, as the iteration attaches one
