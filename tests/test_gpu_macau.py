@@ -222,8 +222,8 @@ def test_determinism_and_stream_overlap(B, monkeypatch):
 
 
 def test_warm_device_and_repeated_sweep_numbers(B, monkeypatch):
-    """(i) bdf_gibbs_warm_device (untimed row launches into the entities' next buffers, set-up of the bench) does not advance
-    the chain; (ii) the hand-over between a draw and the next row launch is keyed on a private epoch, not on the caller's
+    """(i) bdf_gibbs_warm_device (full iterations whose results are discarded, the chain's state put back; set-up of the bench)
+    does not advance the chain; (ii) the hand-over between a draw and the next row launch is keyed on a private epoch, not on the caller's
     sweep number: a number that repeats (same random streams, evolving state) gives the same chain whether the row kernels
     poll for the draw or the row stream waits for its event"""
     from bdf_amd import datasets
@@ -251,6 +251,42 @@ def test_warm_device_and_repeated_sweep_numbers(B, monkeypatch):
     assert not same(base, rep)
     monkeypatch.setenv("BDF_NO_POLL", "1")
     assert same(rep, run(0.0, [7, 7, 7, 3, 3, 7]))
+
+
+def test_warm_device_keeps_a_chain_with_side_information(B):
+    """bdf_gibbs_warm_device with entity side information (beta, uhat, per-row prior means, lambda_beta in the state it puts
+    back): a chain with a warm-up before its first iteration and one in the middle equals, bit for bit, the chain without"""
+    from bdf_amd.engine import GibbsEngine
+    rng = np.random.default_rng(8)
+    N1, N2, nnz, numF, D = 260, 90, 5000, 30, 16
+    ids = np.stack([rng.integers(1, N1 + 1, nnz), rng.integers(1, N2 + 1, nnz)], axis=1)
+    vals = np.clip(np.round(3.5 + rng.standard_normal(nnz)), 1, 5)
+    F = rng.standard_normal((N1, numF))
+
+    def run(warm, ff):
+        rel = B.Relation({"u": ids[:, 0], "v": ids[:, 1], "y": vals}, "r", [B.Entity("u", F=F), B.Entity("v")], dims=[N1, N2])
+        B.setPrecision(rel, 1.5)
+        B.assignToTest(rel, 300, rng=np.random.default_rng(2))
+        rd = B.RelationData(rel)
+        eng = GibbsEngine(rd, D, seed=6, compute_ff_size=6500 if ff else 0)
+        assert eng.native
+        eng.register_test([1.0, 5.0], rel.class_cut)
+        if warm:
+            eng.warm_device(8.0)
+        for i in range(1, 7):
+            eng.step(i, 0 if i < 4 else (1 if i == 4 else 2), [1.0, 5.0], rel.class_cut)
+            if warm and i == 4:
+                eng.warm_device(5.0)
+        eng.sync()
+        en = rd.entities[0]
+        out = [en.model.sample.copy(), en.model.beta.copy(), rd.entities[1].model.sample.copy(), eng.test_pairs().stats.cpu().numpy().copy(),
+               np.concatenate(eng.test_pairs().state())]
+        eng.close()
+        return out
+
+    for ff in (True, False):
+        a, b = run(False, ff), run(True, ff)
+        assert all(np.array_equal(x, y) for x, y in zip(a, b))
 
 
 def test_native_iteration_with_side_information_equals_step_by_step(B, monkeypatch):

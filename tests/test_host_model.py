@@ -402,3 +402,27 @@ def test_bench_launches_its_own_ranks():
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d == {"rendezvous": 2, "rank_sum": 1.0}
+
+
+def test_feature_rows_subset_keeps_kind_and_content(B):
+    """engine._take_rows (a rank's block of a relation's feature rows; the test rows a rank predicts): the chosen rows, in the
+    chosen order, as a matrix of the same kind -- dense, scipy sparse, SparseMatrixCSR, SparseBinMatrix"""
+    import scipy.sparse as sp
+    from bdf_amd.engine import _take_rows
+    from bdf_amd import features as feat
+    rng = np.random.default_rng(4)
+    A = rng.standard_normal((9, 5)) * (rng.random((9, 5)) < 0.5)
+    rows0 = np.array([7, 2, 3])
+    assert np.array_equal(_take_rows(A, rows0), A[rows0])
+    assert np.array_equal(_take_rows(sp.csr_matrix(A), rows0).toarray(), A[rows0])
+    r, c = np.nonzero(A)
+    csr = feat.SparseMatrixCSR(r + 1, c + 1, A[r, c], 9, 5)
+    sub = _take_rows(csr, rows0)
+    dense = np.zeros((3, 5))
+    dense[sub.rows - 1, sub.cols - 1] = sub.vals
+    assert (sub.m, sub.n) == (3, 5) and np.array_equal(dense, A[rows0])
+    bm = feat.SparseBinMatrix(9, 5, r + 1, c + 1)
+    subb = _take_rows(bm, np.arange(2, 6))
+    denseb = np.zeros((4, 5))
+    denseb[subb.rows - 1, subb.cols - 1] = 1.0
+    assert (subb.m, subb.n) == (4, 5) and np.array_equal(denseb, (A[2:6] != 0).astype(float))
