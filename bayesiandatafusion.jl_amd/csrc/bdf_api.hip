@@ -71,6 +71,8 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->scratch_bytes = 0;
     c->item_size = 192;
     c->piece_size = 128;
+    c->small_max = getenv("BDF_K1_SMALL") ? atoi(getenv("BDF_K1_SMALL")) : 48;
+    c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     {
         const char *force = getenv("BDF_GATHER");
         c->gather_mode = force && !strcmp(force, "general") ? 1 : (force && !strcmp(force, "wide") ? 2 : 0);
@@ -156,6 +158,14 @@ extern "C" int bdf_ctx_set_gather(bdf_ctx *ctx, int mode)
 {
     BDF_REQUIRE(ctx && mode >= 0 && mode <= 2, BDF_ERR_ARG, "bdf_ctx_set_gather: mode must be 0 (auto), 1 (general) or 2 (64-bit offsets)");
     ctx->gather_mode = mode;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows)
+{
+    BDF_REQUIRE(ctx && max_observations >= 0 && min_rows >= 0, BDF_ERR_ARG, "bdf_ctx_set_small_rows: bad argument");
+    ctx->small_max = max_observations;
+    ctx->small_min_rows = min_rows;
     return BDF_OK;
 }
 

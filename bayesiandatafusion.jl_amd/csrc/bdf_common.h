@@ -37,6 +37,8 @@ struct bdf_ctx {
     size_t scratch_bytes;
     void *scratch2;            // second block: split-K partials of the dense products (used while `scratch` is held)
     size_t scratch2_bytes;
+    int small_max;             // k_rows_small: longest row (observations) sampled four to a wave at D <= 16; 0: off
+    int64_t small_min_rows;    // ... and the smallest entity (rows) for which it is used
     int *flag_dev;             // not-positive-definite flag (bits 1..32: errors; 64: BDF_WARN_CG_MAXITER): the device address of
     int *flag_host;            // ... a word of mapped, coherent HOST memory (kernels atomicOr into it on their error paths only;
                                // bdf_ctx_sync reads it without a copy -- a 4-byte blocking device-to-host copy is ~10 us)

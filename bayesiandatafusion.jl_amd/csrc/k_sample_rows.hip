@@ -679,17 +679,197 @@ void k_rows(SampleArgs a, PlanDev p)
         process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
 
+// ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
+// At D <= 16 a row of ten observations costs the wave-per-row kernel ~570 vector and ~340 scalar instructions, nearly all of
+// them per-row overhead that 64 lanes execute for one 16 x 16 system (normals, index arithmetic, 15 factorisation steps on
+// a quarter-filled block): that kernel is issue-bound there (the reference's own benchmark shape: 1.5 M rows of ~10
+// observations).  Here every 16-lane row of the wave owns one entity row; lane j of it holds COLUMN j of the index-reversed
+// system (16 doubles) and b_j.  Observations come 16 at a time (lane j loads the id and value of observation c0 + j, the ids
+// are broadcast inside the 16-lane row by DPP and the 16 gathers are all in flight); the rank-1 updates, the LDL'
+// factorisation with the forward solve riding along as one more row, and the backward solve are DPP row-broadcast fmas
+// (v_fmac_f64_dpp row_newbcast: lane k of each 16-lane row).  Same arithmetic contract as k_rows: the sample is
+// x~ = L~^-T (D^-1 L~^-1 b~ + D^-1/2 z~) of the reversed system P~ = L~ D L~', lane j drawing number D - 1 - j of the row's
+// stream; sums over observations run in observation order.
+struct SmallItem {
+    int32_t row;          // where the sample is written; -1: no row (padding of the last wave)
+    int32_t orig;         // the row's original id (random stream)
+    int64_t q_begin;
+    int32_t count, _pad;
+};
+
+template <int K>
+__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v)
+{
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + K, 0xf, 0xf, false);      // row_newbcast:K
+}
+template <int K>
+__device__ __forceinline__ double row_bcast_f64(double v)
+{
+    double o;
+    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(K));
+    return o;
+}
+
+// DR: D rounded up to a multiple of four -- rows DR .. 15 of the padded system are never touched
+template <int DR, int I>
+__device__ __forceinline__ void small_rank1(double (&A)[16], double v)
+{
+    if constexpr (I < DR) {
+        fm1<I>(A[I], v, v);                     // A[I][j] += v_I v_j
+        small_rank1<DR, I + 1>(A, v);
+    }
+}
+template <int DR, int K, int I>
+__device__ __forceinline__ void small_elim(double (&A)[16], double nm)
+{
+    if constexpr (I < DR) {
+        fm1_self<K>(A[I], nm);                  // A[I][j] -= A[I][K] m_j
+        small_elim<DR, K, I + 1>(A, nm);
+    }
+}
+template <int DR, int K>
+__device__ __forceinline__ void small_factor(double (&A)[16], double &b, double &dj, int j, int D)
+{
+    if constexpr (K < DR) {
+        if (K < D) {
+            const double dk = row_bcast_f64<K>(A[K]);
+            dj = (j == K) ? dk : dj;
+            const double nm = (j > K) ? -(A[K] * fast_rcp(dk)) : 0.0;        // -A[K][j] / d_K; finished columns are left alone
+            small_elim<DR, K, K + 1>(A, nm);
+            fm1_self<K>(b, nm);                                            // the forward solve: b_j -= w_K l_jK
+        }
+        small_factor<DR, K + 1>(A, b, dj, j, D);
+    }
+}
+template <int C>
+__device__ __forceinline__ void small_backward(const double (&A)[16], double &y, double rdj, int j, int D)
+{
+    if constexpr (C >= 1) {
+        if (C < D) fm1_self<C>(y, (j < C) ? -(A[C] * rdj) : 0.0);           // y_j -= l_Cj x_C for the columns left of C
+        small_backward<C - 1>(A, y, rdj, j, D);
+    }
+}
+// (the 16 observations of a chunk in two halves of eight: eight gathered doubles live at a time)
+template <int DR, int H, int K>
+__device__ __forceinline__ void small_chunk(double (&A)[16], double &b, const double (&v)[8], double r, int left)
+{
+    if constexpr (K < 8) {
+        if (8 * H + K < left) {                                             // (wave-uniform: the longest of the four rows)
+            b = fma(v[K], row_bcast_f64<8 * H + K>(r), b);
+            small_rank1<DR, 0>(A, v[K]);
+        }
+        small_chunk<DR, H, K + 1>(A, b, v, r, left);
+    }
+}
+template <int H, int K>
+__device__ __forceinline__ void small_gather(double (&v)[8], uint32_t idw, const char *fac, uint32_t rowb, uint32_t eoff, bool jok,
+                                             int n_here, int left)
+{
+    if constexpr (K < 8) {
+        v[K] = 0.0;
+        if (8 * H + K < left) {
+            const uint32_t id = row_bcast_u32<8 * H + K>(idw);
+            if (jok && 8 * H + K < n_here) v[K] = *(const double *)(fac + (__umul24(id, rowb) + eoff));      // (lean gather: 32-bit offsets)
+        }
+        small_gather<H, K + 1>(v, idw, fac, rowb, eoff, jok, n_here, left);
+    }
+}
+
+#ifndef BDF_SMALL_BLOCKS
+#define BDF_SMALL_BLOCKS 1
+#endif
+template <bool CODED, int DR>
+__global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs a, const SmallItem *items, int64_t n_items)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w * 4 >= n_items) return;
+    const SmallItem it = items[w * 4 + (lane >> 4)];
+    const bool live = it.row >= 0;
+    const int D = a.D;
+    const TermDev &T = a.t[0];
+    const int ec = D - 1 - j;                   // natural index of reversed element j
+    const bool jok = ec >= 0;
+    double z = 0.0;
+    if (live && jok) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, ec);
+    double A[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) A[i] = 0.0;
+    double b = 0.0;
+    const int n = live ? it.count : 0;
+    int nmax = n;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    const char *fac = (const char *)T.fac[0];
+    const uint32_t rowb = (uint32_t)D * 8u, eoff = (uint32_t)(jok ? ec : 0) * 8u;
+    const double mean = T.mean;
+    for (int c0 = 0; c0 < nmax; c0 += 16) {
+        const int o = c0 + j;
+        uint32_t idw = 0;
+        double r = 0.0;
+        if (o < n) {
+            if (CODED) {
+                const uint32_t pw = T.packed[it.q_begin + o];
+                idw = pw & 0xffffffu;
+                r = T.table[pw >> 24] - mean;
+            } else {
+                idw = (uint32_t)T.colidx[it.q_begin + o];
+                r = T.vals[it.q_begin + o] - mean;
+            }
+        }
+        const int left = nmax - c0;
+        double v0[8], v1[8];
+        small_gather<0, 0>(v0, idw, fac, rowb, eoff, jok, n - c0, left);
+        if (left > 8) small_gather<1, 0>(v1, idw, fac, rowb, eoff, jok, n - c0, left);
+        small_chunk<DR, 0, 0>(A, b, v0, r, left);
+        if (left > 8) small_chunk<DR, 1, 0>(A, b, v1, r, left);
+    }
+    // prior: the image of the index-reversed Lambda is in k_rows' accumulator layout -- element (i, j) of a one-block system
+    // sits at [(i / 4) * 64 + (i % 4) * 16 + j]; read past the caches when the draw was polled for (as k_rows does)
+    const double alpha = T.alpha;
+    if (a.ready) {
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 22)) { if (lane == 0) atomicOr(a.flag, 16); break; }
+        }
+#pragma unroll
+        for (int i = 0; i < DR; i++)
+            A[i] = fma(alpha, A[i], __hip_atomic_load(a.prior_c + (i / 4) * 64 + (i % 4) * 16 + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        b = fma(alpha, b, jok ? __hip_atomic_load(a.prior_b + ec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0);
+    } else {
+#pragma unroll
+        for (int i = 0; i < DR; i++) A[i] = fma(alpha, A[i], a.prior_c[(i / 4) * 64 + (i % 4) * 16 + j]);
+        b = fma(alpha, b, (jok && live) ? a.prior_b[(a.mu_is_matrix ? (int64_t)it.row * D : 0) + ec] : 0.0);
+    }
+#pragma unroll
+    for (int i = 0; i < DR; i++)
+        if (i >= D || !jok) A[i] = (i == j) ? 1.0 : 0.0;          // padding: identity
+    if (!jok) b = 0.0;
+    double dj = 1.0;
+    small_factor<DR, 0>(A, b, dj, j, D);
+    if (live && jok && !(dj > 0.0)) atomicOr(a.flag, 1);
+    const double rdj = fast_rcp(dj);
+    double y = fma(z, fast_rsqrt(dj), b * rdj);
+    small_backward<15>(A, y, rdj, j, D);
+    if (live && jok) a.out[(int64_t)it.row * D + ec] = y;
+}
+
 // ---- host: the plan (items, split rows, slab) for a (terms, row list) combination, cached per context ---------------
 struct PlanKey {
     uint64_t rel[BDF_MAX_TERMS];      // relation serials
     int mode[BDF_MAX_TERMS];
     int n_terms, DP, T, Tp;
     int shard, n_shards;
+    int small, _pad;                  // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
 struct Plan {
     PlanDev dev;
+    SmallItem *small_dev = nullptr;
+    int64_t n_small = 0;              // entries of small_dev (a multiple of 4)
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
     int32_t *order_dev = nullptr;
@@ -726,6 +906,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
 {
     const int T = key.T;
     std::vector<Item> direct, split;
+    std::vector<SmallItem> small;
     std::vector<SplitRow> srows;
     static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
     for (const RowRef &rr : rows) {
@@ -745,7 +926,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
             Item it{row, 0, 0, 0, -1, -1, rr.orig};
             for (int r = 0; r < key.n_terms; r++)
                 if (rr.cnt[r] > 0) { it.term = r; it.q_begin = rr.qb[r]; it.count = (int32_t)rr.cnt[r]; }
-            direct.push_back(it);
+            if (key.small > 0 && it.count <= key.small) small.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
+            else direct.push_back(it);
         } else {
             if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
                 split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), rr.orig});
@@ -818,6 +1000,9 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         for (int64_t i = head; i < total; i++) order[(size_t)i] = (int32_t)i;
     }
     int rc;
+    while (small.size() % 4) small.push_back(SmallItem{-1, 0, 0, 0, 0});
+    plan.n_small = (int64_t)small.size();
+    if (!small.empty() && (rc = to_device(small, &plan.small_dev))) return rc;
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
         (rc = to_device(srows, &plan.rows_dev)) || (rc = to_device(order, &plan.order_dev)))
         return rc;
@@ -902,6 +1087,7 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
         for (int r = 0; r < kv->first.n_terms; r++) hit = hit || kv->first.rel[r] == rel_serial;
         if (hit) {
             (void)hipFree(kv->second.direct_dev); (void)hipFree(kv->second.split_dev); (void)hipFree(kv->second.rows_dev);
+            if (kv->second.small_dev) (void)hipFree(kv->second.small_dev);
             (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
             kv = plans.erase(kv);
         } else {
@@ -949,6 +1135,18 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     memset(&key, 0, sizeof(key));
     for (int r = 0; r < a.n_terms; r++) { key.rel[r] = rels[r]->serial; key.mode[r] = modes[r]; }
     key.n_terms = a.n_terms; key.DP = DP; key.T = ctx->item_size; key.Tp = std::min(ctx->piece_size, ctx->item_size); key.shard = shard; key.n_shards = n_shards;
+    // D <= 16, one two-mode relation with the lean gather and no per-observation baseline, an entity of many rows: its short
+    // rows four to a wave (k_rows_small).  bdf_ctx_set_small_rows: the longest row taken that way (default 48 observations,
+    // environment BDF_K1_SMALL; 0: off) and the smallest entity (default 8192 rows, BDF_K1_SMALL_MIN_ROWS: below that the
+    // second launch costs more than it saves)
+    {
+        const int small_max = ctx->small_max;
+        const int64_t small_rows = ctx->small_min_rows;
+        const int64_t n_rows_all = rels[0]->sharded ? (int64_t)rels[0]->idx[modes[0]].own_orig.size() : (int64_t)rels[0]->idx[modes[0]].order.size();
+        if (DP == 16 && !dump && small_max > 0 && a.n_terms == 1 && a.t[0].lean == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr &&
+            !getenv("BDF_K1_DECOUPLE") && n_rows_all >= small_rows)
+            key.small = std::min(small_max, ctx->item_size);
+    }
 
     Plan *plan;
     {
@@ -989,6 +1187,26 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             it = cache.plans.emplace(key, np).first;
         }
         plan = &it->second;
+    }
+    if (plan->n_small > 0) {
+        // the short rows first (most of the entity), then k_rows for the others; a caller's timing events and the hand-over of
+        // the draw stay with k_rows when it has anything to do
+        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
+        const dim3 grid((unsigned)((plan->n_small + 15) / 16)), block(256);
+        hipEvent_t e0 = ctx->time_start, e1 = more ? nullptr : ctx->time_stop;
+        const bool coded = a.t[0].packed != nullptr;
+        const SmallItem *si = plan->small_dev;
+        const int64_t ns = plan->n_small;
+#define SMALL_LAUNCH(DRV)                                                                                                     \
+        do {                                                                                                                    \
+            if (coded) hipExtLaunchKernelGGL((k_rows_small<true, DRV>), grid, block, 0, ctx->stream, e0, e1, 0, a, si, ns);     \
+            else hipExtLaunchKernelGGL((k_rows_small<false, DRV>), grid, block, 0, ctx->stream, e0, e1, 0, a, si, ns);          \
+        } while (0)
+        if (a.D <= 4) SMALL_LAUNCH(4); else if (a.D <= 8) SMALL_LAUNCH(8); else if (a.D <= 12) SMALL_LAUNCH(12); else SMALL_LAUNCH(16);
+#undef SMALL_LAUNCH
+        BDF_HIP(hipGetLastError());
+        ctx->time_start = nullptr;
+        if (!more) { ctx->time_stop = nullptr; return BDF_OK; }
     }
     if (DP == 16) return launch<16>(ctx, a, plan->dev, dump);
     if (DP == 32) return launch<32>(ctx, a, plan->dev, dump);

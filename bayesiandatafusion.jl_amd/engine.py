@@ -145,6 +145,11 @@ class Context:
         check(lib().bdf_rows_unfinished(self.handle, C.byref(n)))
         return n.value
 
+    def set_small_rows(self, max_observations, min_rows):
+        """D <= 16: rows of at most max_observations observations four to a wave when the entity has min_rows rows or more
+        (bdf_ctx_set_small_rows; 0 observations: off)"""
+        check(lib().bdf_ctx_set_small_rows(self.handle, int(max_observations), int(min_rows)))
+
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 

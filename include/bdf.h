@@ -105,6 +105,11 @@ int bdf_ctx_warnings(bdf_ctx *ctx, uint32_t *bits_out);
  * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
+/* D <= 16, an entity of one two-mode relation: rows of at most max_observations observations are sampled FOUR TO A WAVE (16 lanes
+ * and a column-per-lane 16 x 16 system each) by a launch of their own when the entity has at least min_rows rows -- at such
+ * D the wave-per-row kernel is bound by its per-row instruction overhead.  Defaults 48 and 8192 (environment BDF_K1_SMALL,
+ * BDF_K1_SMALL_MIN_ROWS); max_observations 0 turns it off.  Same sample up to the order of the floating-point sums. */
+int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows);
 /* parity hook: which gather path the row kernel takes.  0 = chosen by the sizes (default; env BDF_GATHER=general|wide sets the
  * initial value), 1 = the general path (any number of modes, per-observation baselines), 2 = the lean path with 64-bit row
  * offsets (num_latent > 32; what a factor matrix of 4 GiB or more needs, e.g. 10M rows at D = 64).  Same values on every path. */

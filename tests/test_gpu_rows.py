@@ -641,3 +641,47 @@ def test_sample_users_blocked(B, O, ctx):
     with pytest.raises(B.DimensionMismatch):
         B.Block(ux, vx, Yma.T)
     assert B.sample_users_blocked(B.Block([], vx, np.zeros((len(vx), 0))), sample_mt, alpha, mu, Lam, ctx=ctx).shape == (D, 0)
+
+
+@pytest.mark.parametrize("D", [1, 3, 8, 10, 13, 16])
+@pytest.mark.parametrize("coded", [True, False])
+def test_four_rows_per_wave_equals_wave_per_row(B, ctx, D, coded):
+    """D <= 16: the short rows of an entity of one two-mode relation sampled four to a wave (k_rows_small: 16 lanes and a
+    column-per-lane system per row, bdf_ctx_set_small_rows) against the wave-per-row kernel on the same inputs -- the same
+    sample up to the order of the floating-point sums; rows of 0 .. 48 observations take the new path (two chunks of 16
+    included), 49 and more the old one in the same call; a row count that is no multiple of four; ratings (coded ids) and
+    continuous values; with and without per-row prior means"""
+    import ctypes as C
+    from bdf_amd._lib import Term, check, lib
+    rng = np.random.default_rng(100 + D)
+    dims = [203, 90]
+    deg = rng.integers(0, 40, dims[0])
+    deg[:6] = [0, 1, 16, 17, 48, 49]
+    deg[6:9] = [33, 150, 2]
+    rows = np.repeat(np.arange(1, dims[0] + 1), deg)
+    ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
+    vals = rng.integers(1, 6, len(rows)).astype(np.float64) if coded else rng.random(len(rows)) * 4 + 1
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    V = ctx.tensor(rng.standard_normal((dims[1], D)) * 0.5)
+    A = rng.standard_normal((D, D))
+    Lam = ctx.tensor(A @ A.T / max(D, 1) + np.eye(D))
+    mu = ctx.tensor(rng.standard_normal(D))
+    mu_rows = ctx.tensor(rng.standard_normal((dims[0], D)))
+    p = lambda t: C.c_void_p(t.data_ptr())
+    terms = (Term * 1)()
+    terms[0].rel = dr.handle; terms[0].mode = 0; terms[0].alpha = 1.7; terms[0].mean_value = float(vals.mean())
+    terms[0].factors[1] = V.data_ptr()
+    for per_row in (False, True):
+        outs = []
+        for small in (0, 48):
+            ctx.set_small_rows(small, 1)
+            out = ctx.zeros(dims[0], D)
+            ctx.set_sweep(5)
+            check(lib().bdf_sample_rows(ctx.handle, D, dims[0], 1, terms, p(mu_rows if per_row else mu), 1 if per_row else 0, p(Lam), 3, 0, 1,
+                                        p(out), None))
+            ctx.sync()
+            outs.append(out.cpu().numpy())
+        assert np.isfinite(outs[1]).all() and np.abs(outs[1]).max() > 0.05
+        np.testing.assert_allclose(outs[1], outs[0], rtol=1e-11, atol=1e-12)
+        assert np.array_equal(outs[1][deg >= 49], outs[0][deg >= 49])          # the long rows: the same kernel either way
+    ctx.set_small_rows(48, 8192)
