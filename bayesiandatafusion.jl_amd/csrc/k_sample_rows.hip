@@ -727,51 +727,46 @@ __device__ __forceinline__ void small_elim(double (&A)[16], double nm)
         small_elim<DR, K, I + 1>(A, nm);
     }
 }
+// (no branches around the DPP instructions: steps of the padding -- rows and columns D .. DR-1 are the identity -- are
+// no-ops by their values, and a branch costs the copies the compiler makes for the asm operands at every merge)
 template <int DR, int K>
-__device__ __forceinline__ void small_factor(double (&A)[16], double &b, double &dj, int j, int D)
+__device__ __forceinline__ void small_factor(double (&A)[16], double &b, double &dj, int j)
 {
     if constexpr (K < DR) {
-        if (K < D) {
-            const double dk = row_bcast_f64<K>(A[K]);
-            dj = (j == K) ? dk : dj;
-            const double nm = (j > K) ? -(A[K] * fast_rcp(dk)) : 0.0;        // -A[K][j] / d_K; finished columns are left alone
-            small_elim<DR, K, K + 1>(A, nm);
-            fm1_self<K>(b, nm);                                            // the forward solve: b_j -= w_K l_jK
-        }
-        small_factor<DR, K + 1>(A, b, dj, j, D);
+        const double dk = row_bcast_f64<K>(A[K]);
+        dj = (j == K) ? dk : dj;
+        const double nm = (j > K) ? -(A[K] * fast_rcp(dk)) : 0.0;            // -A[K][j] / d_K; finished columns are left alone
+        small_elim<DR, K, K + 1>(A, nm);
+        fm1_self<K>(b, nm);                                                // the forward solve: b_j -= w_K l_jK
+        small_factor<DR, K + 1>(A, b, dj, j);
     }
 }
 template <int C>
-__device__ __forceinline__ void small_backward(const double (&A)[16], double &y, double rdj, int j, int D)
+__device__ __forceinline__ void small_backward(const double (&A)[16], double &y, double rdj, int j)
 {
     if constexpr (C >= 1) {
-        if (C < D) fm1_self<C>(y, (j < C) ? -(A[C] * rdj) : 0.0);           // y_j -= l_Cj x_C for the columns left of C
-        small_backward<C - 1>(A, y, rdj, j, D);
+        fm1_self<C>(y, (j < C) ? -(A[C] * rdj) : 0.0);                     // y_j -= l_Cj x_C for the columns left of C
+        small_backward<C - 1>(A, y, rdj, j);
     }
 }
-// (the 16 observations of a chunk in two halves of eight: eight gathered doubles live at a time)
-template <int DR, int H, int K>
-__device__ __forceinline__ void small_chunk(double (&A)[16], double &b, const double (&v)[8], double r, int left)
-{
-    if constexpr (K < 8) {
-        if (8 * H + K < left) {                                             // (wave-uniform: the longest of the four rows)
-            b = fma(v[K], row_bcast_f64<8 * H + K>(r), b);
-            small_rank1<DR, 0>(A, v[K]);
-        }
-        small_chunk<DR, H, K + 1>(A, b, v, r, left);
-    }
-}
+// eight observations of a chunk: ids broadcast inside the 16-lane row, all eight gathers issued (observations past the row's
+// end gather row 0 and are masked to zero), then the rank-1 updates
 template <int H, int K>
-__device__ __forceinline__ void small_gather(double (&v)[8], uint32_t idw, const char *fac, uint32_t rowb, uint32_t eoff, bool jok,
-                                             int n_here, int left)
+__device__ __forceinline__ void small_gather(double (&v)[8], uint32_t idw, const char *fac, uint32_t rowb, uint32_t eoff)
 {
     if constexpr (K < 8) {
-        v[K] = 0.0;
-        if (8 * H + K < left) {
-            const uint32_t id = row_bcast_u32<8 * H + K>(idw);
-            if (jok && 8 * H + K < n_here) v[K] = *(const double *)(fac + (__umul24(id, rowb) + eoff));      // (lean gather: 32-bit offsets)
-        }
-        small_gather<H, K + 1>(v, idw, fac, rowb, eoff, jok, n_here, left);
+        v[K] = *(const double *)(fac + (__umul24(row_bcast_u32<8 * H + K>(idw), rowb) + eoff));      // (lean gather: 32-bit offsets)
+        small_gather<H, K + 1>(v, idw, fac, rowb, eoff);
+    }
+}
+template <int DR, int H, int K>
+__device__ __forceinline__ void small_chunk(double (&A)[16], double &b, const double (&v)[8], double r, int n_here, bool jok)
+{
+    if constexpr (K < 8) {
+        const double vk = (jok && 8 * H + K < n_here) ? v[K] : 0.0;
+        b = fma(vk, row_bcast_f64<8 * H + K>(r), b);
+        small_rank1<DR, 0>(A, vk);
+        small_chunk<DR, H, K + 1>(A, b, v, r, n_here, jok);
     }
 }
 
@@ -818,12 +813,15 @@ __global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs
                 r = T.vals[it.q_begin + o] - mean;
             }
         }
-        const int left = nmax - c0;
-        double v0[8], v1[8];
-        small_gather<0, 0>(v0, idw, fac, rowb, eoff, jok, n - c0, left);
-        if (left > 8) small_gather<1, 0>(v1, idw, fac, rowb, eoff, jok, n - c0, left);
-        small_chunk<DR, 0, 0>(A, b, v0, r, left);
-        if (left > 8) small_chunk<DR, 1, 0>(A, b, v1, r, left);
+        const int left = nmax - c0;                       // (wave-uniform: the longest of the four rows)
+        double v0[8];
+        small_gather<0, 0>(v0, idw, fac, rowb, eoff);
+        if (left > 8) {
+            double v1[8];
+            small_gather<1, 0>(v1, idw, fac, rowb, eoff);
+            small_chunk<DR, 0, 0>(A, b, v0, r, n - c0, jok);
+            small_chunk<DR, 1, 0>(A, b, v1, r, n - c0, jok);
+        } else small_chunk<DR, 0, 0>(A, b, v0, r, n - c0, jok);
     }
     // prior: the image of the index-reversed Lambda is in k_rows' accumulator layout -- element (i, j) of a one-block system
     // sits at [(i / 4) * 64 + (i % 4) * 16 + j]; read past the caches when the draw was polled for (as k_rows does)
@@ -848,11 +846,11 @@ __global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs
         if (i >= D || !jok) A[i] = (i == j) ? 1.0 : 0.0;          // padding: identity
     if (!jok) b = 0.0;
     double dj = 1.0;
-    small_factor<DR, 0>(A, b, dj, j, D);
+    small_factor<DR, 0>(A, b, dj, j);
     if (live && jok && !(dj > 0.0)) atomicOr(a.flag, 1);
     const double rdj = fast_rcp(dj);
     double y = fma(z, fast_rsqrt(dj), b * rdj);
-    small_backward<15>(A, y, rdj, j, D);
+    small_backward<DR - 1>(A, y, rdj, j);
     if (live && jok) a.out[(int64_t)it.row * D + ec] = y;
 }
 
