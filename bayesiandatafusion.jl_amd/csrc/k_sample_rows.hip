@@ -710,12 +710,25 @@ __device__ __forceinline__ double row_bcast_f64(double v)
     return o;
 }
 
+// (DPP reads of a register need two wait states after a vector instruction wrote it: the s_nop in fm1 / fm1_self.  In the
+// runs below the DPP source was written long before -- the gathered value once per observation, a matrix row in the step
+// before -- so only the first instruction of a run carries the s_nop)
+template <int KJ>
+__device__ __forceinline__ void fm1_run(double &d, double s, double m)
+{
+    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(m), "n"(KJ));
+}
+template <int KJ>
+__device__ __forceinline__ void fm1_self_run(double &d, double m)
+{
+    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(m), "n"(KJ));
+}
 // DR: D rounded up to a multiple of four -- rows DR .. 15 of the padded system are never touched
 template <int DR, int I>
 __device__ __forceinline__ void small_rank1(double (&A)[16], double v)
 {
     if constexpr (I < DR) {
-        fm1<I>(A[I], v, v);                     // A[I][j] += v_I v_j
+        if constexpr (I == 0) fm1<I>(A[I], v, v); else fm1_run<I>(A[I], v, v);       // A[I][j] += v_I v_j
         small_rank1<DR, I + 1>(A, v);
     }
 }
@@ -723,7 +736,7 @@ template <int DR, int K, int I>
 __device__ __forceinline__ void small_elim(double (&A)[16], double nm)
 {
     if constexpr (I < DR) {
-        fm1_self<K>(A[I], nm);                  // A[I][j] -= A[I][K] m_j
+        if constexpr (I == K + 1) fm1_self<K>(A[I], nm); else fm1_self_run<K>(A[I], nm);      // A[I][j] -= A[I][K] m_j
         small_elim<DR, K, I + 1>(A, nm);
     }
 }
