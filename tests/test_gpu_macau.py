@@ -486,6 +486,30 @@ def test_two_ranks_match_one(B):
     assert abs(d2["c5"]["test_rmse"] - d1["c5"]["test_rmse"]) < 1e-5, (d2["c5"], d1["c5"])
 
 
+def test_two_ranks_match_one_with_four_rows_per_wave():
+    """D = 10 / 12 with the short rows four to a wave (k_rows_small, forced for these small entities): rows at internal
+    positions, a rank's own rows only, chunks -- the two-rank chains (host transport) equal the single process's, and both
+    equal the wave-per-row kernel's chain to the reported digits"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    args = ["--steps", "4", "--warmup", "6", "--num-latent", "10", "--no-cpu-baseline", "--no-c3", "--no-mref", "--no-c5",
+            "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "12"]
+    base = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    out = {}
+    for name, extra, env in (("two", ["--gpus", "2"], dict(base, BDF_DIST_BACKEND="gloo", BDF_K1_SMALL_MIN_ROWS="1")),
+                             ("one", ["--replicas", "2"], dict(base, BDF_K1_SMALL_MIN_ROWS="1")),
+                             ("old", ["--replicas", "2"], dict(base, BDF_K1_SMALL="0"))):
+        r = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + extra + args, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        out[name] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert "error" not in out[name]["c4"], out[name]["c4"]
+    for name in ("one", "old"):
+        assert abs(out["two"]["test_rmse"] - out[name]["test_rmse"]) < 2e-5, (name, out["two"]["test_rmse"], out[name]["test_rmse"])
+        assert abs(out["two"]["c4"]["test_rmse"] - out[name]["c4"]["test_rmse"]) < 1e-4, (name, out["two"]["c4"], out[name]["c4"])
+
+
 def test_stream_schedule_soak(B):
     """two runs of 1,500 sweeps of the bench workload (three streams, rows rotating through three buffers, gate hand-overs,
     prediction updates beside the rows) end bit-identical and leave no split row unfinished -- tools/soak_determinism.py runs
