@@ -358,6 +358,168 @@ int orc_sample_rows(int D, int64_t row_begin, int64_t row_end, int n_terms, cons
 }
 
 /* ------------------------------------------------------------------------------------ */
+/* The SECOND row sampler ("low-rank"), for rows with few observations.  NOT the reference's  */
+/* map from normals to the sample -- the same conditional distribution N(inv(P) b, inv(P))    */
+/* (src/sampling.jl:200-212) drawn with D + n normals and an n x n solve instead of a D x D    */
+/* inverse and factorisation.  The HIP library's k_rows_lr follows this function; that it     */
+/* samples the reference's distribution is proved deterministically in                        */
+/* tests/test_oracle_known_answers.py (the map is affine in z: x = m + S z; m == inv(P) b and  */
+/* S S' == inv(P) to 1e-10 for every n in 0 .. D/2) and by moments on the device.             */
+/*                                                                                            */
+/*   Lambda = L L' (lower Cholesky);  per observation o of the row (all terms, in order):     */
+/*   wt_o = sqrt(alpha_o) L^-1 w_o,  rt_o = sqrt(alpha_o) (y_o - base_o)                      */
+/*   e0 = L' mu_i + z[0..D)                          (the prior draw, in L-coordinates)       */
+/*   G  = I_n + Wt' Wt,   tau = G^-1 (rt - Wt' e0 - z[D..D+n))                                */
+/*   x  = L^-T (e0 + Wt tau)                                                                  */
+/* With z = 0: x = mu + Lambda^-1 W' (I + W Lambda^-1 W')^-1 (r - W mu), the posterior mean in  */
+/* its Kalman-gain form; the noise part is the sampler of Bhattacharya, Chakraborty & Mallick  */
+/* (Biometrika 2016) for N(0, (I + Phi' Phi)^-1), Phi = Wt'.                                   */
+/* z: D + n normals.  returns 0 on success, -1 not positive definite, -2 too many observations */
+/* ------------------------------------------------------------------------------------ */
+#define ORC_LR_MAX_N 64
+static int chol_lower_plain(int n, const double *A, double *L)       /* L L' = A (A symmetric, both triangles valid) */
+{
+    memset(L, 0, sizeof(double) * (size_t)n * n);
+    for (int j = 0; j < n; j++) {
+        double s = A[j + (size_t)j * n];
+        for (int k = 0; k < j; k++) s -= L[j + (size_t)k * n] * L[j + (size_t)k * n];
+        if (!(s > 0.0)) return -1;
+        double d = sqrt(s);
+        L[j + (size_t)j * n] = d;
+        for (int i = j + 1; i < n; i++) {
+            double t = A[i + (size_t)j * n];
+            for (int k = 0; k < j; k++) t -= L[i + (size_t)k * n] * L[j + (size_t)k * n];
+            L[i + (size_t)j * n] = t / d;
+        }
+    }
+    return 0;
+}
+
+int64_t orc_row_count(int n_terms, const orc_term *terms, int64_t row)
+{
+    int64_t n = 0;
+    for (int r = 0; r < n_terms; r++) n += terms[r].rowptr[row + 1] - terms[r].rowptr[row];
+    return n;
+}
+
+/* Lchol: the D x D lower Cholesky factor of Lambda (column-major), computed once per entity by the caller */
+static int orc_sample_row_lowrank_L(int D, int n_terms, const orc_term *terms, int64_t row, const double *mu_i,
+                                    const double *Lchol, const double *z, double *x)
+{
+    const int64_t n64 = orc_row_count(n_terms, terms, row);
+    if (n64 > ORC_LR_MAX_N) return -2;
+    const int n = (int)n64;
+    double Wt[ORC_LR_MAX_N][ORC_MAX_D], rt[ORC_LR_MAX_N], e0[ORC_MAX_D], w[ORC_MAX_D];
+    int a = 0;
+    for (int r = 0; r < n_terms; r++) {
+        const orc_term *t = &terms[r];
+        const double sa = sqrt(t->alpha);
+        for (int64_t q = t->rowptr[row]; q < t->rowptr[row + 1]; q++, a++) {
+            int64_t o = t->rowids[q] - 1;
+            rt[a] = sa * (t->values[o] - (t->linear_values ? t->linear_values[o] : t->mean_value));
+            int first = 1;
+            for (int k = 0; k < t->n_modes; k++) {
+                if (k == t->mode) continue;
+                const double *v = t->factors[k] + (size_t)(t->ids[o + (size_t)k * t->nnz] - 1) * D;
+                if (first) { for (int d = 0; d < D; d++) w[d] = v[d]; first = 0; }
+                else       { for (int d = 0; d < D; d++) w[d] *= v[d]; }
+            }
+            /* wt = sqrt(alpha) L^-1 w: forward substitution */
+            for (int i = 0; i < D; i++) {
+                double s = w[i];
+                for (int k = 0; k < i; k++) s -= Lchol[i + (size_t)k * D] * Wt[a][k];
+                Wt[a][i] = s / Lchol[i + (size_t)i * D];
+            }
+            for (int i = 0; i < D; i++) Wt[a][i] *= sa;
+        }
+    }
+    for (int d = 0; d < D; d++) {                       /* e0 = L' mu + u */
+        double s = 0.0;
+        for (int i = d; i < D; i++) s += Lchol[i + (size_t)d * D] * mu_i[i];
+        e0[d] = s + z[d];
+    }
+    double G[ORC_LR_MAX_N * ORC_LR_MAX_N], LG[ORC_LR_MAX_N * ORC_LR_MAX_N], tau[ORC_LR_MAX_N];
+    for (int i = 0; i < n; i++)
+        for (int j = 0; j < n; j++) {
+            double s = (i == j) ? 1.0 : 0.0;
+            for (int d = 0; d < D; d++) s += Wt[i][d] * Wt[j][d];
+            G[i + (size_t)j * n] = s;
+        }
+    if (n > 0 && chol_lower_plain(n, G, LG)) return -1;
+    for (int i = 0; i < n; i++) {                       /* rho = rt - Wt' e0 - delta; forward solve */
+        double s = rt[i] - z[D + i];
+        for (int d = 0; d < D; d++) s -= Wt[i][d] * e0[d];
+        for (int k = 0; k < i; k++) s -= LG[i + (size_t)k * n] * tau[k];
+        tau[i] = s / LG[i + (size_t)i * n];
+    }
+    for (int i = n - 1; i >= 0; i--) {                  /* backward solve */
+        double s = tau[i];
+        for (int k = i + 1; k < n; k++) s -= LG[k + (size_t)i * n] * tau[k];
+        tau[i] = s / LG[i + (size_t)i * n];
+    }
+    double qv[ORC_MAX_D];
+    for (int d = 0; d < D; d++) {
+        double s = e0[d];
+        for (int i = 0; i < n; i++) s += Wt[i][d] * tau[i];
+        qv[d] = s;
+    }
+    for (int i = D - 1; i >= 0; i--) {                  /* x = L^-T q */
+        double s = qv[i];
+        for (int k = i + 1; k < D; k++) s -= Lchol[k + (size_t)i * D] * x[k];
+        x[i] = s / Lchol[i + (size_t)i * D];
+    }
+    return 0;
+}
+
+int orc_sample_row_lowrank(int D, int n_terms, const orc_term *terms, int64_t row, const double *mu_i,
+                           const double *Lambda, const double *z, double *x)
+{
+    double *L = (double *)malloc(sizeof(double) * (size_t)D * D);
+    int rc = chol_lower_plain(D, Lambda, L);
+    if (!rc) rc = orc_sample_row_lowrank_L(D, n_terms, terms, row, mu_i, L, z, x);
+    free(L);
+    return rc;
+}
+
+/* every row in [row_begin, row_end) as the HIP library samples them with the low-rank sampler switched on: rows of at most
+ * lr_max observations by orc_sample_row_lowrank with normals 0 .. D+n-1 of stream (P_ROW, entity_tag, row), the others by
+ * the reference's map (orc_sample_rows) */
+int orc_sample_rows_lowrank(int D, int64_t row_begin, int64_t row_end, int n_terms, const orc_term *terms,
+                            const double *mu, int mu_is_matrix, const double *Lambda, int lr_max,
+                            uint64_t seed, uint32_t sweep, uint32_t entity_tag, double *out, int nthreads)
+{
+    int fail = 0;
+    double *L = (double *)malloc(sizeof(double) * (size_t)D * D);
+    if (chol_lower_plain(D, Lambda, L)) { free(L); return -1; }
+    if (lr_max > ORC_LR_MAX_N) lr_max = ORC_LR_MAX_N;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    {
+        double *work = (double *)malloc(sizeof(double) * ((size_t)D * D * 4 + D));
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 8)
+#endif
+        for (int64_t i = row_begin; i < row_end; i++) {
+            double z[ORC_MAX_D + ORC_LR_MAX_N + 2];
+            const double *mu_i = mu_is_matrix ? mu + (size_t)i * D : mu;
+            const int64_t n = orc_row_count(n_terms, terms, i);
+            if (n <= lr_max) {
+                orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D + (int)n, z);
+                if (orc_sample_row_lowrank_L(D, n_terms, terms, i, mu_i, L, z, out + (size_t)i * D)) fail = 1;
+            } else {
+                orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D, z);
+                if (orc_sample_row_ws(D, n_terms, terms, i, mu_i, Lambda, z, out + (size_t)i * D, NULL, work)) fail = 1;
+            }
+        }
+        free(work);
+    }
+    free(L);
+    (void)nthreads;
+    return fail ? -1 : 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* Hyperprior: ConditionalNormalWishart (src/sampling.jl:116-127) + rand(::NormalWishart) */
 /* (src/normal_wishart.jl:38-42); Wishart by Bartlett decomposition as Distributions.jl   */
 /* does (A lower: A_ii = sqrt(chi2(nu - i)), A_ij ~ N(0,1) i>j; Lam = (L_T A)(L_T A)').   */

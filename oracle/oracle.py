@@ -173,6 +173,48 @@ def sample_rows(D, N, terms, mu, Lambda, seed, sweep, entity_tag, out=None, row_
     return out
 
 
+def row_count(terms, row):
+    return int(sum(t.rowptr[row + 1] - t.rowptr[row] for t in terms))
+
+
+def sample_row_lowrank(D, terms, row, mu_i, Lambda, z):
+    """The second ("low-rank") row sampler (bdf_oracle.c, orc_sample_row_lowrank): z holds D + n normals."""
+    x = np.zeros(D)
+    mu_i, Lambda, z = _f64(mu_i), _f64(Lambda), _f64(z)
+    assert len(z) >= D + row_count(terms, row)
+    rc = lib().orc_sample_row_lowrank(D, len(terms), _terms(terms), C.c_int64(row), _dp(mu_i), _dp(Lambda), _dp(z), _dp(x))
+    if rc:
+        raise np.linalg.LinAlgError("row system not positive definite" if rc == -1 else "too many observations for the low-rank sampler")
+    return x
+
+
+def lowrank_map(D, terms, row, mu_i, Lambda):
+    """dump hook: the low-rank sampler is affine in its normals, x = m + S z; returns (m, S) with S of shape (D, D + n)"""
+    n = row_count(terms, row)
+    m = sample_row_lowrank(D, terms, row, mu_i, Lambda, np.zeros(D + n))
+    S = np.zeros((D, D + n))
+    for k in range(D + n):
+        e = np.zeros(D + n)
+        e[k] = 1.0
+        S[:, k] = sample_row_lowrank(D, terms, row, mu_i, Lambda, e) - m
+    return m, S
+
+
+def sample_rows_lowrank(D, N, terms, mu, Lambda, lr_max, seed, sweep, entity_tag, out=None, row_begin=0, row_end=None, nthreads=1):
+    """All rows as the HIP library samples them with the low-rank sampler on: rows of at most lr_max observations by the
+    low-rank sampler (normals 0 .. D+n-1 of the row's stream), the others by the reference's map. Returns (N, D)."""
+    mu, Lambda = _f64(mu), _f64(Lambda)
+    if out is None:
+        out = np.zeros((N, D), dtype=np.float64)
+    row_end = N if row_end is None else row_end
+    rc = lib().orc_sample_rows_lowrank(D, C.c_int64(row_begin), C.c_int64(row_end), len(terms), _terms(terms), _dp(mu),
+                                       int(mu.ndim == 2), _dp(Lambda), int(lr_max), C.c_uint64(seed), C.c_uint32(sweep),
+                                       C.c_uint32(entity_tag), _dp(out), nthreads)
+    if rc:
+        raise np.linalg.LinAlgError("row system not positive definite")
+    return out
+
+
 # ---------------------------------------------------------------------------------------
 def hyper_params(U, mu0, b0, Tinv, nu):
     """ConditionalNormalWishart (sampling.jl:116-127). U: (N, D). -> mu_N, beta_N, T_N, nu_N"""

@@ -281,6 +281,31 @@ def test_c4_shaped_full_size_properties_and_quality(B):
     eng.close()
 
 
+@pytest.mark.parametrize("D", [10, 30])
+def test_mref_shaped_whole_iterations_match_oracle(B, O, D):
+    """The reference's own benchmark shape (test/benchmark_parallel_latent.jl:8-61: sprand(1_500_000, 1000, 0.01), U(0,1)
+    values, BPMF D = 10 and 30) at a size the oracle sweeps in seconds: 60,000 x 1,000 with 600,000 observations, two whole
+    iterations against the CPU oracle.  At D = 10 the 60,000-row entity is above the row count from which the short rows go four
+    to a wave (k_rows_small, default-on), and the 1,000 rows of ~600 observations are split rows of k_rows; at D = 30 the rows
+    of ~10 observations take whatever short-row sampler the library picks by default."""
+    from bdf_amd.engine import GibbsEngine
+    rng = np.random.default_rng(1500)
+    N, M = 60_000, 1000
+    nnz = 600_000
+    key = np.unique(rng.integers(0, N * M, size=int(nnz * 1.01)))[:nnz]
+    ids = np.stack([key // M + 1, key % M + 1], axis=1)
+    vals = rng.random(len(key))
+    rel = B.Relation((ids, vals), "r", [B.Entity("rows"), B.Entity("cols")], dims=[N, M])
+    rd = B.RelationData(rel)
+    eng = GibbsEngine(rd, D, seed=21)
+    for i in (1, 2):
+        eng.sweep(i)
+    eng.sync()
+    assert eng.ctx.rows_unfinished() == 0
+    _compare(rd, *oracle_macau(O, rd, D, 21, 2, True), tol=1e-6)
+    eng.close()
+
+
 def test_c5_two_ranks_match_one():
     """C5's structure on two ranks -- a shared entity with two relations (3-mode + 2-mode) and binary sparse features, rows
     at internal positions, F's rows with them, noise keyed by the original ids, in-place exchange after every entity -- gives

@@ -685,3 +685,50 @@ def test_four_rows_per_wave_equals_wave_per_row(B, ctx, D, coded):
         np.testing.assert_allclose(outs[1], outs[0], rtol=1e-11, atol=1e-12)
         assert np.array_equal(outs[1][deg >= 49], outs[0][deg >= 49])          # the long rows: the same kernel either way
     ctx.set_small_rows(48, 8192)
+
+
+@pytest.mark.parametrize("D", [1, 3, 8, 10, 12, 13, 16])
+@pytest.mark.parametrize("coded", [True, False])
+def test_four_rows_per_wave_against_oracle(B, O, ctx, D, coded):
+    """k_rows_small (D <= 16, four rows per wave) against the CPU ORACLE (sample_user_basic, sampling.jl:200-212), not
+    against the other kernel: rows of 0 / 1 / 15 / 16 / 17 / 32 / 48 observations on the new path (one, two and three chunks of
+    16, ragged and full), 49 and more through k_rows in the same call; a row count that is no multiple of four; ratings
+    (coded ids) and continuous values; shared and per-row prior means; both modes of the relation.  Row system 1e-12 through
+    the dump, samples 1e-8 for the same normals."""
+    from bdf_amd._lib import Term, check, lib
+    rng = np.random.default_rng(300 + D)
+    dims = [203, 90]
+    deg = rng.integers(0, 49, dims[0])
+    deg[:10] = [0, 1, 15, 16, 17, 32, 48, 49, 150, 2]
+    rows = np.repeat(np.arange(1, dims[0] + 1), deg)
+    ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
+    vals = rng.integers(1, 6, len(rows)).astype(np.float64) if coded else rng.random(len(rows)) * 4 + 1
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    A = rng.standard_normal((D, D))
+    Lam = A @ A.T / max(D, 1) + np.eye(D)
+    alpha, mean = 1.7, float(vals.mean())
+    idx = O.index_build(ids, dims)
+    ctx.set_small_rows(48, 1)
+    try:
+        for mode0 in (0, 1):
+            N = dims[mode0]
+            mu = rng.standard_normal(D)
+            mu_rows = rng.standard_normal((N, D))
+            terms = _dev_terms(B, ctx, [(dr, mode0, alpha, mean, [None if k == mode0 else ft[k] for k in (0, 1)], None)])
+            ot = O.Term(ids, vals, dims, mode0, alpha, mean, [None if k == mode0 else facs[k] for k in (0, 1)], index=idx)
+            Lam_t = ctx.tensor(Lam)
+            for per_row in (False, True):
+                m = mu_rows if per_row else mu
+                mu_t = ctx.tensor(m)
+                ctx.set_sweep(6)
+                out_t = ctx.zeros(N, D)
+                _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 4, out_t)
+                exp = O.sample_rows(D, N, [ot], m, Lam, SEED, 6, 4)
+                got = out_t.cpu().numpy()
+                assert np.isfinite(got).all()
+                np.testing.assert_allclose(got, exp, rtol=1e-8, atol=1e-9)
+    finally:
+        ctx.set_small_rows(48, 8192)
+    dr.close()

@@ -218,3 +218,39 @@ def test_oracle_sample_beta_rel_is_the_reference_formula():
     rhs_np = alpha * Fm.T @ (res + z1 / np.sqrt(alpha)) + np.sqrt(lam) * z2
     np.testing.assert_allclose(rhs, rhs_np, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(beta, np.linalg.solve(alpha * Fm.T @ Fm + lam * np.eye(numF), rhs_np), rtol=1e-10)
+
+
+@pytest.mark.parametrize("D", [4, 10, 30, 32, 64])
+def test_lowrank_sampler_draws_the_reference_distribution(O, D):
+    """The second row sampler (bdf_oracle.c orc_sample_row_lowrank, followed by the HIP library's k_rows_lr for rows of few
+    observations) is NOT the reference's map from normals to the sample (sampling.jl:207-211) -- it must draw the same
+    conditional distribution N(inv(P_i) b_i, inv(P_i)).  The map is affine in its D + n normals, x = m + S z, so this is a
+    deterministic statement: m == inv(P_i) b_i and S S' == inv(P_i), checked to 1e-10 for every n in 0 .. D/2 + 1 (and a
+    two-relation row), with shared and per-row prior means irrelevant to S."""
+    rng = np.random.default_rng(D)
+    n_rows = D // 2 + 2
+    dims = [n_rows, 50]
+    deg = np.arange(n_rows)                       # row r has r observations: 0 .. D/2 + 1
+    rows = np.repeat(np.arange(1, n_rows + 1), deg)
+    ids = np.stack([rows, rng.integers(1, 51, len(rows))], axis=1)
+    vals = rng.standard_normal(len(rows))
+    V = rng.standard_normal((50, D))
+    A = rng.standard_normal((D, D))
+    Lam = A @ A.T / D + np.eye(D)
+    mu = rng.standard_normal(D)
+    t = O.Term(ids, vals, dims, 0, 1.7, 0.2, [None, V])
+    ids2 = np.stack([rng.integers(1, n_rows + 1, 3 * n_rows), rng.integers(1, 8, 3 * n_rows)], axis=1)
+    t2 = O.Term(ids2, rng.standard_normal(3 * n_rows), [n_rows, 7], 0, 0.6, -0.1, [None, rng.standard_normal((7, D))],
+                linear_values=rng.standard_normal(3 * n_rows))
+    for terms in ([t], [t, t2]):
+        for row in range(n_rows):
+            P, b = O.row_system(D, terms, row, mu, Lam)
+            m, S = O.lowrank_map(D, terms, row, mu, Lam)
+            assert S.shape == (D, D + O.row_count(terms, row))
+            cov = np.linalg.inv(P)
+            np.testing.assert_allclose(m, cov @ b, rtol=1e-10, atol=1e-10)
+            np.testing.assert_allclose(S @ S.T, cov, rtol=1e-10, atol=1e-10)
+    # and the dispatch the library uses: rows above the threshold take the reference's map, bit for bit
+    full = O.sample_rows(D, n_rows, [t], mu, Lam, 7, 3, 2)
+    mixed = O.sample_rows_lowrank(D, n_rows, [t], mu, Lam, 3, 7, 3, 2)
+    assert np.array_equal(mixed[4:], full[4:]) and not np.allclose(mixed[:4], full[:4])
