@@ -73,6 +73,10 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->piece_size = 128;
     c->small_max = getenv("BDF_K1_SMALL") ? atoi(getenv("BDF_K1_SMALL")) : 48;
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
+    c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
+    c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
+    c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0;
+    c->lr_key_fac = c->lr_key_Lambda = c->lr_key_mu = nullptr; c->lr_key_sweep = c->lr_key_tag = 0; c->lr_key_D = 0; c->lr_key_M = 0;
     {
         const char *force = getenv("BDF_GATHER");
         c->gather_mode = force && !strcmp(force, "general") ? 1 : (force && !strcmp(force, "wide") ? 2 : 0);
@@ -95,6 +99,8 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
     if (ctx->hyper_count) hipFree(ctx->hyper_count);
+    if (ctx->lr_T) hipFree(ctx->lr_T);
+    if (ctx->lr_vt) hipFree(ctx->lr_vt);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;
@@ -166,6 +172,15 @@ extern "C" int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_
     BDF_REQUIRE(ctx && max_observations >= 0 && min_rows >= 0, BDF_ERR_ARG, "bdf_ctx_set_small_rows: bad argument");
     ctx->small_max = max_observations;
     ctx->small_min_rows = min_rows;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows)
+{
+    BDF_REQUIRE(ctx && max_observations >= -1 && max_observations <= 15 && min_rows >= 0, BDF_ERR_ARG,
+                "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..15");
+    ctx->lr_max = max_observations;
+    ctx->lr_min_rows = min_rows;
     return BDF_OK;
 }
 

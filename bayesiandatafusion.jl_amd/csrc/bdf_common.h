@@ -39,6 +39,14 @@ struct bdf_ctx {
     size_t scratch2_bytes;
     int small_max;             // k_rows_small: longest row (observations) sampled four to a wave at D <= 16; 0: off
     int64_t small_min_rows;    // ... and the smallest entity (rows) for which it is used
+    // k_rows_lr (k_rows_lr.hip): rows of few observations sampled by the low-rank map instead of the reference's
+    int lr_max;                // longest row (observations) sampled that way at D > 16; -1: min(15, D / 2); 0: off
+    int64_t lr_min_rows;       // ... and the smallest number of such rows in a launch for which it is used
+    double *lr_T;              // Tf | Tb (64 x 64 each) | L' mu (64): the launch's constants (k_lr_prep)
+    double *lr_vt;             // the opposite entity's factor matrix transformed (V L^-T), grown on demand
+    size_t lr_vt_bytes;
+    // what lr_T / lr_vt were computed from: a later chunk of the same entity launch reuses them
+    const void *lr_key_fac, *lr_key_Lambda, *lr_key_mu; uint32_t lr_key_sweep, lr_key_tag; int lr_key_D; int64_t lr_key_M;
     int *flag_dev;             // not-positive-definite flag (bits 1..32: errors; 64: BDF_WARN_CG_MAXITER): the device address of
     int *flag_host;            // ... a word of mapped, coherent HOST memory (kernels atomicOr into it on their error paths only;
                                // bdf_ctx_sync reads it without a copy -- a 4-byte blocking device-to-host copy is ~10 us)
@@ -246,6 +254,19 @@ __device__ __forceinline__ double bdf_normal(uint64_t seed, uint32_t sweep, uint
     return (n & 1) ? r * s : r * c;
 }
 
+// both normals of pair `pair` of the stream: numbers 2 pair and 2 pair + 1 (the same values bdf_normal returns)
+__device__ __forceinline__ void bdf_normal_pair(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
+                                       uint64_t row, uint32_t pair, double &z0, double &z1)
+{
+    u32x4 o = bdf_draw(seed, sweep, purpose, entity, row, pair);
+    double u1 = bdf_u01(o.x, o.y), u2 = bdf_u01(o.z, o.w);
+    double r = sqrt(-2.0 * bdf_log01(u1));
+    double s, c;
+    bdf_sincos2pi(u2, s, c);
+    z0 = r * c;
+    z1 = r * s;
+}
+
 __device__ __forceinline__ double bdf_uniform(uint64_t seed, uint32_t sweep, uint32_t purpose, uint32_t entity,
                                      uint64_t row, uint32_t pair)
 {
@@ -326,5 +347,7 @@ struct SampleArgs {
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump);
+int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, const int32_t *rows_dev, bool transform,
+                  hipEvent_t e0, hipEvent_t e1);
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
 int bdf_predict_plain(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value, double *out);   // rel_serial 0: every plan of the context

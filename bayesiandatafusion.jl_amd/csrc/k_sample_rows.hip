@@ -873,7 +873,9 @@ struct PlanKey {
     int mode[BDF_MAX_TERMS];
     int n_terms, DP, T, Tp;
     int shard, n_shards;
-    int small, _pad;                  // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
+    int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
+    int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
+    int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -881,6 +883,9 @@ struct Plan {
     PlanDev dev;
     SmallItem *small_dev = nullptr;
     int64_t n_small = 0;              // entries of small_dev (a multiple of 4)
+    SmallItem *lr_dev = nullptr;      // the rows of the low-rank sampler (same record), and their positions for the back-transform
+    int32_t *lr_rows_dev = nullptr;
+    int64_t n_lr = 0;
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
     int32_t *order_dev = nullptr;
@@ -916,9 +921,20 @@ struct RowRef {
 int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, Plan &plan)
 {
     const int T = key.T;
+    bool lr_on = false;
     std::vector<Item> direct, split;
-    std::vector<SmallItem> small;
+    std::vector<SmallItem> small, lr;
     std::vector<SplitRow> srows;
+    if (key.lr > 0) {
+        // the low-rank sampler pays its set-up (the opposite factor transformed, two more launches) only with enough rows
+        int64_t cnt = 0;
+        for (const RowRef &rr : rows) {
+            int64_t nobs = 0;
+            for (int r = 0; r < key.n_terms; r++) nobs += rr.cnt[r];
+            cnt += nobs <= key.lr;
+        }
+        lr_on = cnt >= key.lr_min && 2 * cnt * key.n_shards >= key.lr_other;
+    }
     static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
     for (const RowRef &rr : rows) {
         const int32_t row = rr.out;
@@ -938,6 +954,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
             for (int r = 0; r < key.n_terms; r++)
                 if (rr.cnt[r] > 0) { it.term = r; it.q_begin = rr.qb[r]; it.count = (int32_t)rr.cnt[r]; }
             if (key.small > 0 && it.count <= key.small) small.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
+            else if (lr_on && it.count <= key.lr) lr.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
             else direct.push_back(it);
         } else {
             if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
@@ -1014,6 +1031,14 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     while (small.size() % 4) small.push_back(SmallItem{-1, 0, 0, 0, 0});
     plan.n_small = (int64_t)small.size();
     if (!small.empty() && (rc = to_device(small, &plan.small_dev))) return rc;
+    plan.n_lr = (int64_t)lr.size();
+    if (!lr.empty()) {
+        // longest first: the waves of a workgroup then have rows of like length
+        std::stable_sort(lr.begin(), lr.end(), [](const SmallItem &x, const SmallItem &y) { return x.count > y.count; });
+        std::vector<int32_t> lr_rows(lr.size());
+        for (size_t i = 0; i < lr.size(); i++) lr_rows[i] = lr[i].row;
+        if ((rc = to_device(lr, &plan.lr_dev)) || (rc = to_device(lr_rows, &plan.lr_rows_dev))) return rc;
+    }
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
         (rc = to_device(srows, &plan.rows_dev)) || (rc = to_device(order, &plan.order_dev)))
         return rc;
@@ -1099,6 +1124,8 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
         if (hit) {
             (void)hipFree(kv->second.direct_dev); (void)hipFree(kv->second.split_dev); (void)hipFree(kv->second.rows_dev);
             if (kv->second.small_dev) (void)hipFree(kv->second.small_dev);
+            if (kv->second.lr_dev) (void)hipFree(kv->second.lr_dev);
+            if (kv->second.lr_rows_dev) (void)hipFree(kv->second.lr_rows_dev);
             (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
             kv = plans.erase(kv);
         } else {
@@ -1159,6 +1186,19 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             key.small = std::min(small_max, ctx->item_size);
     }
 
+    // D > 16, one two-mode relation without per-observation baselines, a shared prior mean, a launch that does not poll for its
+    // prior: the rows of few observations by the low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
+    // the longest such row, -1 = min(15, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
+    int64_t M_other = 0;
+    if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr && !a.mu_is_matrix &&
+        a.ready == nullptr && !getenv("BDF_K1_DECOUPLE")) {
+        const int other = 1 - modes[0];
+        M_other = rels[0]->nint[other];
+        key.lr = std::min(ctx->lr_max < 0 ? std::min(15, a.D / 2) : std::min(ctx->lr_max, 15), ctx->item_size);
+        key.lr_min = std::max<int64_t>(ctx->lr_min_rows, 1);
+        key.lr_other = ctx->lr_min_rows > 0 ? M_other : 0;          // (min_rows = 0, a test hook: whenever a launch has such a row)
+    }
+
     Plan *plan;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -1198,6 +1238,20 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             it = cache.plans.emplace(key, np).first;
         }
         plan = &it->second;
+    }
+    if (plan->n_lr > 0) {
+        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
+        // the constants of the launch (L, the opposite factor transformed): once per entity launch -- a later chunk of the same
+        // launch (same inputs, same iteration) finds them in the context
+        const bool same = shard > 0 && ctx->lr_key_fac == (const void *)a.t[0].fac[0] && ctx->lr_key_Lambda == (const void *)a.Lambda &&
+                          ctx->lr_key_mu == (const void *)a.mu && ctx->lr_key_sweep == a.sweep && ctx->lr_key_tag == a.entity_tag &&
+                          ctx->lr_key_D == a.D && ctx->lr_key_M == M_other;
+        int rc = bdf_lr_launch(ctx, a, M_other, plan->lr_dev, plan->n_lr, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
+        if (rc) return rc;
+        ctx->lr_key_fac = a.t[0].fac[0]; ctx->lr_key_Lambda = a.Lambda; ctx->lr_key_mu = a.mu; ctx->lr_key_sweep = a.sweep;
+        ctx->lr_key_tag = a.entity_tag; ctx->lr_key_D = a.D; ctx->lr_key_M = M_other;
+        ctx->time_start = nullptr;
+        if (!more) { ctx->time_stop = nullptr; return BDF_OK; }
     }
     if (plan->n_small > 0) {
         // the short rows first (most of the entity), then k_rows for the others; a caller's timing events and the hand-over of

@@ -150,6 +150,12 @@ class Context:
         (bdf_ctx_set_small_rows; 0 observations: off)"""
         check(lib().bdf_ctx_set_small_rows(self.handle, int(max_observations), int(min_rows)))
 
+    def set_lowrank(self, max_observations=-1, min_rows=8192):
+        """D > 16: rows of at most max_observations observations (-1: min(15, D / 2); 0: off) by the low-rank sampler when a
+        launch has min_rows such rows or more (bdf_ctx_set_lowrank) -- the same conditional distribution as the reference's
+        map, other sampled values"""
+        check(lib().bdf_ctx_set_lowrank(self.handle, int(max_observations), int(min_rows)))
+
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 

@@ -110,6 +110,16 @@ int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
  * D the wave-per-row kernel is bound by its per-row instruction overhead.  Defaults 48 and 8192 (environment BDF_K1_SMALL,
  * BDF_K1_SMALL_MIN_ROWS); max_observations 0 turns it off.  Same sample up to the order of the floating-point sums. */
 int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows);
+/* D > 16, an entity of one two-mode relation with a shared prior mean: rows of at most max_observations observations (at most
+ * 15; -1 = min(15, num_latent / 2), the default; 0 = off; environment BDF_LOWRANK) are drawn by the LOW-RANK SAMPLER
+ * (k_rows_lr.hip) when a launch has at least min_rows of them (default 8192, BDF_LOWRANK_MIN_ROWS) and at least half as many as
+ * the opposite entity has rows (min_rows = 0: whenever there is such a row).  It replaces sample_user_basic (src/sampling.jl:200-212) for those rows by another map from
+ * standard normals to the SAME conditional distribution N(inv(P_i) b_i, inv(P_i)): D + n normals of the row's stream and an
+ * n x n solve instead of a D x D inverse and factorisation (P_i = Lambda + rank n).  Sampled VALUES therefore differ from the
+ * reference's map for those rows (the distribution does not: oracle/bdf_oracle.c orc_sample_row_lowrank is the same function,
+ * proved equal in mean and covariance to inv(P_i) b_i, inv(P_i)); max_observations = 0 restores the reference's map for
+ * every row. */
+int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
 /* parity hook: which gather path the row kernel takes.  0 = chosen by the sizes (default; env BDF_GATHER=general|wide sets the
  * initial value), 1 = the general path (any number of modes, per-observation baselines), 2 = the lean path with 64-bit row
  * offsets (num_latent > 32; what a factor matrix of 4 GiB or more needs, e.g. 10M rows at D = 64).  Same values on every path. */

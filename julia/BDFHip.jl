@@ -49,6 +49,8 @@ end
 set_item_size!(c::Context, item) = check(ccall((:bdf_ctx_set_item_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, item))
 "D <= 16: rows of at most `max_obs` observations of an entity with at least `min_rows` rows are sampled four to a wave (0: off)"
 set_small_rows!(c::Context, max_obs, min_rows) = check(ccall((:bdf_ctx_set_small_rows, lib), Cint, (Ptr{Cvoid}, Cint, Int64), c.h, max_obs, min_rows))
+# rows of few observations by the low-rank sampler (same distribution as sample_user_basic, other values); max_obs = 0: off
+set_lowrank!(c::Context, max_obs=-1, min_rows=8192) = check(ccall((:bdf_ctx_set_lowrank, lib), Cint, (Ptr{Cvoid}, Cint, Int64), c.h, max_obs, min_rows))
 set_piece_size!(c::Context, piece) = check(ccall((:bdf_ctx_set_piece_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, piece))
 # a row context on a library-owned stream that leaves `reserve_cus` CUs (0, 8, 16, ...) free, and side contexts that really
 # run beside it -- on the reserved CUs (`reserved = true`: the hyperprior's small kernels) or on the others

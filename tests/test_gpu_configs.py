@@ -31,9 +31,10 @@ def _oracle_feat(O, F):
     return O.Feat.from_dense(F), F
 
 
-def oracle_macau(O, rd, D, seed, iters, use_ff):
+def oracle_macau(O, rd, D, seed, iters, use_ff, lowrank=None):
     """macau.jl:80-140 on the CPU oracle for any RelationData without relation-level features: every entity's rows (sum
-    over its relations, tensor relations by Hadamard products), hyperpriors, then the beta updates"""
+    over its relations, tensor relations by Hadamard products), hyperpriors, then the beta updates.  lowrank: {entity index:
+    longest row taken by the low-rank sampler} -- the entities whose short rows the library samples that way"""
     ents, rels = rd.entities, rd.relations
     N = [e.count for e in ents]
     S = [np.zeros((n, D)) for n in N]
@@ -58,7 +59,10 @@ def oracle_macau(O, rd, D, seed, iters, use_ff):
                 S[j] = O.sample_rows(D, N[j], terms, mu[j] + uhat, Lam[j], seed, it, j + 1)
                 U, nu, Tinv = S[j] - uhat, D + feats[j][0].n, np.eye(D) + beta[j].T @ beta[j] * lb[j]
             else:
-                S[j] = O.sample_rows(D, N[j], terms, mu[j], Lam[j], seed, it, j + 1)
+                if lowrank and j in lowrank:
+                    S[j] = O.sample_rows_lowrank(D, N[j], terms, mu[j], Lam[j], lowrank[j], seed, it, j + 1)
+                else:
+                    S[j] = O.sample_rows(D, N[j], terms, mu[j], Lam[j], seed, it, j + 1)
                 U, nu, Tinv = S[j], float(D), np.eye(D)
             mu_N, beta_N, T_N, nu_N = O.hyper_params(U, np.zeros(D), 2.0, Tinv, nu)
             mu[j], Lam[j] = O.hyper_draw(mu_N, beta_N, T_N, nu_N, seed, it, j + 1)
@@ -287,7 +291,7 @@ def test_mref_shaped_whole_iterations_match_oracle(B, O, D):
     values, BPMF D = 10 and 30) at a size the oracle sweeps in seconds: 60,000 x 1,000 with 600,000 observations, two whole
     iterations against the CPU oracle.  At D = 10 the 60,000-row entity is above the row count from which the short rows go four
     to a wave (k_rows_small, default-on), and the 1,000 rows of ~600 observations are split rows of k_rows; at D = 30 the rows
-    of ~10 observations take whatever short-row sampler the library picks by default."""
+    of ~10 observations take the low-rank sampler (k_rows_lr)."""
     from bdf_amd.engine import GibbsEngine
     rng = np.random.default_rng(1500)
     N, M = 60_000, 1000
@@ -302,7 +306,9 @@ def test_mref_shaped_whole_iterations_match_oracle(B, O, D):
         eng.sweep(i)
     eng.sync()
     assert eng.ctx.rows_unfinished() == 0
-    _compare(rd, *oracle_macau(O, rd, D, 21, 2, True), tol=1e-6)
+    # D = 30: the 60,000-row entity's rows of at most 15 observations (nearly all) are drawn by the low-rank sampler (default-on
+    # above 8,192 such rows: bdf_ctx_set_lowrank) -- the oracle dispatches the same way; the 1,000-row entity has none
+    _compare(rd, *oracle_macau(O, rd, D, 21, 2, True, lowrank={0: 15} if D == 30 else None), tol=1e-6)
     eng.close()
 
 

@@ -732,3 +732,109 @@ def test_four_rows_per_wave_against_oracle(B, O, ctx, D, coded):
     finally:
         ctx.set_small_rows(48, 8192)
     dr.close()
+
+
+@pytest.mark.parametrize("D", [17, 24, 30, 32, 33, 48, 64])
+def test_lowrank_rows_against_oracle(B, O, ctx, D):
+    """k_rows_lr (D > 16: rows of at most min(15, D / 2) observations by the low-rank sampler) against the oracle's statement of
+    the same map (orc_sample_row_lowrank: D + n normals, n x n solve) on the same Philox normals, 1e-8; the longer rows of the
+    same launch against the reference's map (they go through k_rows).  Rows of 0 .. 15 observations and more, a row count that
+    is no multiple of four or sixteen, ratings and continuous values, both modes.  (That the low-rank map draws the reference's
+    distribution is the deterministic CPU test test_lowrank_sampler_draws_the_reference_distribution.)"""
+    rng = np.random.default_rng(500 + D)
+    dims = [211, 90]
+    deg = rng.integers(0, 17, dims[0])
+    deg[:8] = [0, 1, 2, 14, 15, 16, 40, 250]
+    rows = np.repeat(np.arange(1, dims[0] + 1), deg)
+    ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
+    lr = min(15, D // 2)
+    idx = O.index_build(ids, dims)
+    Am = rng.standard_normal((D, D))
+    Lam = Am @ Am.T / D + np.eye(D)
+    mu = rng.standard_normal(D)
+    for coded in (True, False):
+        vals = rng.integers(1, 6, len(rows)).astype(np.float64) if coded else rng.random(len(rows)) * 4 + 1
+        dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+        facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
+        ft = [ctx.tensor(f) for f in facs]
+        alpha, mean = 1.7, float(vals.mean())
+        ctx.set_lowrank(-1, 0)
+        try:
+            for mode0 in (0, 1):
+                N = dims[mode0]
+                terms = _dev_terms(B, ctx, [(dr, mode0, alpha, mean, [None if k == mode0 else ft[k] for k in (0, 1)], None)])
+                ot = O.Term(ids, vals, dims, mode0, alpha, mean, [None if k == mode0 else facs[k] for k in (0, 1)], index=idx)
+                Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
+                ctx.set_sweep(7)
+                out_t = ctx.zeros(N, D)
+                _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 5, out_t)
+                got = out_t.cpu().numpy()
+                exp = O.sample_rows_lowrank(D, N, [ot], mu, Lam, lr, SEED, 7, 5)
+                assert np.isfinite(got).all()
+                np.testing.assert_allclose(got, exp, rtol=1e-8, atol=1e-9)
+                if mode0 == 0:
+                    # switched off: the reference's map for every row
+                    ctx.set_lowrank(0, 0)
+                    out2 = ctx.zeros(N, D)
+                    _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 5, out2)
+                    ctx.set_lowrank(-1, 0)
+                    lit = O.sample_rows(D, N, [ot], mu, Lam, SEED, 7, 5)
+                    np.testing.assert_allclose(out2.cpu().numpy(), lit, rtol=1e-8, atol=1e-9)
+                    cnt = np.bincount(ids[:, 0] - 1, minlength=N)
+                    assert np.array_equal(out2.cpu().numpy()[cnt > lr], got[cnt > lr])       # the long rows: the same kernel either way
+                    assert not np.allclose(lit[cnt <= lr], got[cnt <= lr])
+        finally:
+            ctx.set_lowrank(-1, 8192)
+        dr.close()
+
+
+@pytest.mark.parametrize("D,n", [(32, 0), (32, 3), (32, 15), (64, 10)])
+def test_lowrank_row_moments(B, O, ctx, D, n):
+    """>= 10^5 draws of one row by the low-rank sampler on the device: every row of a 512-row entity has the SAME observations
+    (so the same conditional distribution) and its own random stream; 200 sweeps x 512 rows = 102,400 draws.  Sample mean within
+    5 sigma / sqrt(draws) of inv(P) b in every coordinate; sample covariance within 3 % of inv(P) (relative Frobenius norm;
+    the sampling error of a D x D covariance from 10^5 draws is ~ D / sqrt(draws) = 1 % at D = 32)."""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(900 + D + n)
+    N, M = 512, 40
+    cols = rng.choice(M, size=max(n, 1), replace=False)[:n] + 1
+    # (one more row, with 20 observations, so that the relation is never empty: it takes the reference's map and is not looked at)
+    ids = np.concatenate([np.stack([np.repeat(np.arange(1, N + 1), n), np.tile(cols, N)], axis=1).reshape(-1, 2),
+                          np.stack([np.full(20, N + 1), np.arange(1, 21)], axis=1)]).astype(np.int64)
+    vals = np.concatenate([np.tile(rng.standard_normal(n), N), rng.standard_normal(20)])
+    dims = [N + 1, M]
+    V = rng.standard_normal((M, D)) * 0.6
+    Am = rng.standard_normal((D, D))
+    Lam = Am @ Am.T / D + np.eye(D)
+    mu = rng.standard_normal(D) * 0.3
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    Vt = ctx.tensor(V)
+    terms = _dev_terms(B, ctx, [(dr, 0, 2.0, 0.1, [None, Vt], None)])
+    Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
+    ctx.set_lowrank(15, 0)
+    try:
+        sweeps = 200
+        import torch
+        acc = torch.zeros(sweeps, N + 1, D, dtype=torch.float64, device=Lam_t.device)
+        for s in range(sweeps):
+            ctx.set_sweep(s + 1)
+            out_t = acc[s]
+            check(lib().bdf_sample_rows(ctx.handle, D, N + 1, 1, terms, _p(mu_t), 0, _p(Lam_t), 1, 0, 1, _p(out_t), None))
+        ctx.sync()
+    finally:
+        ctx.set_lowrank(-1, 8192)
+    draws = acc.cpu().numpy()[:, :N].reshape(-1, D)
+    ot = O.Term(ids, vals, dims, 0, 2.0, 0.1, [None, V])
+    P, b = O.row_system(D, [ot], 0, mu, Lam)
+    cov = np.linalg.inv(P)
+    mean = cov @ b
+    nd = draws.shape[0]
+    assert nd >= 100_000
+    se = np.sqrt(np.diag(cov) / nd)
+    assert np.all(np.abs(draws.mean(0) - mean) < 5 * se)
+    emp = np.cov(draws.T)
+    assert np.linalg.norm(emp - cov) / np.linalg.norm(cov) < 0.03
+    # and it IS the low-rank map (not the reference's) that ran
+    exp1 = O.sample_row_lowrank(D, [ot], 3, mu, Lam, O.normals(SEED, 1, 1, 1, 3, D + n))
+    np.testing.assert_allclose(draws[3], exp1, rtol=1e-8, atol=1e-9)
+    dr.close()
