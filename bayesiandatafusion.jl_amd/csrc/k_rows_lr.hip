@@ -8,9 +8,11 @@
 // over all rows).  With Lambda = L L' (lower Cholesky, once per launch) and Vt = V L^-T (the opposite entity's whole factor
 // matrix transformed once per launch: wt_o = L^-1 w_o is then a gathered row of Vt):
 //
-//     e0  = L' mu + u                      u   = normals 0 .. D-1   of the row's stream (BDF_P_ROW, entity_tag, original id)
+//     e0  = L' mu + u                      u, delta: D + n normals of the row's stream (BDF_P_ROW, entity_tag, original id):
+//                                          u_d = number 2 (d % 16 + 16 (d / 32)) + (d / 16) % 2, delta_a = number
+//                                          2 (16 ceil(ceil(D / 16) / 2) + a / 2) + a % 2 (the lanes that make them: k_rows_lr4)
 //     G   = I_n + alpha Wt' Wt             n x n, on the matrix cores
-//     tau = G^-1 (r - Wt' e0 - delta / sqrt(alpha))      delta = normals D .. D+n-1
+//     tau = G^-1 (r - Wt' e0 - delta / sqrt(alpha))
 //     q   = e0 + alpha Wt tau
 //     x   = L^-T q                         (k_rowmat: a dense N x D x D product over the rows of the launch, in place)
 //
@@ -28,14 +30,18 @@
 #include "bdf_common.h"
 #include "wave_linalg.h"
 #include "c_layout_chol.h"
+#include "dpp_rows16.h"
 
 namespace {
 
 template <int DP>
 struct LrGeo {
     static constexpr int DB = DP / 16;
-    static constexpr int KQ = DP / 4;                  // contraction elements per lane row of the MFMA operand
-    static constexpr int LD = DP + 2;                  // doubles between staged rows: even (16-byte reads), odd multiple of two banks
+    static constexpr int KQ = DP / 4;                  // contraction elements per lane row of the MFMA operand (k_rowmat)
+    // the rows go through LDS in pieces of HW = 32 elements (D = 64: two halves): 4.3 KB of staging per wave instead of 8.4,
+    // six resident waves per SIMD instead of four
+    static constexpr int HW = 32, NH = DP / HW, KH = HW / 4;
+    static constexpr int LD = HW + 2;                  // doubles between staged rows: even (16-byte reads), odd multiple of two banks
     static constexpr int STAGE = 16 * LD;
     static constexpr int TRI = Geo<16>::WAVE_LDS;      // packed 16 x 16 factor (+ the extra row's panel); the normals sit there first
     static constexpr int WAVE_LDS = STAGE + TRI;
@@ -49,9 +55,11 @@ struct LrGeo {
 // both matrices DP x DP row-major, zero outside D x D.  One wavefront; the matrix lives in LDS.
 template <int DP>
 __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *__restrict__ Lambda, const double *__restrict__ mu,
-                                                 double *__restrict__ Tf, double *__restrict__ Tb, double *__restrict__ mt, int *flag)
+                                                 double *__restrict__ Tf, double *__restrict__ Tb, double *__restrict__ mt, double *__restrict__ zero_row,
+                                                 int *flag)
 {
     constexpr int LDL = DP + 1;
+    if (threadIdx.x < DP) zero_row[threadIdx.x] = 0.0;       // the row the padding lanes of k_rows_lr4 gather
     // sA[i * LDL + c]: the Schur complement's lower triangle, then L in place; L^-1 (lower triangular too) goes TRANSPOSED
     // into the strict upper triangle -- X[i][c], i > c, at sA[c * LDL + i] -- and its diagonal into sD
     __shared__ double sA[DP * LDL];
@@ -112,7 +120,7 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *__restrict_
 // DP/4 consecutive doubles of its row.  rows == nullptr: rows 0 .. n_rows-1; else the listed rows (entries < 0: none).
 // In place (Y == X) is allowed: every wave of a tile has read the tile before any of them writes (workgroup barrier).
 template <int DP>
-__global__ __launch_bounds__(256) void k_rowmat(const double *X, double *Y, const double *__restrict__ T, int D, const int32_t *__restrict__ rows,
+__global__ __launch_bounds__(256) void k_rowmat(const double *X, double *Y, const double *__restrict__ T, int D, int ldy, const int32_t *__restrict__ rows,
                                                 int64_t n_rows, int64_t n_iters)
 {
     constexpr int DB = DP / 16, KQ = DP / 4, TPW = 4 / DB;
@@ -149,7 +157,7 @@ __global__ __launch_bounds__(256) void k_rowmat(const double *X, double *Y, cons
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
             const int64_t rowm = __shfl((long long)row, kk + 4 * rr);
-            if (rowm >= 0 && col < D) Y[rowm * D + col] = acc[rr];
+            if (rowm >= 0 && col < ldy) Y[rowm * ldy + col] = acc[rr];       // (columns D .. ldy-1: zeros, T is zero-padded)
         }
     }
 }
@@ -164,7 +172,8 @@ struct LrItem {
 struct LrArgs {
     const int32_t *colidx;      // the relation's other-mode ids, mode order
     const double *vals;
-    const double *vt;           // the opposite factor transformed: rows of D doubles
+    const double *vt;           // the opposite factor transformed: rows of DP doubles (zeros behind the first D), then one all-zero row
+    int64_t zero_row;           // ... its index
     const double *mt;           // L' mu
     double *out;
     double alpha, mean;
@@ -175,11 +184,11 @@ struct LrArgs {
 };
 
 template <int DP>
-__global__ __launch_bounds__(256, (DP == 64 ? 4 : 5)) void k_rows_lr(LrArgs a, const LrItem *__restrict__ items, int64_t n_items)
+__global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__restrict__ items, int64_t n_items)
 {
     using LG = LrGeo<DP>;
     using G16 = Geo<16>;
-    constexpr int DB = LG::DB, KQ = LG::KQ, LD = LG::LD;
+    constexpr int DB = LG::DB, LD = LG::LD;
     __shared__ __attribute__((aligned(16))) double lds[4 * LG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * 4 + wave;
@@ -190,7 +199,10 @@ __global__ __launch_bounds__(256, (DP == 64 ? 4 : 5)) void k_rows_lr(LrArgs a, c
     const int D = a.D, n = it.count;
 
     // ---- the row's D + n normals, one Philox block and one Box-Muller pair per lane, through LDS (the packed factor's space)
-    if (2 * lane < D + n) {
+    // (which numbers of the stream are u_d and delta_a: lr_u_index / lr_delta_index below -- the assignment follows the lanes of
+    // the four-rows-per-wave kernel)
+    const int zbase = 16 * (((D + 15) / 16 + 1) / 2);
+    if (lane < zbase + (n + 1) / 2) {
         double z0, z1;
         bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)lane, z0, z1);
         tri[2 * lane] = z0;
@@ -212,7 +224,7 @@ __global__ __launch_bounds__(256, (DP == 64 ? 4 : 5)) void k_rows_lr(LrArgs a, c
 #pragma unroll
             for (int I = 0; I < DB; I++) {
                 const int e = 16 * I + j;
-                const double v = a.vt[ix[k] * D + (e < D ? e : 0)];
+                const double v = a.vt[ix[k] * DP + e];
                 wv[k][I] = (4 * k + h < n && e < D) ? v : 0.0;
             }
     } else {
@@ -227,24 +239,27 @@ __global__ __launch_bounds__(256, (DP == 64 ? 4 : 5)) void k_rows_lr(LrArgs a, c
 #pragma unroll
     for (int I = 0; I < DB; I++) {
         const int e = 16 * I + j;
-        e0[I] = (e < D) ? a.mt[e] + tri[e] : 0.0;
+        e0[I] = (e < D) ? a.mt[e] + tri[2 * (j + 16 * (I / 2)) + (I & 1)] : 0.0;
     }
-    const double dl = (j < n) ? tri[D + j] : 0.0;
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-        for (int I = 0; I < DB; I++)
-            st[(4 * k + h) * LD + 16 * I + j] = (k == 3 && h == 3) ? e0[I] : wv[k][I];
-    wave_sync();
-    // ---- G~ = S S' with S = [Wt' ; 0 ; e0'] (16 x D): operand lane (i = j, kk = h), k-step s: S[i][kk KQ + s]
+    const double dl = (j < n) ? tri[2 * (zbase + (j >> 1)) + (j & 1)] : 0.0;
+    // ---- G~ = S S' with S = [Wt' ; 0 ; e0'] (16 x D), HW columns at a time: operand lane (i = j, kk = h), k-step s:
+    // S[i][HW hh + kk KH + s]
     d4 acc = d4{0.0, 0.0, 0.0, 0.0};
-    {
-        const double *src = st + j * LD + h * KQ;
-        double x[KQ];
 #pragma unroll
-        for (int s = 0; s < KQ; s += 2) { const d2 v = *(const d2 *)(src + s); x[s] = v[0]; x[s + 1] = v[1]; }
+    for (int hh = 0; hh < LG::NH; hh++) {
+        if (hh > 0) wave_sync();                      // the previous piece has been read
 #pragma unroll
-        for (int s = 0; s < KQ; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s], x[s], acc, 0, 0, 0);
+        for (int k = 0; k < 4; k++)
+#pragma unroll
+            for (int I2 = 0; I2 < 2; I2++)
+                st[(4 * k + h) * LD + 16 * I2 + j] = (k == 3 && h == 3) ? e0[2 * hh + I2] : wv[k][2 * hh + I2];
+        wave_sync();
+        const double *src = st + j * LD + h * LG::KH;
+        double x[LG::KH];
+#pragma unroll
+        for (int s = 0; s < LG::KH; s += 2) { const d2 v = *(const d2 *)(src + s); x[s] = v[0]; x[s + 1] = v[1]; }
+#pragma unroll
+        for (int s = 0; s < LG::KH; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(x[s], x[s], acc, 0, 0, 0);
     }
     // ---- the n x n system G tau = rho in the accumulator layout (lane (j, h), register r: row h + 4 r, column j),
     // identity outside n x n; Wt' e0 is row 15 of the product
@@ -287,12 +302,159 @@ __global__ __launch_bounds__(256, (DP == 64 ? 4 : 5)) void k_rows_lr(LrArgs a, c
         for (int k = 0; k < 4; k++) s = fma(wv[k][I], t4[k], s);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        const double e = st[15 * LD + 16 * I + j];
-        const double v = fma(a.alpha, s, e);
+        const double v = fma(a.alpha, s, e0[I]);
         qv = (h == I) ? v : qv;
     }
     const int e = 16 * h + j;
     if (h < DB && e < D) a.out[(int64_t)it.row * D + e] = qv;
+}
+
+
+// ---- FOUR ROWS PER WAVE: every row of 16 lanes takes one entity row; lane b of it takes OBSERVATION b (n <= 16) -----------------
+// The wave-per-row kernel above spends ~850 vector instructions and 16 matrix instructions on a row whatever its length; most
+// of it (normals, the 16 x 16 factorisation, index arithmetic) is per-row overhead on a quarter-filled wave, and at D = 30 on
+// an L2-resident factor that instruction stream is what bounds the launch.  Here lane b streams ITS observation's row of Vt
+// through registers, eight elements at a time, and the Gram matrix grows by one rank-1 update per ELEMENT d -- G[., b] += wt_d[.]
+// wt_d[b]: DR fmac_dpp with lane a of the lane row as the broadcast source, the same instruction k_rows_small uses per
+// observation; Wt' e0 rides along as one more row.  The n x n system is then k_rows_small's column-per-lane LDL' with the
+// right-hand side riding along, and q = e0 + alpha Wt tau takes a second, element-major read of the same rows (lane j:
+// elements j, j + 16, ... of observation a, tau_a broadcast by DPP), which the caches hold.  ~2,000 vector instructions per
+// FOUR rows at D = 64, ~1,300 at D <= 32.  Lane j makes pair j + 16 r of the row's stream -- u of elements 32 r + j and
+// 32 r + 16 + j -- and pair DP / 2 + j / 2 for delta_j (orc_lowrank_normals is this assignment).
+template <int S, int C>
+__device__ __forceinline__ void lr4_load(double (&W)[2][8], const d2 *rowp)
+{
+#pragma unroll
+    for (int u = 0; u < 4; u++) { const d2 v = rowp[4 * C + u]; W[S][2 * u] = v[0]; W[S][2 * u + 1] = v[1]; }
+}
+template <int DP, int DR, int C, int U>
+__device__ __forceinline__ void lr4_gram_el(double (&A)[16], double &gacc, const double (&e0)[DP / 16], const double (&Wc)[8])
+{
+    if constexpr (U < 8) {
+        const double w = Wc[U];
+        small_rank1<DR, 0>(A, w);                                       // G[., b] += wt_d[.] wt_d[b]
+        constexpr int d = 8 * C + U;
+        fm1_run<d % 16>(gacc, e0[d / 16], w);                           // (Wt' e0)_b += e0_d wt_d[b]
+        lr4_gram_el<DP, DR, C, U + 1>(A, gacc, e0, Wc);
+    }
+}
+template <int DP, int DR, int C>
+__device__ __forceinline__ void lr4_gram(double (&A)[16], double &gacc, const double (&e0)[DP / 16], double (&W)[2][8], const d2 *rowp)
+{
+    if constexpr (C < DP / 8) {
+        lr4_gram_el<DP, DR, C, 0>(A, gacc, e0, W[C & 1]);
+        if constexpr (C + 2 < DP / 8) lr4_load<(C & 1), C + 2>(W, rowp);
+        lr4_gram<DP, DR, C + 1>(A, gacc, e0, W, rowp);
+    }
+}
+template <int DP, int A0, int T>
+__device__ __forceinline__ void lr4_cgather(double (&wc)[4][DP / 16], uint32_t idw, const double *vt, int j)
+{
+    if constexpr (T < 4) {
+        const double *rp = vt + (int64_t)row_bcast_u32<A0 + T>(idw) * DP + j;
+#pragma unroll
+        for (int k = 0; k < DP / 16; k++) wc[T][k] = rp[16 * k];
+        lr4_cgather<DP, A0, T + 1>(wc, idw, vt, j);
+    }
+}
+template <int DP, int A0, int T>
+__device__ __forceinline__ void lr4_cfma(double (&q)[DP / 16], const double (&wc)[4][DP / 16], double tau)
+{
+    if constexpr (T < 4) {
+#pragma unroll
+        for (int k = 0; k < DP / 16; k++) fm1_run<A0 + T>(q[k], tau, wc[T][k]);      // q_k += tau_a wt_a[16 k + j]
+        lr4_cfma<DP, A0, T + 1>(q, wc, tau);
+    }
+}
+template <int DP, int DR, int A0>
+__device__ __forceinline__ void lr4_phase_c(double (&q)[DP / 16], uint32_t idw, const double *vt, int j, double tau)
+{
+    if constexpr (A0 < DR) {
+        double wc[4][DP / 16];
+        lr4_cgather<DP, A0, 0>(wc, idw, vt, j);
+        lr4_cfma<DP, A0, 0>(q, wc, tau);
+        lr4_phase_c<DP, DR, A0 + 4>(q, idw, vt, j, tau);
+    }
+}
+
+template <int DP, int DR>
+__device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, const int j)
+{
+    constexpr int DB = DP / 16, NR = DP / 32;
+    const bool live = it.row >= 0;
+    const int D = a.D, n = live ? it.count : 0;
+    uint32_t idw = (uint32_t)a.zero_row;
+    double rv = 0.0;
+    if (j < n) {
+        idw = (uint32_t)a.colidx[it.q_begin + j];
+        rv = a.vals[it.q_begin + j] - a.mean;
+    }
+    const d2 *rowp = (const d2 *)(a.vt + (int64_t)idw * DP);
+    double W[2][8];
+    lr4_load<0, 0>(W, rowp);
+    lr4_load<1, 1>(W, rowp);
+    // the normals under the first loads
+    double e0[DB];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        double z0, z1;
+        bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(j + 16 * r), z0, z1);
+        e0[2 * r] = a.mt[32 * r + j] + z0;
+        e0[2 * r + 1] = a.mt[32 * r + 16 + j] + z1;
+    }
+    double dl;
+    {
+        double z0, z1;
+        bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(DP / 2 + (j >> 1)), z0, z1);
+        dl = (j & 1) ? z1 : z0;
+    }
+    double A[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) A[i] = 0.0;
+    double gacc = 0.0;
+    asm volatile("s_nop 1" ::: "memory");              // (e0 is a DPP source below: written by the vector adds just above)
+    lr4_gram<DP, DR, 0>(A, gacc, e0, W, rowp);
+    // G = I + alpha Wt' Wt on n x n, identity outside; rho = r - Wt' e0 - delta / sqrt(alpha)
+#pragma unroll
+    for (int i = 0; i < DR; i++) {
+        const double id = (i == j) ? 1.0 : 0.0;
+        A[i] = (i < n && j < n) ? fma(a.alpha, A[i], id) : id;
+    }
+    double rho = (j < n) ? rv - gacc - dl * fast_rsqrt(a.alpha) : 0.0;
+    double dj = 1.0;
+    small_factor<DR, 0>(A, rho, dj, j);
+    if (j < n && !(dj > 0.0)) atomicOr(a.flag, 1);
+    const double rdj = fast_rcp(dj);
+    double tau = rho * rdj;
+    small_backward<DR - 1>(A, tau, rdj, j);
+    // q = e0 + alpha Wt tau: the rows once more, element-major (the padding's observations are the zero row, their tau is 0)
+    double q[DB];
+#pragma unroll
+    for (int k = 0; k < DB; k++) q[k] = 0.0;
+    asm volatile("s_nop 1" ::: "memory");              // (tau is a DPP source below)
+    lr4_phase_c<DP, DR, 0>(q, idw, a.vt, j, tau);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < DB; k++)
+            if (16 * k + j < D) a.out[(int64_t)it.row * D + 16 * k + j] = fma(a.alpha, q[k], e0[k]);
+    }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 3) void k_rows_lr4(LrArgs a, const LrItem *__restrict__ items, int64_t n_items)
+{
+    const int lane = threadIdx.x & 63, j = lane & 15;
+    const int64_t w = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w * 4 >= n_items) return;
+    const LrItem it = items[w * 4 + (lane >> 4)];
+    int nmax = it.row >= 0 ? it.count : 0;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    if (nmax <= 4) lr4_body<DP, 4>(a, it, j);
+    else if (nmax <= 8) lr4_body<DP, 8>(a, it, j);
+    else if (nmax <= 12) lr4_body<DP, 12>(a, it, j);
+    else lr4_body<DP, 16>(a, it, j);
 }
 
 int lr_buffers(bdf_ctx *ctx, size_t vt_bytes)
@@ -310,41 +472,51 @@ int lr_buffers(bdf_ctx *ctx, size_t vt_bytes)
 }
 
 template <int DP>
-int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, const int32_t *rows_dev, bool transform,
-                hipEvent_t e0, hipEvent_t e1)
+int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, const int32_t *rows_dev,
+                bool transform, hipEvent_t e0, hipEvent_t e1)
 {
     const int D = a.D;
     double *Tf = ctx->lr_T, *Tb = Tf + 64 * 64, *mt = Tb + 64 * 64;
     constexpr int TPW = 4 / (DP / 16);
     if (transform) {
-        hipExtLaunchKernelGGL((k_lr_prep<DP>), dim3(1), dim3(64), 0, ctx->stream, e0, nullptr, 0, D, a.Lambda, a.mu, Tf, Tb, mt, a.flag);
+        // (k_lr_prep also zeroes row M_other of the transformed matrix: what lanes without an observation gather)
+        hipExtLaunchKernelGGL((k_lr_prep<DP>), dim3(1), dim3(64), 0, ctx->stream, e0, nullptr, 0, D, a.Lambda, a.mu, Tf, Tb, mt,
+                              ctx->lr_vt + M_other * DP, a.flag);
         e0 = nullptr;
         const int64_t iters = (M_other + 16 * TPW - 1) / (16 * TPW);
         hipLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(iters, 4096)), dim3(256), 0, ctx->stream, a.t[0].fac[0], ctx->lr_vt,
-                           (const double *)Tf, D, (const int32_t *)nullptr, M_other, iters);
+                           (const double *)Tf, D, DP, (const int32_t *)nullptr, M_other, iters);
     }
     LrArgs la;
-    la.colidx = a.t[0].colidx; la.vals = a.t[0].vals; la.vt = ctx->lr_vt; la.mt = mt; la.out = a.out;
+    la.colidx = a.t[0].colidx; la.vals = a.t[0].vals; la.vt = ctx->lr_vt; la.zero_row = M_other; la.mt = mt; la.out = a.out;
     la.alpha = a.t[0].alpha; la.mean = a.t[0].mean; la.seed = a.seed; la.sweep = a.sweep; la.entity_tag = a.entity_tag;
     la.D = D; la._pad = 0; la.flag = a.flag;
-    hipExtLaunchKernelGGL((k_rows_lr<DP>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_items);
+    static const bool wave_per_row = getenv("BDF_LR_WAVE") != nullptr;        // the wave-per-row kernel instead (rows of at most 15 observations)
+    if (wave_per_row)
+        hipExtLaunchKernelGGL((k_rows_lr<DP>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_items);
+    else
+        hipExtLaunchKernelGGL((k_rows_lr4<DP>), dim3((unsigned)((n_padded + 15) / 16)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_padded);
     const int64_t iters = (n_items + 16 * TPW - 1) / (16 * TPW);
     hipExtLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(iters, 4096)), dim3(256), 0, ctx->stream, nullptr, e1, 0, (const double *)a.out, a.out,
-                          (const double *)Tb, D, rows_dev, n_items, iters);
+                          (const double *)Tb, D, D, rows_dev, n_items, iters);
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
 
 }  // namespace
 
-// The rows `items` (LrItem: one two-mode relation, at most 15 observations each, shared prior mean) of the launch described by
-// `a`.  transform: L = chol(Lambda), the opposite factor's M_other rows transformed into the context's buffer (false: both
-// are still valid from the previous chunk of the same entity launch).  rows_dev: the rows' positions (n_items int32).
-int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, const int32_t *rows_dev, bool transform,
-                  hipEvent_t e0, hipEvent_t e1)
+// The rows `items` (LrItem: one two-mode relation, at most 16 observations each, shared prior mean; n_items of them, padded
+// with row = -1 records to n_padded, a multiple of four) of the launch described by `a`.  transform: L = chol(Lambda), the
+// opposite factor's M_other rows transformed into the context's buffer (false: both are still valid from the previous chunk
+// of the same entity launch).  rows_dev: the rows' positions (n_items int32).
+int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, const int32_t *rows_dev,
+                  bool transform, hipEvent_t e0, hipEvent_t e1)
 {
-    int rc = lr_buffers(ctx, (size_t)M_other * a.D * sizeof(double));
+    const int DP = a.D <= 32 ? 32 : 64;
+    int rc = lr_buffers(ctx, ((size_t)M_other + 2) * DP * sizeof(double));         // rows of DP doubles, the zero row, slack
     if (rc) return rc;
-    if (a.D <= 32) return lr_launch_t<32>(ctx, a, M_other, items, n_items, rows_dev, transform, e0, e1);
-    return lr_launch_t<64>(ctx, a, M_other, items, n_items, rows_dev, transform, e0, e1);
+    if (DP == 32) return lr_launch_t<32>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);
+    return lr_launch_t<64>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);
 }
+
+int bdf_lr_max_observations() { return getenv("BDF_LR_WAVE") ? 15 : 16; }

@@ -43,6 +43,7 @@
 #include "bdf_common.h"
 #include "wave_linalg.h"
 #include "c_layout_chol.h"
+#include "dpp_rows16.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -697,71 +698,6 @@ struct SmallItem {
     int32_t count, _pad;
 };
 
-template <int K>
-__device__ __forceinline__ uint32_t row_bcast_u32(uint32_t v)
-{
-    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x150 + K, 0xf, 0xf, false);      // row_newbcast:K
-}
-template <int K>
-__device__ __forceinline__ double row_bcast_f64(double v)
-{
-    double o;
-    asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "=v"(o) : "v"(v), "n"(K));
-    return o;
-}
-
-// (DPP reads of a register need two wait states after a vector instruction wrote it: the s_nop in fm1 / fm1_self.  In the
-// runs below the DPP source was written long before -- the gathered value once per observation, a matrix row in the step
-// before -- so only the first instruction of a run carries the s_nop)
-template <int KJ>
-__device__ __forceinline__ void fm1_run(double &d, double s, double m)
-{
-    asm volatile("v_fmac_f64_dpp %0, %1, %2 row_newbcast:%3 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(s), "v"(m), "n"(KJ));
-}
-template <int KJ>
-__device__ __forceinline__ void fm1_self_run(double &d, double m)
-{
-    asm volatile("v_fmac_f64_dpp %0, %0, %1 row_newbcast:%2 row_mask:0xf bank_mask:0xf" : "+v"(d) : "v"(m), "n"(KJ));
-}
-// DR: D rounded up to a multiple of four -- rows DR .. 15 of the padded system are never touched
-template <int DR, int I>
-__device__ __forceinline__ void small_rank1(double (&A)[16], double v)
-{
-    if constexpr (I < DR) {
-        if constexpr (I == 0) fm1<I>(A[I], v, v); else fm1_run<I>(A[I], v, v);       // A[I][j] += v_I v_j
-        small_rank1<DR, I + 1>(A, v);
-    }
-}
-template <int DR, int K, int I>
-__device__ __forceinline__ void small_elim(double (&A)[16], double nm)
-{
-    if constexpr (I < DR) {
-        if constexpr (I == K + 1) fm1_self<K>(A[I], nm); else fm1_self_run<K>(A[I], nm);      // A[I][j] -= A[I][K] m_j
-        small_elim<DR, K, I + 1>(A, nm);
-    }
-}
-// (no branches around the DPP instructions: steps of the padding -- rows and columns D .. DR-1 are the identity -- are
-// no-ops by their values, and a branch costs the copies the compiler makes for the asm operands at every merge)
-template <int DR, int K>
-__device__ __forceinline__ void small_factor(double (&A)[16], double &b, double &dj, int j)
-{
-    if constexpr (K < DR) {
-        const double dk = row_bcast_f64<K>(A[K]);
-        dj = (j == K) ? dk : dj;
-        const double nm = (j > K) ? -(A[K] * fast_rcp(dk)) : 0.0;            // -A[K][j] / d_K; finished columns are left alone
-        small_elim<DR, K, K + 1>(A, nm);
-        fm1_self<K>(b, nm);                                                // the forward solve: b_j -= w_K l_jK
-        small_factor<DR, K + 1>(A, b, dj, j);
-    }
-}
-template <int C>
-__device__ __forceinline__ void small_backward(const double (&A)[16], double &y, double rdj, int j)
-{
-    if constexpr (C >= 1) {
-        fm1_self<C>(y, (j < C) ? -(A[C] * rdj) : 0.0);                     // y_j -= l_Cj x_C for the columns left of C
-        small_backward<C - 1>(A, y, rdj, j);
-    }
-}
 // eight observations of a chunk: ids broadcast inside the 16-lane row, all eight gathers issued (observations past the row's
 // end gather row 0 and are masked to zero), then the rank-1 updates
 template <int H, int K>
@@ -885,7 +821,7 @@ struct Plan {
     int64_t n_small = 0;              // entries of small_dev (a multiple of 4)
     SmallItem *lr_dev = nullptr;      // the rows of the low-rank sampler (same record), and their positions for the back-transform
     int32_t *lr_rows_dev = nullptr;
-    int64_t n_lr = 0;
+    int64_t n_lr = 0, n_lr_padded = 0;
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
     int32_t *order_dev = nullptr;
@@ -1037,6 +973,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         std::stable_sort(lr.begin(), lr.end(), [](const SmallItem &x, const SmallItem &y) { return x.count > y.count; });
         std::vector<int32_t> lr_rows(lr.size());
         for (size_t i = 0; i < lr.size(); i++) lr_rows[i] = lr[i].row;
+        while (lr.size() % 4) lr.push_back(SmallItem{-1, 0, 0, 0, 0});      // four rows per wave
+        plan.n_lr_padded = (int64_t)lr.size();
         if ((rc = to_device(lr, &plan.lr_dev)) || (rc = to_device(lr_rows, &plan.lr_rows_dev))) return rc;
     }
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
@@ -1194,7 +1132,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         a.ready == nullptr && !getenv("BDF_K1_DECOUPLE")) {
         const int other = 1 - modes[0];
         M_other = rels[0]->nint[other];
-        key.lr = std::min(ctx->lr_max < 0 ? std::min(15, a.D / 2) : std::min(ctx->lr_max, 15), ctx->item_size);
+        key.lr = std::min(std::min(ctx->lr_max < 0 ? a.D / 2 : ctx->lr_max, bdf_lr_max_observations()), ctx->item_size);
         key.lr_min = std::max<int64_t>(ctx->lr_min_rows, 1);
         key.lr_other = ctx->lr_min_rows > 0 ? M_other : 0;          // (min_rows = 0, a test hook: whenever a launch has such a row)
     }
@@ -1246,7 +1184,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         const bool same = shard > 0 && ctx->lr_key_fac == (const void *)a.t[0].fac[0] && ctx->lr_key_Lambda == (const void *)a.Lambda &&
                           ctx->lr_key_mu == (const void *)a.mu && ctx->lr_key_sweep == a.sweep && ctx->lr_key_tag == a.entity_tag &&
                           ctx->lr_key_D == a.D && ctx->lr_key_M == M_other;
-        int rc = bdf_lr_launch(ctx, a, M_other, plan->lr_dev, plan->n_lr, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
+        int rc = bdf_lr_launch(ctx, a, M_other, plan->lr_dev, plan->n_lr, plan->n_lr_padded, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
         if (rc) return rc;
         ctx->lr_key_fac = a.t[0].fac[0]; ctx->lr_key_Lambda = a.Lambda; ctx->lr_key_mu = a.mu; ctx->lr_key_sweep = a.sweep;
         ctx->lr_key_tag = a.entity_tag; ctx->lr_key_D = a.D; ctx->lr_key_M = M_other;

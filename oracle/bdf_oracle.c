@@ -481,9 +481,27 @@ int orc_sample_row_lowrank(int D, int n_terms, const orc_term *terms, int64_t ro
     return rc;
 }
 
+/* Which numbers of the row's stream (P_ROW, entity_tag, row) are the low-rank sampler's D + n normals.  The HIP kernel gives
+ * every observation of a row one of sixteen lanes and every lane the elements d = j, j + 16, ... of a D-vector; a lane makes
+ * one Philox block = one pair of normals at a time, so the assignment follows the lanes: with j = d % 16, k = d / 16
+ *     u_d     = number 2 (j + 16 (k / 2)) + k % 2                         (pair j + 16 (k / 2), element k % 2)
+ *     delta_a = number 2 (16 ceil(ceil(D / 16) / 2) + a / 2) + a % 2      (pairs behind the u's)
+ * z: D + n doubles out; scratch: 2 (D + n) + 4 doubles */
+void orc_lowrank_normals(uint64_t seed, uint32_t sweep, uint32_t entity_tag, uint64_t row, int D, int n, double *z, double *scratch)
+{
+    const int DB = (D + 15) / 16, base = 16 * ((DB + 1) / 2);
+    const int total = 2 * (base + (n + 1) / 2);
+    orc_normals(seed, sweep, P_ROW, entity_tag, row, total, scratch);
+    for (int d = 0; d < D; d++) {
+        const int j = d % 16, k = d / 16;
+        z[d] = scratch[2 * (j + 16 * (k / 2)) + k % 2];
+    }
+    for (int a = 0; a < n; a++) z[D + a] = scratch[2 * (base + a / 2) + a % 2];
+}
+
 /* every row in [row_begin, row_end) as the HIP library samples them with the low-rank sampler switched on: rows of at most
- * lr_max observations by orc_sample_row_lowrank with normals 0 .. D+n-1 of stream (P_ROW, entity_tag, row), the others by
- * the reference's map (orc_sample_rows) */
+ * lr_max observations by orc_sample_row_lowrank with the normals orc_lowrank_normals assigns, the others by the reference's
+ * map (orc_sample_rows) */
 int orc_sample_rows_lowrank(int D, int64_t row_begin, int64_t row_end, int n_terms, const orc_term *terms,
                             const double *mu, int mu_is_matrix, const double *Lambda, int lr_max,
                             uint64_t seed, uint32_t sweep, uint32_t entity_tag, double *out, int nthreads)
@@ -501,11 +519,11 @@ int orc_sample_rows_lowrank(int D, int64_t row_begin, int64_t row_end, int n_ter
 #pragma omp for schedule(dynamic, 8)
 #endif
         for (int64_t i = row_begin; i < row_end; i++) {
-            double z[ORC_MAX_D + ORC_LR_MAX_N + 2];
+            double z[ORC_MAX_D + ORC_LR_MAX_N + 2], zz[2 * (ORC_MAX_D + ORC_LR_MAX_N) + 4];
             const double *mu_i = mu_is_matrix ? mu + (size_t)i * D : mu;
             const int64_t n = orc_row_count(n_terms, terms, i);
             if (n <= lr_max) {
-                orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D + (int)n, z);
+                orc_lowrank_normals(seed, sweep, entity_tag, (uint64_t)i, D, (int)n, z, zz);
                 if (orc_sample_row_lowrank_L(D, n_terms, terms, i, mu_i, L, z, out + (size_t)i * D)) fail = 1;
             } else {
                 orc_normals(seed, sweep, P_ROW, entity_tag, (uint64_t)i, D, z);

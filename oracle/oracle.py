@@ -188,6 +188,14 @@ def sample_row_lowrank(D, terms, row, mu_i, Lambda, z):
     return x
 
 
+def lowrank_normals(seed, sweep, entity_tag, row, D, n):
+    """the D + n normals of the low-rank sampler for a row, in the order sample_row_lowrank takes them (orc_lowrank_normals)"""
+    z = np.zeros(D + n + 1)
+    scratch = np.zeros(2 * (D + n) + 70)
+    lib().orc_lowrank_normals(C.c_uint64(seed), C.c_uint32(sweep), C.c_uint32(entity_tag), C.c_uint64(row), int(D), int(n), _dp(z), _dp(scratch))
+    return z[:D + n]
+
+
 def lowrank_map(D, terms, row, mu_i, Lambda):
     """dump hook: the low-rank sampler is affine in its normals, x = m + S z; returns (m, S) with S of shape (D, D + n)"""
     n = row_count(terms, row)

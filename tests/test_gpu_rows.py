@@ -736,18 +736,19 @@ def test_four_rows_per_wave_against_oracle(B, O, ctx, D, coded):
 
 @pytest.mark.parametrize("D", [17, 24, 30, 32, 33, 48, 64])
 def test_lowrank_rows_against_oracle(B, O, ctx, D):
-    """k_rows_lr (D > 16: rows of at most min(15, D / 2) observations by the low-rank sampler) against the oracle's statement of
+    """k_rows_lr4 (D > 16: rows of at most min(16, D / 2) observations by the low-rank sampler, four rows to a wave) against the oracle's statement of
     the same map (orc_sample_row_lowrank: D + n normals, n x n solve) on the same Philox normals, 1e-8; the longer rows of the
     same launch against the reference's map (they go through k_rows).  Rows of 0 .. 15 observations and more, a row count that
     is no multiple of four or sixteen, ratings and continuous values, both modes.  (That the low-rank map draws the reference's
     distribution is the deterministic CPU test test_lowrank_sampler_draws_the_reference_distribution.)"""
     rng = np.random.default_rng(500 + D)
     dims = [211, 90]
-    deg = rng.integers(0, 17, dims[0])
-    deg[:8] = [0, 1, 2, 14, 15, 16, 40, 250]
+    deg = rng.integers(0, 18, dims[0])
+    deg[:10] = [0, 1, 2, 4, 5, 14, 15, 16, 40, 250]
+    deg[10:14] = [17, 8, 9, 12]
     rows = np.repeat(np.arange(1, dims[0] + 1), deg)
     ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
-    lr = min(15, D // 2)
+    lr = min(16, D // 2)
     idx = O.index_build(ids, dims)
     Am = rng.standard_normal((D, D))
     Lam = Am @ Am.T / D + np.eye(D)
@@ -788,7 +789,7 @@ def test_lowrank_rows_against_oracle(B, O, ctx, D):
         dr.close()
 
 
-@pytest.mark.parametrize("D,n", [(32, 0), (32, 3), (32, 15), (64, 10)])
+@pytest.mark.parametrize("D,n", [(32, 0), (32, 3), (32, 16), (64, 10)])
 def test_lowrank_row_moments(B, O, ctx, D, n):
     """>= 10^5 draws of one row by the low-rank sampler on the device: every row of a 512-row entity has the SAME observations
     (so the same conditional distribution) and its own random stream; 200 sweeps x 512 rows = 102,400 draws.  Sample mean within
@@ -811,7 +812,7 @@ def test_lowrank_row_moments(B, O, ctx, D, n):
     Vt = ctx.tensor(V)
     terms = _dev_terms(B, ctx, [(dr, 0, 2.0, 0.1, [None, Vt], None)])
     Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
-    ctx.set_lowrank(15, 0)
+    ctx.set_lowrank(16, 0)
     try:
         sweeps = 200
         import torch
@@ -835,6 +836,6 @@ def test_lowrank_row_moments(B, O, ctx, D, n):
     emp = np.cov(draws.T)
     assert np.linalg.norm(emp - cov) / np.linalg.norm(cov) < 0.03
     # and it IS the low-rank map (not the reference's) that ran
-    exp1 = O.sample_row_lowrank(D, [ot], 3, mu, Lam, O.normals(SEED, 1, 1, 1, 3, D + n))
+    exp1 = O.sample_row_lowrank(D, [ot], 3, mu, Lam, O.lowrank_normals(SEED, 1, 1, 3, D, n))
     np.testing.assert_allclose(draws[3], exp1, rtol=1e-8, atol=1e-9)
     dr.close()
