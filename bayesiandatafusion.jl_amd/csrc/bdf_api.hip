@@ -71,6 +71,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->scratch_bytes = 0;
     c->item_size = 192;
     c->piece_size = 128;
+    c->item_auto = !getenv("BDF_ITEM_FIXED");
     c->small_max = getenv("BDF_K1_SMALL") ? atoi(getenv("BDF_K1_SMALL")) : 48;
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
@@ -157,6 +158,7 @@ extern "C" int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations)
     BDF_REQUIRE(ctx && observations >= 8 && observations <= (1 << 20), BDF_ERR_ARG, "bdf_ctx_set_item_size: 8..2^20 observations");
     ctx->item_size = observations;
     ctx->piece_size = std::max(8, observations * 2 / 3);
+    ctx->item_auto = false;
     return BDF_OK;
 }
 
@@ -189,6 +191,7 @@ extern "C" int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations)
     BDF_REQUIRE(ctx && observations >= 8 && observations <= ctx->item_size, BDF_ERR_ARG,
                 "bdf_ctx_set_piece_size: 8..item size (%d) observations", ctx ? ctx->item_size : 0);
     ctx->piece_size = observations;
+    ctx->item_auto = false;
     return BDF_OK;
 }
 

@@ -53,6 +53,7 @@ struct bdf_ctx {
     uint32_t warnings;         // non-fatal bits seen by bdf_ctx_sync, until bdf_ctx_warnings takes them
     int item_size;             // K1: observations per work item (rows longer than this are split)
     int piece_size;            // K1: ... into pieces of at most this many observations
+    bool item_auto;            // K1: neither was set by the caller: large launches take larger items (bdf_launch_sample_rows)
     int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
     const uint32_t *rows_ready;            // (library-internal) SampleArgs::ready of the next row launch, then cleared
@@ -342,7 +343,8 @@ struct SampleArgs {
     // it reaches ready_want right before it adds the prior (bdf_gibbs_sweep on reserved CUs), and reads the pack past
     // the non-coherent caches
     const uint32_t *ready;
-    uint32_t ready_want, _pad4;
+    uint32_t ready_want;
+    uint32_t stagger;          // k_rows: the workgroups with an odd index start this many clock cycles late (0: none)
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

@@ -676,8 +676,16 @@ void k_rows(SampleArgs a, PlanDev p)
     __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
-    if (w < (int64_t)p.n_split + p.n_direct)
+    if (w < (int64_t)p.n_split + p.n_direct) {
+        // A launch that fits the device in one generation starts all its waves together: they all gather first (the texture
+        // path saturated, the FP64 pipe idle) and all factor afterwards (the reverse).  Every other workgroup starts late, so
+        // that one half's gathers run under the other half's factorisations.
+        if (a.stagger && (blockIdx.x & 1)) {
+            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
+        }
         process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+    }
 }
 
 // ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
@@ -996,6 +1004,18 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     return BDF_OK;
 }
 
+// waves up to which a launch is "one generation" (staggered starts only make sense then): twice the device's resident waves
+int64_t stagger_max_waves(bdf_ctx *ctx)
+{
+    static int cus = 0;
+    if (!cus) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return 0;
+        cus = prop.multiProcessorCount;
+    }
+    return (int64_t)cus * 4 * 8 * 2;
+}
+
 template <int DP>
 int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
@@ -1013,8 +1033,11 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
+        static const unsigned stagger = getenv("BDF_K1_STAGGER") ? (unsigned)atoi(getenv("BDF_K1_STAGGER")) : 0u;
+        SampleArgs as = a;
+        as.stagger = (!dump && waves <= (int64_t)stagger_max_waves(ctx)) ? stagger : 0u;
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
-        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
+        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, as, p);
         if (!dump) ctx->time_start = ctx->time_stop = nullptr;
         BDF_HIP(hipGetLastError());
     }
@@ -1111,6 +1134,23 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     memset(&key, 0, sizeof(key));
     for (int r = 0; r < a.n_terms; r++) { key.rel[r] = rels[r]->serial; key.mode[r] = modes[r]; }
     key.n_terms = a.n_terms; key.DP = DP; key.T = ctx->item_size; key.Tp = std::min(ctx->piece_size, ctx->item_size); key.shard = shard; key.n_shards = n_shards;
+    if (ctx->item_auto) {
+        // Rows are cut into pieces so that a launch of a few thousand rows has no wave much longer than the others.  A launch with
+        // hundreds of waves per resident slot has no such tail, and every piece costs a partial sum written to the slab and read
+        // back (21 KB at D = 64: the 540,000 pieces of configuration C4's item launch moved 22 GB): larger items there -- about
+        // sixteen waves per slot, between the default and 2048 observations (the same for every shard of the launch).
+        static int cus = 0;
+        if (!cus) {
+            hipDeviceProp_t prop;
+            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            cus = prop.multiProcessorCount;
+        }
+        int64_t nnz_launch = 0;
+        for (int r = 0; r < a.n_terms; r++) nnz_launch += rels[r]->idx[modes[r]].own_nnz;
+        const int64_t slots = (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * (DP == 64 ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8));
+        const int64_t t = std::min<int64_t>(2048, (nnz_launch / (slots * 16) + 63) / 64 * 64);
+        if (t > key.T) { key.T = (int)t; key.Tp = (int)(t * 2 / 3); }
+    }
     // D <= 16, one two-mode relation with the lean gather and no per-observation baseline, an entity of many rows: its short
     // rows four to a wave (k_rows_small).  bdf_ctx_set_small_rows: the longest row taken that way (default 48 observations,
     // environment BDF_K1_SMALL; 0: off) and the smallest entity (default 8192 rows, BDF_K1_SMALL_MIN_ROWS: below that the

@@ -587,6 +587,13 @@ def main():
             bytes_sweep = sum(eng4.k1_algorithmic_bytes(j) for j in range(2))
             c4.update({"sweeps_per_s": round(args.c4_sweeps / el4, 3), "ms_per_sweep": round(1e3 * el4 / args.c4_sweeps, 3),
                        "test_rmse": round(float(np.sqrt(float(sse4.item()) / max(n4, 1))), 5),
+                       # what the held-out RMSE is to be read against: the spread of the held-out values = the RMSE of predicting
+                       # their mean, and the generator's noise floor sqrt(0.5^2 + 1/12) (rounded N(., 0.5)); after only
+                       # c4-sweeps + c4-sweeps sweeps the chain is still near the first (profiles/r04_c4_quality.json: the same
+                       # relation run 30 + 30)
+                       "value_std": round(float(np.asarray(rel4.test_vec.values).std()), 4),
+                       "mean_predictor_rmse": round(float(np.sqrt(np.mean((np.asarray(rel4.test_vec.values) - rel4.model.mean_value) ** 2))), 4),
+                       "noise_floor": 0.5774,
                        "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
                        "algorithmic_tb_per_s": round(bytes_sweep / (el4 / args.c4_sweeps) / 1e12, 3),
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
