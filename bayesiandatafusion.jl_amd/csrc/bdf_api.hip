@@ -155,7 +155,11 @@ extern "C" int bdf_ctx_advance_sweep(bdf_ctx *ctx)
 
 extern "C" int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations)
 {
-    BDF_REQUIRE(ctx && observations >= 8 && observations <= (1 << 20), BDF_ERR_ARG, "bdf_ctx_set_item_size: 8..2^20 observations");
+    BDF_REQUIRE(ctx && (observations == 0 || (observations >= 8 && observations <= (1 << 20))), BDF_ERR_ARG, "bdf_ctx_set_item_size: 0 (automatic) or 8..2^20 observations");
+    if (observations == 0) {          // the default: 192 / 128, larger for launches with hundreds of waves per resident slot
+        ctx->item_size = 192; ctx->piece_size = 128; ctx->item_auto = !getenv("BDF_ITEM_FIXED");
+        return BDF_OK;
+    }
     ctx->item_size = observations;
     ctx->piece_size = std::max(8, observations * 2 / 3);
     ctx->item_auto = false;

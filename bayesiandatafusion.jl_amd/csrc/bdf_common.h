@@ -343,8 +343,7 @@ struct SampleArgs {
     // it reaches ready_want right before it adds the prior (bdf_gibbs_sweep on reserved CUs), and reads the pack past
     // the non-coherent caches
     const uint32_t *ready;
-    uint32_t ready_want;
-    uint32_t stagger;          // k_rows: the workgroups with an odd index start this many clock cycles late (0: none)
+    uint32_t ready_want, _pad4;
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

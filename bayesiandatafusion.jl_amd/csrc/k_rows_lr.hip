@@ -54,12 +54,22 @@ struct LrGeo {
 //      mt[d]    = (L' mu)[d]
 // both matrices DP x DP row-major, zero outside D x D.  One wavefront; the matrix lives in LDS.
 template <int DP>
-__global__ __launch_bounds__(64) void k_lr_prep(int D, const double *__restrict__ Lambda, const double *__restrict__ mu,
+__global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, const double *mu,
                                                  double *__restrict__ Tf, double *__restrict__ Tb, double *__restrict__ mt, double *__restrict__ zero_row,
-                                                 int *flag)
+                                                 int *flag, const uint32_t *ready, uint32_t ready_want)
 {
     constexpr int LDL = DP + 1;
     if (threadIdx.x < DP) zero_row[threadIdx.x] = 0.0;       // the row the padding lanes of k_rows_lr4 gather
+    // launched without waiting for the hyperprior draw that writes (mu, Lambda) (bdf_gibbs_sweep on reserved CUs: the draw runs
+    // on CUs the row stream never uses): poll its flag as the row kernel's waves do, then read past the non-coherent caches
+    if (ready) {
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ready_want) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 22)) { if (threadIdx.x == 0) atomicOr(flag, 16); break; }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
     // sA[i * LDL + c]: the Schur complement's lower triangle, then L in place; L^-1 (lower triangular too) goes TRANSPOSED
     // into the strict upper triangle -- X[i][c], i > c, at sA[c * LDL + i] -- and its diagonal into sD
     __shared__ double sA[DP * LDL];
@@ -67,7 +77,8 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *__restrict_
     const int c = threadIdx.x;
     for (int e = c; e < DP * DP; e += 64) {
         const int i = e / DP, cc = e % DP;
-        sA[i * LDL + cc] = (i < D && cc < D) ? Lambda[i + (int64_t)cc * D] : ((i == cc) ? 1.0 : 0.0);
+        sA[i * LDL + cc] = (i < D && cc < D) ? __hip_atomic_load(Lambda + i + (int64_t)cc * D, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                             : ((i == cc) ? 1.0 : 0.0);
     }
     wave_sync();
     bool bad = false;
@@ -109,7 +120,7 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *__restrict_
     if (c < DP) {
         double s = 0.0;
         if (c < D)
-            for (int i = c; i < D; i++) s = fma(sA[i * LDL + c], mu[i], s);
+            for (int i = c; i < D; i++) s = fma(sA[i * LDL + c], __hip_atomic_load(mu + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s);
         mt[c] = s;
     }
 }
@@ -481,7 +492,7 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
     if (transform) {
         // (k_lr_prep also zeroes row M_other of the transformed matrix: what lanes without an observation gather)
         hipExtLaunchKernelGGL((k_lr_prep<DP>), dim3(1), dim3(64), 0, ctx->stream, e0, nullptr, 0, D, a.Lambda, a.mu, Tf, Tb, mt,
-                              ctx->lr_vt + M_other * DP, a.flag);
+                              ctx->lr_vt + M_other * DP, a.flag, a.ready, a.ready_want);
         e0 = nullptr;
         const int64_t iters = (M_other + 16 * TPW - 1) / (16 * TPW);
         hipLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(iters, 4096)), dim3(256), 0, ctx->stream, a.t[0].fac[0], ctx->lr_vt,

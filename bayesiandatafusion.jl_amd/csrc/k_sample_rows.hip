@@ -54,6 +54,9 @@
 #ifndef BDF_CHOL_BLOCKED
 #define BDF_CHOL_BLOCKED 1        // the row's factorisation in 16-column panels: multipliers without an LDS round trip, trailing update on the matrix cores (c_layout_chol.h); 0: the plain right-looking variant
 #endif
+#ifndef BDF_K1_DEEP_MIN
+#define BDF_K1_DEEP_MIN 48        // D = 64: items of at least this many observations gather through three register sets (accumulate_deep); a huge value: off
+#endif
 #ifndef BDF_K1_KS
 #define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
 #endif
@@ -343,6 +346,105 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     }
 }
 
+// ---- accumulate one LONG item at D = DP (no padding), one other mode, shared baseline: THREE register sets ------------------------
+// The two-set pipeline above has the factor rows of ONE trip in flight while a trip multiplies.  That is enough when the gathered
+// factor sits in the L2 (MovieLens) or when six or seven waves share a SIMD; at D = 64 two waves share it, and configuration
+// C4's item launch gathers 512-byte rows at random from a 5 GB factor matrix: every trip then waits out a whole HBM round trip
+// (~2.5 us for 8 observations = 0.5 us of matrix instructions; 12.5 M trips on 2,048 waves: 15 of the launch's 23 ms).  Here the
+// rows (and values) of trips t + 1 and t + 2 are in flight while trip t multiplies.  The loads complete in order, so the ids of a
+// trip are fetched two trips before its rows are (four before it multiplies): waiting for them then forces only loads that
+// are needed by then anyway.  (Four sets -- three trips in flight -- need more than the 256 registers two waves per SIMD leave.)
+template <int DP, bool WIDE>
+__device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                       double (&bred)[Geo<DP>::DB])
+{
+    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, KS = 2, NS = 3;
+    const TermDev &T = a.t[it.term];
+    const int j = lane & 15, h = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    double bpart[DB];
+    uint32_t eoff[DB];
+#pragma unroll
+    for (int I = 0; I < DB; I++) { bpart[I] = 0.0; eoff[I] = (uint32_t)(DP - 1 - (16 * I + j)) * 8u; }
+    const uint32_t n = (uint32_t)it.count, rowb = (uint32_t)DP * 8u;
+    const uint32_t ntrips = (n + 4 * KS - 1) / (4 * KS);
+    const char *ids = (const char *)(T.colidx + it.q_begin), *fac = (const char *)T.fac[0], *vals = (const char *)(T.vals + it.q_begin);
+    const double mean = T.mean;
+    uint32_t ix[NS][KS];
+    double rr[NS][KS];
+    double w[NS][KS][DB];
+#define OBS(t, k) ((t) * (4 * KS) + KS * h + (k))
+#define LOAD_IDX(t, S)                                                                          \
+    {                                                                                           \
+        uint32_t o = OBS(t, 0);                                                                 \
+        o = (o < n ? o : n - 1) * 4u;                                                           \
+        const uint2 pi = *(const uint2 *)(ids + o);      /* (the arrays carry a spare entry) */  \
+        ix[S][0] = pi.x; ix[S][1] = pi.y;                                                       \
+    }
+#define LOAD_DATA(t, S)                                                                         \
+    {                                                                                           \
+        uint32_t o = OBS(t, 0);                                                                 \
+        o = (o < n ? o : n - 1) * 8u;                                                           \
+        const d2 pv = *(const d2 *)(vals + o);                                                  \
+        rr[S][0] = pv[0]; rr[S][1] = pv[1];                                                     \
+        _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
+                w[S][k][I] = WIDE ? *(const double *)(fac + ((uint64_t)ix[S][k] * rowb + eoff[I]))      \
+                                  : *(const double *)(fac + (__umul24(ix[S][k], rowb) + eoff[I]));      \
+    }
+#define TRIP(t, C)                                                                              \
+    {                                                                                           \
+        LOAD_DATA((t) + 2, ((C) + 2) % NS)                                                      \
+        double w_c[KS][DB];                                                                     \
+        _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = w[C][k][I];              \
+        if ((t) + 1 >= ntrips) {              /* the ragged last trip, and the empty ones behind it */ \
+            _Pragma("unroll") for (int k = 0; k < KS; k++) {                                    \
+                const bool valid = OBS(t, k) < n;                                               \
+                _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = valid ? w_c[k][I] : 0.0; \
+            }                                                                                   \
+        }                                                                                       \
+        _Pragma("unroll") for (int k = 0; k < KS; k++) {                                        \
+            const double r = rr[C][k] - mean;                                                   \
+            int b = 0;                                                                          \
+            _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
+                _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
+                    b++;                                                                        \
+                }                                                                               \
+                bpart[I] = fma(w_c[k][I], r, bpart[I]);                                         \
+            }                                                                                   \
+        }                                                                                       \
+        LOAD_IDX((t) + 4, ((C) + 1) % NS)                                                       \
+    }
+    LOAD_IDX(0u, 0)
+    LOAD_IDX(1u, 1)
+    LOAD_DATA(0u, 0)
+    LOAD_DATA(1u, 1)
+    LOAD_IDX(2u, 2)
+    LOAD_IDX(3u, 0)
+    for (uint32_t t = 0; t < ntrips; t += 3) {
+        TRIP(t, 0)
+        TRIP(t + 1, 1)
+        TRIP(t + 2, 2)
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef LOAD_IDX
+#undef LOAD_DATA
+#undef TRIP
+#undef OBS
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        double v = bpart[I] * T.alpha;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        bred[I] = v;
+    }
+}
+
 // path and other-mode count are wave-uniform.  MATRIX: the kernel variant for launches whose terms are all two-mode
 // relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
 // 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
@@ -357,6 +459,12 @@ __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &
     }
     const int no = a.t[it.term].n_other;
     if constexpr (DP == 64) {
+        // long items at D = 64 (two waves per SIMD): the three-set pipeline
+        if (a.D == DP && no == 1 && it.count >= BDF_K1_DEEP_MIN && a.t[it.term].lean != 0) {
+            if (a.t[it.term].lean == 2) accumulate_deep<DP, true>(a, it, lane, acc, bred);
+            else accumulate_deep<DP, false>(a, it, lane, acc, bred);
+            return;
+        }
         if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
             if (a.D == DP) {
                 if (no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
@@ -676,16 +784,8 @@ void k_rows(SampleArgs a, PlanDev p)
     __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
-    if (w < (int64_t)p.n_split + p.n_direct) {
-        // A launch that fits the device in one generation starts all its waves together: they all gather first (the texture
-        // path saturated, the FP64 pipe idle) and all factor afterwards (the reverse).  Every other workgroup starts late, so
-        // that one half's gathers run under the other half's factorisations.
-        if (a.stagger && (blockIdx.x & 1)) {
-            const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-            while (__builtin_amdgcn_s_memtime() - t0 < (unsigned long long)a.stagger) __builtin_amdgcn_s_sleep(32);
-        }
+    if (w < (int64_t)p.n_split + p.n_direct)
         process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
-    }
 }
 
 // ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
@@ -862,23 +962,12 @@ struct RowRef {
     int64_t cnt[BDF_MAX_TERMS];
 };
 
-int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, Plan &plan)
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, bool lr_on, Plan &plan)
 {
     const int T = key.T;
-    bool lr_on = false;
     std::vector<Item> direct, split;
     std::vector<SmallItem> small, lr;
     std::vector<SplitRow> srows;
-    if (key.lr > 0) {
-        // the low-rank sampler pays its set-up (the opposite factor transformed, two more launches) only with enough rows
-        int64_t cnt = 0;
-        for (const RowRef &rr : rows) {
-            int64_t nobs = 0;
-            for (int r = 0; r < key.n_terms; r++) nobs += rr.cnt[r];
-            cnt += nobs <= key.lr;
-        }
-        lr_on = cnt >= key.lr_min && 2 * cnt * key.n_shards >= key.lr_other;
-    }
     static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
     for (const RowRef &rr : rows) {
         const int32_t row = rr.out;
@@ -1004,18 +1093,6 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     return BDF_OK;
 }
 
-// waves up to which a launch is "one generation" (staggered starts only make sense then): twice the device's resident waves
-int64_t stagger_max_waves(bdf_ctx *ctx)
-{
-    static int cus = 0;
-    if (!cus) {
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) != hipSuccess) return 0;
-        cus = prop.multiProcessorCount;
-    }
-    return (int64_t)cus * 4 * 8 * 2;
-}
-
 template <int DP>
 int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
 {
@@ -1033,11 +1110,8 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
-        static const unsigned stagger = getenv("BDF_K1_STAGGER") ? (unsigned)atoi(getenv("BDF_K1_STAGGER")) : 0u;
-        SampleArgs as = a;
-        as.stagger = (!dump && waves <= (int64_t)stagger_max_waves(ctx)) ? stagger : 0u;
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
-        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, as, p);
+        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
         if (!dump) ctx->time_start = ctx->time_stop = nullptr;
         BDF_HIP(hipGetLastError());
     }
@@ -1164,17 +1238,17 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             key.small = std::min(small_max, ctx->item_size);
     }
 
-    // D > 16, one two-mode relation without per-observation baselines, a shared prior mean, a launch that does not poll for its
-    // prior: the rows of few observations by the low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
+    // D > 16, one two-mode relation without per-observation baselines, a shared prior mean: the rows of few observations by the
+    // low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
     // the longest such row, -1 = min(15, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
     int64_t M_other = 0;
     if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr && !a.mu_is_matrix &&
-        a.ready == nullptr && !getenv("BDF_K1_DECOUPLE")) {
+        !getenv("BDF_K1_DECOUPLE")) {
         const int other = 1 - modes[0];
         M_other = rels[0]->nint[other];
         key.lr = std::min(std::min(ctx->lr_max < 0 ? a.D / 2 : ctx->lr_max, bdf_lr_max_observations()), ctx->item_size);
         key.lr_min = std::max<int64_t>(ctx->lr_min_rows, 1);
-        key.lr_other = ctx->lr_min_rows > 0 ? M_other : 0;          // (min_rows = 0, a test hook: whenever a launch has such a row)
+        key.lr_other = ctx->lr_min_rows > 0 ? rels[0]->dims[other] : 0;          // (min_rows = 0, a test hook: whenever the entity has such a row)
     }
 
     Plan *plan;
@@ -1210,8 +1284,18 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
                     rows.push_back(rr);
                 }
             }
+            // the low-rank sampler pays its set-up (the opposite factor transformed, two more launches) only with enough rows:
+            // counted over the WHOLE entity (the host's index is the whole relation's on every rank), so that shards, chunks and
+            // ranks decide alike
+            bool lr_on = false;
+            if (key.lr > 0) {
+                const std::vector<int64_t> &rp = rels[0]->idx[modes[0]].rowptr;
+                int64_t cnt = 0;
+                for (size_t i = 0; i + 1 < rp.size(); i++) cnt += rp[i + 1] - rp[i] <= key.lr;
+                lr_on = cnt >= key.lr_min && 2 * cnt >= key.lr_other;
+            }
             Plan np;
-            int rc = build_plan(ctx, key, rows, psz, np);
+            int rc = build_plan(ctx, key, rows, psz, lr_on, np);
             if (rc) return rc;
             it = cache.plans.emplace(key, np).first;
         }

@@ -102,7 +102,10 @@ int bdf_ctx_sync(bdf_ctx *ctx);   /* waits for the stream; BDF_ERR_NOTPD if a ke
 #define BDF_WARN_CG_MAXITER 64u
 int bdf_ctx_warnings(bdf_ctx *ctx, uint32_t *bits_out);
 /* tuning: observations per K1 work item (rows with more are split over several wavefronts; default 192), and the size
- * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size) */
+ * of the pieces such a row is split into (default 128; set_item_size resets it to 2/3 of the item size).  Until either is set
+ * (and again after set_item_size(ctx, 0)) the sizes are automatic: the defaults, and up to 2048 / 1365 for launches with
+ * hundreds of waves per resident slot, where pieces only cost partial sums.  Results do not depend on them beyond the order
+ * of the floating-point sums. */
 int bdf_ctx_set_item_size(bdf_ctx *ctx, int observations);
 int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
 /* D <= 16, an entity of one two-mode relation: rows of at most max_observations observations are sampled FOUR TO A WAVE (16 lanes

@@ -99,9 +99,10 @@ def _shards_items_map(eng, j, D, rows_checked, mu_is_matrix=False, tol=1e-8):
         ctx.sync()
         return out.cpu().numpy()
 
+    assert np.all(np.isfinite(rows(1)))           # (with the automatic item size)
+    ctx.set_item_size(192)           # (explicit: the comparisons below are between launches of known item sizes)
     a = rows(1)
     assert np.array_equal(a, rows(2)), "union of two shards differs from the unsharded launch"
-    assert np.all(np.isfinite(a))
     ctx.set_item_size(64)
     b = rows(1)
     ctx.set_item_size(192)
