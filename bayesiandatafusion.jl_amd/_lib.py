@@ -51,7 +51,8 @@ c_i32p = C.POINTER(C.c_int32)
 class Term(C.Structure):
     """bdf_term"""
     _fields_ = [("rel", C.c_void_p), ("mode", C.c_int32), ("_pad", C.c_int32), ("alpha", C.c_double),
-                ("mean_value", C.c_double), ("linear_values", C.c_void_p), ("factors", C.c_void_p * BDF_MAX_MODES)]
+                ("mean_value", C.c_double), ("linear_values", C.c_void_p), ("factors", C.c_void_p * BDF_MAX_MODES),
+                ("alpha_dev", C.c_void_p)]
 
 
 BDF_COMM_ID_BYTES = 128
@@ -72,6 +73,15 @@ class GibbsEntity(C.Structure):
                 ("feat", C.c_void_p), ("beta", C.c_void_p), ("uhat", C.c_void_p), ("mu_matrix", C.c_void_p), ("Tinv", C.c_void_p),
                 ("lambda_beta", C.c_void_p), ("cg_iters", C.c_void_p), ("use_ff", C.c_int32), ("sample_lambda_beta", C.c_int32),
                 ("full_lambda_u", C.c_int32), ("_pad", C.c_int32), ("tol", C.c_double), ("lb_nu", C.c_double), ("lb_mu", C.c_double)]
+
+
+class GibbsRelation(C.Structure):
+    """bdf_gibbs_relation"""
+    _fields_ = [("rel", C.c_void_p), ("entity_of_mode", C.c_int32 * BDF_MAX_MODES), ("mean_value", C.c_double), ("alpha_dev", C.c_void_p),
+                ("alpha_sample", C.c_int32), ("rel_tag", C.c_uint32), ("alpha_lambda0", C.c_double), ("alpha_nu0", C.c_double),
+                ("nnz", C.c_int64), ("train", C.c_void_p), ("first_obs", C.c_int64), ("obs_block", C.c_int64), ("feat", C.c_void_p),
+                ("beta", C.c_void_p), ("linear", C.c_void_p), ("lambda_beta", C.c_double), ("feat_test", C.c_void_p),
+                ("test_baseline", C.c_void_p)]
 
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
@@ -115,6 +125,7 @@ _SIGS = {
     "bdf_normals": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_int64, C.c_int64, C.c_int, C.c_void_p]),
     "bdf_philox": (C.c_int, [C.c_void_p, C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32)]),
     "bdf_hyper_sums": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "bdf_hyper_sums_ranks": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_hyper_sample": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p,
                                    C.c_double, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "bdf_hyper_draws": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_double, C.c_uint32, C.c_void_p]),
@@ -175,6 +186,7 @@ _SIGS = {
     "bdf_gibbs_set_test": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_int32), C.c_double, C.c_double, C.c_double, C.c_double,
                                      C.c_void_p]),
     "bdf_gibbs_set_comm": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "bdf_gibbs_set_relations": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
     "bdf_gibbs_sweep": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "bdf_gibbs_current": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "bdf_gibbs_time_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),

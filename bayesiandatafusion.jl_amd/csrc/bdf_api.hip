@@ -647,6 +647,7 @@ static int fill_args(bdf_ctx *ctx, const char *who, int D, int64_t N, int n_term
         if (ctx->gather_mode == 1) T.lean = 0;
         if (ctx->gather_mode == 2 && lean && D > 32) T.lean = 2;
         T.alpha = t.alpha;
+        T.alpha_dev = t.alpha_dev;
         T.mean = t.mean_value;
         if (T.lean == 1 && T.n_other == 1 && ix.packed_dev) { T.packed = ix.packed_dev; T.table = t.rel->table_dev; T.n_codes = t.rel->n_codes; }
     }

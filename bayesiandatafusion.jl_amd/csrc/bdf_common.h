@@ -82,6 +82,10 @@ struct bdf_ctx {
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);
 int bdf_scratch2(bdf_ctx *ctx, size_t bytes, void **out);
+int bdf_sum_ranks_into(bdf_ctx *ctx, bdf_comm *comm, double *x, int64_t n, double *gather);
+int bdf_sample_beta_rel_impl(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *fc, const bdf_pairs *train, int64_t first_obs, int D,
+                             const double *const *factors, double mean_value, double alpha, const double *alpha_dev, double lambda_beta,
+                             uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out);
 #define BDF_DRAWS_BATCH 8
 int bdf_hyper_draws_batch(bdf_ctx *ctx, int D, int n, const int64_t *N, const double *nu, const uint32_t *entity_tag, double *const *draws_out);
 
@@ -323,7 +327,10 @@ struct TermDev {
     const uint32_t *packed;    // nullable: (value code << 24) | other-mode id per observation, with
     const double *table;       // the code -> value table (256 doubles)
     int32_t n_codes, _padc;
+    const double *alpha_dev;   // nullable: the relation's precision in device memory (sampled on the device: sample_alpha inside bdf_gibbs_sweep); else `alpha`
 };
+
+__device__ __forceinline__ double term_alpha(const TermDev &T) { return T.alpha_dev ? *T.alpha_dev : T.alpha; }
 
 struct SampleArgs {
     TermDev t[BDF_MAX_TERMS];

@@ -47,6 +47,8 @@ struct bdf_gibbs {
     uint64_t n_pred;                     // prediction updates enqueued so far
     uint64_t n_iter = 0;                 // iterations enqueued so far (with or without a prediction update)
     bdf_comm *comm;                      // nullable: exchange of the sampled rows between the ranks after every entity
+    std::vector<bdf_gibbs_relation> rels; // relations with a model of their own (alpha sampled, relation features): bdf_gibbs_set_relations
+    double *rel_sse = nullptr;           // dev, 8 doubles: the squared-error statistics of sample_alpha
     // The row stream has NO wait for the hyperprior draws when they run on reserved CUs (bdf_ctx_create_rows): a draw there
     // cannot be starved by the chip-filling row kernel, so the row kernel is enqueued right behind its predecessor (back-to-back
     // row kernels start with no gap; a wait for another stream's event costs the row stream ~10 us even when long satisfied:
@@ -295,6 +297,7 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
     for (int k = 0; k < 3; k++)
         if (g->ev_pred[k]) (void)hipEventDestroy(g->ev_pred[k]);
     if (g->ready_dev) (void)hipFree(g->ready_dev);
+    if (g->rel_sse) (void)hipFree(g->rel_sse);
     if (g->pred) bdf_ctx_destroy(g->pred);
     if (g->hyper) bdf_ctx_destroy(g->hyper);
     delete g;
@@ -329,6 +332,71 @@ extern "C" int bdf_gibbs_set_test(bdf_gibbs *g, bdf_pairs *pairs, const int32_t 
     return BDF_OK;
 }
 
+extern "C" int bdf_gibbs_set_relations(bdf_gibbs *g, int n_relations, const bdf_gibbs_relation *rels)
+{
+    BDF_REQUIRE(g && n_relations >= 0 && (n_relations == 0 || rels), BDF_ERR_ARG, "bdf_gibbs_set_relations: bad argument");
+    for (int k = 0; k < n_relations; k++) {
+        const bdf_gibbs_relation &r = rels[k];
+        BDF_REQUIRE(r.rel && r.alpha_dev, BDF_ERR_ARG, "bdf_gibbs_set_relations: relation %d has no handle or no alpha_dev", k);
+        BDF_REQUIRE(!(r.alpha_sample || r.feat) || r.train, BDF_ERR_ARG, "bdf_gibbs_set_relations: relation %d needs its observations as pairs (train)", k);
+        BDF_REQUIRE(!r.feat || (r.beta && r.linear), BDF_ERR_ARG, "bdf_gibbs_set_relations: relation %d has features but no beta / linear buffer", k);
+        BDF_REQUIRE(!r.feat_test || r.test_baseline, BDF_ERR_ARG, "bdf_gibbs_set_relations: relation %d has test features but no baseline buffer", k);
+        for (int m = 0; m < r.rel->n_modes; m++)
+            BDF_REQUIRE(r.entity_of_mode[m] >= 0 && r.entity_of_mode[m] < (int)g->ent.size(), BDF_ERR_ARG,
+                        "bdf_gibbs_set_relations: relation %d mode %d names entity %d", k, m, r.entity_of_mode[m]);
+    }
+    g->rels.assign(rels, rels + n_relations);
+    if (n_relations > 0 && !g->rel_sse) BDF_HIP(hipMalloc((void **)&g->rel_sse, 8 * sizeof(double)));
+    return BDF_OK;
+}
+
+namespace {
+// the registered relation of a term (by its bdf_rel), or NULL
+const bdf_gibbs_relation *relation_of(const bdf_gibbs *g, const bdf_rel *rel)
+{
+    for (const auto &r : g->rels)
+        if (r.rel == rel) return &r;
+    return nullptr;
+}
+
+// macau.jl:83-92 on the row stream, before the entities' rows
+int update_relations(bdf_gibbs *g)
+{
+    bdf_ctx *R = g->rows;
+    const int D = g->D;
+    int rc;
+    for (const auto &r : g->rels) {
+        if (!r.alpha_sample && !r.feat) continue;
+        const double *fac[BDF_MAX_MODES];
+        for (int m = 0; m < r.rel->n_modes; m++) {
+            const auto &O = g->ent[(size_t)r.entity_of_mode[m]];
+            fac[m] = O.d.sample[O.cur];
+        }
+        if (r.alpha_sample) {
+            // err' err over this rank's block (the pairs carry linear_values as their baseline), summed over the ranks
+            if ((rc = bdf_predict_sse(R, r.train, D, fac, r.mean_value, nullptr, g->rel_sse))) return rc;
+            if (g->comm && (rc = bdf_sum_ranks(R, g->comm, g->rel_sse + 1, 1))) return rc;
+            if ((rc = bdf_sample_alpha(R, r.alpha_lambda0, r.alpha_nu0, r.nnz, g->rel_sse + 1, r.rel_tag, r.alpha_dev))) return rc;
+        }
+        if (r.feat) {
+            if ((rc = bdf_sample_beta_rel_impl(R, g->comm, r.feat, r.train, r.first_obs, D, fac, r.mean_value, 1.0, r.alpha_dev, r.lambda_beta,
+                                               r.rel_tag, r.beta, r.linear + r.first_obs, nullptr)))
+                return rc;
+            if (g->comm) {          // every rank's row kernels read linear_values of their own rows' observations
+                if ((rc = bdf_allgather_block(R, g->comm, r.linear, sizeof(double) * (size_t)r.obs_block)) || (rc = bdf_allgather_join(R, g->comm))) return rc;
+            }
+            if (r.feat_test) {
+                // the test pairs' baseline is read by the prediction stream: its updates so far must have completed
+                for (int k = 0; k < 3; k++)
+                    if (g->n_pred > (uint64_t)k) BDF_HIP(hipStreamWaitEvent(R->stream, g->ev_pred[(g->n_pred - 1 - (uint64_t)k) % 3], 0));
+                if ((rc = bdf_feat_linear(R, r.feat_test, r.beta, r.mean_value, r.test_baseline))) return rc;
+            }
+        }
+    }
+    return BDF_OK;
+}
+}  // namespace
+
 extern "C" int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm)
 {
     BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_set_comm: NULL argument");
@@ -354,6 +422,11 @@ extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
     for (int t = 0; t < e.n_terms; t++) {
         terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
         terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
+        terms[t].alpha_dev = nullptr;
+        if (const bdf_gibbs_relation *gr = relation_of(g, e.terms[t].rel)) {
+            terms[t].alpha_dev = gr->alpha_dev;
+            terms[t].linear_values = gr->feat ? gr->linear : nullptr;
+        }
         for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
         for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
             const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
@@ -407,6 +480,16 @@ extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
             if (e.cg_iters) pieces.push_back({e.cg_iters, (size_t)D * sizeof(int32_t), false, j});
         }
         flags.push_back(E.hyper_recorded ? 1 : 0); flags.push_back(E.beta_recorded ? 1 : 0);
+    }
+    for (const auto &r : g->rels) {         // the relation models: alpha, relation-level beta, linear_values, the test pairs' baseline
+        pieces.push_back({r.alpha_dev, sizeof(double), false, 0});
+        if (r.feat) {
+            int world = 1, rk = 0;
+            if (g->comm) (void)bdf_comm_size(g->comm, &rk, &world);
+            pieces.push_back({r.beta, (size_t)r.feat->n * sizeof(double), false, 0});
+            pieces.push_back({r.linear, (size_t)r.obs_block * (size_t)world * sizeof(double), false, 0});
+            if (r.feat_test) pieces.push_back({r.test_baseline, (size_t)r.feat_test->m * sizeof(double), false, 0});
+        }
     }
     size_t total = 0;
     for (auto &pc : pieces) total += (pc.bytes + 255) & ~(size_t)255;
@@ -523,7 +606,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     static const bool fuse_sums_ = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);
     static const bool one_launch_ = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
     static const bool draws_ahead_ = getenv("BDF_DRAWS_AHEAD") != nullptr;
-    bool draws_in_chain = fuse_sums_ && one_launch_ && !draws_ahead_;
+    bool draws_in_chain = fuse_sums_ && one_launch_ && !draws_ahead_ && !g->comm;      // (several ranks: the sums are not the chain's, bdf_hyper_sums_ranks)
     for (int j = 0; j < n; j++) draws_in_chain = draws_in_chain && g->ent[(size_t)j].d.N <= 16384;
     if (!draws_in_chain && n <= BDF_DRAWS_BATCH) {
         int64_t Ns[BDF_DRAWS_BATCH]; double nus[BDF_DRAWS_BATCH]; uint32_t tags[BDF_DRAWS_BATCH]; double *outs[BDF_DRAWS_BATCH];
@@ -533,6 +616,8 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         }
         if ((rc = bdf_hyper_draws_batch(H, D, n, Ns, nus, tags, outs))) return rc;
     }
+    // the relation models (alpha, relation-level beta and linear_values) with the rows of the previous iteration (macau.jl:83-92)
+    if (!g->rels.empty() && (rc = update_relations(g))) return rc;
     for (int j = 0; j < n; j++) {
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
@@ -549,6 +634,11 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         for (int t = 0; t < e.n_terms; t++) {
             terms[t].rel = e.terms[t].rel; terms[t].mode = e.terms[t].mode; terms[t]._pad = 0;
             terms[t].alpha = e.terms[t].alpha; terms[t].mean_value = e.terms[t].mean_value; terms[t].linear_values = nullptr;
+            terms[t].alpha_dev = nullptr;
+            if (const bdf_gibbs_relation *gr = relation_of(g, e.terms[t].rel)) {        // a relation with a model of its own
+                terms[t].alpha_dev = gr->alpha_dev;
+                terms[t].linear_values = gr->feat ? gr->linear : nullptr;
+            }
             for (int k = 0; k < BDF_MAX_MODES; k++) terms[t].factors[k] = nullptr;
             for (int k = 0; k < e.terms[t].rel->n_modes; k++) {
                 const auto &O = g->ent[(size_t)e.terms[t].entity_of_mode[k]];
@@ -584,7 +674,10 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             if ((rc = bdf_hyper_feature_terms(H, D, e.feat->n, e.beta, e.WI, e.lambda_beta, e.Tinv))) return rc;
             Tinv = e.Tinv;
         }
-        if ((rc = bdf_hyper_sums(H, D, e.N, e.sample[E.cur], e.feat ? e.uhat : nullptr, e.sumU, e.UUt))) return rc;
+        // (several ranks: every rank sums its own rows, the D + D^2 partial sums are added over the ranks in rank order)
+        if ((rc = g->comm ? bdf_hyper_sums_ranks(H, g->comm, D, e.N, nch, e.sample[E.cur], e.feat ? e.uhat : nullptr, e.sumU, e.UUt)
+                          : bdf_hyper_sums(H, D, e.N, e.sample[E.cur], e.feat ? e.uhat : nullptr, e.sumU, e.UUt)))
+            return rc;
         H->hyper_chain_draws = draws_in_chain ? e.draws : nullptr;
         H->time_h_stop = E.ev_hyper;
         H->hyper_ready = g->ready_dev + j;

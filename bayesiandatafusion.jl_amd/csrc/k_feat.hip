@@ -1524,16 +1524,18 @@ extern "C" int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_fea
 
 // ---- relation-level side information (sample_beta_rel, src/sampling.jl:322-337) and alpha (sample_alpha, :129-134) -----
 __global__ void k_rel_target(int64_t N, int64_t first_obs, const double *values, const double *pred, double inv_sqrt_alpha,
-                             uint64_t seed, uint32_t sweep, uint32_t tag, double *v)
+                             const double *alpha_dev, uint64_t seed, uint32_t sweep, uint32_t tag, double *v)
 {
+    if (alpha_dev) inv_sqrt_alpha = 1.0 / sqrt(*alpha_dev);          // (alpha sampled on the device: the same two IEEE operations as the host's)
     // v = (values - udot - mean) + alpha^-1/2 z,  pred = udot + mean; the noise is keyed by the observation's place in the relation
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < N) v[i] = (values[i] - pred[i]) + inv_sqrt_alpha * bdf_normal(seed, sweep, BDF_P_BETA_REL1, tag, (uint64_t)(first_obs + i), 0);
 }
 
-__global__ void k_rel_rhs(int64_t numF, double alpha, double lambda, uint64_t seed, uint32_t sweep, uint32_t tag,
+__global__ void k_rel_rhs(int64_t numF, double alpha, const double *alpha_dev, double lambda, uint64_t seed, uint32_t sweep, uint32_t tag,
                           double *rhs, double *rhs_scaled, double *lam_scaled)
 {
+    if (alpha_dev) alpha = *alpha_dev;
     // aFt_y = alpha F'v + sqrt(lambda) z;  the solve runs on (FF + (lambda / alpha) I) beta = aFt_y / alpha
     const int64_t f = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (f < numF) {
@@ -1603,6 +1605,14 @@ static int sum_ranks_in(bdf_ctx *ctx, bdf_comm *comm, int rank, int world, doubl
     return BDF_OK;
 }
 
+// (internal) the same with the caller's gather buffer (world * n doubles): for callers that hold the context's scratch themselves
+int bdf_sum_ranks_into(bdf_ctx *ctx, bdf_comm *comm, double *x, int64_t n, double *gather)
+{
+    int rank = 0, world = 1, rc;
+    if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
+    return sum_ranks_in(ctx, comm, rank, world, x, n, gather);
+}
+
 extern "C" int bdf_sum_ranks(bdf_ctx *ctx, bdf_comm *comm, double *x, int64_t n)
 {
     BDF_REQUIRE(ctx && x && n >= 0, BDF_ERR_ARG, "bdf_sum_ranks: NULL argument or negative length");
@@ -1626,8 +1636,17 @@ extern "C" int bdf_sample_beta_rel_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf
                                          int64_t first_obs, int D, const double *const *factors, double mean_value, double alpha,
                                          double lambda_beta, uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out)
 {
+    return bdf_sample_beta_rel_impl(ctx, comm, fc, train, first_obs, D, factors, mean_value, alpha, nullptr, lambda_beta, rel_tag, beta_out,
+                                    linear_out, rhs_out);
+}
+
+// (alpha_dev, nullable: the relation's precision in device memory -- sampled there inside bdf_gibbs_sweep -- instead of `alpha`)
+int bdf_sample_beta_rel_impl(bdf_ctx *ctx, bdf_comm *comm, const bdf_feat *fc, const bdf_pairs *train, int64_t first_obs, int D,
+                             const double *const *factors, double mean_value, double alpha, const double *alpha_dev, double lambda_beta,
+                             uint32_t rel_tag, double *beta_out, double *linear_out, double *rhs_out)
+{
     BDF_REQUIRE(ctx && fc && train && factors && beta_out && linear_out, BDF_ERR_ARG, "bdf_sample_beta_rel: NULL argument");
-    BDF_REQUIRE(alpha > 0.0 && lambda_beta >= 0.0, BDF_ERR_ARG, "bdf_sample_beta_rel: alpha must be positive, lambda_beta >= 0");
+    BDF_REQUIRE((alpha_dev || alpha > 0.0) && lambda_beta >= 0.0, BDF_ERR_ARG, "bdf_sample_beta_rel: alpha must be positive, lambda_beta >= 0");
     BDF_REQUIRE(first_obs >= 0, BDF_ERR_ARG, "bdf_sample_beta_rel: first_obs must not be negative");
     int rank = 0, world = 1;
     if (comm) { int rcw = bdf_comm_size(comm, &rank, &world); if (rcw) return rcw; }
@@ -1652,13 +1671,13 @@ extern "C" int bdf_sample_beta_rel_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf
     if ((rc = bdf_predict_plain(ctx, train, D, factors, mean_value, pred))) return rc;
     if (N > 0) {
         hipLaunchKernelGGL(k_rel_target, dim3((unsigned)((N + 255) / 256)), dim3(256), 0, ctx->stream, N, first_obs,
-                           (const double *)train->values_dev, (const double *)pred, 1.0 / sqrt(alpha), ctx->seed,
+                           (const double *)train->values_dev, (const double *)pred, 1.0 / sqrt(alpha), alpha_dev, ctx->seed,
                            ctx->sweep_host, tag, v);
         BDF_HIP(hipGetLastError());
     }
     if ((rc = feat_apply(ctx, f, true, v, 1, N, 1, t, 1, numF))) return rc;
     if ((rc = sum_ranks_in(ctx, comm, rank, world, t, numF, gb))) return rc;
-    hipLaunchKernelGGL(k_rel_rhs, dim3((unsigned)((numF + 255) / 256)), dim3(256), 0, ctx->stream, numF, alpha, lambda_beta,
+    hipLaunchKernelGGL(k_rel_rhs, dim3((unsigned)((numF + 255) / 256)), dim3(256), 0, ctx->stream, numF, alpha, alpha_dev, lambda_beta,
                        ctx->seed, ctx->sweep_host, tag, t, rs, lam);
     BDF_HIP(hipGetLastError());
     if (rhs_out) BDF_HIP(hipMemcpyAsync(rhs_out, t, numF * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));

@@ -219,6 +219,54 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     return BDF_OK;
 }
 
+// Several ranks (the reference sums on the master, src/sampling.jl:117-119): every rank adds the rows IT OWNS -- with
+// the layout of bdf_layout_build chunk c of rank p is the contiguous block of positions [(c P + p) cmax, + cmax) -- and the
+// ranks' D + D^2 partial sums are gathered and added in rank order (bdf_sum_ranks): the same bits on every rank, and the
+// reduction's work shrinks with the number of ranks instead of being repeated over the whole replica on each of them.
+extern "C" int bdf_hyper_sums_ranks(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t N, int chunks, const double *sample, const double *uhat,
+                                    double *sumU, double *UUt)
+{
+    int rank = 0, world = 1, rc;
+    if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
+    if (world <= 1) return bdf_hyper_sums(ctx, D, N, sample, uhat, sumU, UUt);
+    if (ctx) { ctx->hyper_fuse = false; ctx->hyper_partial = nullptr; ctx->hyper_chain = false; }
+    BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums_ranks: NULL argument");
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums_ranks: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    BDF_REQUIRE(chunks >= 1 && N >= 0 && N % ((int64_t)chunks * world) == 0, BDF_ERR_ARG,
+                "bdf_hyper_sums_ranks: %lld rows are not %d chunks x %d ranks x cmax", (long long)N, chunks, world);
+    const int64_t cmax = N / ((int64_t)chunks * world);
+    const int64_t nch = std::max<int64_t>(1, (cmax + HS_ROWS - 1) / HS_ROWS);
+    const int64_t per_chunk_cap = std::max<int64_t>(1, 2048 / chunks);
+    const int64_t rpb = HS_ROWS * ((nch + per_chunk_cap - 1) / per_chunk_cap);
+    const int nb = (int)std::max<int64_t>(1, (cmax + rpb - 1) / rpb);              // workgroups per chunk
+    const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
+    const int psz = DP == 16 ? HGeo<16>::PSZ : (DP == 32 ? HGeo<32>::PSZ : HGeo<64>::PSZ);
+    const size_t pack = (size_t)D + (size_t)D * D;
+    void *scratch;
+    if ((rc = bdf_scratch(ctx, ((size_t)nb * chunks * psz + pack * ((size_t)world + 1)) * sizeof(double), &scratch))) return rc;
+    double *part = (double *)scratch, *mine = part + (size_t)nb * chunks * psz, *gathered = mine + pack;
+    for (int c = 0; c < chunks; c++) {
+        const int64_t r0 = ((int64_t)c * world + rank) * cmax;
+        const double *sp = sample + r0 * D, *up = uhat ? uhat + r0 * D : nullptr;
+        double *pp = part + (size_t)c * nb * psz;
+        hipEvent_t e0 = c == 0 ? ctx->time_h_start : nullptr;
+        if (DP == 16) hipExtLaunchKernelGGL(k_hyper_partial<16>, dim3(nb), dim3(HS_THREADS), 0, ctx->stream, e0, nullptr, 0, D, cmax, rpb, sp, up, pp);
+        else if (DP == 32) hipExtLaunchKernelGGL(k_hyper_partial<32>, dim3(nb), dim3(HS_THREADS), 0, ctx->stream, e0, nullptr, 0, D, cmax, rpb, sp, up, pp);
+        else hipExtLaunchKernelGGL(k_hyper_partial<64>, dim3(nb), dim3(HS_THREADS), 0, ctx->stream, e0, nullptr, 0, D, cmax, rpb, sp, up, pp);
+    }
+    ctx->time_h_start = nullptr;
+    const dim3 fgrid((psz + 15) / 16);
+    if (DP == 16) hipLaunchKernelGGL(k_hyper_final<16>, fgrid, dim3(256), 0, ctx->stream, D, nb * chunks, (const double *)part, mine, mine + D);
+    else if (DP == 32) hipLaunchKernelGGL(k_hyper_final<32>, fgrid, dim3(256), 0, ctx->stream, D, nb * chunks, (const double *)part, mine, mine + D);
+    else hipLaunchKernelGGL(k_hyper_final<64>, fgrid, dim3(256), 0, ctx->stream, D, nb * chunks, (const double *)part, mine, mine + D);
+    BDF_HIP(hipGetLastError());
+    if ((rc = bdf_sum_ranks_into(ctx, comm, mine, (int64_t)pack, gathered))) return rc;
+    BDF_HIP(hipMemcpyAsync(sumU, mine, (size_t)D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    BDF_HIP(hipMemcpyAsync(UUt, mine + D, (size_t)D * D * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+    ctx->hyper_sumU = sumU; ctx->hyper_UUt = UUt;
+    return BDF_OK;
+}
+
 extern "C" int bdf_hyper_draws(bdf_ctx *ctx, int D, int64_t N, double nu, uint32_t entity_tag, double *draws_out)
 {
     BDF_REQUIRE(ctx && draws_out, BDF_ERR_ARG, "bdf_hyper_draws: NULL argument");

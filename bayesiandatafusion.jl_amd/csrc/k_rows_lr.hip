@@ -188,6 +188,7 @@ struct LrArgs {
     const double *mt;           // L' mu
     double *out;
     double alpha, mean;
+    const double *alpha_dev;    // nullable: the precision in device memory (else `alpha`)
     uint64_t seed;
     uint32_t sweep, entity_tag;
     int32_t D, _pad;
@@ -208,6 +209,7 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
     const int j = lane & 15, h = lane >> 4;
     const LrItem it = items[w];
     const int D = a.D, n = it.count;
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
 
     // ---- the row's D + n normals, one Philox block and one Box-Muller pair per lane, through LDS (the packed factor's space)
     // (which numbers of the stream are u_d and delta_a: lr_u_index / lr_delta_index below -- the assignment follows the lanes of
@@ -280,9 +282,9 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
     for (int r = 0; r < 4; r++) {
         const int m = h + 4 * r;
         const double id = (m == j) ? 1.0 : 0.0;
-        A[r] = (m < n && j < n) ? fma(a.alpha, acc[r], id) : id;
+        A[r] = (m < n && j < n) ? fma(alpha, acc[r], id) : id;
     }
-    bv[0] = (j < n) ? rv - g - dl * fast_rsqrt(a.alpha) : 0.0;
+    bv[0] = (j < n) ? rv - g - dl * fast_rsqrt(alpha) : 0.0;
     ts[0] = 0.0;
     const int Ds = n > 1 ? n : 1;
     wave_sync();                                       // the normals have been read: the space is the packed factor's now
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
         for (int k = 0; k < 4; k++) s = fma(wv[k][I], t4[k], s);
         s += __shfl_xor(s, 16);
         s += __shfl_xor(s, 32);
-        const double v = fma(a.alpha, s, e0[I]);
+        const double v = fma(alpha, s, e0[I]);
         qv = (h == I) ? v : qv;
     }
     const int e = 16 * h + j;
@@ -394,6 +396,7 @@ __device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, cons
     constexpr int DB = DP / 16, NR = DP / 32;
     const bool live = it.row >= 0;
     const int D = a.D, n = live ? it.count : 0;
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
     uint32_t idw = (uint32_t)a.zero_row;
     double rv = 0.0;
     if (j < n) {
@@ -429,9 +432,9 @@ __device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, cons
 #pragma unroll
     for (int i = 0; i < DR; i++) {
         const double id = (i == j) ? 1.0 : 0.0;
-        A[i] = (i < n && j < n) ? fma(a.alpha, A[i], id) : id;
+        A[i] = (i < n && j < n) ? fma(alpha, A[i], id) : id;
     }
-    double rho = (j < n) ? rv - gacc - dl * fast_rsqrt(a.alpha) : 0.0;
+    double rho = (j < n) ? rv - gacc - dl * fast_rsqrt(alpha) : 0.0;
     double dj = 1.0;
     small_factor<DR, 0>(A, rho, dj, j);
     if (j < n && !(dj > 0.0)) atomicOr(a.flag, 1);
@@ -447,7 +450,7 @@ __device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, cons
     if (live) {
 #pragma unroll
         for (int k = 0; k < DB; k++)
-            if (16 * k + j < D) a.out[(int64_t)it.row * D + 16 * k + j] = fma(a.alpha, q[k], e0[k]);
+            if (16 * k + j < D) a.out[(int64_t)it.row * D + 16 * k + j] = fma(alpha, q[k], e0[k]);
     }
 }
 
@@ -500,7 +503,7 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
     }
     LrArgs la;
     la.colidx = a.t[0].colidx; la.vals = a.t[0].vals; la.vt = ctx->lr_vt; la.zero_row = M_other; la.mt = mt; la.out = a.out;
-    la.alpha = a.t[0].alpha; la.mean = a.t[0].mean; la.seed = a.seed; la.sweep = a.sweep; la.entity_tag = a.entity_tag;
+    la.alpha = a.t[0].alpha; la.alpha_dev = a.t[0].alpha_dev; la.mean = a.t[0].mean; la.seed = a.seed; la.sweep = a.sweep; la.entity_tag = a.entity_tag;
     la.D = D; la._pad = 0; la.flag = a.flag;
     static const bool wave_per_row = getenv("BDF_LR_WAVE") != nullptr;        // the wave-per-row kernel instead (rows of at most 15 observations)
     if (wave_per_row)

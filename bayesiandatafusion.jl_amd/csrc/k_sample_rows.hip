@@ -196,11 +196,12 @@ __device__ __forceinline__ void accumulate_reg(const SampleArgs &a, const Item &
 #undef LOAD_IDX
 #undef LOAD_DATA
     // scale by alpha; reduce b over the four observation groups (lanes j, j+16, j+32, j+48)
+    const double alpha = term_alpha(T);
 #pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+    for (int b = 0; b < NB; b++) acc[b] *= alpha;
 #pragma unroll
     for (int I = 0; I < DB; I++) {
-        double v = bpart[I] * T.alpha;
+        double v = bpart[I] * alpha;
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         bred[I] = v;
@@ -335,11 +336,12 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
 #undef LOAD_DATA
 #undef TRIP
 #undef OBS
+    const double alpha = term_alpha(T);
 #pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+    for (int b = 0; b < NB; b++) acc[b] *= alpha;
 #pragma unroll
     for (int I = 0; I < DB; I++) {
-        double v = bpart[I] * T.alpha;
+        double v = bpart[I] * alpha;
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         bred[I] = v;
@@ -434,11 +436,12 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
 #undef LOAD_DATA
 #undef TRIP
 #undef OBS
+    const double alpha = term_alpha(T);
 #pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] *= T.alpha;
+    for (int b = 0; b < NB; b++) acc[b] *= alpha;
 #pragma unroll
     for (int I = 0; I < DB; I++) {
-        double v = bpart[I] * T.alpha;
+        double v = bpart[I] * alpha;
         v += __shfl_xor(v, 16);
         v += __shfl_xor(v, 32);
         bred[I] = v;
@@ -882,7 +885,7 @@ __global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs
     }
     // prior: the image of the index-reversed Lambda is in k_rows' accumulator layout -- element (i, j) of a one-block system
     // sits at [(i / 4) * 64 + (i % 4) * 16 + j]; read past the caches when the draw was polled for (as k_rows does)
-    const double alpha = T.alpha;
+    const double alpha = term_alpha(T);
     if (a.ready) {
         int spins = 0;
         while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {

@@ -544,10 +544,10 @@ class GibbsEngine:
         self.full_lambda_u = bool(full_lambda_u)
         self.tol = float(tol)
         self.compute_ff_size = compute_ff_size
-        rel_feat = any(not feat.isempty(r.F) for r in data.relations)
-        # the whole iteration in one native call (entity side information included) unless something needs the step-by-step
-        # path: relation-level side information, alpha sampling
-        self.native = not rel_feat and not any(r.model.alpha_sample for r in data.relations) and not os.environ.get("BDF_NO_NATIVE")
+        # the whole iteration in one native call: entity side information, the relation models (alpha sampled, relation-level
+        # side information: bdf_gibbs_set_relations) and the exchange between ranks included.  BDF_NO_NATIVE: enqueued step by
+        # step from here instead (the same entry points, the same values)
+        self.native = not os.environ.get("BDF_NO_NATIVE")
         # ---- row layouts (several ranks): degree of a row = its observations over all the entity's relations
         if chunks is None:
             chunks = int(os.environ.get("BDF_CHUNKS", "0"))
@@ -613,7 +613,7 @@ class GibbsEngine:
                 dr.train = self._pairs(self.ctx, r, np.asarray(r.data.ids)[dr.obs_lo:dr.obs_hi], np.asarray(r.data.values)[dr.obs_lo:dr.obs_hi])
                 if dr.F is not None:         # pred(r) = udot + linear_values on the training table (sampling.jl:16-18)
                     check(lib().bdf_pairs_set_baseline(dr.train.handle, C.c_void_p(dr.linear.data_ptr() + 8 * dr.obs_lo)))
-            dr.alpha_dev = self.ctx.zeros(1)
+            dr.alpha_dev = self.ctx.tensor([float(r.model.alpha)])
         self._test_pairs = None
         self._train_pairs = None
         self._test_opts = None
@@ -673,6 +673,33 @@ class GibbsEngine:
         if self.world > 1:
             self.comm = make_comm(self.ctx, self.rank, self.world)
             check(lib().bdf_gibbs_set_comm(self.gibbs, self.comm.handle))
+        self._register_relations()
+
+    def _register_relations(self):
+        """(native iteration) the relations with a model of their own -- alpha sampled, relation-level side information: the
+        library runs sample_alpha / sample_beta_rel / linear_values before the rows of every iteration (macau.jl:83-92)"""
+        if not self.gibbs:
+            return
+        from ._lib import GibbsRelation
+        rows = [(ri, r, self.rel[ri]) for ri, r in enumerate(self.data.relations) if r.model.alpha_sample or self.rel[ri].F is not None]
+        arr = (GibbsRelation * max(len(rows), 1))()
+        for k, (ri, r, dr) in enumerate(rows):
+            g = arr[k]
+            g.rel = dr.handle
+            for m, e2 in enumerate(r.entities):
+                g.entity_of_mode[m] = self._entity_index(e2)
+            g.mean_value = r.model.mean_value
+            g.alpha_dev = dr.alpha_dev.data_ptr()
+            g.alpha_sample, g.rel_tag = int(bool(r.model.alpha_sample)), ri + 1
+            g.alpha_lambda0, g.alpha_nu0, g.nnz = r.model.alpha_lambda0, r.model.alpha_nu0, r.data.nnz()
+            g.train = dr.train.handle
+            g.first_obs, g.obs_block = dr.obs_lo, dr.obs_block
+            if dr.F is not None:
+                g.feat, g.beta, g.linear, g.lambda_beta = dr.F.handle, dr.beta.data_ptr(), dr.linear.data_ptr(), r.model.lambda_beta
+                if ri == 0 and getattr(dr, "F_test", None) is not None:
+                    g.feat_test, g.test_baseline = dr.F_test.handle, dr.test_baseline.data_ptr()
+        self._gibbs_relations = arr            # (the library copies the records; the tensors they point at live in self.rel)
+        check(lib().bdf_gibbs_set_relations(self.gibbs, len(rows), C.cast(arr, C.c_void_p)))
 
     def warm_device(self, milliseconds=50.0):
         """set-up (native iteration): bring the device to its working state before the first iteration
@@ -718,6 +745,7 @@ class GibbsEngine:
             terms[t].alpha = r.model.alpha
             terms[t].mean_value = r.model.mean_value
             terms[t].linear_values = self.rel[ri].linear.data_ptr() if self.rel[ri].linear is not None else None
+            terms[t].alpha_dev = self.rel[ri].alpha_dev.data_ptr() if (self.native and r.model.alpha_sample) else None
             for k, e2 in enumerate(r.entities):
                 terms[t].factors[k] = self.ent[self._entity_index(e2)].sample.data_ptr()
         return terms
@@ -796,8 +824,12 @@ class GibbsEngine:
         L = lib()
         h = self.ctx_h.handle
         draws = st.draws if (sweep is not None and st.draws_sweep == sweep) else None
-        check(L.bdf_hyper_sums(h, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
-                               _ptr(st.sumU), _ptr(st.UUt)))
+        if self.comm is not None and self.world > 1:      # own rows, then the ranks' partial sums added in rank order
+            check(L.bdf_hyper_sums_ranks(h, self.comm.handle, self.D, st.N, st.layout.chunks, _ptr(st.sample),
+                                         _ptr(st.uhat) if st.F is not None else None, _ptr(st.sumU), _ptr(st.UUt)))
+        else:
+            check(L.bdf_hyper_sums(h, self.D, st.N, _ptr(st.sample), _ptr(st.uhat) if st.F is not None else None,
+                                   _ptr(st.sumU), _ptr(st.UUt)))
         nu, Tinv = st.nu0, st.WI
         if st.F is not None and self.full_lambda_u:
             nu += st.numF
@@ -825,6 +857,8 @@ class GibbsEngine:
         for r, dr in zip(self.data.relations, self.rel):
             if dr.F is not None:
                 r.model.beta = dr.beta.cpu().numpy().copy()
+            if r.model.alpha_sample and self.native:       # (step by step the host reads it every iteration)
+                r.model.alpha = float(dr.alpha_dev.item())
 
     # ---- one Gibbs iteration (the timed unit of bench.py) ------------------------------------------------------
     def step(self, i, phase, clamp=(), class_cut=0.0):
@@ -967,6 +1001,7 @@ class GibbsEngine:
                 dr.F_test = FeatOperator(self.ctx, r.test_F if subset is None else _take_rows(r.test_F, np.asarray(subset)))
                 dr.test_baseline = self.ctx.zeros(self._test_pairs.n)
                 check(lib().bdf_pairs_set_baseline(self._test_pairs.handle, _ptr(dr.test_baseline)))
+                self._register_relations()          # (native iteration: the library refreshes the baseline after every relation beta)
         return self._test_pairs
 
     def refresh_baselines(self):

@@ -168,6 +168,7 @@ typedef struct {
     double mean_value;            /* rel.model.mean_value                                    */
     const double *linear_values;  /* dev, nullable: rel.temp.linear_values in COO order      */
     const double *factors[BDF_MAX_MODES]; /* dev: D x N_k sample of every mode of rel; [mode] ignored */
+    const double *alpha_dev;      /* dev, nullable: rel.model.alpha in device memory (sampled there, bdf_sample_alpha): read instead of `alpha` */
 } bdf_term;
 
 /* sample_latent_all2! (src/sampling.jl:149-172) and sample_user2_all! (:251-264):
@@ -212,6 +213,11 @@ int bdf_philox(bdf_ctx *ctx, uint32_t purpose, uint32_t entity_tag, uint64_t row
  * deterministic summation order. */
 int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *sample, const double *uhat,
                    double *sumU, double *UUt);
+/* Several ranks: the sums over the rows THIS rank owns (chunk c of rank p: positions [(c world + p) cmax, + cmax) of the
+ * N = chunks x world x cmax rows, bdf_layout_build) and the ranks' D + D^2 partial sums gathered and added in rank order: the
+ * same bits on every rank (src/sampling.jl:117-119 on the master).  comm NULL or one rank: bdf_hyper_sums. */
+int bdf_hyper_sums_ranks(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t N, int chunks, const double *sample, const double *uhat,
+                         double *sumU, double *UUt);
 /* ConditionalNormalWishart + rand(::NormalWishart): draws (mu, Lambda) on the device from the sums.
  * mu0 (dev D), Tinv (dev D x D), b0, nu: the hyper-prior AFTER the feature terms of macau.jl:124-129.
  * params_out (dev, nullable): mu_N (D) followed by inv(T_N) (D x D, the matrix sampling.jl:124 inverts)
@@ -424,6 +430,32 @@ int bdf_ctx_stream(const bdf_ctx *ctx, void **stream);
  * the other arguments as bdf_predict_update's */
 int bdf_gibbs_set_test(bdf_gibbs *g, bdf_pairs *pairs, const int32_t *entity_of_mode, double mean_value, double clamp_lo,
                        double clamp_hi, double class_cut, double *stats_dev);
+/* The relation model inside the native iteration (src/macau.jl:83-92): for every relation registered here bdf_gibbs_sweep runs,
+ * BEFORE the entities' rows and on the row stream, sample_alpha (src/sampling.jl:129-134) when alpha_sample is set -- the squared
+ * error over `train` (this rank's block of the relation's observations as pairs, with linear_values as their baseline when the
+ * relation has features), summed over the ranks, the draw into alpha_dev -- and sample_beta_rel + linear_values
+ * (src/sampling.jl:322-337, macau.jl:89-92) when `feat` is set; the row kernels of the relation's entities then read alpha_dev
+ * and `linear` (terms are matched to relations by their bdf_rel).  feat_test / test_baseline: the registered test pairs'
+ * baseline mean_value + F_test beta is refreshed after the draw (sampling.jl:9-14).  Relations without either need no entry. */
+typedef struct {
+    const bdf_rel *rel;
+    int32_t entity_of_mode[BDF_MAX_MODES];   /* which entity (index into bdf_gibbs_create's array) every mode of rel is          */
+    double mean_value;
+    double *alpha_dev;            /* dev, 1 double: the current alpha (initialised by the caller)                              */
+    int32_t alpha_sample;
+    uint32_t rel_tag;             /* 1-based relation number: keys the random streams (0x800000 | rel_tag)                      */
+    double alpha_lambda0, alpha_nu0;
+    int64_t nnz;                  /* observations of the whole relation (n of sample_alpha)                                     */
+    bdf_pairs *train;             /* this rank's block of the observations (COO order) as pairs                                */
+    int64_t first_obs, obs_block; /* its first observation; observations per rank block (linear is world x obs_block long)     */
+    const bdf_feat *feat;         /* nullable: the block's rows of the relation's feature matrix                               */
+    double *beta;                 /* dev, numF                                                                                  */
+    double *linear;               /* dev, linear_values of the whole relation                                                   */
+    double lambda_beta;
+    const bdf_feat *feat_test;    /* nullable: feature rows of the registered test pairs ...                                    */
+    double *test_baseline;        /* ... and their baseline (dev, one double per test pair)                                     */
+} bdf_gibbs_relation;
+int bdf_gibbs_set_relations(bdf_gibbs *g, int n_relations, const bdf_gibbs_relation *rels);
 /* several ranks: exchange every entity's rows after sampling them (NULL: none) */
 int bdf_gibbs_set_comm(bdf_gibbs *g, bdf_comm *comm);
 /* one iteration.  predict_phase: bdf_predict_update's phase (0 burn-in, 1 first posterior sample, 2 later ones), -1: none */

@@ -125,6 +125,7 @@ struct Term
     mean_value::Float64
     linear_values::Ptr{Cvoid}
     factors::NTuple{4,Ptr{Cvoid}}
+    alpha_dev::Ptr{Cvoid}             # C_NULL, or rel.model.alpha in device memory (sampled there: sample_alpha inside sweep!)
 end
 
 """
@@ -363,6 +364,120 @@ function sample_beta_rel!(c::Context, m::Comm, f::Ptr{Cvoid}, train::DevPairs, f
                 c.h, m.h, f, train.h, first_obs, D, fp, mean_value, alpha, lambda_beta, rel_tag, beta.p, linear_values.p + 8 * first_obs, C_NULL))
     check(ccall((:bdf_allgather_block, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, m.h, linear_values.p, 8 * block))
     allgather_join!(c, m)
+end
+
+# ---- IndexedDF index, launch order, value mean (a1; src/IndexedDF.jl:10-21, 26, 41-43) ----------------------------------------
+"IndexedDF.index on the host, without a device: per mode (rowptr[dims[m]+1] 0-based offsets, rowids[nnz] 1-based COO row numbers)"
+function index_build(ids::Matrix{Int64}, dims::Vector{Int64})
+    nnz, nm = size(ids)
+    rp = [zeros(Int64, d + 1) for d in dims]; ri = [zeros(Int64, max(nnz, 1)) for _ in dims]
+    rpp = Ptr{Int64}[pointer(x) for x in rp]; rip = Ptr{Int64}[pointer(x) for x in ri]
+    GC.@preserve rp ri check(ccall((:bdf_index_build, lib), Cint, (Cint, Ptr{Int64}, Int64, Ptr{Cvoid}, Cint, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}),
+                                   nm, dims, nnz, ids, 8, rpp, rip))
+    return [(rp[m], ri[m][1:nnz]) for m in 1:nm]
+end
+"the device relation's own index of `mode` (1-based mode): getData / getCount / getI (IndexedDF.jl:41-43, 67-70)"
+function relation_index(r::DevRelation, mode::Integer, dim::Integer, nnz::Integer)
+    rp = Ref{Ptr{Int64}}(C_NULL); ri = Ref{Ptr{Int64}}(C_NULL)
+    check(ccall((:bdf_relation_index, lib), Cint, (Ptr{Cvoid}, Cint, Ref{Ptr{Int64}}, Ref{Ptr{Int64}}), r.h, mode - 1, rp, ri))
+    return copy(unsafe_wrap(Array, rp[], dim + 1)), copy(unsafe_wrap(Array, ri[], nnz))
+end
+function relation_value_mean(r::DevRelation)            # valueMean (IndexedDF.jl:26)
+    m = Ref{Float64}(0.0)
+    check(ccall((:bdf_relation_value_mean, lib), Cint, (Ptr{Cvoid}, Ref{Float64}), r.h, m))
+    return m[]
+end
+"rows of `mode` (1-based) by falling number of observations: the order the row kernel deals its shards from (sampling.jl:154)"
+function relation_order(r::DevRelation, mode::Integer, dim::Integer)
+    o = zeros(Int32, dim)
+    check(ccall((:bdf_relation_order, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Int32}), r.h, mode - 1, o))
+    return o .+ Int32(1)
+end
+
+# ---- Block / sample_users_blocked (src/sampling.jl:236-249) ---------------------------------------------------------------
+"the users of a Block share one covariance: vx (device Int32, 0-based item ids), Yma (device nv x nu), factor (device D x M) -> out (device D x nu)"
+sample_block!(c::Context, D, nu, nv, vx::DevArray{Int32}, Yma::DevArray{Float64}, factor::DevArray{Float64}, alpha, mu::DevArray{Float64},
+              Lambda::DevArray{Float64}, entity_tag, out::DevArray{Float64}) =
+    check(ccall((:bdf_sample_block, lib), Cint,
+                (Ptr{Cvoid}, Cint, Int64, Int64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}, Ptr{Cvoid}, UInt32, Ptr{Cvoid}),
+                c.h, D, nu, nv, vx.p, Yma.p, factor.p, alpha, mu.p, Lambda.p, entity_tag, out.p))
+
+# ---- prediction (src/sampling.jl:9-45) --------------------------------------------------------------------------------------
+"pred(r, probe_vec): udot over the pairs + mean_value (or the pairs' baseline, set_baseline!) -> out (device, one double per pair)"
+function predict!(c::Context, p::DevPairs, D, factors::Vector{<:DevArray}, mean_value, out::DevArray{Float64})
+    fp = Ptr{Cvoid}[f.p for f in factors]
+    check(ccall((:bdf_predict, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Ptr{Cvoid}), c.h, p.h, D, fp, mean_value, out.p))
+end
+"per-pair baseline replacing mean_value: mean_value + F_test beta of pred(r, probe_vec, F) (sampling.jl:9-14); `nothing` clears it"
+set_baseline!(p::DevPairs, baseline) =
+    check(ccall((:bdf_pairs_set_baseline, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), p.h, baseline === nothing ? C_NULL : baseline.p))
+"out = mean_value + F beta: linear_values (macau.jl:91) and the test rows' baseline"
+feat_linear!(c::Context, f::Ptr{Cvoid}, beta::DevArray{Float64}, mean_value, out::DevArray{Float64}) =
+    check(ccall((:bdf_feat_linear, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Float64, Ptr{Cvoid}), c.h, f, beta.p, mean_value, out.p))
+"store the pairs sorted by their id in `mode` (1-based): halves the gather traffic of the updates; results stay in the caller's order"
+pairs_sort!(p::DevPairs, mode::Integer) = check(ccall((:bdf_pairs_sort, lib), Cint, (Ptr{Cvoid}, Cint), p.h, mode - 1))
+"storage position -> the caller's index (1-based) after pairs_sort!"
+function pairs_order(p::DevPairs)
+    o = zeros(Int64, p.n)
+    check(ccall((:bdf_pairs_order, lib), Cint, (Ptr{Cvoid}, Ptr{Int64}), p.h, o))
+    return o .+ 1
+end
+"running posterior mean and sum of squares of the pairs (macau.jl:171-183, 235-241), in STORAGE order (pairs_order)"
+function pairs_state(c::Context, p::DevPairs)
+    a = Ref{Ptr{Cvoid}}(C_NULL); q = Ref{Ptr{Cvoid}}(C_NULL); n = Ref{Int64}(0)
+    check(ccall((:bdf_pairs_state, lib), Cint, (Ptr{Cvoid}, Ref{Ptr{Cvoid}}, Ref{Ptr{Cvoid}}, Ref{Int64}), p.h, a, q, n))
+    avg = zeros(n[]); sq = zeros(n[])
+    if n[] > 0
+        check(ccall((:bdf_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, avg, a[], 8 * n[]))
+        check(ccall((:bdf_d2h, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, sq, q[], 8 * n[]))
+    end
+    return avg, sq
+end
+
+# ---- feature operators on several ranks; the hyperprior's sums over the ranks ----------------------------------------------
+"original id (0-based) of every row of F: rows moved to an entity's internal positions keep their noise streams (several GPUs)"
+feat_set_row_ids!(f::Ptr{Cvoid}, row_ids::Vector{Int32}) = check(ccall((:bdf_feat_set_row_ids, lib), Cint, (Ptr{Cvoid}, Ptr{Int32}), f, row_ids))
+function feat_size(f::Ptr{Cvoid})
+    m = Ref{Int64}(0); n = Ref{Int64}(0); z = Ref{Int64}(0)
+    check(ccall((:bdf_feat_size, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}, Ref{Int64}), f, m, n, z))
+    return m[], n[], z[]
+end
+"sum_i U_i and U U' over the rows this rank owns, the ranks' partial sums added in rank order (src/sampling.jl:117-119 on the master)"
+hyper_sums!(c::Context, m::Comm, D, N, chunks, sample::DevArray, uhat, sumU::DevArray, UUt::DevArray) =
+    check(ccall((:bdf_hyper_sums_ranks, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Cint, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                c.h, m.h, D, N, chunks, sample.p, uhat === nothing ? C_NULL : uhat.p, sumU.p, UUt.p))
+"the data-independent part of the hyperprior draw (Bartlett matrix, mean normals), ahead of the rows: D*D + D doubles"
+hyper_draws!(c::Context, D, N, nu, entity_tag, draws::DevArray{Float64}) =
+    check(ccall((:bdf_hyper_draws, lib), Cint, (Ptr{Cvoid}, Cint, Int64, Float64, UInt32, Ptr{Cvoid}), c.h, D, N, nu, entity_tag, draws.p))
+prior_pack_doubles(D::Integer) = Int(ccall((:bdf_prior_pack_doubles, lib), Cint, (Cint,), D))
+
+# ---- the relation model inside the native iteration (src/macau.jl:83-92; bdf_gibbs_set_relations) ----------------------------
+struct GibbsRelation                              # bdf_gibbs_relation, field for field
+    rel::Ptr{Cvoid}
+    entity_of_mode::NTuple{4,Int32}
+    mean_value::Float64
+    alpha_dev::Ptr{Cvoid}
+    alpha_sample::Int32
+    rel_tag::UInt32
+    alpha_lambda0::Float64
+    alpha_nu0::Float64
+    nnz::Int64
+    train::Ptr{Cvoid}
+    first_obs::Int64
+    obs_block::Int64
+    feat::Ptr{Cvoid}
+    beta::Ptr{Cvoid}
+    linear::Ptr{Cvoid}
+    lambda_beta::Float64
+    feat_test::Ptr{Cvoid}
+    test_baseline::Ptr{Cvoid}
+end
+"register the relations whose alpha is sampled and / or that carry features: sweep! then runs sample_alpha, sample_beta_rel and
+linear_values before the rows of every iteration; `keep`: what the records point into"
+function set_relations!(g::Gibbs, rels::Vector{GibbsRelation}; keep::Vector=Any[])
+    check(ccall((:bdf_gibbs_set_relations, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{GibbsRelation}), g.h, length(rels), rels))
+    append!(g.keep, keep)
+    nothing
 end
 
 end # module

@@ -315,6 +315,41 @@ def test_native_iteration_with_side_information_equals_step_by_step(B, monkeypat
         assert np.array_equal(n1[1], n0[1]) and np.array_equal(n1[2], n0[2]) and n1[3] == n0[3] and np.array_equal(n1[4], n0[4])
 
 
+def test_native_relation_model_equals_step_by_step(B, monkeypatch):
+    """the relation model inside bdf_gibbs_sweep (macau.jl:83-92: sample_alpha, sample_beta_rel, linear_values before the rows;
+    the test pairs' baseline mean + F_test beta refreshed for the prediction update) gives bit for bit the chain of the
+    iteration enqueued step by step from the host -- alpha alone, relation features alone, both"""
+    import pandas as pd
+    rng = np.random.default_rng(3)
+    A, Bm = rng.standard_normal((30, 2)), rng.standard_normal((40, 2))
+    ii, jj = np.meshgrid(np.arange(1, 31), np.arange(1, 41), indexing="ij")
+    feat = rng.standard_normal((1200, 2))
+    v = (A @ Bm.T).ravel() + feat @ np.array([1.0, -1.0]) + 0.1 * rng.standard_normal(1200)
+
+    def run(alpha_sample, with_feat):
+        rd = B.RelationData(pd.DataFrame({"A": ii.ravel(), "B": jj.ravel(), "v": v}))
+        r = rd.relations[0]
+        r.model.alpha_sample = alpha_sample
+        if with_feat:
+            r.F = feat
+        B.assignToTest(r, 10, rng=np.random.default_rng(1))
+        res = B.macau(rd, burnin=6, psamples=5, num_latent=3, verbose=False, seed=9)
+        return (rd._engine.native, rd.entities[0].model.sample.copy(), rd.entities[1].model.sample.copy(), float(r.model.alpha),
+                None if not with_feat else np.asarray(r.model.beta).copy(), res["RMSE"], np.asarray(res["predictions"]["pred"]).copy())
+
+    for alpha_sample, with_feat in ((True, False), (False, True), (True, True)):
+        n1 = run(alpha_sample, with_feat)
+        monkeypatch.setenv("BDF_NO_NATIVE", "1")
+        n0 = run(alpha_sample, with_feat)
+        monkeypatch.delenv("BDF_NO_NATIVE")
+        assert n1[0] is True and n0[0] is False
+        assert np.array_equal(n1[1], n0[1]) and np.array_equal(n1[2], n0[2]), (alpha_sample, with_feat)
+        assert n1[3] == n0[3] and (not alpha_sample or n1[3] != 5.0)
+        if with_feat:
+            assert np.array_equal(n1[4], n0[4])
+        assert n1[5] == n0[5] and np.array_equal(n1[6], n0[6])
+
+
 def test_argument_errors(B):
     Y = _sprand(15, 10, 0.3, 1)
     rd = B.RelationData(Y)
@@ -359,6 +394,7 @@ def test_alpha_sampling(B):
     rd = B.RelationData(Y, class_cut=0.5, alpha_sample=True)
     B.assignToTest(rd.relations[0], 2, rng=np.random.default_rng(0))
     B.macau(rd, burnin=5, psamples=6, verbose=False)
+    assert rd._engine.native               # sample_alpha runs inside the native iteration
     assert rd.relations[0].model.alpha > 0 and rd.relations[0].model.alpha != 1.0
 
 
@@ -379,6 +415,7 @@ def test_relation_features(B):
     B.assignToTest(rd.relations[0], 10, rng=np.random.default_rng(1))
     assert rd.relations[0].test_F.shape == (10, 2)
     result = B.macau(rd, burnin=50, psamples=10, num_latent=2, verbose=False)
+    assert rd._engine.native               # sample_alpha, sample_beta_rel and linear_values run inside the native iteration
     # the model is exact (rank 2 + linear features): the relation beta is recovered and the held-out cells are predicted
     np.testing.assert_allclose(rd.relations[0].model.beta, beta, atol=0.1)
     assert result["RMSE"] < 0.3

@@ -426,3 +426,46 @@ def test_feature_rows_subset_keeps_kind_and_content(B):
     denseb = np.zeros((4, 5))
     denseb[subb.rows - 1, subb.cols - 1] = 1.0
     assert (subb.m, subb.n) == (4, 5) and np.array_equal(denseb, (A[2:6] != 0).astype(float))
+
+
+def test_julia_binding_covers_every_product_export():
+    """julia/BDFHip.jl (the ccall layer a BayesianDataFusion.jl maintainer would add; no Julia in this image, so it is checked
+    as text): every entry point include/bdf.h declares is bound, except the ones listed here as diagnostics / test hooks /
+    host-language plumbing a Julia host has no use for; and the structs it mirrors have the C structs' fields in order."""
+    import re
+    h = open(os.path.join(ROOT, "include", "bdf.h")).read()
+    jl = open(os.path.join(ROOT, "julia", "BDFHip.jl")).read()
+    exports = sorted(set(re.findall(r"\b(bdf_[a-z0-9_]+)\s*\(", h)))
+    not_needed = {
+        "bdf_version", "bdf_ctx_stream", "bdf_ctx_advance_sweep",                                   # plumbing
+        "bdf_comm_create_host", "bdf_comm_size",                                                     # the one-GPU test rig's transport
+        "bdf_ctx_set_gather", "bdf_row_system", "bdf_normals", "bdf_philox", "bdf_rows_unfinished",  # parity hooks
+        "bdf_event_create", "bdf_event_destroy", "bdf_event_elapsed_us", "bdf_ctx_time_next_rows", "bdf_ctx_time_next_hyper",
+        "bdf_gibbs_time_rows", "bdf_gibbs_rows_only", "bdf_gibbs_contexts", "bdf_gibbs_recorded", "bdf_gibbs_set_recorded",   # measurement
+        "bdf_synth_ratings",                                                                         # the bench's generator
+    }
+    unbound = [n for n in exports if (":" + n) not in jl and n not in not_needed]
+    assert not unbound, unbound
+    assert not [n for n in not_needed if n not in exports], "stale names in the exemption list"
+
+    def c_fields(name):
+        end = h.index("} " + name + ";")
+        body = h[h.rindex("typedef struct {", 0, end) + len("typedef struct {"):end]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        body = re.sub(r"struct \{.*?\} (\w+)\[[^\]]*\];", r"X \1;", body, flags=re.S)
+        out = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if decl:
+                for v in decl.split(","):
+                    out.append(re.sub(r"\[.*", "", v.strip().split()[-1].lstrip("*")))
+        return out
+
+    def jl_fields(name):
+        body = re.search(r"struct " + name + r"\b(.*?)\nend", jl, re.S).group(1)
+        body = re.sub(r"#.*", "", body)
+        return [f.split("::")[0].strip() for f in re.split(r"[;\n]", body) if "::" in f]
+
+    assert jl_fields("Term") == c_fields("bdf_term")
+    assert jl_fields("GibbsRelation") == c_fields("bdf_gibbs_relation")
+    assert jl_fields("GibbsEntity") == c_fields("bdf_gibbs_entity")

@@ -41,14 +41,14 @@ B.assignToTest(rel, 600, rng=np.random.default_rng(2))
 rd = B.RelationData(rel)
 sweeps = int(os.environ.get("RELFEAT_SWEEPS", "12"))
 eng = B.GibbsEngine(rd, D, seed=9, shard=(rank, world), chunks=int(os.environ.get("RELFEAT_CHUNKS", "0")))
-assert not eng.native
+assert eng.native or os.environ.get("BDF_NO_NATIVE")       # the relation model runs inside the native iteration
 n_test = len(rel.test_vec.values)
 mine = np.arange(n_test * rank // world, n_test * (rank + 1) // world)
 test = eng.test_pairs(subset=mine if world > 1 else None)
 alphas = []
 for i in range(1, 2 * sweeps + 1):
     eng.step(i, 0 if i <= sweeps else (1 if i == sweeps + 1 else 2), [], rel.class_cut)
-    alphas.append(rel.model.alpha)
+    alphas.append(float(eng.rel[0].alpha_dev.item()))
 eng.sync()
 sse = test.stats[:1].clone().cpu()
 if dist is not None:
