@@ -623,7 +623,11 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         const bdf_gibbs_entity &e = E.d;
         // (mu, Lambda) of the previous iteration: an event wait, or -- draws on reserved CUs -- the row kernel polls for it
         // (with side information the prior mean is a matrix, computed here from mu: nothing to poll for)
-        const bool poll = g->polling && !g->comm && E.hyper_recorded && !e.feat;
+        // (several ranks: event waits unless BDF_POLL_WITH_COMM is set -- the draws of an iteration depend on nothing the rows of
+        // the next one produce, so polling cannot deadlock with the exchange's kernels either, but that schedule has only run
+        // with a one-rank RCCL communicator: tools/soak_determinism.py rccl)
+        static const bool poll_with_comm = getenv("BDF_POLL_WITH_COMM") != nullptr;
+        const bool poll = g->polling && (!g->comm || poll_with_comm) && E.hyper_recorded && !e.feat;
         if (E.hyper_recorded && !poll) BDF_HIP(hipStreamWaitEvent(R->stream, E.ev_hyper, 0));
         // side information: uhat = (F beta)' with the beta of the previous iteration, per-row prior means mu + uhat (macau.jl:103-104)
         if (e.feat && (rc = bdf_uhat(R, e.feat, D, e.beta, e.mu, e.uhat, e.mu_matrix))) return rc;

@@ -670,7 +670,9 @@ class GibbsEngine:
         check(lib().bdf_gibbs_contexts(self.gibbs, C.byref(h), C.byref(p)))
         self.ctx_h = Context.wrap(h, self.ctx.device, self.ctx.seed)
         self.ctx_p = Context.wrap(p, self.ctx.device, self.ctx.seed)
-        if self.world > 1:
+        if self.world > 1 or os.environ.get("BDF_FORCE_COMM"):
+            # (BDF_FORCE_COMM: a ONE-rank communicator all the same -- the exchange's kernels then run between the row launches
+            # of a single-GPU run: the soak of the schedule with RCCL on the device, tools/soak_determinism.py rccl)
             self.comm = make_comm(self.ctx, self.rank, self.world)
             check(lib().bdf_gibbs_set_comm(self.gibbs, self.comm.handle))
         self._register_relations()

@@ -547,12 +547,19 @@ def test_two_ranks_match_one_with_four_rows_per_wave():
         assert abs(out["two"]["c4"]["test_rmse"] - out[name]["c4"]["test_rmse"]) < 1e-4, (name, out["two"]["c4"], out[name]["c4"])
 
 
-def test_stream_schedule_soak(B):
-    """two runs of 1,500 sweeps of the bench workload (three streams, rows rotating through three buffers, gate hand-overs,
-    prediction updates beside the rows) end bit-identical and leave no split row unfinished -- tools/soak_determinism.py runs
-    20,000"""
+@pytest.mark.parametrize("mode", ["plain", "rccl"])
+def test_stream_schedule_soak(B, mode):
+    """two runs of 1,500 sweeps of the bench workload (three streams, rows rotating through three buffers, the row kernels
+    polling for the hyperprior draws, prediction updates beside the rows) end bit-identical and leave no split row unfinished --
+    tools/soak_determinism.py runs 20,000.  rccl: the same with a ONE-rank RCCL communicator in the iteration -- ncclAllGather
+    kernels on the device between the row launches, the row kernels still polling (BDF_POLL_WITH_COMM) -- twice, and equal to
+    the run without a communicator; no spin bound hit (flag 16 would raise at the next synchronisation)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_determinism.py"), "1500"], capture_output=True, text=True, timeout=600)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "BDF_DIST_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "soak_determinism.py"), "1500"] + (["rccl"] if mode == "rccl" else []),
+                       env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0 and "bit-identical: True" in r.stdout and "unfinished=0" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+    if mode == "rccl":
+        assert r.stdout.count("communicator=RCCL") == 2 and "communicator=None" in r.stdout, r.stdout[-1500:]
