@@ -160,6 +160,7 @@ struct bdf_feat {
     double *eig_s;        // n eigenvalues (dev)
     double *eig_y;        // n x D workspace (dev), eig_y_cols columns
     int eig_y_cols;
+    bool eig_failed;      // the decomposition's QL iteration did not converge: this operator takes the factorisation (bdf_chol_solve) instead
     bool FF_summed;       // several ranks, F split by rows (bdf_sample_beta_rel_ranks): FF_dev already holds the sum over the ranks
 };
 #define BDF_EIG_MAX 640

@@ -444,10 +444,15 @@ extern "C" int bdf_gibbs_rows_only(bdf_gibbs *g, int entity, uint32_t sweep)
     return BDF_OK;
 }
 
-// set-up: bring the device to its working state (clocks, power gating: a row launch right after idle time runs ~10 % slower
-// than the same launch 30 ms into sustained work) with untimed row launches that do NOT advance the chain -- every entity's
-// row kernel in turn, as bdf_gibbs_sweep makes it, written into the entity's NEXT buffer (which the next real iteration
-// overwrites in full) without rotating the buffers, random streams of iteration numbers no real iteration uses.
+// set-up: bring the device to its working state (clocks, power gating: an iteration right after idle time runs ~10 % slower than
+// the same iteration 30 ms into sustained work, and what ran before matters as much as how long: DESIGN.md section 6) with FULL
+// iterations whose results are discarded -- rows of every entity, exchanges, hyperprior chains, beta, the relation models, the
+// prediction kernel without running state -- under iteration numbers no real iteration uses.  The chain's state (every entity's
+// current sample, (mu, Lambda), sums, prior pack, draws, beta, uhat, per-row prior means, lambda_beta, the relations' alpha, beta
+// and linear_values, the prediction statistics, the "a draw / beta of an earlier iteration exists" flags) is saved first and put
+// back bit for bit afterwards; the buffers have rotated (bdf_gibbs_current).  One rank: iterations for `milliseconds`.  Several
+// ranks: every rank must make the same number of exchanges -- the first batch of eight is timed, every rank derives a count from
+// its own time, and the ranks agree on the mean of the counts (bdf_sum_ranks).
 extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
 {
     BDF_REQUIRE(g && milliseconds >= 0.0 && milliseconds <= 10000.0, BDF_ERR_ARG, "bdf_gibbs_warm_device: bad argument");
@@ -481,6 +486,7 @@ extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
         }
         flags.push_back(E.hyper_recorded ? 1 : 0); flags.push_back(E.beta_recorded ? 1 : 0);
     }
+    if (g->stats_dev) pieces.push_back({g->stats_dev, 4 * sizeof(double), false, 0});       // the prediction statistics of the last real update
     for (const auto &r : g->rels) {         // the relation models: alpha, relation-level beta, linear_values, the test pairs' baseline
         pieces.push_back({r.alpha_dev, sizeof(double), false, 0});
         if (r.feat) {
@@ -505,12 +511,30 @@ extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
     // full iterations with numbers no real iteration uses; the prediction kernel without running state.  One rank: for the
     // time asked for; several ranks: a fixed count (every rank must make the same number of exchanges)
     const uint32_t keep = R->sweep_host;
-    const int64_t fixed = g->comm ? std::max<int64_t>(1, (int64_t)(milliseconds / 0.1)) : 0;
+    int64_t fixed = 0;                  // several ranks: the iteration count they agreed on (0: not yet known / one rank)
     const auto t0 = std::chrono::steady_clock::now();
     int64_t k = 0;
     rc = BDF_OK;
     while (!rc) {
         for (int b = 0; b < 8 && !rc; b++, k++) rc = bdf_gibbs_sweep(g, 0xfffe0000u + (uint32_t)(k & 0xffff), g->test ? 3 : -1);
+        if (rc) break;
+        if (g->comm && fixed == 0) {
+            // the first batch, timed to its end on this rank; the ranks' counts summed in rank order: the same number everywhere
+            if ((rc = bdf_gibbs_sync(g))) break;
+            const double per_iter = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / 8.0;
+            const double mine = std::max(8.0, std::min(20000.0, milliseconds / std::max(per_iter, 1e-3)));
+            int rank = 0, world = 1;
+            if ((rc = bdf_comm_size(g->comm, &rank, &world))) break;
+            void *sv;
+            if ((rc = bdf_scratch(R, ((size_t)world + 1) * sizeof(double), &sv))) break;
+            double *cnt = (double *)sv;
+            BDF_HIP(hipMemcpyAsync(cnt, &mine, sizeof(double), hipMemcpyHostToDevice, R->stream));
+            if ((rc = bdf_sum_ranks_into(R, g->comm, cnt, 1, cnt + 1))) break;
+            double sum = 0.0;
+            BDF_HIP(hipMemcpyAsync(&sum, cnt, sizeof(double), hipMemcpyDeviceToHost, R->stream));
+            BDF_HIP(hipStreamSynchronize(R->stream));
+            fixed = std::max<int64_t>(8, (int64_t)(sum / (double)world + 0.5));
+        }
         if (fixed ? k >= fixed : std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() >= milliseconds) break;
     }
     const int rc_sync = bdf_gibbs_sync(g);

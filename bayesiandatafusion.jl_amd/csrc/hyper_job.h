@@ -249,7 +249,7 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
         const typename GG::ColRT cr = GG::col_rt(lane < DP ? lane : 0);
         double dv = 1.0;
         if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];
-        if (!(dv > 0.0)) atomicOr(a.flag, 2);
+        if (!(dv > 0.0)) atomicOr_system(a.flag, 2);
         dv_out = dv;
         return cr;
     };

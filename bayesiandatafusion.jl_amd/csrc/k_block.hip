@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_block_factor(int D, int64_t nv, const in
         const typename GG::ColRT cr = GG::col_rt(lane);
         double dv = 1.0;
         if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];
-        if (!(dv > 0.0)) { atomicOr(flag, 1); dv = 1.0; }
+        if (!(dv > 0.0)) { atomicOr_system(flag, 1); dv = 1.0; }
         piv_out[lane] = dv;
         piv_out[DP + lane] = fast_rcp(dv);
         piv_out[2 * DP + lane] = dv * fast_rsqrt(dv);

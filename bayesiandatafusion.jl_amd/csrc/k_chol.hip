@@ -86,7 +86,7 @@ __global__ __launch_bounds__(64) void k_chol_diag(CholWork w, int k, int *flag)
     const int c = lane;
     const typename GG::ColRT cr = GG::col_rt(c);
     double dv = tri[cr.cbase + (c & 3) * cr.nr4];
-    if (!(dv > 0.0)) { atomicOr(flag, 8); dv = 1.0; }
+    if (!(dv > 0.0)) { atomicOr_system(flag, 8); dv = 1.0; }
     const double rs = fast_rsqrt(dv);
     for (int i = 0; i < CB; i++) {
         double v = 0.0;

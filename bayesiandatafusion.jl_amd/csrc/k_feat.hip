@@ -475,7 +475,7 @@ __global__ __launch_bounds__(64) void k_noise_prep(int D, const double *Lambda, 
         col[i] = w;
     }
     double p_own, rp_own;
-    if (wl_factor<DP, true>(col, p_own, rp_own, tri, lane) && lane == 0) atomicOr(flag, 4);
+    if (wl_factor<DP, true>(col, p_own, rp_own, tri, lane) && lane == 0) atomicOr_system(flag, 4);
     if (lane < DP) {
 #pragma unroll
         for (int k = 0; k < DP; k++) Lr[c * DP + k] = col[k];
@@ -681,7 +681,7 @@ __global__ __launch_bounds__(1024) void k_cg_step(CgState s, const double *lambd
     __threadfence_block();
     __syncthreads();
     if (iter < maxiter) cg_pre(s, iter + 1, red, go);
-    else if (threadIdx.x == 0 && s.active[blockIdx.x] && s.iters[blockIdx.x] == iter) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
+    else if (threadIdx.x == 0 && s.active[blockIdx.x] && s.iters[blockIdx.x] == iter) atomicOr_system(s.flag, (int)BDF_WARN_CG_MAXITER);
     // the last column to finish reports (iteration, active columns) to the host, which enqueues ahead of the device and
     // stops when it reads 0 active columns: no stream synchronisation inside the solve
     __syncthreads();
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void k_cg_step_short(CgState s, const double *
             bknum = fma(r[e], r[e], bknum);
         }
         bool proceed = false;
-        if (iter >= maxiter && tid == 0) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
+        if (iter >= maxiter && tid == 0) atomicOr_system(s.flag, (int)BDF_WARN_CG_MAXITER);
         if (iter < maxiter) {                              // top of iteration iter + 1 (cg_pre)
             bknum = block_sum(bknum, red);
             if (tid == 0) {
@@ -845,7 +845,7 @@ __global__ __launch_bounds__(256) void k_cg_long_c(CgState s, CgChunks c, int it
 {
     if (*s.nactive == 0) return;                          // (a) has reported
     const int d = blockIdx.x, g = blockIdx.y;
-    if (s.active[d] && s.iters[d] == iter && iter >= maxiter && g == 0 && threadIdx.x == 0) atomicOr(s.flag, (int)BDF_WARN_CG_MAXITER);
+    if (s.active[d] && s.iters[d] == iter && iter >= maxiter && g == 0 && threadIdx.x == 0) atomicOr_system(s.flag, (int)BDF_WARN_CG_MAXITER);
     if (s.active[d] && s.iters[d] == iter && iter < maxiter) {      // top of iteration iter + 1 (cg_pre)
         double rr = 0.0;
         for (int q = 0; q < c.G; q++) rr += c.partB[d * c.G + q];
@@ -929,7 +929,7 @@ __global__ __launch_bounds__(64) void k_solve_small(int n, int ncol, const doubl
         rowm[i] = w;
     }
     double p_own, rp_own;
-    if (wl_factor<DP, true>(rowm, p_own, rp_own, tri, lane) && lane == 0) atomicOr(flag, 8);
+    if (wl_factor<DP, true>(rowm, p_own, rp_own, tri, lane) && lane == 0) atomicOr_system(flag, 8);
     for (int q = 0; q < ncol; q++) {
         double b = (lane < DP && c < n) ? rhs[c + (int64_t)q * n] : 0.0;
         b = wl_forward<DP>(rowm, b, rp_own, lane);       // b' = wh p;  yh = w sqrt(p) = b'
@@ -1237,8 +1237,10 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
 namespace {
 
 // symmetric A (n x n, column-major, both triangles) -> eigenvalues d (ascending), eigenvectors in the columns of V
-void eig_sym_host(int n, const double *A, std::vector<double> &d, std::vector<double> &V)
+// returns false if the QL iteration did not converge for some eigenvalue within 200 sweeps (the caller then takes the factorisation)
+bool eig_sym_host(int n, const double *A, std::vector<double> &d, std::vector<double> &V)
 {
+    bool converged = true;
     V.assign(A, A + (size_t)n * n);
     d.assign((size_t)n, 0.0);
     std::vector<double> e((size_t)n, 0.0);
@@ -1339,17 +1341,23 @@ void eig_sym_host(int n, const double *A, std::vector<double> &d, std::vector<do
                 e[l] = s * p;
                 d[l] = c * p;
             } while (fabs(e[l]) > eps * tst1 && iter < 200);
+            if (fabs(e[l]) > eps * tst1) converged = false;
         }
         d[l] += f;
         e[l] = 0.0;
     }
+    return converged;
 }
 
-__global__ void k_eig_scale(int64_t n, int D, const double *s, const double *lambda_p, double *Y)      // Y(i, c) /= s_i + lambda
+__global__ void k_eig_scale(int64_t n, int D, const double *s, const double *lambda_p, double *Y, int *flag)      // Y(i, c) /= s_i + lambda
 {
     const double lambda = *lambda_p;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < n * D) Y[t] = Y[t] / (s[t % n] + lambda);
+    if (t < n * D) {
+        const double den = s[t % n] + lambda;          // (s >= 0: clamped when the decomposition was made)
+        if (!(den > 0.0) && t < n) atomicOr_system(flag, 8);      // F'F + lambda I not positive definite (what the Cholesky path reports); the flag is host memory
+        Y[t] = Y[t] / den;
+    }
 }
 
 int ensure_eig(bdf_feat *f, int D)
@@ -1364,7 +1372,8 @@ int ensure_eig(bdf_feat *f, int D)
         BDF_HIP(hipMemcpy(A.data(), f->FF_dev, A.size() * sizeof(double), hipMemcpyDeviceToHost));
         for (int64_t j = 0; j < n; j++)          // exactly symmetric input (the product's two triangles agree to rounding only)
             for (int64_t i = j + 1; i < n; i++) A[(size_t)i + (size_t)j * n] = A[(size_t)j + (size_t)i * n];
-        eig_sym_host((int)n, A.data(), s, Q);
+        if (!eig_sym_host((int)n, A.data(), s, Q)) { f->eig_failed = true; return BDF_OK; }      // (the caller falls back to bdf_chol_solve)
+        for (double &x : s) x = std::max(x, 0.0);       // F'F is positive semi-definite: an eigenvalue below zero is rounding
         bdf_feat *q = new bdf_feat();
         q->ctx = ctx; q->kind = 0; q->m = n; q->n = n; q->nnz = n * n;
         if (hipMalloc((void **)&q->dense_dev, Q.size() * sizeof(double)) != hipSuccess ||
@@ -1392,9 +1401,12 @@ int eig_solve(bdf_ctx *ctx, bdf_feat *f, int D, const double *lambda_dev, const 
 {
     const int64_t n = f->n;
     int rc;
+    if (f->eig_failed) return bdf_chol_solve(ctx, f, D, lambda_dev, rhs, beta_out);
     if ((rc = ensure_eig(f, D))) return rc;
+    if (f->eig_failed) return bdf_chol_solve(ctx, f, D, lambda_dev, rhs, beta_out);        // the QL iteration did not converge: factor instead
     if ((rc = feat_apply(ctx, f->eig_Q, true, rhs, 1, n, D, f->eig_y, 1, n))) return rc;              // Y = Q' rhs
-    hipLaunchKernelGGL(k_eig_scale, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, ctx->stream, n, D, (const double *)f->eig_s, lambda_dev, f->eig_y);
+    hipLaunchKernelGGL(k_eig_scale, dim3((unsigned)((n * D + 255) / 256)), dim3(256), 0, ctx->stream, n, D, (const double *)f->eig_s, lambda_dev, f->eig_y,
+                       ctx->flag_dev);
     BDF_HIP(hipGetLastError());
     return feat_apply(ctx, f->eig_Q, false, f->eig_y, 1, n, D, beta_out, 1, n);                       // beta = Q Y
 }

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
         int spins = 0;
         while (__hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(c.nblocks + c.ndraw)) {
             __builtin_amdgcn_s_sleep(4);
-            if (++spins > (1 << 24)) { atomicOr(a.flag, 16); break; }       // bounded: a bug must not hang the device
+            if (++spins > (1 << 24)) { atomicOr_system(a.flag, 16); break; }       // bounded: a bug must not hang the device
         }
         __hip_atomic_store(c.count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);       // ready for the next launch
     }

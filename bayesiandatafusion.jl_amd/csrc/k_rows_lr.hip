@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, con
         int spins = 0;
         while ((int32_t)(__hip_atomic_load(ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - ready_want) < 0) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 22)) { if (threadIdx.x == 0) atomicOr(flag, 16); break; }
+            if (++spins > (1 << 22)) { if (threadIdx.x == 0) atomicOr_system(flag, 16); break; }
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, con
             for (int m = k + 1; m <= c; m++) sA[c * LDL + m] = fma(-lck, sA[m * LDL + k], sA[c * LDL + m]);
         wave_sync();
     }
-    if (bad && c == 0) atomicOr(flag, 1);
+    if (bad && c == 0) atomicOr_system(flag, 1);
     // L^-1 by columns: lane c solves L x = e_c (x_i = 0 above the diagonal); its entries sit in row c of the upper triangle
     if (c < D) {
         const double xd = 1.0 / sA[c * LDL + c];
@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
     wave_sync();
     double dv = 1.0, tv = 0.0;
     if (lane < Ds) { dv = tri[cr.cbase + (lane & 3) * cr.nr4]; tv = ts[0]; }
-    if (!(dv > 0.0)) atomicOr(a.flag, 1);
+    if (!(dv > 0.0)) atomicOr_system(a.flag, 1);
     const double rdv = fast_rcp(dv);
     double yh = tv;
     unsigned colq[4];
@@ -437,7 +437,7 @@ __device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, cons
     double rho = (j < n) ? rv - gacc - dl * fast_rsqrt(alpha) : 0.0;
     double dj = 1.0;
     small_factor<DR, 0>(A, rho, dj, j);
-    if (j < n && !(dj > 0.0)) atomicOr(a.flag, 1);
+    if (j < n && !(dj > 0.0)) atomicOr_system(a.flag, 1);
     const double rdj = fast_rcp(dj);
     double tau = rho * rdj;
     small_backward<DR - 1>(A, tau, rdj, j);

@@ -621,7 +621,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
             if (seen >= sr.n_slots) break;
             __builtin_amdgcn_s_sleep(8);
         }
-        if (seen < sr.n_slots && lane == 0) atomicOr(a.flag, 16);
+        if (seen < sr.n_slots && lane == 0) atomicOr_system(a.flag, 16);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
         if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
@@ -686,7 +686,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
 #endif
         while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 22)) { if (lane == 0) atomicOr(a.flag, 16); break; }      // bounded: ~seconds
+            if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }      // bounded: ~seconds
         }
         SPAN_WAIT(t_poll);
 #pragma unroll
@@ -762,7 +762,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     wave_sync();
     double dv = 1.0, tv = 0.0;
     if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];      // the diagonal entry is the first of its row class
-    if (!(dv > 0.0)) atomicOr(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
+    if (!(dv > 0.0)) atomicOr_system(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
 #pragma unroll
     for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? ts[J] : tv;
     const double rdv = fast_rcp(dv);
@@ -890,7 +890,7 @@ __global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs
         int spins = 0;
         while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
             __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 22)) { if (lane == 0) atomicOr(a.flag, 16); break; }
+            if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }
         }
 #pragma unroll
         for (int i = 0; i < DR; i++)
@@ -907,7 +907,7 @@ __global__ __launch_bounds__(256, BDF_SMALL_BLOCKS) void k_rows_small(SampleArgs
     if (!jok) b = 0.0;
     double dj = 1.0;
     small_factor<DR, 0>(A, b, dj, j);
-    if (live && jok && !(dj > 0.0)) atomicOr(a.flag, 1);
+    if (live && jok && !(dj > 0.0)) atomicOr_system(a.flag, 1);
     const double rdj = fast_rcp(dj);
     double y = fma(z, fast_rsqrt(dj), b * rdj);
     small_backward<DR - 1>(A, y, rdj, j);

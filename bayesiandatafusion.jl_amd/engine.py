@@ -733,6 +733,26 @@ class GibbsEngine:
             b += r.data.nnz() * ((4 + 8 * D) * (len(r.entities) - 1) + 8)
         return b
 
+    def lowrank_rows(self, j):
+        """rows of entity j the library draws with the low-rank sampler (k_rows_lr.hip) instead of the reference's map: the rule
+        of bdf_launch_sample_rows restated for reports -- D > 16, one two-mode relation, no side information on the entity or
+        the relation, rows of at most min(16, D / 2) observations (BDF_LOWRANK), at least 8,192 of them (BDF_LOWRANK_MIN_ROWS)
+        and at least half as many as the opposite entity has rows"""
+        en, st, D = self.data.entities[j], self.ent[j], self.D
+        lr = int(os.environ.get("BDF_LOWRANK", "-1"))
+        lr = min(16, D // 2) if lr < 0 else min(lr, 16)
+        if D <= 16 or lr == 0 or len(en.relations) != 1 or len(en.relations[0].entities) != 2 or st.F is not None:
+            return 0
+        r = en.relations[0]
+        ri = [x is r for x in self.data.relations].index(True)
+        if self.rel[ri].F is not None:
+            return 0
+        m = [e is en for e in r.entities].index(True)
+        deg = np.bincount(np.asarray(r.data.ids[:, m], dtype=np.int64) - 1, minlength=en.count)
+        cnt = int((deg <= lr).sum())
+        min_rows = int(os.environ.get("BDF_LOWRANK_MIN_ROWS", "8192"))
+        return cnt if (cnt >= max(min_rows, 1) and 2 * cnt >= r.data.dims[1 - m]) else 0
+
     # ---- helpers ----------------------------------------------------------------------------------------
     def _entity_index(self, en):
         return [e is en for e in self.data.entities].index(True)
@@ -1062,22 +1082,36 @@ class Comm:
         self._cb = None
         self.transport = "RCCL (ncclAllGather in place, librccl resolved by the library)"
         if dist.get_backend() == "nccl":
+            # every rank must end up on the same transport.  First the LOCAL preconditions of the library's own communicator --
+            # librccl resolvable (bdf_comm_unique_id loads it and asks it for an id) -- agreed on over torch's process group
+            # BEFORE any rank enters ncclCommInitRank: a rank that failed here alone would otherwise skip the collective
+            # initialisation the others then block in
+            err = ""
+            raw0 = (C.c_char * _lib.BDF_COMM_ID_BYTES)()
+            try:
+                if os.environ.get("BDF_COMM_FORCE_STAGED"):
+                    raise _lib.HipError("BDF_COMM_FORCE_STAGED is set")
+                check(lib().bdf_comm_unique_id(raw0))
+            except Exception as e:          # noqa: BLE001 -- agreed on below, then reported
+                err = f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctx.device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            pre_ok = int(ok.item()) == 1
             buf = torch.zeros(_lib.BDF_COMM_ID_BYTES, dtype=torch.uint8)
-            if rank == 0:
-                raw = (C.c_char * _lib.BDF_COMM_ID_BYTES)()
-                check(lib().bdf_comm_unique_id(raw))
-                buf = torch.frombuffer(bytearray(raw.raw), dtype=torch.uint8).clone()
+            if rank == 0 and pre_ok:
+                buf = torch.frombuffer(bytearray(raw0.raw), dtype=torch.uint8).clone()
             dev = buf.to(ctx.device)
             dist.broadcast(dev, src=0)
             raw = bytes(dev.cpu().numpy().tobytes())
             # every rank must end up on the same transport: the outcome of the library's own communicator is agreed on over
             # torch's process group; if any rank could not create it, all of them exchange through torch.distributed instead
             # (the library's host transport: staged through host memory -- slower, and said so in `transport`)
-            err = ""
+            # ... then the collective initialisation itself (every rank enters it, or none does), its outcome agreed on again
             try:
-                if os.environ.get("BDF_COMM_FORCE_STAGED"):
-                    raise _lib.HipError("BDF_COMM_FORCE_STAGED is set")
-                check(lib().bdf_comm_create(ctx.handle, rank, world, raw, C.byref(self.handle)))
+                if pre_ok:
+                    check(lib().bdf_comm_create(ctx.handle, rank, world, raw, C.byref(self.handle)))
+                elif not err:
+                    err = "another rank cannot load librccl"
             except Exception as e:          # noqa: BLE001 -- agreed on below, then reported
                 err = f"{type(e).__name__}: {e}"
             ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctx.device)

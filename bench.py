@@ -222,7 +222,9 @@ def mref_block(B, device, cpu):
         dt = (time.perf_counter() - t0) / 2
         bytes_sweep = sum(eng.k1_algorithmic_bytes(j) for j in (0, 1))
         blk = {"ms_per_sweep": round(1e3 * dt, 3), "sweeps_per_s": round(1.0 / dt, 2), "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
-               "algorithmic_tb_per_s": round(bytes_sweep / dt / 1e12, 3)}
+               "algorithmic_tb_per_s": round(bytes_sweep / dt / 1e12, 3),
+               # rows drawn by the low-rank sampler (same conditional distribution as the reference's map, other values: DESIGN 4)
+               "lowrank_rows": [eng.lowrank_rows(j) for j in (0, 1)]}
         train_ids, train_vals = np.asarray(rel.data.ids), np.asarray(rel.data.values, dtype=np.float64)
         eng.close()
         if cpu:
@@ -363,13 +365,10 @@ def main():
         # `python bench.py --gpus N` as typed: start the N ranks ourselves -- one process per GPU through torch's launcher, as
         # a CHILD process (nothing in this process has touched the GPU runtime yet, and nothing will) -- and relay its output
         # and exit code.  The form `python -m torch.distributed.run ... bench.py --gpus N` keeps working: it sets WORLD_SIZE.
-        import socket
+        # (--standalone: the launcher's own rendezvous on a port IT binds -- no port picked here and released before use)
         import subprocess
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+               "--nproc-per-node", str(args.gpus), os.path.abspath(__file__)] + sys.argv[1:]
         raise SystemExit(subprocess.call(cmd))
 
     rank = int(os.environ.get("RANK", "0"))
@@ -435,6 +434,27 @@ def main():
     replicas = args.replicas if args.replicas > 0 else world
     rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5, replicas=replicas)
     rel = rd.relations[0]
+    # continuity with the rounds before the set-up warm-up existed: the same --warmup + --steps on a throw-away
+    # engine WITHOUT it, first thing in the process -- a cold device, as those rounds' driver lines were measured
+    value_cold = None
+    if world == 1 and args.device_warmup_ms > 0 and not os.environ.get("BDF_BENCH_NO_COLD"):
+        eng0 = B.GibbsEngine(rd, D, seed=args.seed, device=local_rank)
+        eng0.test_pairs()
+        eng0.register_test([1.0, 5.0], rel.class_cut)
+        for i in range(1, args.warmup + 1):
+            eng0.step(i, 0, [1.0, 5.0], rel.class_cut)
+        eng0.sync()
+        t0c = time.perf_counter()
+        for k in range(args.steps):
+            eng0.step(args.warmup + 1 + k, 1 if k == 0 else 2, [1.0, 5.0], rel.class_cut)
+        eng0.sync()
+        value_cold = args.steps / (time.perf_counter() - t0c)
+        eng0.close()
+        del eng0
+        from bdf_amd.relation_data import EntityModel
+        for en in rd.entities:              # (the model the throw-away engine attached to the entities: the real one makes its own)
+            en.model = EntityModel()
+
     eng = B.GibbsEngine(rd, D, seed=args.seed, device=local_rank, shard=(rank, world))
     n_test_total = len(np.asarray(rel.test_vec.values))
     test = eng.test_pairs(subset=my_share(n_test_total) if world > 1 else None)
@@ -529,7 +549,10 @@ def main():
             "dtype": "f64",
             "data": source,
             "config": {"workload": f"BPMF MovieLens-1M 6040x3952, 500209 training ratings (500000 held out), D={D}, alpha=1.5, "
-                                   f"step = rows of both entities + hyperpriors + test prediction update (one native call)"
+                                   f"step = rows of both entities + hyperpriors + test prediction update (one native call); "
+                                   f"BEFORE the --warmup steps the engine's set-up runs {args.device_warmup_ms:g} ms of full "
+                                   f"iterations whose results are discarded (device_warmup_ms; the value without it: "
+                                   f"value_without_device_warmup)"
                                    + (f"; {replicas} such units: the ratings stacked over {replicas} disjoint user blocks, "
                                       f"value = {replicas} x sweeps/s" if replicas > 1 else ""),
                        "num_latent": D, "burnin": args.warmup, "psamples": args.steps, "units_per_sweep": replicas,
@@ -541,6 +564,7 @@ def main():
                                        f"transport: {eng.comm.transport if eng.comm is not None else 'none'}")
                        if world > 1 else "1 GPU"},
             "test_rmse": None if rmse is None else round(rmse, 5),
+            "value_without_device_warmup": None if value_cold is None else round(value_cold, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
                          "kernel": "k_rows (k_sample_rows.hip)", "launches_timed": n_launch,
@@ -596,6 +620,7 @@ def main():
                        "noise_floor": 0.5774,
                        "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
                        "algorithmic_tb_per_s": round(bytes_sweep / (el4 / args.c4_sweeps) / 1e12, 3),
+                       "lowrank_rows": [eng4.lowrank_rows(j) for j in range(2)],
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
             eng4.close()

@@ -469,3 +469,30 @@ def test_julia_binding_covers_every_product_export():
     assert jl_fields("Term") == c_fields("bdf_term")
     assert jl_fields("GibbsRelation") == c_fields("bdf_gibbs_relation")
     assert jl_fields("GibbsEntity") == c_fields("bdf_gibbs_entity")
+
+
+def test_no_dpp_read_inside_a_hazard_window():
+    """the row kernels' DPP instructions are inline assembly (the compiler's hazard recogniser does not look inside) and runs of
+    them drop the `s_nop` on the strength of "the source was written long before": the build leaves the device assembly of
+    those translation units in csrc/*.s and tools/dpp_hazard_check.py walks it -- no vector (2 wait states) or matrix (18)
+    instruction may write a DPP source inside its window.  ~18,000 DPP instructions."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("dpp_hazard_check", os.path.join(ROOT, "tools", "dpp_hazard_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc", "*.s")))
+    assert {os.path.basename(f) for f in files} >= {"k_sample_rows.s", "k_rows_lr.s", "k_hyper.s", "k_block.s"}, "build with __graft_entry__.build() (make)"
+    total = 0
+    for f in files:
+        bad, n = mod.check(f)
+        assert not bad, bad[:5]
+        total += n
+    assert total > 10000
+    # and the checker does see a hazard when there is one
+    import tempfile
+    with tempfile.NamedTemporaryFile("w", suffix=".s", delete=False) as t:
+        t.write("f:\n\tv_add_f64 v[2:3], v[4:5], v[6:7]\n\tv_fmac_f64_dpp v[8:9], v[2:3], v[10:11] row_newbcast:1 row_mask:0xf bank_mask:0xf\n")
+    bad, n = mod.check(t.name)
+    os.unlink(t.name)
+    assert n == 1 and len(bad) == 1
