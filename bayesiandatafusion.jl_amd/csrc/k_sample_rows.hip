@@ -356,10 +356,11 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
 // rows (and values) of trips t + 1 and t + 2 are in flight while trip t multiplies.  The loads complete in order, so the ids of a
 // trip are fetched two trips before its rows are (four before it multiplies): waiting for them then forces only loads that
 // are needed by then anyway.  (Four sets -- three trips in flight -- need more than the 256 registers two waves per SIMD leave.)
-template <int DP, bool WIDE>
+template <int DP, bool WIDE, bool CODED = false>
 __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
-                                       double (&bred)[Geo<DP>::DB])
+                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
+    static_assert(!CODED || !WIDE, "coded values: 32-bit row offsets");
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, KS = 2, NS = 3;
     const TermDev &T = a.t[it.term];
     const int j = lane & 15, h = lane >> 4;
@@ -371,9 +372,13 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
     for (int I = 0; I < DB; I++) { bpart[I] = 0.0; eoff[I] = (uint32_t)(DP - 1 - (16 * I + j)) * 8u; }
     const uint32_t n = (uint32_t)it.count, rowb = (uint32_t)DP * 8u;
     const uint32_t ntrips = (n + 4 * KS - 1) / (4 * KS);
-    const char *ids = (const char *)(T.colidx + it.q_begin), *fac = (const char *)T.fac[0], *vals = (const char *)(T.vals + it.q_begin);
+    const char *ids = CODED ? (const char *)(T.packed + it.q_begin) : (const char *)(T.colidx + it.q_begin);
+    const char *fac = (const char *)T.fac[0], *vals = (const char *)(T.vals + it.q_begin);
     const double mean = T.mean;
+    double tab_v = 0.0;
+    if (CODED && lane < BDF_K1_CODES) tab_v = T.table[lane] - mean;      // this wave's copy of the table: value - mean by code
     uint32_t ix[NS][KS];
+    uint32_t cd[NS][KS];                  // CODED: the value codes of a set's observations (its ids' slot is reused before the trip multiplies)
     double rr[NS][KS];
     double w[NS][KS][DB];
 #define OBS(t, k) ((t) * (4 * KS) + KS * h + (k))
@@ -386,10 +391,14 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
     }
 #define LOAD_DATA(t, S)                                                                         \
     {                                                                                           \
-        uint32_t o = OBS(t, 0);                                                                 \
-        o = (o < n ? o : n - 1) * 8u;                                                           \
-        const d2 pv = *(const d2 *)(vals + o);                                                  \
-        rr[S][0] = pv[0]; rr[S][1] = pv[1];                                                     \
+        if (!CODED) {                                                                           \
+            uint32_t o = OBS(t, 0);                                                             \
+            o = (o < n ? o : n - 1) * 8u;                                                       \
+            const d2 pv = *(const d2 *)(vals + o);                                              \
+            rr[S][0] = pv[0]; rr[S][1] = pv[1];                                                 \
+        } else {                                                                                \
+            cd[S][0] = ix[S][0] >> 24; cd[S][1] = ix[S][1] >> 24;                               \
+        }                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
                 w[S][k][I] = WIDE ? *(const double *)(fac + ((uint64_t)ix[S][k] * rowb + eoff[I]))      \
@@ -408,7 +417,7 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
             }                                                                                   \
         }                                                                                       \
         _Pragma("unroll") for (int k = 0; k < KS; k++) {                                        \
-            const double r = rr[C][k] - mean;                                                   \
+            const double r = CODED ? tab[cd[C][k]] : rr[C][k] - mean;                           \
             int b = 0;                                                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
                 _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
@@ -426,6 +435,7 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
     LOAD_DATA(1u, 1)
     LOAD_IDX(2u, 2)
     LOAD_IDX(3u, 0)
+    if (CODED && lane < BDF_K1_CODES) const_cast<double *>(tab)[lane] = tab_v;
     for (uint32_t t = 0; t < ntrips; t += 3) {
         TRIP(t, 0)
         TRIP(t + 1, 1)
@@ -456,6 +466,9 @@ __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &
                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
     if constexpr (CODED) {                   // one two-mode relation, lean gather, coded values (checked by the host)
+#ifdef BDF_K1_DEEP32
+        if (a.D == DP && it.count >= BDF_K1_DEEP32) { accumulate_deep<DP, false, true>(a, it, lane, acc, bred, tab); return; }
+#endif
         if (a.D == DP) accumulate_lean<DP, 1, true, false, true>(a, it, lane, acc, bred, tab);
         else accumulate_lean<DP, 1, false, false, true>(a, it, lane, acc, bred, tab);
         return;
