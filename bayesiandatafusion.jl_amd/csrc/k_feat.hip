@@ -1608,7 +1608,8 @@ __global__ void k_sum_blocks(int64_t n, int world, const double *gb, double *x)
 
 static int sum_ranks_in(bdf_ctx *ctx, bdf_comm *comm, int rank, int world, double *x, int64_t n, double *gb)
 {
-    if (world <= 1 || n <= 0) return BDF_OK;
+    static const bool force = getenv("BDF_FORCE_COMM") != nullptr;      // (one rank through the collective all the same: tools/soak_determinism.py rccl)
+    if ((world <= 1 && !(force && comm)) || n <= 0) return BDF_OK;
     int rc;
     BDF_HIP(hipMemcpyAsync(gb + (size_t)rank * n, x, (size_t)n * sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
     if ((rc = bdf_allgather_block(ctx, comm, gb, (size_t)n * sizeof(double))) || (rc = bdf_allgather_join(ctx, comm))) return rc;

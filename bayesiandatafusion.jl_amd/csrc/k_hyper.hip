@@ -228,7 +228,9 @@ extern "C" int bdf_hyper_sums_ranks(bdf_ctx *ctx, bdf_comm *comm, int D, int64_t
 {
     int rank = 0, world = 1, rc;
     if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
-    if (world <= 1) return bdf_hyper_sums(ctx, D, N, sample, uhat, sumU, UUt);
+    // (BDF_FORCE_COMM: the ranks' path with ONE rank too -- the soak of the schedule with RCCL's kernels on the device)
+    static const bool force = getenv("BDF_FORCE_COMM") != nullptr;
+    if (world <= 1 && !(force && comm)) return bdf_hyper_sums(ctx, D, N, sample, uhat, sumU, UUt);
     if (ctx) { ctx->hyper_fuse = false; ctx->hyper_partial = nullptr; ctx->hyper_chain = false; }
     BDF_REQUIRE(ctx && sample && sumU && UUt, BDF_ERR_ARG, "bdf_hyper_sums_ranks: NULL argument");
     BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_hyper_sums_ranks: num_latent=%d must be in 1..%d", D, BDF_MAX_D);

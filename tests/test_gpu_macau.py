@@ -552,8 +552,9 @@ def test_stream_schedule_soak(B, mode):
     """two runs of 1,500 sweeps of the bench workload (three streams, rows rotating through three buffers, the row kernels
     polling for the hyperprior draws, prediction updates beside the rows) end bit-identical and leave no split row unfinished --
     tools/soak_determinism.py runs 20,000.  rccl: the same with a ONE-rank RCCL communicator in the iteration -- ncclAllGather
-    kernels on the device between the row launches, the row kernels still polling (BDF_POLL_WITH_COMM) -- twice, and equal to
-    the run without a communicator; no spin bound hit (flag 16 would raise at the next synchronisation)."""
+    kernels on the device between the row launches AND inside the hyperprior's sums (bdf_hyper_sums_ranks through the
+    collective), the row kernels still polling (BDF_POLL_WITH_COMM) -- twice, bit-identical, and equal to rounding to the run
+    without a communicator; no spin bound hit (flag 16 would raise at the next synchronisation)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
