@@ -290,7 +290,7 @@ def pin_to_quiet_core(share, shares):
         return None, None
 
 
-TRAFFIC_JSON = "profiles/r03_hbm_traffic.json"
+TRAFFIC_JSON = "profiles/r04_hbm_traffic.json"
 
 
 def k1_source_sha1():
