@@ -348,7 +348,8 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     }
 }
 
-// ---- accumulate one LONG item at D = DP (no padding), one other mode, shared baseline: THREE register sets ------------------------
+// ---- (experiments: -DBDF_K1_DEEP64, -DBDF_K1_DEEP32=n; neither is a gain) accumulate one LONG item at
+// D = DP (no padding), one other mode, shared baseline, through THREE register sets ----------------------------------------------
 // The two-set pipeline above has the factor rows of ONE trip in flight while a trip multiplies.  That is enough when the gathered
 // factor sits in the L2 (MovieLens) or when six or seven waves share a SIMD; at D = 64 two waves share it, and configuration
 // C4's item launch gathers 512-byte rows at random from a 5 GB factor matrix: every trip then waits out a whole HBM round trip
@@ -475,12 +476,15 @@ __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &
     }
     const int no = a.t[it.term].n_other;
     if constexpr (DP == 64) {
-        // long items at D = 64 (two waves per SIMD): the three-set pipeline
+#ifdef BDF_K1_DEEP64
+        // (experiment, off: long items at D = 64 through the three-set pipeline -- configuration C4's item launch 23.6 ms with it,
+        // 23.5 without: that launch is bound by the FP64 pipe at two waves per SIMD, not by its gathers; 216 registers instead of 192)
         if (a.D == DP && no == 1 && it.count >= BDF_K1_DEEP_MIN && a.t[it.term].lean != 0) {
             if (a.t[it.term].lean == 2) accumulate_deep<DP, true>(a, it, lane, acc, bred);
             else accumulate_deep<DP, false>(a, it, lane, acc, bred);
             return;
         }
+#endif
         if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
             if (a.D == DP) {
                 if (no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
