@@ -65,6 +65,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->hyper_fuse = false; c->hyper_partial = nullptr; c->hyper_nblocks = 0; c->hyper_sumU = c->hyper_UUt = nullptr;
     c->hyper_chain = false; c->hyper_count = nullptr; c->hyper_chain_draws = nullptr;
     c->cg_gen = 0;
+    c->cg_bar = nullptr;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
     c->scratch2_bytes = 0;
@@ -99,6 +100,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->scratch2) hipFree(ctx->scratch2);
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
+    if (ctx->cg_bar) hipFree(ctx->cg_bar);
     if (ctx->hyper_count) hipFree(ctx->hyper_count);
     if (ctx->lr_T) hipFree(ctx->lr_T);
     if (ctx->lr_vt) hipFree(ctx->lr_vt);

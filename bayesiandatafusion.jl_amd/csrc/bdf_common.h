@@ -78,6 +78,7 @@ struct bdf_ctx {
     double *hyper_chain_draws;          // (bdf_gibbs_sweep) the chain's launch also makes the entity's random part (k_hyper_draws' values) into this buffer
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
+    unsigned *cg_bar;                   // the hand-over counter of the one-launch CG solve (k_cg_resident), allocated at first use
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);

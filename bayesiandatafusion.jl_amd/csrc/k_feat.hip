@@ -593,7 +593,8 @@ __device__ __forceinline__ double block_sum(double v, double *red)
 }
 
 // The CG kernels take one workgroup per column (no grid-wide reduction); long columns get 1024 threads (CG_THREADS_LONG)
-__global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, double tol)
+// (bar, nullable: the hand-over counter of k_cg_resident, zeroed here)
+__global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, double tol, unsigned *bar)
 {
     __shared__ double red[16];
     const int d = blockIdx.x;
@@ -608,7 +609,7 @@ __global__ __launch_bounds__(1024) void k_cg_init(CgState s, const double *rhs, 
     if (threadIdx.x == 0) {
         s.tolb[d] = tol * sqrt(nb);      // tol = tol * norm(b), parallel_cg.jl:65
         s.bkden[d] = 0.0; s.active[d] = 1; s.iters[d] = 0;
-        if (d == 0) { *s.nactive = s.D; *s.done_blocks = 0; }
+        if (d == 0) { *s.nactive = s.D; *s.done_blocks = 0; if (bar) *bar = 0u; }
     }
 }
 
@@ -779,6 +780,178 @@ __global__ __launch_bounds__(256) void k_cg_step_short(CgState s, const double *
             __threadfence_system();
             s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
         }
+    }
+}
+
+// ---- the whole solve in ONE launch for a small resident operator (F'F of at most 512 features, at most 32 columns) -----------------
+// An iteration of the batched solve is two dependent launches (product 10.4 us, step 7.2 us at numF = 500, D = 32), and both
+// are the floor of a dependent launch of a few workgroups (~5 us) plus a little work: fifteen iterations are 0.26 of configuration
+// C3's 0.54 ms.  Here ceil(numF / 16) workgroups stay resident for the whole solve.  Workgroup w is (a) the owner of the rows
+// 16 w .. 16 w + 15 of the operator -- its waves keep their quarter of K of those rows in REGISTERS as matrix operands across all
+// iterations -- and (b) the owner of column w of the solve: that column's p, x, r and scalars live in its registers.  An
+// iteration: every workgroup multiplies its rows into all columns of P (read from memory past the caches) and writes its rows of Z
+// write-through; a grid-wide hand-over; the column owners run EXACTLY k_cg_step_short's arithmetic on their column (same sums in
+// the same order) and write the new p write-through; a second hand-over.  The hand-overs are a monotonic counter (arrive after
+// the wave's write-through stores have completed, poll with agent-scope loads); nothing is fenced: what crosses workgroups is
+// written with write-through stores and read with agent-scope loads.  All workgroups are co-resident (at most 32 of 256 threads).
+struct CgResident {
+    CgState s;
+    const double *FF;                 // n x n, column-major, symmetric
+    const double *lambda_p;
+    int maxiter, nwg;
+    unsigned *bar;                    // zeroed before the launch
+};
+
+__device__ __forceinline__ void cg_grid_sync(unsigned *bar, unsigned target, int *flag)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have completed
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int spins = 0;
+        while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 25)) { atomicOr_system(flag, 16); break; }       // bounded: a bug must not hang the device
+        }
+    }
+    __syncthreads();
+}
+
+template <int CB>
+__global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
+{
+    __shared__ double red[3][CB][4][64];
+    __shared__ double sred[16];
+    __shared__ int go;
+    const CgState &s = c.s;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, h = lane >> 4;
+    const int w = blockIdx.x;
+    const int64_t n = s.n;
+    const int D = s.D;
+    // (a) this workgroup's rows of the operator: every wave keeps its quarter of K of rows 16 w + i as matrix operands
+    // (k_dense_nn's split of K over the waves and its assignment of k to lanes and matrix instructions: the same sums in the same
+    // order, so the iterates -- and the iteration counts -- are those of the two-launch solve to the last bit)
+    constexpr int KS = 32;
+    const int64_t kq = ((n + 3) / 4 + 15) / 16 * 16;               // <= 128 = 4 KS for n <= 512
+    const int64_t row = (int64_t)w * 16 + i, kb = (int64_t)wave * kq, ke = (kb + kq < n) ? kb + kq : n;
+    double a[KS];
+#pragma unroll
+    for (int t = 0; t < KS; t++) {
+        const int64_t k = kb + 16 * (t >> 2) + 4 * h + (t & 3);
+        a[t] = (row < n && k < ke) ? c.FF[k + row * n] : 0.0;      // (symmetric: row `row` is the contiguous column `row`)
+    }
+    // (b) column w of the solve (k_cg_init and k_cg_pre(1) have run: x = 0, r = p = b, bknum = bkden = |b|^2, iters = 1)
+    const int d = w;
+    const bool owner = d < D;
+    const int64_t off = (int64_t)d * n;
+    constexpr int EPT = 2;
+    double p[EPT], x[EPT], r[EPT];
+    bool active = false;
+    double bknum_d = 0.0, bkden_d = 0.0, tolb_d = 0.0;
+    int iters_d = 0;
+    if (owner) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int64_t q = tid + 256 * e;
+            const bool ok = q < n;
+            p[e] = ok ? s.P[off + q] : 0.0; x[e] = ok ? s.X[off + q] : 0.0; r[e] = ok ? s.R[off + q] : 0.0;
+        }
+        active = s.active[d] != 0; bknum_d = s.bknum[d]; bkden_d = s.bkden[d]; tolb_d = s.tolb[d]; iters_d = s.iters[d];
+    }
+    const double lambda = *c.lambda_p;
+    unsigned sync_no = 0;
+    for (int iter = 1; iter <= c.maxiter; iter++) {
+        if (__hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;      // (the same value in every workgroup: read after a hand-over)
+        // ---- Z[rows of w, :] = FF[rows of w, :] P
+        fd4 acc[CB];
+#pragma unroll
+        for (int cb = 0; cb < CB; cb++) acc[cb] = fd4{0.0, 0.0, 0.0, 0.0};
+        {
+            double b[CB][KS];
+#pragma unroll
+            for (int t = 0; t < KS; t++) {
+                const int64_t k = kb + 16 * (t >> 2) + 4 * h + (t & 3);
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) {
+                    const int col = 16 * cb + i;
+                    b[cb][t] = (k < ke && col < D) ? __hip_atomic_load(s.P + k + (int64_t)col * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < KS; t++)
+#pragma unroll
+                for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[cb][t], acc[cb], 0, 0, 0);
+        }
+        if (wave > 0) {
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) red[wave - 1][cb][rr][lane] = acc[cb][rr];
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int cb = 0; cb < CB; cb++)
+#pragma unroll
+                for (int rr = 0; rr < 4; rr++) {
+                    const double v = ((acc[cb][rr] + red[0][cb][rr][lane]) + red[1][cb][rr][lane]) + red[2][cb][rr][lane];
+                    const int64_t zr = (int64_t)w * 16 + h + 4 * rr;
+                    const int col = 16 * cb + i;
+                    if (zr < n && col < D) __hip_atomic_store(s.Z + zr + (int64_t)col * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+        }
+        cg_grid_sync(c.bar, ++sync_no * (unsigned)c.nwg, s.flag);
+        // ---- the step of column w: bottom of iteration `iter`, top of iteration `iter + 1` (k_cg_step_short's arithmetic)
+        if (owner && active && iters_d == iter) {           // (workgroup-uniform)
+            double z[EPT];
+            double zp = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                const int64_t q = tid + 256 * e;
+                z[e] = q < n ? __hip_atomic_load(s.Z + off + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                z[e] = fma(lambda, p[e], z[e]);
+                zp = fma(z[e], p[e], zp);
+            }
+            zp = block_sum(zp, sred);
+            const double ak = bknum_d / zp;
+            double bknum = 0.0;
+#pragma unroll
+            for (int e = 0; e < EPT; e++) {
+                x[e] = fma(ak, p[e], x[e]);
+                r[e] = fma(-ak, z[e], r[e]);
+                bknum = fma(r[e], r[e], bknum);
+            }
+            if (iter >= c.maxiter) {
+                if (tid == 0) atomicOr_system(s.flag, (int)BDF_WARN_CG_MAXITER);
+            } else {
+                bknum = block_sum(bknum, sred);
+                if (tid == 0) go = !(sqrt(bknum) < tolb_d);
+                __syncthreads();
+                if (go) {
+                    const double bk = bknum / bkden_d;
+#pragma unroll
+                    for (int e = 0; e < EPT; e++) {
+                        p[e] = fma(bk, p[e], r[e]);
+                        const int64_t q = tid + 256 * e;
+                        if (q < n) __hip_atomic_store(s.P + off + q, p[e], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    bkden_d = bknum; bknum_d = bknum; iters_d = iter + 1;
+                } else {
+                    active = false;
+                    if (tid == 0) __hip_atomic_fetch_sub(s.nactive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                __syncthreads();                          // (`go` is rewritten in the next iteration)
+            }
+        }
+        cg_grid_sync(c.bar, ++sync_no * (unsigned)c.nwg, s.flag);
+    }
+    if (owner) {
+#pragma unroll
+        for (int e = 0; e < EPT; e++) {
+            const int64_t q = tid + 256 * e;
+            if (q < n) { s.X[off + q] = x[e]; s.R[off + q] = r[e]; }
+        }
+        if (tid == 0) { s.active[d] = active ? 1 : 0; s.iters[d] = iters_d; s.bknum[d] = bknum_d; s.bkden[d] = bkden_d; }
     }
 }
 
@@ -1163,7 +1336,11 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     s.flag = ctx->flag_dev;
     s.gen = ++ctx->cg_gen;
     const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
-    hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol);
+    // a small resident operator: the whole solve in one launch (k_cg_resident; BDF_CG_RESIDENT=0: the two launches per iteration)
+    static const bool resident_ok = !(getenv("BDF_CG_RESIDENT") && atoi(getenv("BDF_CG_RESIDENT")) == 0);
+    const bool resident = resident_ok && use_ff && numF <= 512 && D <= 32 && D <= (numF + 15) / 16;
+    if (resident && !ctx->cg_bar) BDF_HIP(hipMalloc((void **)&ctx->cg_bar, sizeof(unsigned)));
+    hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol, resident ? ctx->cg_bar : (unsigned *)nullptr);
     BDF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cg_pre, dim3(D), cgb, 0, ctx->stream, s, 1);
     // The host enqueues iterations AHEAD of the device (no stream synchronisation: the device never idles between
@@ -1181,6 +1358,15 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
         constexpr size_t PART = (size_t)2 * BDF_MAX_D * 64 + BDF_MAX_D;     // (the scratch buffers are reused by the products inside the loop)
         if (!ctx->cg_part) BDF_HIP(hipMalloc((void **)&ctx->cg_part, PART * sizeof(double)));
         ch.partA = ctx->cg_part; ch.partB = ch.partA + (size_t)BDF_MAX_D * 64; ch.bkden0 = ch.partB + (size_t)BDF_MAX_D * 64;
+    }
+    if (resident) {
+        CgResident c;
+        c.s = s; c.FF = f->FF_dev; c.lambda_p = lambda_beta_dev; c.maxiter = maxiter; c.nwg = (int)((numF + 15) / 16); c.bar = ctx->cg_bar;
+        if (D <= 16) hipLaunchKernelGGL(k_cg_resident<1>, dim3(c.nwg), dim3(256), 0, ctx->stream, c);
+        else hipLaunchKernelGGL(k_cg_resident<2>, dim3(c.nwg), dim3(256), 0, ctx->stream, c);
+        BDF_HIP(hipGetLastError());
+        *iters_dev = s.iters;
+        return BDF_OK;
     }
     constexpr int CG_AHEAD = 3;
     ctx->skip_flag = s.nactive;

@@ -270,3 +270,56 @@ def test_sample_beta_rel_matches_oracle(B, O, ctx, numF):
     np.testing.assert_allclose(lin_t.cpu().numpy(), mean + Fm @ beta_t.cpu().numpy(), rtol=1e-11, atol=1e-11)
     op.close()
     pairs.close()
+
+
+@pytest.mark.parametrize("N,numF,D", [(700, 200, 12), (900, 500, 32), (600, 333, 17), (600, 500, 1)])
+def test_cg_one_launch_solve_matches_the_two_launch_solve_and_the_oracle(B, O, N, numF, D):
+    """k_cg_resident (the whole batched conjugate-gradient solve in ONE launch for a resident F'F of at most 512 features and at
+    most min(32, ceil(numF / 16)) columns: row slices of the operator in registers, two grid-wide hand-overs per iteration)
+    against the two-launches-per-iteration solve (BDF_CG_RESIDENT=0, read once per process: a child each) -- the same
+    per-column iteration counts (cg_AtA's stopping rule, src/parallel_cg.jl:63-94) and beta to 1e-9 -- and against the oracle's
+    literal cg_AtA on the same noise streams; a loose tolerance makes the columns stop at different iterations."""
+    import os, subprocess, sys, tempfile, textwrap
+    code = textwrap.dedent('''
+        import numpy as np, sys, ctypes as C, torch
+        sys.path.insert(0, %r)
+        import bdf_amd as B
+        from bdf_amd._lib import check, lib
+        N, numF, D = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
+        rng = np.random.default_rng(N + numF + D)
+        F = rng.standard_normal((N, numF)) * (0.2 + rng.random(numF))
+        sample = rng.standard_normal((N, D)); mu = rng.standard_normal(D) * 0.1
+        M = rng.standard_normal((D, D)); Lam = M @ M.T / D + np.eye(D)
+        ctx = B.Context(seed=77); ctx.set_sweep(4)
+        op = B.FeatOperator(ctx, F)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        out = {}
+        for name, tol in (("tight", float("nan")), ("loose", 1e-4)):
+            S_t, mu_t, Lam_t, lb_t = ctx.tensor(sample), ctx.tensor(mu), ctx.tensor(Lam), ctx.tensor([0.6])
+            beta_t, rhs_t = ctx.zeros(D, numF), ctx.zeros(D, numF)
+            it_t = torch.zeros(D, dtype=torch.int32, device=ctx.device)
+            check(lib().bdf_sample_beta(ctx.handle, op.handle, D, p(S_t), p(mu_t), p(Lam_t), p(lb_t), 0, tol, 0, 0, 1e-3, 1.0, 3,
+                                        p(beta_t), p(rhs_t), p(it_t)))
+            try:
+                ctx.sync()
+            except RuntimeWarning:
+                pass
+            out["beta_" + name] = beta_t.cpu().numpy(); out["rhs_" + name] = rhs_t.cpu().numpy(); out["it_" + name] = it_t.cpu().numpy()
+        np.savez(sys.argv[1], F=F, sample=sample, mu=mu, Lam=Lam, **out)
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    got = {}
+    for resident in ("1", "0"):
+        with tempfile.TemporaryDirectory() as td:
+            f = os.path.join(td, "o.npz")
+            env = dict(os.environ, BDF_CG_RESIDENT=resident)
+            subprocess.run([sys.executable, "-W", "ignore", "-c", code, f, str(N), str(numF), str(D)], check=True, env=env, timeout=600)
+            got[resident] = dict(np.load(f))
+    a, b = got["1"], got["0"]
+    for name in ("tight", "loose"):
+        assert np.array_equal(a["it_" + name], b["it_" + name]), (name, a["it_" + name], b["it_" + name])
+        np.testing.assert_array_equal(a["rhs_" + name], b["rhs_" + name])
+        np.testing.assert_allclose(a["beta_" + name], b["beta_" + name], rtol=1e-9, atol=1e-11)
+    assert a["it_loose"].max() < a["it_tight"].max()
+    # the oracle's literal cg_AtA on the same right-hand side (two products with F per iteration): same solution to the solver's tolerance
+    beta_o, _, _ = O.sample_beta(O.Feat.from_dense(a["F"]), a["sample"], a["mu"], a["Lam"], 0.6, False, None, 77, 4, 3)
+    np.testing.assert_allclose(a["beta_tight"].reshape(D, numF).T, beta_o, rtol=1e-6, atol=1e-8)
