@@ -77,7 +77,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
     c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
-    c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0;
+    c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0; c->lr_mrows = nullptr; c->lr_mrows_bytes = 0;
     c->lr_key_fac = c->lr_key_Lambda = c->lr_key_mu = nullptr; c->lr_key_sweep = c->lr_key_tag = 0; c->lr_key_D = 0; c->lr_key_M = 0;
     {
         const char *force = getenv("BDF_GATHER");
@@ -104,6 +104,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->hyper_count) hipFree(ctx->hyper_count);
     if (ctx->lr_T) hipFree(ctx->lr_T);
     if (ctx->lr_vt) hipFree(ctx->lr_vt);
+    if (ctx->lr_mrows) hipFree(ctx->lr_mrows);
     if (ctx->own_stream) hipStreamDestroy(ctx->stream);
     delete ctx;
     return BDF_OK;

@@ -42,7 +42,9 @@ struct bdf_ctx {
     // k_rows_lr (k_rows_lr.hip): rows of few observations sampled by the low-rank map instead of the reference's
     int lr_max;                // longest row (observations) sampled that way at D > 16; -1: min(16, D / 2); 0: off
     int64_t lr_min_rows;       // ... and the smallest number of such rows in a launch for which it is used
-    double *lr_T;              // Tf | Tb (64 x 64 each) | L' mu (64): the launch's constants (k_lr_prep)
+    double *lr_T;              // Tf | Tb | Tm (64 x 64 each) | L' mu (64): the launch's constants (k_lr_prep)
+    double *lr_mrows;          // per-row prior means transformed (L' mu_i, rows of DP doubles), grown on demand
+    size_t lr_mrows_bytes;
     double *lr_vt;             // the opposite entity's factor matrix transformed (V L^-T), grown on demand
     size_t lr_vt_bytes;
     // what lr_T / lr_vt were computed from: a later chunk of the same entity launch reuses them
@@ -357,8 +359,8 @@ struct SampleArgs {
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump);
-int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, const int32_t *rows_dev,
-                  bool transform, hipEvent_t e0, hipEvent_t e1);
+int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded,
+                  const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1);
 int bdf_lr_max_observations();
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
 int bdf_predict_plain(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value, double *out);   // rel_serial 0: every plan of the context

@@ -51,12 +51,12 @@ struct LrGeo {
 // ---- the launch's constants: L = chol(Lambda) (lower, natural order), then
 //      Tf[d][c] = L^-T[d][c] = L^-1[c][d]   (Vt = V Tf: row m of Vt is L^-1 v_m)
 //      Tb[d][c] = L^-1[d][c]                (x' = q' Tb:  x = L^-T q)
-//      mt[d]    = (L' mu)[d]
+//      mt[d]    = (L' mu)[d]                 (shared prior mean; per-row prior means: Tm = L, and k_rowmat forms mu_i' L row by row)
 // both matrices DP x DP row-major, zero outside D x D.  One wavefront; the matrix lives in LDS.
 template <int DP>
 __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, const double *mu,
-                                                 double *__restrict__ Tf, double *__restrict__ Tb, double *__restrict__ mt, double *__restrict__ zero_row,
-                                                 int *flag, const uint32_t *ready, uint32_t ready_want)
+                                                 double *__restrict__ Tf, double *__restrict__ Tb, double *__restrict__ Tm, double *__restrict__ mt,
+                                                 double *__restrict__ zero_row, int *flag, const uint32_t *ready, uint32_t ready_want)
 {
     constexpr int LDL = DP + 1;
     if (threadIdx.x < DP) zero_row[threadIdx.x] = 0.0;       // the row the padding lanes of k_rows_lr4 gather
@@ -117,7 +117,12 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, con
         Tb[e] = in ? lo : 0.0;
         Tf[e] = in ? up : 0.0;
     }
-    if (c < DP) {
+    wave_sync();
+    for (int e = c; e < DP * DP; e += 64) {            // Tm[d][cc] = L[d][cc]: (mu_i' L)[cc] = (L' mu_i)[cc] for per-row prior means
+        const int d = e / DP, cc = e % DP;
+        Tm[e] = (d < D && cc <= d) ? sA[d * LDL + cc] : 0.0;
+    }
+    if (c < DP && mu) {                                // (mu NULL: per-row prior means, transformed by k_rowmat)
         double s = 0.0;
         if (c < D)
             for (int i = c; i < D; i++) s = fma(sA[i * LDL + c], __hip_atomic_load(mu + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), s);
@@ -185,7 +190,8 @@ struct LrArgs {
     const double *vals;
     const double *vt;           // the opposite factor transformed: rows of DP doubles (zeros behind the first D), then one all-zero row
     int64_t zero_row;           // ... its index
-    const double *mt;           // L' mu
+    const double *mt;           // L' mu (mt_stride = 0), or row i's L' mu_i at mt + i * mt_stride (per-row prior means, macau.jl:104)
+    int64_t mt_stride;
     double *out;
     double alpha, mean;
     const double *alpha_dev;    // nullable: the precision in device memory (else `alpha`)
@@ -252,7 +258,7 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
 #pragma unroll
     for (int I = 0; I < DB; I++) {
         const int e = 16 * I + j;
-        e0[I] = (e < D) ? a.mt[e] + tri[2 * (j + 16 * (I / 2)) + (I & 1)] : 0.0;
+        e0[I] = (e < D) ? a.mt[(int64_t)it.row * a.mt_stride + e] + tri[2 * (j + 16 * (I / 2)) + (I & 1)] : 0.0;
     }
     const double dl = (j < n) ? tri[2 * (zbase + (j >> 1)) + (j & 1)] : 0.0;
     // ---- G~ = S S' with S = [Wt' ; 0 ; e0'] (16 x D), HW columns at a time: operand lane (i = j, kk = h), k-step s:
@@ -413,8 +419,9 @@ __device__ __forceinline__ void lr4_body(const LrArgs &a, const LrItem &it, cons
     for (int r = 0; r < NR; r++) {
         double z0, z1;
         bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(j + 16 * r), z0, z1);
-        e0[2 * r] = a.mt[32 * r + j] + z0;
-        e0[2 * r + 1] = a.mt[32 * r + 16 + j] + z1;
+        const double *mrow = a.mt + (live ? (int64_t)it.row * a.mt_stride : 0);
+        e0[2 * r] = mrow[32 * r + j] + z0;
+        e0[2 * r + 1] = mrow[32 * r + 16 + j] + z1;
     }
     double dl;
     {
@@ -471,9 +478,17 @@ __global__ __launch_bounds__(256, 3) void k_rows_lr4(LrArgs a, const LrItem *__r
     else lr4_body<DP, 16>(a, it, j);
 }
 
-int lr_buffers(bdf_ctx *ctx, size_t vt_bytes)
+int lr_buffers(bdf_ctx *ctx, size_t vt_bytes, size_t mrows_bytes)
 {
-    if (!ctx->lr_T) BDF_HIP(hipMalloc((void **)&ctx->lr_T, (size_t)(2 * 64 * 64 + 64) * sizeof(double)));
+    if (!ctx->lr_T) BDF_HIP(hipMalloc((void **)&ctx->lr_T, (size_t)(3 * 64 * 64 + 64) * sizeof(double)));
+    if (mrows_bytes > ctx->lr_mrows_bytes) {
+        BDF_HIP(hipStreamSynchronize(ctx->stream));
+        if (ctx->lr_mrows) BDF_HIP(hipFree(ctx->lr_mrows));
+        ctx->lr_mrows = nullptr; ctx->lr_mrows_bytes = 0;
+        const size_t nb = (mrows_bytes + 255) & ~(size_t)255;
+        BDF_HIP(hipMalloc((void **)&ctx->lr_mrows, nb));
+        ctx->lr_mrows_bytes = nb;
+    }
     if (vt_bytes > ctx->lr_vt_bytes) {
         BDF_HIP(hipStreamSynchronize(ctx->stream));
         if (ctx->lr_vt) BDF_HIP(hipFree(ctx->lr_vt));
@@ -490,19 +505,26 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
                 bool transform, hipEvent_t e0, hipEvent_t e1)
 {
     const int D = a.D;
-    double *Tf = ctx->lr_T, *Tb = Tf + 64 * 64, *mt = Tb + 64 * 64;
+    double *Tf = ctx->lr_T, *Tb = Tf + 64 * 64, *Tm = Tb + 64 * 64, *mt = Tm + 64 * 64;
     constexpr int TPW = 4 / (DP / 16);
     if (transform) {
         // (k_lr_prep also zeroes row M_other of the transformed matrix: what lanes without an observation gather)
-        hipExtLaunchKernelGGL((k_lr_prep<DP>), dim3(1), dim3(64), 0, ctx->stream, e0, nullptr, 0, D, a.Lambda, a.mu, Tf, Tb, mt,
-                              ctx->lr_vt + M_other * DP, a.flag, a.ready, a.ready_want);
+        hipExtLaunchKernelGGL((k_lr_prep<DP>), dim3(1), dim3(64), 0, ctx->stream, e0, nullptr, 0, D, a.Lambda, a.mu_is_matrix ? (const double *)nullptr : a.mu,
+                              Tf, Tb, Tm, mt, ctx->lr_vt + M_other * DP, a.flag, a.ready, a.ready_want);
         e0 = nullptr;
         const int64_t iters = (M_other + 16 * TPW - 1) / (16 * TPW);
         hipLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(iters, 4096)), dim3(256), 0, ctx->stream, a.t[0].fac[0], ctx->lr_vt,
                            (const double *)Tf, D, DP, (const int32_t *)nullptr, M_other, iters);
     }
+    if (a.mu_is_matrix) {
+        // per-row prior means (entity side information, macau.jl:103-104): L' mu_i for the rows of this launch, (mu_i' L) row by row
+        const int64_t it2 = (n_items + 16 * TPW - 1) / (16 * TPW);
+        hipLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(it2, 4096)), dim3(256), 0, ctx->stream, a.mu, ctx->lr_mrows,
+                           (const double *)Tm, D, DP, rows_dev, n_items, it2);
+    }
     LrArgs la;
-    la.colidx = a.t[0].colidx; la.vals = a.t[0].vals; la.vt = ctx->lr_vt; la.zero_row = M_other; la.mt = mt; la.out = a.out;
+    la.colidx = a.t[0].colidx; la.vals = a.t[0].vals; la.vt = ctx->lr_vt; la.zero_row = M_other; la.out = a.out;
+    la.mt = a.mu_is_matrix ? ctx->lr_mrows : mt; la.mt_stride = a.mu_is_matrix ? DP : 0;
     la.alpha = a.t[0].alpha; la.alpha_dev = a.t[0].alpha_dev; la.mean = a.t[0].mean; la.seed = a.seed; la.sweep = a.sweep; la.entity_tag = a.entity_tag;
     la.D = D; la._pad = 0; la.flag = a.flag;
     static const bool wave_per_row = getenv("BDF_LR_WAVE") != nullptr;        // the wave-per-row kernel instead (rows of at most 15 observations)
@@ -519,15 +541,17 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
 
 }  // namespace
 
-// The rows `items` (LrItem: one two-mode relation, at most 16 observations each, shared prior mean; n_items of them, padded
+// The rows `items` (LrItem: one two-mode relation, at most 16 observations each, shared or per-row prior means (n_rows_entity rows
+// of the factor matrix); n_items of them, padded
 // with row = -1 records to n_padded, a multiple of four) of the launch described by `a`.  transform: L = chol(Lambda), the
 // opposite factor's M_other rows transformed into the context's buffer (false: both are still valid from the previous chunk
 // of the same entity launch).  rows_dev: the rows' positions (n_items int32).
-int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, const int32_t *rows_dev,
-                  bool transform, hipEvent_t e0, hipEvent_t e1)
+int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded,
+                  const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1)
 {
     const int DP = a.D <= 32 ? 32 : 64;
-    int rc = lr_buffers(ctx, ((size_t)M_other + 2) * DP * sizeof(double));         // rows of DP doubles, the zero row, slack
+    int rc = lr_buffers(ctx, ((size_t)M_other + 2) * DP * sizeof(double),         // rows of DP doubles, the zero row, slack
+                        a.mu_is_matrix ? (size_t)n_rows_entity * DP * sizeof(double) : 0);
     if (rc) return rc;
     if (DP == 32) return lr_launch_t<32>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);
     return lr_launch_t<64>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);

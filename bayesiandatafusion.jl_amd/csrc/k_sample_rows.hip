@@ -1258,11 +1258,11 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             key.small = std::min(small_max, ctx->item_size);
     }
 
-    // D > 16, one two-mode relation without per-observation baselines, a shared prior mean: the rows of few observations by the
-    // low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
+    // D > 16, one two-mode relation without per-observation baselines (shared or per-row prior means): the rows of few observations
+    // by the low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
     // the longest such row, -1 = min(15, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
     int64_t M_other = 0;
-    if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr && !a.mu_is_matrix &&
+    if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr &&
         !getenv("BDF_K1_DECOUPLE")) {
         const int other = 1 - modes[0];
         M_other = rels[0]->nint[other];
@@ -1328,7 +1328,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         const bool same = shard > 0 && ctx->lr_key_fac == (const void *)a.t[0].fac[0] && ctx->lr_key_Lambda == (const void *)a.Lambda &&
                           ctx->lr_key_mu == (const void *)a.mu && ctx->lr_key_sweep == a.sweep && ctx->lr_key_tag == a.entity_tag &&
                           ctx->lr_key_D == a.D && ctx->lr_key_M == M_other;
-        int rc = bdf_lr_launch(ctx, a, M_other, plan->lr_dev, plan->n_lr, plan->n_lr_padded, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
+        int rc = bdf_lr_launch(ctx, a, M_other, rels[0]->nint[modes[0]], plan->lr_dev, plan->n_lr, plan->n_lr_padded, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
         if (rc) return rc;
         ctx->lr_key_fac = a.t[0].fac[0]; ctx->lr_key_Lambda = a.Lambda; ctx->lr_key_mu = a.mu; ctx->lr_key_sweep = a.sweep;
         ctx->lr_key_tag = a.entity_tag; ctx->lr_key_D = a.D; ctx->lr_key_M = M_other;

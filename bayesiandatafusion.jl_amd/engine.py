@@ -735,13 +735,13 @@ class GibbsEngine:
 
     def lowrank_rows(self, j):
         """rows of entity j the library draws with the low-rank sampler (k_rows_lr.hip) instead of the reference's map: the rule
-        of bdf_launch_sample_rows restated for reports -- D > 16, one two-mode relation, no side information on the entity or
-        the relation, rows of at most min(16, D / 2) observations (BDF_LOWRANK), at least 8,192 of them (BDF_LOWRANK_MIN_ROWS)
+        of bdf_launch_sample_rows restated for reports -- D > 16, one two-mode relation, no side information on the relation
+        (the entity's own is fine: per-row prior means), rows of at most min(16, D / 2) observations (BDF_LOWRANK), at least 8,192 of them (BDF_LOWRANK_MIN_ROWS)
         and at least half as many as the opposite entity has rows"""
         en, st, D = self.data.entities[j], self.ent[j], self.D
         lr = int(os.environ.get("BDF_LOWRANK", "-1"))
         lr = min(16, D // 2) if lr < 0 else min(lr, 16)
-        if D <= 16 or lr == 0 or len(en.relations) != 1 or len(en.relations[0].entities) != 2 or st.F is not None:
+        if D <= 16 or lr == 0 or len(en.relations) != 1 or len(en.relations[0].entities) != 2:
             return 0
         r = en.relations[0]
         ri = [x is r for x in self.data.relations].index(True)

@@ -113,7 +113,7 @@ int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
  * D the wave-per-row kernel is bound by its per-row instruction overhead.  Defaults 48 and 8192 (environment BDF_K1_SMALL,
  * BDF_K1_SMALL_MIN_ROWS); max_observations 0 turns it off.  Same sample up to the order of the floating-point sums. */
 int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows);
-/* D > 16, an entity of one two-mode relation with a shared prior mean: rows of at most max_observations observations (at most
+/* D > 16, an entity of one two-mode relation (shared or per-row prior means): rows of at most max_observations observations (at most
  * 16; -1 = min(16, num_latent / 2), the default; 0 = off; environment BDF_LOWRANK) are drawn by the LOW-RANK SAMPLER
  * (k_rows_lr.hip) when a launch has at least min_rows of them (default 8192, BDF_LOWRANK_MIN_ROWS) and at least half as many as
  * the opposite entity has rows (min_rows = 0: whenever there is such a row).  It replaces sample_user_basic (src/sampling.jl:200-212) for those rows by another map from

@@ -56,7 +56,10 @@ def oracle_macau(O, rd, D, seed, iters, use_ff, lowrank=None):
                 terms.append(O.Term(r.data.ids, r.data.values, list(r.data.dims), mode, r.model.alpha, means[ri], facs, index=index[ri]))
             if feats[j] is not None:
                 uhat = np.stack([feats[j][0].mul(beta[j][:, d]) for d in range(D)], axis=1)
-                S[j] = O.sample_rows(D, N[j], terms, mu[j] + uhat, Lam[j], seed, it, j + 1)
+                if lowrank and j in lowrank:
+                    S[j] = O.sample_rows_lowrank(D, N[j], terms, mu[j] + uhat, Lam[j], lowrank[j], seed, it, j + 1)
+                else:
+                    S[j] = O.sample_rows(D, N[j], terms, mu[j] + uhat, Lam[j], seed, it, j + 1)
                 U, nu, Tinv = S[j] - uhat, D + feats[j][0].n, np.eye(D) + beta[j].T @ beta[j] * lb[j]
             else:
                 if lowrank and j in lowrank:
@@ -310,6 +313,33 @@ def test_mref_shaped_whole_iterations_match_oracle(B, O, D):
     # D = 30: the 60,000-row entity's rows of at most 15 observations (nearly all) are drawn by the low-rank sampler (default-on
     # above 8,192 such rows: bdf_ctx_set_lowrank) -- the oracle dispatches the same way; the 1,000-row entity has none
     _compare(rd, *oracle_macau(O, rd, D, 21, 2, True, lowrank={0: 15} if D == 30 else None), tol=1e-6)
+    eng.close()
+
+
+def test_macau_with_side_information_and_lowrank_rows_match_oracle(B, O):
+    """Macau at the shape side information is for (the reference's ChEMBL example, docs/index.md: thousands of compounds with a
+    handful of measurements each and a feature vector): 12,000 x 300, 60,000 observations, dense entity features 12,000 x 24,
+    D = 24.  The 12,000-row entity's rows of at most 12 observations -- nearly all -- are drawn by the low-rank sampler with
+    PER-ROW prior means (mu + uhat_i: L' mu_i row by row); two whole native iterations (uhat, rows, hyperprior with the
+    feature terms, beta by the direct solve, lambda_beta) against the oracle dispatching the same way."""
+    from bdf_amd.engine import GibbsEngine
+    rng = np.random.default_rng(24)
+    N1, N2, D, numF, nnz = 12_000, 300, 24, 24, 60_000
+    key = np.unique(rng.integers(0, N1 * N2, size=int(nnz * 1.02)))[:nnz]
+    ids = np.stack([key // N2 + 1, key % N2 + 1], axis=1)
+    F = rng.standard_normal((N1, numF))
+    W = rng.standard_normal((numF, 3)) * 0.4
+    vals = np.sum((F @ W)[ids[:, 0] - 1] * rng.standard_normal((N2, 3))[ids[:, 1] - 1], axis=1) + 0.3 * rng.standard_normal(nnz)
+    rel = B.Relation((ids, vals), "r", [B.Entity("compounds", F=F), B.Entity("proteins")], dims=[N1, N2])
+    B.setPrecision(rel, 2.0)
+    rd = B.RelationData(rel)
+    eng = GibbsEngine(rd, D, seed=31)
+    assert eng.native and eng.lowrank_rows(0) > 11_000 and eng.lowrank_rows(1) == 0
+    for i in (1, 2):
+        eng.sweep(i)
+    eng.sync()
+    eng.sync_host_scalars()
+    _compare(rd, *oracle_macau(O, rd, D, 31, 2, True, lowrank={0: 12}), tol=1e-6)
     eng.close()
 
 

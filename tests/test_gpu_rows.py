@@ -739,7 +739,7 @@ def test_lowrank_rows_against_oracle(B, O, ctx, D):
     """k_rows_lr4 (D > 16: rows of at most min(16, D / 2) observations by the low-rank sampler, four rows to a wave) against the oracle's statement of
     the same map (orc_sample_row_lowrank: D + n normals, n x n solve) on the same Philox normals, 1e-8; the longer rows of the
     same launch against the reference's map (they go through k_rows).  Rows of 0 .. 15 observations and more, a row count that
-    is no multiple of four or sixteen, ratings and continuous values, both modes.  (That the low-rank map draws the reference's
+    is no multiple of four or sixteen, ratings and continuous values, both modes, shared and per-row prior means.  (That the low-rank map draws the reference's
     distribution is the deterministic CPU test test_lowrank_sampler_draws_the_reference_distribution.)"""
     rng = np.random.default_rng(500 + D)
     dims = [211, 90]
@@ -773,6 +773,13 @@ def test_lowrank_rows_against_oracle(B, O, ctx, D):
                 exp = O.sample_rows_lowrank(D, N, [ot], mu, Lam, lr, SEED, 7, 5)
                 assert np.isfinite(got).all()
                 np.testing.assert_allclose(got, exp, rtol=1e-8, atol=1e-9)
+                # per-row prior means (entity side information: mu + uhat_i, macau.jl:103-104): L' mu_i row by row
+                mu_rows = rng.standard_normal((N, D))
+                mur_t = ctx.tensor(mu_rows)
+                out_r = ctx.zeros(N, D)
+                _run_rows(B, ctx, D, N, terms, mur_t, Lam_t, 5, out_r)
+                exp_r = O.sample_rows_lowrank(D, N, [ot], mu_rows, Lam, lr, SEED, 7, 5)
+                np.testing.assert_allclose(out_r.cpu().numpy(), exp_r, rtol=1e-8, atol=1e-9)
                 if mode0 == 0:
                     # switched off: the reference's map for every row
                     ctx.set_lowrank(0, 0)
