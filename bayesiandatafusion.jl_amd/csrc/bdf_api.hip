@@ -77,6 +77,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
     c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
+    c->fin_min_rows = getenv("BDF_K1_TWO_PHASE") ? atoll(getenv("BDF_K1_TWO_PHASE")) : 1024;
     c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0; c->lr_mrows = nullptr; c->lr_mrows_bytes = 0;
     c->lr_key_fac = c->lr_key_Lambda = c->lr_key_mu = nullptr; c->lr_key_sweep = c->lr_key_tag = 0; c->lr_key_D = 0; c->lr_key_M = 0;
     {
@@ -190,6 +191,13 @@ extern "C" int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t m
                 "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..16");
     ctx->lr_max = max_observations;
     ctx->lr_min_rows = min_rows;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_two_phase(bdf_ctx *ctx, int64_t min_rows)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_set_two_phase: NULL context");
+    ctx->fin_min_rows = min_rows;
     return BDF_OK;
 }
 

@@ -84,7 +84,7 @@ struct Item {             // one wave's accumulation work
     int32_t term;
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
-    int32_t slot;         // partial slot, or -1 for a direct row
+    int32_t slot;         // partial slot; a direct row: -1, or (two-phase launch) the row's slot in the slab of systems
     int32_t srow;         // index of the row in the split-row table (split items)
     int32_t orig;         // the row's ORIGINAL id: keys its random stream (== row unless the relation was created with a layout)
 };
@@ -92,7 +92,7 @@ struct Item {             // one wave's accumulation work
 struct SplitRow {
     int32_t row;
     int32_t slot_begin, n_slots;
-    int32_t _pad;
+    int32_t sys;          // two-phase launch: the row's slot in the slab of systems
 };
 
 struct PlanDev {
@@ -103,6 +103,9 @@ struct PlanDev {
     int32_t *arrived;                            // per split row: items that have published their partial (self-resetting)
     const int32_t *order;                        // launch order: wave w takes item order[w] of [split | direct]
     int32_t decoupled, _pad;                     // 1: every row is accumulated by producer waves and finished by another wave
+    uint32_t *ticket;                            // queue-fed launch (k_rows_queue): the next position of `order`, counted on from
+    uint32_t ticket_base, _pad2;                 // (the launch's number: its parity picks the counter)
+    double *sys;                                 // two-phase launch (k_rows<SYS> + k_rows_fin): one slot of PSZ doubles per row
 };
 
 
@@ -599,7 +602,7 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool SYS = false>
 __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     double *const tab = tri;          // CODED: the wave's value table (BDF_K1_CODES doubles) sits in the packed factor's space until the factorisation
@@ -626,7 +629,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
-    const bool early_z = !DUMP && !is_split && !p.decoupled;
+    const bool early_z = !DUMP && !SYS && !is_split && !p.decoupled;
     if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
     if (p.decoupled && !is_split) {
         // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
@@ -676,10 +679,39 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
         // the finisher's normals before the partial sums are loaded: the Box-Muller arithmetic needs ~40 registers
-        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
+        if (!DUMP && !SYS && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
+    if constexpr (SYS) {
+        // two-phase launch: the row's system (alpha S, alpha W r; the pieces of a split row summed) goes to the slab in the
+        // partial-slot format and k_rows_fin (k_rows_fin.hip) takes it from there, four rows to a wave
+        double *dst = p.sys + (int64_t)(is_split ? p.rows[it.srow].sys : it.slot) * PSZ;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
+        if (lane < 16) {
+#pragma unroll
+            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bv[I];
+        }
+        SPAN_END();
+        return;
+    }
+#ifdef BDF_EXP_ACC_ONLY       // experiment: what the launch costs without the finish phase (the row's system goes to the slab instead)
+    {
+        double *dst = p.partials + (int64_t)(is_split ? it.slot : wid) * PSZ;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
+        if (lane < 16) {
+#pragma unroll
+            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bv[I];
+        }
+        return;
+    }
+#endif
 #ifdef BDF_EXP_NO_PRIOR       // experiment: what the prior's loads cost (wrong results: 5 I instead of the prior's image)
     if (true) {
         int b = 0;
@@ -795,8 +827,9 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     SPAN_END();
 }
 
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool SYS = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, SYS ? (CODED ? Geo<DP>::WAVES_SYS_CODED : (MATRIX ? Geo<DP>::WAVES_SYS_MATRIX : Geo<DP>::WAVES_SYS))
+                                                    : (CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES)))
 void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
@@ -805,8 +838,51 @@ void k_rows(SampleArgs a, PlanDev p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct)
-        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+        process_item<DP, DUMP, MATRIX, CODED, SYS>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
+
+// Queue-fed launch (an experiment, DESIGN.md section 4, K1: built with -DBDF_K1_QUEUE_BUILD -mllvm -disable-machine-licm --
+// hoisted out of the item loop, the constants of the normals' polynomials cost the kernel its registers -- and switched on
+// with BDF_K1_QUEUE=<waves per SIMD>): exactly the resident wave count is launched and every wave takes positions of `order`
+// from a global counter until they run out.  The results are the one-item-per-wave launch's to the last bit: split rows are
+// summed in slot order whoever finishes them.
+#ifdef BDF_K1_QUEUE_BUILD
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
+void k_rows_queue(SampleArgs a, PlanDev p)
+{
+    using GG = Geo<DP>;
+    constexpr int WPB = GG::WPB;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t total = (uint32_t)p.n_split + (uint32_t)p.n_direct;
+    // the first item of a wave is its own number (7,000 waves drawing from one counter at once are served one after the other,
+    // ~9 ns each: the launch took 177 us that way); later ones come from the counter of this launch's parity, which the
+    // launch before left at zero -- wave 0 zeroes the other one for the launch after
+    uint32_t *const ctr = p.ticket + 16 * (p.ticket_base & 1u);
+    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(p.ticket + 16 * ((p.ticket_base & 1u) ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const uint32_t n_waves = gridDim.x * WPB;
+    uint32_t t = blockIdx.x * WPB + wave;
+    for (;;) {
+        if (t >= total) break;
+        // the arguments are read again for every item (an index the compiler cannot see through): kept live around the loop they
+        // would cost the kernel its registers
+        int zero = 0;
+        asm volatile("" : "+s"(zero));
+        const SampleArgs &ai = (&a)[zero];
+        const PlanDev &pi = (&p)[zero];
+        int lane_i = lane, wave_i = wave;                  // (and nothing derived from the lane or the wave number either)
+        asm volatile("" : "+v"(lane_i), "+s"(wave_i));
+        process_item<DP, DUMP, MATRIX, CODED>(ai, pi, pi.order[t], lane_i, lds + wave_i * GG::WAVE_LDS);
+        // a look before the draw: once the items have run out the waves leave without touching the counter
+        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + n_waves >= total) break;
+        t = 0;
+        if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_waves;
+        t = __builtin_amdgcn_readfirstlane(t);
+        wave_sync();          // the next item's value table goes where this item's packed factor was
+    }
+}
+#endif
 
 // ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
 // At D <= 16 a row of ten observations costs the wave-per-row kernel ~570 vector and ~340 scalar instructions, nearly all of
@@ -940,6 +1016,7 @@ struct PlanKey {
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
+    int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows<SYS> + k_rows_fin) if the launch has at least this many
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -955,6 +1032,11 @@ struct Plan {
     int32_t *order_dev = nullptr;
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
+    uint32_t *ticket_dev = nullptr;   // queue-fed launch: the counter and what it stands at when the next launch begins
+    uint32_t ticket_base = 0;
+    bdf_fin_item *fin_dev = nullptr;  // two-phase launch: the rows of k_rows_fin (a multiple of 4) and the slab of their systems
+    int64_t n_fin = 0;
+    double *sys_dev = nullptr;
 };
 
 struct PlanCache {
@@ -1030,6 +1112,16 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         }
         if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});      // the row's finisher
     }
+    // two-phase launch: every row of k_rows gets a slot in the slab of systems; k_rows_fin takes the rows in this order
+    std::vector<bdf_fin_item> fin;
+    if (key.fin_min >= 0 && !decoupled && (int64_t)direct.size() + (int64_t)srows.size() >= std::max<int64_t>(key.fin_min, 1)) {
+        for (Item &it : direct) { it.slot = (int32_t)fin.size(); fin.push_back(bdf_fin_item{it.row, it.orig, it.slot, 0}); }
+        for (SplitRow &sr : srows) {
+            sr.sys = (int32_t)fin.size();
+            fin.push_back(bdf_fin_item{sr.row, split[(size_t)sr.slot_begin].orig, sr.sys, 0});
+        }
+        while (fin.size() % 4) fin.push_back(bdf_fin_item{-1, 0, 0, 0});
+    }
     // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
     // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
     // so neighbours in launch order should differ in length: a fixed stride permutation of the sorted list.
@@ -1097,12 +1189,25 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
         (rc = to_device(srows, &plan.rows_dev)) || (rc = to_device(order, &plan.order_dev)))
         return rc;
+#ifdef BDF_EXP_ACC_ONLY
+    BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>((split.size() + direct.size()) * (size_t)psz * sizeof(double), 8)));
+#else
     BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
+#endif
     BDF_HIP(hipMalloc((void **)&plan.arrived_dev, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
     // on the launch stream: hipMemset runs on the NULL stream and returns before the device has done it, and a kernel on a
     // non-blocking stream does not wait for it -- the first launch of a new plan could have its counters zeroed under it
     // (a split row then never finds its last piece: the row keeps its old content)
     BDF_HIP(hipMemsetAsync(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8), ctx->stream));
+    plan.n_fin = (int64_t)fin.size();
+    if (!fin.empty()) {
+        if ((rc = to_device(fin, &plan.fin_dev))) return rc;
+        BDF_HIP(hipMalloc((void **)&plan.sys_dev, fin.size() * (size_t)psz * sizeof(double)));
+        plan.dev.sys = plan.sys_dev;
+    }
+    BDF_HIP(hipMalloc((void **)&plan.ticket_dev, 128));
+    BDF_HIP(hipMemsetAsync(plan.ticket_dev, 0, 128, ctx->stream));
+    plan.dev.ticket = plan.ticket_dev;
     plan.dev.direct = plan.direct_dev; plan.dev.n_direct = (int32_t)direct.size();
     plan.dev.split = plan.split_dev;   plan.dev.n_split = (int32_t)split.size();
     plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
@@ -1114,12 +1219,31 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
 }
 
 template <int DP>
-int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
+int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
 {
     constexpr int WPB = Geo<DP>::WPB;
+    PlanDev p = plan.dev;
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
         dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
+        // BDF_K1_QUEUE=w: exactly w waves per SIMD of the row stream's CUs are launched and pull their items from a counter
+#ifdef BDF_K1_QUEUE_BUILD
+        static const int queue = getenv("BDF_K1_QUEUE") ? atoi(getenv("BDF_K1_QUEUE")) : 0;
+#else
+        constexpr int queue = 0;
+#endif
+        static int cus = 0;
+        if (queue > 0 && !cus) {
+            hipDeviceProp_t prop;
+            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            cus = prop.multiProcessorCount;
+        }
+        const int64_t slots_wg = queue > 0 ? (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * queue / WPB : 0;
+        const bool queued = queue > 0 && !dump && !p.decoupled && plan.n_fin == 0 && (int64_t)grid.x > slots_wg;
+        if (queued) {
+            grid.x = (unsigned)slots_wg;
+            p.ticket_base = plan.ticket_base++;          // (its parity picks the counter)
+        }
         bool matrix = true;
         for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
         static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
@@ -1128,12 +1252,28 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, const PlanDev &p, bool dump)
         const bool coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
         auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
+        // two phases (16 < D <= 32, plans built with slots for the rows' systems): the accumulate-only variant here, then
+        // k_rows_fin for four rows per wave
+        const bool two_phase = plan.n_fin > 0 && !dump;
+        if constexpr (DP == 32) {
+            if (two_phase)
+                kern = coded ? k_rows<DP, false, true, true, true> : (matrix ? k_rows<DP, false, true, false, true> : k_rows<DP, false, false, false, true>);
+        }
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
-        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
-        if (!dump) ctx->time_start = ctx->time_stop = nullptr;
+#ifdef BDF_K1_QUEUE_BUILD
+        if (queued)
+            kern = coded ? k_rows_queue<DP, false, true, true> : (matrix ? k_rows_queue<DP, false, true> : k_rows_queue<DP, false, false>);
+#endif
+        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start,
+                              (dump || two_phase) ? nullptr : ctx->time_stop, 0, a, p);
         BDF_HIP(hipGetLastError());
+        if (two_phase) {
+            int rc = bdf_fin_launch(ctx, a, plan.fin_dev, plan.n_fin, plan.sys_dev, nullptr, ctx->time_stop);
+            if (rc) return rc;
+        }
+        if (!dump) ctx->time_start = ctx->time_stop = nullptr;
     }
     return BDF_OK;
 }
@@ -1182,6 +1322,9 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
             if (kv->second.lr_dev) (void)hipFree(kv->second.lr_dev);
             if (kv->second.lr_rows_dev) (void)hipFree(kv->second.lr_rows_dev);
             (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
+            if (kv->second.ticket_dev) (void)hipFree(kv->second.ticket_dev);
+            if (kv->second.fin_dev) (void)hipFree(kv->second.fin_dev);
+            if (kv->second.sys_dev) (void)hipFree(kv->second.sys_dev);
             kv = plans.erase(kv);
         } else {
             ++kv;
@@ -1271,6 +1414,10 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         key.lr_other = ctx->lr_min_rows > 0 ? rels[0]->dims[other] : 0;          // (min_rows = 0, a test hook: whenever the entity has such a row)
     }
 
+    // 16 < D <= 32: accumulate and finish as two kernels (k_rows<SYS> + k_rows_fin, four rows per wave) for launches of
+    // bdf_ctx_set_two_phase's row count or more (environment BDF_K1_TWO_PHASE; negative: never)
+    key.fin_min = (DP == 32 && a.D > 16 && !dump && !getenv("BDF_K1_DECOUPLE")) ? ctx->fin_min_rows : -1;
+
     Plan *plan;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -1355,7 +1502,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         ctx->time_start = nullptr;
         if (!more) { ctx->time_stop = nullptr; return BDF_OK; }
     }
-    if (DP == 16) return launch<16>(ctx, a, plan->dev, dump);
-    if (DP == 32) return launch<32>(ctx, a, plan->dev, dump);
-    return launch<64>(ctx, a, plan->dev, dump);
+    if (DP == 16) return launch<16>(ctx, a, *plan, dump);
+    if (DP == 32) return launch<32>(ctx, a, *plan, dump);
+    return launch<64>(ctx, a, *plan, dump);
 }

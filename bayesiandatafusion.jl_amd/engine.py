@@ -156,6 +156,11 @@ class Context:
         map, other sampled values"""
         check(lib().bdf_ctx_set_lowrank(self.handle, int(max_observations), int(min_rows)))
 
+    def set_two_phase(self, min_rows=1024):
+        """16 < D <= 32: row launches of min_rows rows or more as two kernels -- accumulate every row's system, then factor,
+        solve and draw four rows per wave (bdf_ctx_set_two_phase; negative: never)"""
+        check(lib().bdf_ctx_set_two_phase(self.handle, int(min_rows)))
+
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 

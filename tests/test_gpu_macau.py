@@ -189,6 +189,30 @@ def test_whole_iterations_match_oracle(B, O, with_feat, use_ff):
         assert math.isclose(rd.entities[0].lambda_beta, lb, rel_tol=1e-6)
 
 
+@pytest.mark.parametrize("D", [24, 32])
+def test_whole_iterations_two_phase_rows_match_oracle(B, O, monkeypatch, D):
+    """the native iteration with the two-kernel row launch forced (BDF_K1_TWO_PHASE=1: k_rows<SYS> + k_rows_fin, the finish kernel
+    polling for the hyperprior's draw): three whole iterations with entity side information against the oracle"""
+    monkeypatch.setenv("BDF_K1_TWO_PHASE", "1")
+    monkeypatch.setenv("BDF_LOWRANK", "0")
+    rng = np.random.default_rng(80 + D)
+    N1, N2, nnz = 150, 70, 4000
+    ids = np.stack([rng.integers(1, N1 + 1, nnz), rng.integers(1, N2 + 1, nnz)], axis=1)
+    vals = rng.standard_normal(nnz)
+    F = rng.standard_normal((N1, 4))
+    e1, e2 = B.Entity("u", F=F), B.Entity("v")
+    rel = B.Relation({"u": ids[:, 0], "v": ids[:, 1], "y": vals}, "r", [e1, e2], dims=[N1, N2])
+    B.setPrecision(rel, 2.0)
+    rd = B.RelationData(rel)
+    B.macau(rd, burnin=3, psamples=0, num_latent=D, verbose=False, seed=77)
+    S, mu, Lam, beta, lb = _oracle_macau(O, rd, D, 77, 3, F, True)
+    for j in (0, 1):
+        np.testing.assert_allclose(rd.entities[j].model.sample.T, S[j], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rd.entities[j].model.mu, mu[j], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(rd.entities[j].model.Lambda, Lam[j], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(rd.entities[0].model.beta, beta, rtol=1e-5, atol=1e-7)
+
+
 def test_determinism_and_stream_overlap(B, monkeypatch):
     """same seed -> bit-identical chain; the native three-stream iteration, the step-by-step one and the single-stream one
     give the same values"""

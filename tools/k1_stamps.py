@@ -16,6 +16,10 @@ from bdf_amd._lib import lib
 D = int(os.environ.get("D", "32"))
 rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
 eng = B.GibbsEngine(rd, D, seed=1, device=0)
+if os.environ.get("ITEM"):           # observations per work item / per piece of a split row
+    eng.ctx.set_item_size(int(os.environ["ITEM"]))
+if os.environ.get("PIECE"):
+    eng.ctx.set_piece_size(int(os.environ["PIECE"]))
 for i in range(1, 6):
     eng.sweep(i)
 eng.sync()
