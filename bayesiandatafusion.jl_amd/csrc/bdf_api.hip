@@ -77,7 +77,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
     c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
-    c->fin_min_rows = getenv("BDF_K1_TWO_PHASE") ? atoll(getenv("BDF_K1_TWO_PHASE")) : 1024;
+    c->fin_min_rows = getenv("BDF_K1_TWO_PHASE") ? atoll(getenv("BDF_K1_TWO_PHASE")) : -1;      // (off: measured slower than the one-kernel launch)
     c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0; c->lr_mrows = nullptr; c->lr_mrows_bytes = 0;
     c->lr_key_fac = c->lr_key_Lambda = c->lr_key_mu = nullptr; c->lr_key_sweep = c->lr_key_tag = 0; c->lr_key_D = 0; c->lr_key_M = 0;
     {

@@ -28,10 +28,10 @@
 #define BDF_K1_WAVES32S 5         // the accumulate-only kernels of a two-phase launch: general,
 #endif
 #ifndef BDF_K1_WAVES32SM
-#define BDF_K1_WAVES32SM 7        // two-mode relations,
+#define BDF_K1_WAVES32SM 6        // two-mode relations,
 #endif
 #ifndef BDF_K1_WAVES32SC
-#define BDF_K1_WAVES32SC 8        // one two-mode relation with coded values
+#define BDF_K1_WAVES32SC 7        // one two-mode relation with coded values
 #endif
 
 namespace {

@@ -116,6 +116,25 @@ __device__ __forceinline__ void fin_load(double (&A)[33], const double *sys, con
     }
 }
 
+// one more slot of the row (a piece of a long row, another relation's part) added to the system, eight rows at a time
+template <int S, int I, int I1>
+__device__ __forceinline__ void fin_add16(double (&A)[33], const double *sys, int j)
+{
+    if constexpr (I < I1) {
+        A[I] += sys[sys_off<S, I>(j)];
+        fin_add16<S, I + 1, I1>(A, sys, j);
+    }
+}
+template <int S, int I, int DR>
+__device__ __forceinline__ void fin_add(double (&A)[33], const double *sys, int j)
+{
+    if constexpr (I < DR) {
+        fin_add16<S, I, (I + 8 < DR ? I + 8 : DR)>(A, sys, j);
+        asm volatile("" ::: "memory");
+        fin_add<S, I + 8, DR>(A, sys, j);
+    }
+}
+
 constexpr int FIN_PSZ = 3 * 4 * 64 + 2 * 16;          // Geo<32>::PSZ
 
 template <int DR, bool POLLED>
@@ -139,6 +158,7 @@ __global__ __launch_bounds__(64, 2) void k_rows_fin(SampleArgs a, const FinItem 
     asm volatile("" ::: "memory");
 
     // the row's system (after the normals: their arithmetic needs ~60 registers of its own) plus the prior
+    const int n_slots = live ? it._pad : 0;              // (a row without observations has none: `sys` is then the slab's zero slot)
     const double *sys = slab + (int64_t)(live ? it.sys : 0) * FIN_PSZ;
     double A0[33], A1[33];
     const int ob0 = 3 * 4 * 64 + j, ob1 = ob0 + 16;
@@ -159,6 +179,20 @@ __global__ __launch_bounds__(64, 2) void k_rows_fin(SampleArgs a, const FinItem 
     }
     fin_load<0, 0, DR, POLLED>(A0, sys, a.prior_c, j);
     fin_load<1, 0, DR, POLLED>(A1, sys, a.prior_c, j);
+    // the other slots of rows that have several, in slot order (the rows of a wave were sorted to have like counts)
+    int nmax = n_slots;
+    nmax = max(nmax, __shfl_xor(nmax, 16));
+    nmax = max(nmax, __shfl_xor(nmax, 32));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    for (int sl = 1; sl < nmax; sl++) {
+        if (sl < n_slots) {
+            const double *sp = sys + (int64_t)sl * FIN_PSZ;
+            A0[32] += sp[ob0];
+            A1[32] += sp[ob1];
+            fin_add<0, 0, DR>(A0, sp, j);
+            fin_add<1, 0, DR>(A1, sp, j);
+        }
+    }
     // (rows and columns D .. 31 of the system are the identity by construction: masked gathers, the prior's image)
     double d0 = 1.0, d1 = 1.0;
     fin_factor<DR, 0>(A0, A1, d0, d1, j);

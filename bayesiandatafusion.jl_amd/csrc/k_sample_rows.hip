@@ -49,6 +49,7 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
+#include <queue>
 #include <utility>
 
 #ifndef BDF_CHOL_BLOCKED
@@ -84,7 +85,7 @@ struct Item {             // one wave's accumulation work
     int32_t term;
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
-    int32_t slot;         // partial slot; a direct row: -1, or (two-phase launch) the row's slot in the slab of systems
+    int32_t slot;         // partial slot, or -1 for a direct row (k_rows_bundle: the job's slot in the slab)
     int32_t srow;         // index of the row in the split-row table (split items)
     int32_t orig;         // the row's ORIGINAL id: keys its random stream (== row unless the relation was created with a layout)
 };
@@ -92,7 +93,7 @@ struct Item {             // one wave's accumulation work
 struct SplitRow {
     int32_t row;
     int32_t slot_begin, n_slots;
-    int32_t sys;          // two-phase launch: the row's slot in the slab of systems
+    int32_t _pad;
 };
 
 struct PlanDev {
@@ -105,7 +106,10 @@ struct PlanDev {
     int32_t decoupled, _pad;                     // 1: every row is accumulated by producer waves and finished by another wave
     uint32_t *ticket;                            // queue-fed launch (k_rows_queue): the next position of `order`, counted on from
     uint32_t ticket_base, _pad2;                 // (the launch's number: its parity picks the counter)
-    double *sys;                                 // two-phase launch (k_rows<SYS> + k_rows_fin): one slot of PSZ doubles per row
+    double *sys;                                 // two-phase launch (k_rows_bundle + k_rows_fin): one slot of PSZ doubles per job
+    const Item *segs;                            // ... the jobs (row or piece of a row: `slot` = its slot in the slab), wave by wave,
+    const int32_t *wave_seg;                     // wave w takes segs[wave_seg[w]] .. segs[wave_seg[w + 1] - 1]
+    int32_t n_bwaves, _pad3;
 };
 
 
@@ -602,7 +606,7 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool SYS = false>
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
 __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     double *const tab = tri;          // CODED: the wave's value table (BDF_K1_CODES doubles) sits in the packed factor's space until the factorisation
@@ -629,7 +633,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
-    const bool early_z = !DUMP && !SYS && !is_split && !p.decoupled;
+    const bool early_z = !DUMP && !is_split && !p.decoupled;
     if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
     if (p.decoupled && !is_split) {
         // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
@@ -679,24 +683,9 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
         // the finisher's normals before the partial sums are loaded: the Box-Muller arithmetic needs ~40 registers
-        if (!DUMP && !SYS && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
+        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
-    }
-    if constexpr (SYS) {
-        // two-phase launch: the row's system (alpha S, alpha W r; the pieces of a split row summed) goes to the slab in the
-        // partial-slot format and k_rows_fin (k_rows_fin.hip) takes it from there, four rows to a wave
-        double *dst = p.sys + (int64_t)(is_split ? p.rows[it.srow].sys : it.slot) * PSZ;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
-        if (lane < 16) {
-#pragma unroll
-            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bv[I];
-        }
-        SPAN_END();
-        return;
     }
 #ifdef BDF_EXP_ACC_ONLY       // experiment: what the launch costs without the finish phase (the row's system goes to the slab instead)
     {
@@ -827,9 +816,8 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     SPAN_END();
 }
 
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool SYS = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, SYS ? (CODED ? Geo<DP>::WAVES_SYS_CODED : (MATRIX ? Geo<DP>::WAVES_SYS_MATRIX : Geo<DP>::WAVES_SYS))
-                                                    : (CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES)))
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
 void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
@@ -838,7 +826,49 @@ void k_rows(SampleArgs a, PlanDev p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct)
-        process_item<DP, DUMP, MATRIX, CODED, SYS>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+}
+
+// ---- two-phase launch, first kernel: EQUAL WORK PER WAVE ---------------------------------------------------------------------
+// The one-kernel launch gives every wave one item -- a row, or a piece of a long one -- and ends with its longest chain: 24
+// trips of gathers for a 192-observation row while the mean is 9 (the accumulation alone: 31 us of the launch's 39 at
+// MovieLens's size, against 10 us of matrix-pipe time).  Here a wave takes a BUNDLE of jobs: rows are cut into pieces of at
+// most the mean work per wave, the pieces and the whole rows are dealt to the waves longest first (build_plan), and every job
+// leaves its part of the row's system -- alpha S and alpha W r in the partial-slot format -- in its own slot of the slab.
+// The factorisation, the solves and the draw are k_rows_fin's (k_rows_fin.hip), four rows per wave.
+template <int DP, bool MATRIX, bool CODED = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_SYS_CODED : (MATRIX ? Geo<DP>::WAVES_SYS_MATRIX : Geo<DP>::WAVES_SYS))
+void k_rows_bundle(SampleArgs a, PlanDev p)
+{
+    using GG = Geo<DP>;
+    constexpr int WPB = GG::WPB, DB = GG::DB, NB = GG::NB, PSZ = GG::PSZ;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * BDF_K1_CODES];       // CODED: the wave's value table
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int w = (int)blockIdx.x * WPB + wave;
+    if (w >= p.n_bwaves) return;
+    const int s1 = p.wave_seg[w + 1];
+    for (int s = p.wave_seg[w]; s < s1; s++) {
+        // (the arguments, the lane and the wave number through an index the compiler cannot see through: kept live around the
+        // loop, what it derives from them would cost the kernel its registers)
+        int zero = 0, lane_i = lane, wave_i = wave;
+        asm volatile("" : "+s"(zero), "+v"(lane_i), "+s"(wave_i));
+        const SampleArgs &ai = (&a)[zero];
+        const PlanDev &pi = (&p)[zero];
+        const Item it = pi.segs[s];
+        d4 acc[NB];
+        double bv[DB];
+        accumulate_any<DP, MATRIX, CODED>(ai, it, lane_i, acc, bv, lds + wave_i * BDF_K1_CODES);
+        double *dst = pi.sys + (int64_t)it.slot * PSZ;
+#pragma unroll
+        for (int b = 0; b < NB; b++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane_i] = acc[b][r];
+        if (lane_i < 16) {
+#pragma unroll
+            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane_i] = bv[I];
+        }
+        wave_sync();          // the next job's value table replaces this one's
+    }
 }
 
 // Queue-fed launch (an experiment, DESIGN.md section 4, K1: built with -DBDF_K1_QUEUE_BUILD -mllvm -disable-machine-licm --
@@ -1016,7 +1046,7 @@ struct PlanKey {
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
-    int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows<SYS> + k_rows_fin) if the launch has at least this many
+    int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows_bundle + k_rows_fin) if the launch has at least this many
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -1034,9 +1064,11 @@ struct Plan {
     int32_t *arrived_dev = nullptr;
     uint32_t *ticket_dev = nullptr;   // queue-fed launch: the counter and what it stands at when the next launch begins
     uint32_t ticket_base = 0;
-    bdf_fin_item *fin_dev = nullptr;  // two-phase launch: the rows of k_rows_fin (a multiple of 4) and the slab of their systems
-    int64_t n_fin = 0;
+    bdf_fin_item *fin_dev = nullptr;  // two-phase launch: the rows of k_rows_fin (a multiple of 4), the jobs of k_rows_bundle wave by
+    int64_t n_fin = 0;                // wave, and the slab with a slot per job
     double *sys_dev = nullptr;
+    Item *segs_dev = nullptr;
+    int32_t *wave_seg_dev = nullptr;
 };
 
 struct PlanCache {
@@ -1064,14 +1096,33 @@ struct RowRef {
     int64_t cnt[BDF_MAX_TERMS];
 };
 
-int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, bool lr_on, Plan &plan)
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, bool lr_on, int64_t bundle_waves, Plan &plan)
 {
     const int T = key.T;
     std::vector<Item> direct, split;
     std::vector<SmallItem> small, lr;
     std::vector<SplitRow> srows;
     static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
+    // two-phase launch (16 < D <= 32): the rows that neither k_rows_small nor the low-rank sampler takes go to k_rows_bundle +
+    // k_rows_fin when there are at least key.fin_min of them
+    auto row_total = [&](const RowRef &rr) { int64_t n = 0; for (int r = 0; r < key.n_terms; r++) n += rr.cnt[r]; return n; };
+    auto row_is_k1 = [&](const RowRef &rr) {
+        int nz = 0;
+        for (int r = 0; r < key.n_terms; r++) nz += rr.cnt[r] > 0;
+        const int64_t n = row_total(rr);
+        if (nz <= 1 && key.small > 0 && n <= key.small) return false;
+        if (nz <= 1 && lr_on && n <= key.lr) return false;
+        return true;
+    };
+    bool two_phase = false;
+    if (key.fin_min >= 0 && !decoupled) {
+        int64_t n_k1 = 0;
+        for (const RowRef &rr : rows) n_k1 += row_is_k1(rr);
+        two_phase = n_k1 >= std::max<int64_t>(key.fin_min, 1);
+    }
+    std::vector<const RowRef *> brows;
     for (const RowRef &rr : rows) {
+        if (two_phase && row_is_k1(rr)) { brows.push_back(&rr); continue; }
         const int32_t row = rr.out;
         int n_items = 0;
         for (int r = 0; r < key.n_terms; r++) n_items += (int)std::min<int64_t>((rr.cnt[r] + T - 1) / T, MAX_PIECES);
@@ -1112,15 +1163,62 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         }
         if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});      // the row's finisher
     }
-    // two-phase launch: every row of k_rows gets a slot in the slab of systems; k_rows_fin takes the rows in this order
+    // two-phase launch: jobs (whole rows, pieces of the long ones; one slot of the slab each) dealt to bundle_waves waves so
+    // that every wave has the same number of trips (8 observations) plus a trip's worth per job for its start and its store
     std::vector<bdf_fin_item> fin;
-    if (key.fin_min >= 0 && !decoupled && (int64_t)direct.size() + (int64_t)srows.size() >= std::max<int64_t>(key.fin_min, 1)) {
-        for (Item &it : direct) { it.slot = (int32_t)fin.size(); fin.push_back(bdf_fin_item{it.row, it.orig, it.slot, 0}); }
-        for (SplitRow &sr : srows) {
-            sr.sys = (int32_t)fin.size();
-            fin.push_back(bdf_fin_item{sr.row, split[(size_t)sr.slot_begin].orig, sr.sys, 0});
+    std::vector<Item> segs;
+    std::vector<int32_t> wave_seg;
+    if (two_phase) {
+        auto trips_of = [](int64_t n) { return (n + 7) / 8; };
+        int64_t total = 0;
+        for (const RowRef *rr : brows)
+            for (int r = 0; r < key.n_terms; r++) total += trips_of(rr->cnt[r]) + (rr->cnt[r] > 0);
+        const int64_t nw = std::max<int64_t>(1, std::min<int64_t>(bundle_waves, total));
+        static const double slack = getenv("BDF_K1_BUNDLE_SLACK") ? atof(getenv("BDF_K1_BUNDLE_SLACK")) : 1.0;
+        const int64_t cap = std::max<int64_t>(2, (int64_t)(slack * (double)((total + nw - 1) / nw)));       // trips per job at most
+        struct Job { int64_t trips; int32_t seg; };
+        std::vector<Job> jobs;
+        for (const RowRef *rr : brows) {
+            bdf_fin_item fi{rr->out, rr->orig, (int32_t)segs.size(), 0};
+            for (int r = 0; r < key.n_terms; r++) {
+                const int64_t n = rr->cnt[r];
+                if (n <= 0) continue;
+                const int64_t t = trips_of(n), pieces = (t + cap - 1) / cap;
+                for (int64_t q = 0; q < pieces; q++) {
+                    // equal pieces, cut at multiples of a trip
+                    const int64_t t0 = t * q / pieces, t1 = t * (q + 1) / pieces;
+                    const int64_t b0 = rr->qb[r] + 8 * t0, b1 = rr->qb[r] + std::min<int64_t>(8 * t1, n);
+                    jobs.push_back(Job{t1 - t0, (int32_t)segs.size()});
+                    segs.push_back(Item{rr->out, r, b0, (int32_t)(b1 - b0), (int32_t)segs.size(), -1, rr->orig});
+                    fi._pad++;                   // (the row's number of slots)
+                }
+            }
+            fin.push_back(fi);
         }
+        for (bdf_fin_item &fi : fin)
+            if (fi._pad == 0) fi.sys = (int32_t)segs.size();          // no observations: the slab's last slot, all zeros
+        // the rows of one finish wave go through as many rounds of slot sums as the longest of them has slots: like with like
+        std::stable_sort(fin.begin(), fin.end(), [](const bdf_fin_item &x, const bdf_fin_item &y) { return x._pad > y._pad; });
         while (fin.size() % 4) fin.push_back(bdf_fin_item{-1, 0, 0, 0});
+        // longest job first, each to the wave with the least work so far
+        std::stable_sort(jobs.begin(), jobs.end(), [](const Job &x, const Job &y) { return x.trips > y.trips; });
+        std::vector<std::vector<int32_t>> bins((size_t)nw);
+        std::priority_queue<std::pair<int64_t, int64_t>, std::vector<std::pair<int64_t, int64_t>>, std::greater<std::pair<int64_t, int64_t>>> heap;
+        for (int64_t w = 0; w < nw; w++) heap.push({0, w});
+        for (const Job &j : jobs) {
+            auto top = heap.top();
+            heap.pop();
+            bins[(size_t)top.second].push_back(j.seg);
+            heap.push({top.first + j.trips + 1, top.second});
+        }
+        // the slab's slots stay numbered by row (a row's slots are neighbours); the waves' job lists are a permutation
+        std::vector<Item> ordered;
+        wave_seg.push_back(0);
+        for (int64_t w = 0; w < nw; w++) {
+            for (int32_t sg : bins[(size_t)w]) ordered.push_back(segs[(size_t)sg]);
+            wave_seg.push_back((int32_t)ordered.size());
+        }
+        segs.swap(ordered);
     }
     // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
     // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
@@ -1201,9 +1299,13 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     BDF_HIP(hipMemsetAsync(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8), ctx->stream));
     plan.n_fin = (int64_t)fin.size();
     if (!fin.empty()) {
-        if ((rc = to_device(fin, &plan.fin_dev))) return rc;
-        BDF_HIP(hipMalloc((void **)&plan.sys_dev, fin.size() * (size_t)psz * sizeof(double)));
+        if ((rc = to_device(fin, &plan.fin_dev)) || (rc = to_device(segs, &plan.segs_dev)) || (rc = to_device(wave_seg, &plan.wave_seg_dev))) return rc;
+        BDF_HIP(hipMalloc((void **)&plan.sys_dev, (segs.size() + 1) * (size_t)psz * sizeof(double)));
+        BDF_HIP(hipMemsetAsync(plan.sys_dev + segs.size() * (size_t)psz, 0, (size_t)psz * sizeof(double), ctx->stream));
         plan.dev.sys = plan.sys_dev;
+        plan.dev.segs = plan.segs_dev;
+        plan.dev.wave_seg = plan.wave_seg_dev;
+        plan.dev.n_bwaves = (int32_t)wave_seg.size() - 1;
     }
     BDF_HIP(hipMalloc((void **)&plan.ticket_dev, 128));
     BDF_HIP(hipMemsetAsync(plan.ticket_dev, 0, 128, ctx->stream));
@@ -1223,6 +1325,30 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
 {
     constexpr int WPB = Geo<DP>::WPB;
     PlanDev p = plan.dev;
+    bool matrix = true;
+    for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
+    static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
+    matrix = matrix && !no_matrix;
+    static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
+    const bool coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
+    if (plan.n_fin > 0 && !dump) {
+        // two phases (16 < D <= 32): equal bundles of jobs accumulate every row's system into the slab, then k_rows_fin
+        // factors, solves and draws four rows per wave.  The caller's start event rides on the first kernel, its stop event
+        // on the second.
+        if constexpr (DP == 32) {
+            if (p.n_bwaves > 0) {
+                const dim3 grid((unsigned)((p.n_bwaves + WPB - 1) / WPB)), block(64 * WPB);
+                auto kern = coded ? k_rows_bundle<DP, true, true> : (matrix ? k_rows_bundle<DP, true, false> : k_rows_bundle<DP, false, false>);
+                hipExtLaunchKernelGGL(kern, grid, block, 0, ctx->stream, ctx->time_start, nullptr, 0, a, p);
+                BDF_HIP(hipGetLastError());
+                ctx->time_start = nullptr;
+            }
+            int rc = bdf_fin_launch(ctx, a, plan.fin_dev, plan.n_fin, plan.sys_dev, ctx->time_start, ctx->time_stop);
+            if (rc) return rc;
+        }
+        ctx->time_start = ctx->time_stop = nullptr;
+        return BDF_OK;
+    }
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
         dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
@@ -1239,26 +1365,13 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
             cus = prop.multiProcessorCount;
         }
         const int64_t slots_wg = queue > 0 ? (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * queue / WPB : 0;
-        const bool queued = queue > 0 && !dump && !p.decoupled && plan.n_fin == 0 && (int64_t)grid.x > slots_wg;
+        const bool queued = queue > 0 && !dump && !p.decoupled && (int64_t)grid.x > slots_wg;
         if (queued) {
             grid.x = (unsigned)slots_wg;
             p.ticket_base = plan.ticket_base++;          // (its parity picks the counter)
         }
-        bool matrix = true;
-        for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
-        static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
-        matrix = matrix && !no_matrix;
-        static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
-        const bool coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
         auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
-        // two phases (16 < D <= 32, plans built with slots for the rows' systems): the accumulate-only variant here, then
-        // k_rows_fin for four rows per wave
-        const bool two_phase = plan.n_fin > 0 && !dump;
-        if constexpr (DP == 32) {
-            if (two_phase)
-                kern = coded ? k_rows<DP, false, true, true, true> : (matrix ? k_rows<DP, false, true, false, true> : k_rows<DP, false, false, false, true>);
-        }
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
@@ -1266,14 +1379,9 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
         if (queued)
             kern = coded ? k_rows_queue<DP, false, true, true> : (matrix ? k_rows_queue<DP, false, true> : k_rows_queue<DP, false, false>);
 #endif
-        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start,
-                              (dump || two_phase) ? nullptr : ctx->time_stop, 0, a, p);
-        BDF_HIP(hipGetLastError());
-        if (two_phase) {
-            int rc = bdf_fin_launch(ctx, a, plan.fin_dev, plan.n_fin, plan.sys_dev, nullptr, ctx->time_stop);
-            if (rc) return rc;
-        }
+        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
         if (!dump) ctx->time_start = ctx->time_stop = nullptr;
+        BDF_HIP(hipGetLastError());
     }
     return BDF_OK;
 }
@@ -1325,6 +1433,8 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
             if (kv->second.ticket_dev) (void)hipFree(kv->second.ticket_dev);
             if (kv->second.fin_dev) (void)hipFree(kv->second.fin_dev);
             if (kv->second.sys_dev) (void)hipFree(kv->second.sys_dev);
+            if (kv->second.segs_dev) (void)hipFree(kv->second.segs_dev);
+            if (kv->second.wave_seg_dev) (void)hipFree(kv->second.wave_seg_dev);
             kv = plans.erase(kv);
         } else {
             ++kv;
@@ -1414,7 +1524,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         key.lr_other = ctx->lr_min_rows > 0 ? rels[0]->dims[other] : 0;          // (min_rows = 0, a test hook: whenever the entity has such a row)
     }
 
-    // 16 < D <= 32: accumulate and finish as two kernels (k_rows<SYS> + k_rows_fin, four rows per wave) for launches of
+    // 16 < D <= 32: accumulate and finish as two kernels (k_rows_bundle + k_rows_fin, four rows per wave) for launches of
     // bdf_ctx_set_two_phase's row count or more (environment BDF_K1_TWO_PHASE; negative: never)
     key.fin_min = (DP == 32 && a.D > 16 && !dump && !getenv("BDF_K1_DECOUPLE")) ? ctx->fin_min_rows : -1;
 
@@ -1462,7 +1572,15 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
                 lr_on = cnt >= key.lr_min && 2 * cnt >= key.lr_other;
             }
             Plan np;
-            int rc = build_plan(ctx, key, rows, psz, lr_on, np);
+            // two-phase launch: as many bundles as the row stream's CUs hold waves of the accumulate kernel at once
+            int64_t bundle_waves = 0;
+            if (key.fin_min >= 0) {
+                hipDeviceProp_t prop;
+                BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+                static const int per_simd = getenv("BDF_K1_BUNDLE_WAVES") ? atoi(getenv("BDF_K1_BUNDLE_WAVES")) : BDF_K1_WAVES32SC;
+                bundle_waves = (int64_t)std::max(1, prop.multiProcessorCount - ctx->reserve_cus) * 4 * per_simd;
+            }
+            int rc = build_plan(ctx, key, rows, psz, lr_on, bundle_waves, np);
             if (rc) return rc;
             it = cache.plans.emplace(key, np).first;
         }
