@@ -24,6 +24,9 @@
 #define BDF_K1_WAVES32C 7         // ... its variant for one two-mode relation with coded values (70 registers)
 #endif
 
+#ifndef BDF_K1_WAVES32G
+#define BDF_K1_WAVES32G 7         // ... its variant with the rows gathered straight into LDS (D = 32, coded values)
+#endif
 #ifndef BDF_K1_WAVES32S
 #define BDF_K1_WAVES32S 5         // the accumulate-only kernels of a two-phase launch: general,
 #endif

@@ -77,6 +77,17 @@
 #define STAMP(slot) do { } while (0)
 #endif
 
+#ifdef BDF_EXP_NO_GATHER          // experiments (wrong results): the accumulation without its row gathers / without its matrix instructions
+#define BDF_EXP_NO_GATHER_V 1
+#else
+#define BDF_EXP_NO_GATHER_V 0
+#endif
+#ifdef BDF_EXP_NO_MFMA
+#define BDF_EXP_NO_MFMA_V 1
+#else
+#define BDF_EXP_NO_MFMA_V 0
+#endif
+
 namespace {
 
 
@@ -293,8 +304,9 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
         _Pragma("unroll") for (int m = 0; m < NO; m++)                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
-                w[S][k][m][I] = WIDE ? *(const double *)(fac[m] + ((uint64_t)ix[S][k][m] * rowb + eoff[I]))           \
-                                     : *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I]));
+                w[S][k][m][I] = BDF_EXP_NO_GATHER_V ? (double)(int)(ix[S][k][m] & 255u) :                            \
+                                (WIDE ? *(const double *)(fac[m] + ((uint64_t)ix[S][k][m] * rowb + eoff[I]))           \
+                                     : *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I])));
 #define TRIP(t, C, X)                                                                           \
     {                                                                                           \
         LOAD_DATA(X)  /* unconditional (ids are clamped to the item): a branch here would cost exact waitcnts */ \
@@ -317,7 +329,8 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
             int b = 0;                                                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
                 _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
+                    if (BDF_EXP_NO_MFMA_V) acc[b][0] = fma(w_c[k][I], w_c[k][J], acc[b][0]);             \
+                    else acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
                     b++;                                                                        \
                 }                                                                               \
                 bpart[I] = fma(w_c[k][I], r, bpart[I]);                                         \
@@ -466,13 +479,129 @@ __device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item 
     }
 }
 
+// ---- accumulate one item, rows gathered STRAIGHT INTO LDS (D = DP = 32, one two-mode relation with coded values) ----------------
+// The register pipeline above has the factor rows of ONE trip in flight per wave (2 KB: two register sets are what 7 waves per
+// SIMD leave room for), and the accumulation runs at the rate that allows -- 26-31 us of the launch's 39 at MovieLens's size
+// whatever the balance of the waves, against 10 us of matrix-pipe time: 4.9 TB/s of gathered rows where the
+// gather alone reaches 14.5.  Here the rows never pass through vector registers on their way in: global_load_lds_dwordx4 writes
+// 64 lanes x 16 bytes = four 256-byte rows per instruction into a two-trip ring in the wave's LDS (the packed factor's space,
+// idle until the factorisation), and the matrix operands are read from there (ds_read_b64) when the trip multiplies.  TWO trips
+// (4 KB) are in flight per wave, the 16 registers of the two sets are gone (8 waves per SIMD), and the item's packed words
+// (ids + value codes, <= 160 observations: bdf_launch_sample_rows caps the item size) are fetched once, also by LDS-DMA.
+// LDS of the wave, bytes from `tri`: [0, 256) value table, [256, 896) packed words, [896, 4992) the ring (2 x 2 x 1 KB).
+// Same operands to the same matrix instructions in the same order as accumulate_lean<.., CODED>: bit-identical sums.
+#define BDF_GLDS_MAX_OBS 160
+__device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void glds4(unsigned voff, const void *sbase, unsigned lds_dst)
+{
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
+}
+template <int DP>
+__device__ __forceinline__ void accumulate_glds(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
+                                       double (&bred)[Geo<DP>::DB], double *tri)
+{
+    static_assert(DP == 32, "LDS-direct gather: D = 32");
+    constexpr int DB = 2, NB = 3;
+    const TermDev &T = a.t[it.term];
+    const int j = lane & 15, h = lane >> 4;
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    double bpart[DB] = {0.0, 0.0};
+    const uint32_t n = (uint32_t)it.count, ntrips = (n + 7) / 8;
+    // (wave-uniform by construction; the scalar-register operands of the LDS-DMA statements need the compiler to know it)
+    auto uniform = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return (const void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    const void *fac = uniform((const void *)T.fac[0]);
+    const void *packed = uniform((const void *)(T.packed + it.q_begin));
+    const double mean = T.mean;
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)tri);
+    double *const tab = tri;
+    const uint2 *const idw = (const uint2 *)(tri + 32);          // pair p = observations 2p, 2p + 1 of the item
+    const double *const ring = tri + 112;
+    if (lane < BDF_K1_CODES) tab[lane] = T.table[lane] - mean;      // this wave's copy of the table: value - mean by code
+    // the item's packed words: word w (clamped to the item: positions past its end repeat the last observation) by lane w % 64
+    {
+        uint32_t w0 = (uint32_t)lane, w1 = w0 + 64, w2 = w0 + 128;
+        w0 = (w0 < n ? w0 : n - 1) * 4u; w1 = (w1 < n ? w1 : n - 1) * 4u; w2 = (w2 < n ? w2 : n - 1) * 4u;
+        glds4(w0, packed, lds0 + 256);
+        if (n > 64) glds4(w1, packed, lds0 + 512);
+        if (n > 128 && lane < 32) glds4(w2, packed, lds0 + 768);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    const unsigned chunk = (unsigned)j * 16u, ringb = lds0 + 896;
+    // gather trip tt (its 8 observations: lane group h takes observations 8 tt + 2 h + k in piece k) into ring slot tt & 1
+#define GLDS_TRIP(tt)                                                                            \
+    {                                                                                            \
+        const uint2 pw = idw[4 * (tt) + h];                                                      \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
+        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + ((tt) & 1u) * 2048u);                  \
+        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + ((tt) & 1u) * 2048u + 1024u);          \
+    }
+    GLDS_TRIP(0u)
+    if (ntrips > 1) GLDS_TRIP(1u)
+    const int eo0 = 31 - j, eo1 = 15 - j;                // natural index of reversed elements j, 16 + j
+    for (uint32_t t = 0; t < ntrips; t++) {
+        // everything but the newest trip's two pieces has landed
+        if (t + 1 < ntrips) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const double *sl = ring + (t & 1u) * 256 + h * 32;
+        double w_c[2][DB];
+        w_c[0][0] = sl[eo0]; w_c[0][1] = sl[eo1];
+        w_c[1][0] = sl[128 + eo0]; w_c[1][1] = sl[128 + eo1];
+        const uint2 pw = idw[4 * t + h];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: the trip after next may land in it
+        if (t + 2 < ntrips) GLDS_TRIP(t + 2)
+        if (t + 1 >= ntrips) {                                  // ragged last trip
+            const uint32_t o = 8 * t + 2 * (uint32_t)h;
+            if (!(o < n)) { w_c[0][0] = 0.0; w_c[0][1] = 0.0; }
+            if (!(o + 1 < n)) { w_c[1][0] = 0.0; w_c[1][1] = 0.0; }
+        }
+        const double r0 = tab[pw.x >> 24], r1 = tab[pw.y >> 24];
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][0], w_c[0][0], acc[0], 0, 0, 0);
+        bpart[0] = fma(w_c[0][0], r0, bpart[0]);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][0], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][1], acc[2], 0, 0, 0);
+        bpart[1] = fma(w_c[0][1], r0, bpart[1]);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][0], w_c[1][0], acc[0], 0, 0, 0);
+        bpart[0] = fma(w_c[1][0], r1, bpart[0]);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][0], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][1], acc[2], 0, 0, 0);
+        bpart[1] = fma(w_c[1][1], r1, bpart[1]);
+    }
+#undef GLDS_TRIP
+    const double alpha = term_alpha(T);
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] *= alpha;
+#pragma unroll
+    for (int I = 0; I < DB; I++) {
+        double v = bpart[I] * alpha;
+        v += __shfl_xor(v, 16);
+        v += __shfl_xor(v, 32);
+        bred[I] = v;
+    }
+}
+
 // path and other-mode count are wave-uniform.  MATRIX: the kernel variant for launches whose terms are all two-mode
 // relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
 // 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
-template <int DP, bool MATRIX, bool CODED = false>
+template <int DP, bool MATRIX, bool CODED = false, bool GLDS = false>
 __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
+    if constexpr (GLDS) {                    // ... at D = DP = 32 with items of at most BDF_GLDS_MAX_OBS observations (checked by the host)
+        accumulate_glds<DP>(a, it, lane, acc, bred, const_cast<double *>(tab));
+        return;
+    }
     if constexpr (CODED) {                   // one two-mode relation, lean gather, coded values (checked by the host)
 #ifdef BDF_K1_DEEP32
         if (a.D == DP && it.count >= BDF_K1_DEEP32) { accumulate_deep<DP, false, true>(a, it, lane, acc, bred, tab); return; }
@@ -606,7 +735,7 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool GLDS = false>
 __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     double *const tab = tri;          // CODED: the wave's value table (BDF_K1_CODES doubles) sits in the packed factor's space until the factorisation
@@ -651,7 +780,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
-    } else if (it.count > 0) accumulate_any<DP, MATRIX, CODED>(a, it, lane, acc, bv, tab);
+    } else if (it.count > 0) accumulate_any<DP, MATRIX, CODED, GLDS>(a, it, lane, acc, bv, tab);
     else {
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
@@ -816,8 +945,8 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     SPAN_END();
 }
 
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool GLDS = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, GLDS ? BDF_K1_WAVES32G : (CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES)))
 void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
@@ -826,7 +955,7 @@ void k_rows(SampleArgs a, PlanDev p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct)
-        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+        process_item<DP, DUMP, MATRIX, CODED, GLDS>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
 
 // ---- two-phase launch, first kernel: EQUAL WORK PER WAVE ---------------------------------------------------------------------
@@ -1046,6 +1175,7 @@ struct PlanKey {
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
+    int glds, _padg;                  // 1: D = 32 with coded values, items of at most BDF_GLDS_MAX_OBS observations: rows gathered straight into LDS
     int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows_bundle + k_rows_fin) if the launch has at least this many
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
@@ -1062,6 +1192,7 @@ struct Plan {
     int32_t *order_dev = nullptr;
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
+    bool glds = false;                // every item has at most BDF_GLDS_MAX_OBS observations and the launch is D = 32 with coded values
     uint32_t *ticket_dev = nullptr;   // queue-fed launch: the counter and what it stands at when the next launch begins
     uint32_t ticket_base = 0;
     bdf_fin_item *fin_dev = nullptr;  // two-phase launch: the rows of k_rows_fin (a multiple of 4), the jobs of k_rows_bundle wave by
@@ -1317,7 +1448,20 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     plan.dev.arrived = plan.arrived_dev;
     plan.dev.order = plan.order_dev;
     plan.dev.decoupled = decoupled;
+    plan.glds = key.glds != 0;
     return BDF_OK;
+}
+
+// which k_rows variant a launch takes: every term a two-mode relation on the lean gather path (matrix), and of those the
+// launches with ONE relation whose values are coded (ratings)
+void launch_kind(const SampleArgs &a, bool dump, bool &matrix, bool &coded)
+{
+    matrix = true;
+    for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
+    static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
+    matrix = matrix && !no_matrix;
+    static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
+    coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
 }
 
 template <int DP>
@@ -1325,12 +1469,8 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
 {
     constexpr int WPB = Geo<DP>::WPB;
     PlanDev p = plan.dev;
-    bool matrix = true;
-    for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
-    static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
-    matrix = matrix && !no_matrix;
-    static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
-    const bool coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
+    bool matrix, coded;
+    launch_kind(a, dump, matrix, coded);
     if (plan.n_fin > 0 && !dump) {
         // two phases (16 < D <= 32): equal bundles of jobs accumulate every row's system into the slab, then k_rows_fin
         // factors, solves and draws four rows per wave.  The caller's start event rides on the first kernel, its stop event
@@ -1372,6 +1512,11 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
         }
         auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
+        if constexpr (DP == 32) {
+            // D = 32 with coded values and items of at most BDF_GLDS_MAX_OBS observations (the plan was built that way): the
+            // rows gathered straight into LDS
+            if (coded && plan.glds) kern = k_rows<DP, false, true, true, true>;
+        }
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
         static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
@@ -1497,6 +1642,18 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         const int64_t slots = (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * (DP == 64 ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8));
         const int64_t t = std::min<int64_t>(2048, (nnz_launch / (slots * 16) + 63) / 64 * 64);
         if (t > key.T) { key.T = (int)t; key.Tp = (int)(t * 2 / 3); }
+    }
+    // D = 32, one two-mode relation with coded values, environment BDF_K1_GLDS=1: the rows gathered straight into LDS
+    // (accumulate_glds) -- the item's packed words sit in the wave's LDS too, which caps an item at BDF_GLDS_MAX_OBS observations
+    {
+        bool matrix, coded;
+        launch_kind(a, dump, matrix, coded);
+        static const bool glds_on = getenv("BDF_K1_GLDS") && atoi(getenv("BDF_K1_GLDS")) != 0;      // (opt-in: bit-identical, 3 % faster alone, no gain in the iteration)
+        if (DP == 32 && a.D == 32 && coded && glds_on && !getenv("BDF_K1_DECOUPLE") && key.T <= 192) {
+            key.T = std::min(key.T, BDF_GLDS_MAX_OBS);
+            key.Tp = std::min(key.Tp, key.T);
+            key.glds = 1;
+        }
     }
     // D <= 16, one two-mode relation with the lean gather and no per-observation baseline, an entity of many rows: its short
     // rows four to a wave (k_rows_small).  bdf_ctx_set_small_rows: the longest row taken that way (default 48 observations,

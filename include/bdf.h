@@ -123,7 +123,8 @@ int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows)
  * proved equal in mean and covariance to inv(P_i) b_i, inv(P_i)); max_observations = 0 restores the reference's map for
  * every row. */
 int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
-/* 16 < D <= 32: a row launch of at least min_rows rows (default 1024, environment BDF_K1_TWO_PHASE; negative: never) runs as TWO
+/* (an experiment, OFF by default -- measured slower than the one-kernel launch)  16 < D <= 32: a row launch of
+ * at least min_rows rows (environment BDF_K1_TWO_PHASE; negative, the default: never) runs as TWO
  * kernels -- the accumulation of every row's system (src/sampling.jl:205-207: Lambda_i's data part and its right-hand side) into a
  * slab, then the factorisation, solves and draw (src/sampling.jl:208-211) FOUR ROWS PER WAVE (k_rows_fin.hip: 16 lanes and two
  * columns per lane for each 32 x 32 system).  The same map from the row's normals to the sample as the one-kernel launch (the

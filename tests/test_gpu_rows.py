@@ -511,7 +511,8 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
     8-bit value code in one word, the value from a table in LDS, seven resident waves at D <= 32; up to 32 distinct values,
     33 fall back to the plain two-mode variant.  Same arithmetic: the rows equal the uncoded variant's (BDF_K1_NO_CODED, read
     once per process: a child) to the last bit, and the oracle's to tolerance.  Rows of 0 .. 900 observations: whole rows,
-    ragged last trips, split rows."""
+    ragged last trips, split rows.  At D = 32 the coded variant has a second form, the rows gathered straight into LDS
+    (accumulate_glds, BDF_K1_GLDS=1: items of at most 160 observations -- every child runs with that item size): the same bits again."""
     import subprocess, sys, textwrap, tempfile
     code = textwrap.dedent('''
         import ctypes as C, numpy as np, sys
@@ -529,6 +530,8 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
         vals = table[rng.integers(0, n_values, len(rows))]
         vals[:n_values] = table                              # every value occurs
         ctx = B.Context(seed=11)
+        ctx.set_item_size(160)
+        ctx.set_piece_size(128)
         dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
         ft = [ctx.tensor(rng.standard_normal((d, D)) * 0.4) for d in dims]
         A = rng.standard_normal((D, D)); Lam = ctx.tensor(A @ A.T / D + np.eye(D)); mu = ctx.tensor(rng.standard_normal(D))
@@ -547,18 +550,20 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
                  Lam=Lam.cpu().numpy(), mu=mu.cpu().numpy())
     ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for no_coded in (False, True):
+    for variant in ("coded", "uncoded", "coded_lds"):
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npz")
             env = dict(os.environ)
             env.pop("BDF_K1_NO_CODED", None); env.pop("BDF_NO_CODES", None)
-            if no_coded:
+            env["BDF_K1_GLDS"] = "1" if variant == "coded_lds" else "0"
+            if variant == "uncoded":
                 env["BDF_K1_NO_CODED"] = "1"
             subprocess.run([sys.executable, "-c", code, f, str(D), str(n_values)], check=True, env=env, timeout=300)
-            got[no_coded] = dict(np.load(f))
+            got[variant] = dict(np.load(f))
     for k in ("u", "v"):
-        assert np.array_equal(got[False][k], got[True][k]), k
-    g = got[False]
+        assert np.array_equal(got["coded"][k], got["uncoded"][k]), k
+        assert np.array_equal(got["coded"][k], got["coded_lds"][k]), k
+    g = got["coded"]
     dims = [300, 120]
     idx = O.index_build(g["ids"], dims)
     for mode, key in ((0, "u"), (1, "v")):

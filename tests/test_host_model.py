@@ -359,8 +359,9 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
     for k, v in hot.items():
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256 and v.get("VGPRs Spill".split(" ")[0], 0) >= 0, (k, v)
     occ = {k: v["Occupancy"] for k, v in hot.items()}
-    k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dEEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values>
-    assert occ[k % (32, 1, 1)] >= 7       # one two-mode relation with coded values (ratings), D <= 32: the bench's kernel
+    k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dELb0EEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values, rows through registers>
+    assert occ[k.replace("ELb0EEEv", "ELb1EEEv") % (32, 1, 1)] >= 7       # ... with the rows gathered straight into LDS (D = 32): the bench's kernel
+    assert occ[k % (32, 1, 1)] >= 7       # one two-mode relation with coded values (ratings), D <= 32
     assert occ[k % (32, 1, 0)] >= 6       # two-mode variant, D <= 32
     assert occ[k % (32, 0, 0)] >= 5
     assert occ[k % (64, 1, 0)] >= 2
