@@ -44,6 +44,7 @@
 #include "wave_linalg.h"
 #include "c_layout_chol.h"
 #include "dpp_rows16.h"
+#include "dpp_rows32.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -503,11 +504,12 @@ __device__ __forceinline__ void glds4(unsigned voff, const void *sbase, unsigned
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
 }
-template <int DP>
+// R: trips in flight (ring slots of 2 KB; k_rows: 2 -- what the packed factor's space holds; k_rows4: BDF_K4_RING)
+template <int DP, int R = 2>
 __device__ __forceinline__ void accumulate_glds(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                        double (&bred)[Geo<DP>::DB], double *tri)
 {
-    static_assert(DP == 32, "LDS-direct gather: D = 32");
+    static_assert(DP == 32 && (R & (R - 1)) == 0 && R >= 2 && R <= 8, "LDS-direct gather: D = 32, a power-of-two ring");
     constexpr int DB = 2, NB = 3;
     const TermDev &T = a.t[it.term];
     const int j = lane & 15, h = lane >> 4;
@@ -544,23 +546,42 @@ __device__ __forceinline__ void accumulate_glds(const SampleArgs &a, const Item 
     {                                                                                            \
         const uint2 pw = idw[4 * (tt) + h];                                                      \
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + ((tt) & 1u) * 2048u);                  \
-        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + ((tt) & 1u) * 2048u + 1024u);          \
+        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + ((tt) & (unsigned)(R - 1)) * 2048u);          \
+        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + ((tt) & (unsigned)(R - 1)) * 2048u + 1024u);  \
     }
     GLDS_TRIP(0u)
     if (ntrips > 1) GLDS_TRIP(1u)
+    if constexpr (R > 2) {
+        if (ntrips > 2) GLDS_TRIP(2u)
+        if (ntrips > 3) GLDS_TRIP(3u)
+    }
+    if constexpr (R > 4) {
+        if (ntrips > 4) GLDS_TRIP(4u)
+        if (ntrips > 5) GLDS_TRIP(5u)
+        if (ntrips > 6) GLDS_TRIP(6u)
+        if (ntrips > 7) GLDS_TRIP(7u)
+    }
     const int eo0 = 31 - j, eo1 = 15 - j;                // natural index of reversed elements j, 16 + j
     for (uint32_t t = 0; t < ntrips; t++) {
-        // everything but the newest trip's two pieces has landed
-        if (t + 1 < ntrips) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        const double *sl = ring + (t & 1u) * 256 + h * 32;
+        // trip t has landed: the R - 1 trips after it (as many as the item still has) may be in flight, two pieces each
+        {
+            const uint32_t m = ntrips - 1 - t < (uint32_t)(R - 1) ? ntrips - 1 - t : (uint32_t)(R - 1);
+            if (m == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (m == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (m == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (m == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (m == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (m == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (m == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        }
+        const double *sl = ring + (t & (unsigned)(R - 1)) * 256 + h * 32;
         double w_c[2][DB];
         w_c[0][0] = sl[eo0]; w_c[0][1] = sl[eo1];
         w_c[1][0] = sl[128 + eo0]; w_c[1][1] = sl[128 + eo1];
         const uint2 pw = idw[4 * t + h];
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: the trip after next may land in it
-        if (t + 2 < ntrips) GLDS_TRIP(t + 2)
+        if (t + R < ntrips) GLDS_TRIP(t + R)
         if (t + 1 >= ntrips) {                                  // ragged last trip
             const uint32_t o = 8 * t + 2 * (uint32_t)h;
             if (!(o < n)) { w_c[0][0] = 0.0; w_c[0][1] = 0.0; }
@@ -1000,6 +1021,298 @@ void k_rows_bundle(SampleArgs a, PlanDev p)
     }
 }
 
+// ---- FOUR ROWS PER WAVE THROUGHOUT (D = 32, one two-mode relation with coded values; environment BDF_K1_FUSED4=1) -----------
+// What the round's measurements say a launch of MovieLens's size is made of: ~10 us of accumulation at the
+// matrix pipe's rate and ~29 us of 32 x 32 factorisations, solves and their tails -- one per wave, ~800 vector instructions each in
+// the accumulator layout at a fifth of the lanes' rate.  k_rows_fin's finish needs 310 per row, but as a kernel of its own it pays
+// a slab (every row's system written and read back at 2 TB/s).  Here a wave takes FOUR jobs (rows, or pieces of long rows: at
+// most BDF_GLDS_MAX_OBS observations each), one for each of its 16-lane rows: it accumulates them one after the other on the
+// matrix cores (rows gathered straight into an LDS ring, BDF_K4_RING trips in flight: two waves per SIMD have no other latency
+// cover), passes each finished system through 6.4 KB of its own LDS into the two-columns-per-lane layout of dpp_rows32.h, and
+// then factors, solves and draws all four at once.  Pieces of long rows publish their partial sums to the slab exactly as
+// k_rows' split items do; the piece whose publication completes the row sums the partials in slot order and keeps the row.
+#ifndef BDF_K4_RING
+#define BDF_K4_RING 4
+#endif
+template <bool POLLED>
+__global__ __launch_bounds__(64, 2) void k_rows4(SampleArgs a, PlanDev p, const int32_t *wave_jobs, int n_waves)
+{
+    constexpr int DP = 32, DB = 2, NB = 3, PSZ = Geo<32>::PSZ, R = BDF_K4_RING, DR = 32;
+    // LDS of the wave (doubles): value table [0, 32) | the four jobs' packed words 4 x 80 | ring R x 256 | staging slot PSZ
+    __shared__ __attribute__((aligned(16))) double lds[32 + 320 + R * 256 + PSZ];
+    double *const tab = lds;
+    const uint2 *const idw = (const uint2 *)(lds + 32);
+    const double *const ring = lds + 352;
+    double *const stage = lds + 352 + R * 256;
+    const int lane = threadIdx.x & 63, j = lane & 15, h = lane >> 4;
+    const int w = (int)blockIdx.x;
+    if (w >= n_waves) return;
+    const int64_t wid = w;                     // (diagnostic builds: the stamps' index)
+    STAMP(0);
+#ifdef BDF_K1_STAMPS
+    if (lane == 0 && a.b_dump) {
+        ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
+            ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) );
+        ((unsigned long long *)a.b_dump)[wid * 16 + 10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
+    }
+#endif
+    double A0[33], A1[33];
+#pragma unroll
+    for (int i = 0; i < 33; i++) { A0[i] = 0.0; A1[i] = 0.0; }
+    int my_row = -1;
+
+    // ---- the wave's four jobs as ONE stream of trips: the gathers run ahead across the jobs' boundaries ----
+    const TermDev &T = a.t[0];
+    auto uniform = [](const void *q) {
+        const uint64_t v = (uint64_t)q;
+        return (const void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
+                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
+    };
+    const void *fac = uniform((const void *)T.fac[0]);
+    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)lds);
+    const double mean = T.mean, alpha = term_alpha(T);
+    if (lane < BDF_K1_CODES) tab[lane] = T.table[lane] - mean;
+    int jw[4];                                 // item numbers (-1: none)
+    uint32_t jn[4], jt[4];                     // observations and trips of the four jobs
+    uint32_t U = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        jw[g] = __builtin_amdgcn_readfirstlane(wave_jobs[4 * w + g]);
+        int cnt = 0;
+        const void *packed = nullptr;
+        if (jw[g] >= 0) {
+            const Item &it = jw[g] < p.n_split ? p.split[jw[g]] : p.direct[jw[g] - p.n_split];
+            cnt = __builtin_amdgcn_readfirstlane(it.count);
+            packed = uniform((const void *)(T.packed + it.q_begin));
+        }
+        jn[g] = (uint32_t)cnt;
+        jt[g] = (jn[g] + 7) / 8;
+        U += jt[g];
+        if (cnt > 0) {
+            // the job's packed words: word w (clamped to the job: positions past its end repeat the last observation) by lane w % 64
+            const uint32_t n = jn[g];
+            uint32_t w0 = (uint32_t)lane, w1 = w0 + 64, w2 = w0 + 128;
+            w0 = (w0 < n ? w0 : n - 1) * 4u; w1 = (w1 < n ? w1 : n - 1) * 4u; w2 = (w2 < n ? w2 : n - 1) * 4u;
+            const unsigned dstb = lds0 + 256 + (unsigned)g * 640u;
+            glds4(w0, packed, dstb);
+            if (n > 64) glds4(w1, packed, dstb + 256);
+            if (n > 128 && lane < 32) glds4(w2, packed, dstb + 512);
+        }
+    }
+    // the normals of the row this lane row will hold -- if its job turns out to complete a row -- while the packed words arrive
+    const int D = a.D;
+    const int ec0 = D - 1 - j, ec1 = D - 17 - j;
+    const int n0 = ec0 >= 0 ? ec0 : 0, n1 = ec1 >= 0 ? ec1 : 0;
+    double z0 = 0.0, z1 = 0.0;
+    {
+        const int mywid = h == 0 ? jw[0] : (h == 1 ? jw[1] : (h == 2 ? jw[2] : jw[3]));
+        int orig_h = 0;
+        if (mywid >= 0) orig_h = (mywid < p.n_split ? p.split[mywid] : p.direct[mywid - p.n_split]).orig;
+        double ze = 0.0, zo = 0.0;
+        if (mywid >= 0 && 2 * j < D) bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)orig_h, (uint32_t)j, ze, zo);
+        const int base = lane & 48;
+        const double ze0 = __shfl(ze, base + (n0 >> 1)), zo0 = __shfl(zo, base + (n0 >> 1));
+        const double ze1 = __shfl(ze, base + (n1 >> 1)), zo1 = __shfl(zo, base + (n1 >> 1));
+        z0 = ec0 >= 0 ? ((n0 & 1) ? zo0 : ze0) : 0.0;
+        z1 = ec1 >= 0 ? ((n1 & 1) ? zo1 : ze1) : 0.0;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned chunk = (unsigned)j * 16u, ringb = lds0 + 352 * 8;
+    // issue side of the stream: trip (gi, ti) is the next to be gathered, into ring slot ui % R
+    int gi = 0;
+    uint32_t ti = 0, ui = 0;
+    while (gi < 4 && jt[gi == 0 ? 0 : (gi == 1 ? 1 : (gi == 2 ? 2 : 3))] == 0) gi++;
+#define JT(g) ((g) == 0 ? jt[0] : ((g) == 1 ? jt[1] : ((g) == 2 ? jt[2] : jt[3])))
+#define JN(g) ((g) == 0 ? jn[0] : ((g) == 1 ? jn[1] : ((g) == 2 ? jn[2] : jn[3])))
+#define JW(g) ((g) == 0 ? jw[0] : ((g) == 1 ? jw[1] : ((g) == 2 ? jw[2] : jw[3])))
+#define ISSUE_TRIP()                                                                              \
+    {                                                                                             \
+        const uint2 pw = idw[gi * 80 + 4 * (int)ti + h];                                          \
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
+        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + (ui & (unsigned)(R - 1)) * 2048u);          \
+        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + (ui & (unsigned)(R - 1)) * 2048u + 1024u);  \
+        ui++; ti++;                                                                               \
+        if (ti == JT(gi)) { ti = 0; gi++; while (gi < 4 && JT(gi) == 0) gi++; }                   \
+    }
+#pragma unroll 1
+    for (int q = 0; q < R; q++)
+        if (ui < U) ISSUE_TRIP()
+    // consume side
+    d4 acc[NB];
+    double bpart[DB] = {0.0, 0.0};
+#pragma unroll
+    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+    const int eo0 = 31 - j, eo1 = 15 - j;
+    int gc = 0;
+    while (gc < 4 && JT(gc) == 0) gc++;
+    uint32_t tc = 0;
+#ifdef BDF_K1_STAMPS
+    unsigned long long ph_wait = 0, ph_read = 0, ph_issue = 0, ph_mfma = 0, ph_flush = 0, ph_t = __builtin_amdgcn_s_memtime();
+#define PH(x) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); x += now_ - ph_t; ph_t = now_; } while (0)
+#else
+#define PH(x) do { } while (0)
+#endif
+#pragma unroll 1
+    for (uint32_t uc = 0; uc < U; uc++) {
+        {
+            const uint32_t m = ui - 1 - uc;            // trips in flight behind this one (at most R - 1)
+            if (m == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else if (m == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            else if (m == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else if (m == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else if (m == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (m == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
+            else if (m == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
+        }
+        PH(ph_wait);
+        const double *sl = ring + (uc & (unsigned)(R - 1)) * 256 + h * 32;
+        double w_c[2][DB];
+        w_c[0][0] = sl[eo0]; w_c[0][1] = sl[eo1];
+        w_c[1][0] = sl[128 + eo0]; w_c[1][1] = sl[128 + eo1];
+        const uint2 pw = idw[gc * 80 + 4 * (int)tc + h];
+        const double r0 = tab[pw.x >> 24], r1 = tab[pw.y >> 24];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: a later trip may land in it
+        PH(ph_read);
+        if (ui < U) ISSUE_TRIP()
+        PH(ph_issue);
+        const uint32_t ntr = JT(gc);
+        const bool last = tc + 1 == ntr;
+        if (last) {                                             // ragged last trip of the job
+            const uint32_t o = 8 * tc + 2 * (uint32_t)h, n = JN(gc);
+            if (!(o < n)) { w_c[0][0] = 0.0; w_c[0][1] = 0.0; }
+            if (!(o + 1 < n)) { w_c[1][0] = 0.0; w_c[1][1] = 0.0; }
+        }
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][0], w_c[0][0], acc[0], 0, 0, 0);
+        bpart[0] = fma(w_c[0][0], r0, bpart[0]);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][0], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][1], acc[2], 0, 0, 0);
+        bpart[1] = fma(w_c[0][1], r0, bpart[1]);
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][0], w_c[1][0], acc[0], 0, 0, 0);
+        bpart[0] = fma(w_c[1][0], r1, bpart[0]);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][0], acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][1], acc[2], 0, 0, 0);
+        bpart[1] = fma(w_c[1][1], r1, bpart[1]);
+        tc++;
+#ifdef BDF_K1_STAMPS
+        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));      // (the matrix instructions have issued)
+#endif
+        PH(ph_mfma);
+        if (!last) continue;
+        // ---- the job is complete: its system to this wave's lane row gc (pieces of long rows through the slab first) ----
+        const int g = gc, widj = JW(gc);
+        tc = 0; gc++;
+        while (gc < 4 && JT(gc) == 0) gc++;
+        const bool is_split = widj < p.n_split;
+        const Item it = is_split ? p.split[widj] : p.direct[widj - p.n_split];
+        double bv[DB];
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] *= alpha;
+#pragma unroll
+        for (int I = 0; I < DB; I++) {
+            double v = bpart[I] * alpha;
+            v += __shfl_xor(v, 16);
+            v += __shfl_xor(v, 32);
+            bv[I] = v;
+            bpart[I] = 0.0;
+        }
+        bool has = true;
+        if (is_split) {
+            double *dst = p.partials + (int64_t)it.slot * PSZ;
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    __hip_atomic_store(dst + (b * 4 + r) * 64 + lane, acc[b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane < 16) {
+#pragma unroll
+                for (int I = 0; I < DB; I++)
+                    __hip_atomic_store(dst + NB * 4 * 64 + I * 16 + lane, bv[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            const SplitRow sr = p.rows[it.srow];
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            int old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = __builtin_amdgcn_readfirstlane(old);
+            if (old != sr.n_slots - 1) has = false;                 // not the last piece of the row: this lane row stays empty
+            else {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (lane == 0) p.arrived[it.srow] = 0;              // ready for the next launch
+                sum_partials<DP>(p, sr, lane, acc, bv);
+            }
+        }
+        if (has) {
+#pragma unroll
+            for (int b = 0; b < NB; b++)
+#pragma unroll
+                for (int r = 0; r < 4; r++) stage[(b * 4 + r) * 64 + lane] = acc[b][r];
+            if (lane < 16) { stage[NB * 4 * 64 + lane] = bv[0]; stage[NB * 4 * 64 + 16 + lane] = bv[1]; }
+            wave_sync();
+            if (h == g) {
+                fin_from_lds<0, 0, DR>(A0, stage, j);
+                fin_from_lds<1, 0, DR>(A1, stage, j);
+                A0[32] = stage[NB * 4 * 64 + j];
+                A1[32] = stage[NB * 4 * 64 + 16 + j];
+                my_row = it.row;
+            }
+            wave_sync();
+        }
+#pragma unroll
+        for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
+        PH(ph_flush);
+    }
+#ifdef BDF_K1_STAMPS
+    if (lane == 0 && a.b_dump) {
+        unsigned long long *d = (unsigned long long *)a.b_dump + wid * 16;
+        d[11] = ph_wait; d[12] = ph_read; d[13] = ph_issue; d[14] = ph_mfma; d[15] = ph_flush; d[6] = U;
+    }
+#endif
+#undef PH
+#undef ISSUE_TRIP
+    // jobs without observations (rows of none): their systems are the prior alone
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (jw[g] >= 0 && jn[g] == 0) {
+            const Item &it = jw[g] < p.n_split ? p.split[jw[g]] : p.direct[jw[g] - p.n_split];
+            if (h == g) my_row = it.row;
+        }
+    }
+#undef JT
+#undef JN
+#undef JW
+    // ---- the four systems: normals, prior, LDL' with the forward solve, backward solve (k_rows_fin's finish) ----
+    STAMP(1);
+    const bool live = my_row >= 0;
+    const int64_t pb = a.mu_is_matrix && live ? (int64_t)my_row * D : 0;
+    if constexpr (POLLED) {
+        int spins = 0;
+        while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }
+        }
+        A0[32] += ec0 >= 0 ? __hip_atomic_load(a.prior_b + pb + n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        A1[32] += ec1 >= 0 ? __hip_atomic_load(a.prior_b + pb + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    } else {
+        A0[32] += ec0 >= 0 ? a.prior_b[pb + n0] : 0.0;
+        A1[32] += ec1 >= 0 ? a.prior_b[pb + n1] : 0.0;
+    }
+    STAMP(3);
+    fin_prior<0, 0, DR, POLLED>(A0, a.prior_c, j);
+    fin_prior<1, 0, DR, POLLED>(A1, a.prior_c, j);
+    STAMP(4);
+    double d0 = 1.0, d1 = 1.0;
+    fin_factor<DR, 0>(A0, A1, d0, d1, j);
+    STAMP(5);
+    if (live && ((ec0 >= 0 && !(d0 > 0.0)) || (ec1 >= 0 && !(d1 > 0.0)))) atomicOr_system(a.flag, 1);      // not positive definite
+    const double rd0 = fast_rcp(d0), rd1 = fast_rcp(d1);
+    double y0 = fma(z0, fast_rsqrt(d0), A0[32] * rd0), y1 = fma(z1, fast_rsqrt(d1), A1[32] * rd1);
+    fin_backward<DR - 1>(A0, A1, y0, y1, rd0, rd1, j);
+    if (live && ec0 >= 0) a.out[(int64_t)my_row * D + ec0] = y0;
+    if (live && ec1 >= 0) a.out[(int64_t)my_row * D + ec1] = y1;
+    STAMP(8);
+}
+
 // Queue-fed launch (an experiment, DESIGN.md section 4, K1: built with -DBDF_K1_QUEUE_BUILD -mllvm -disable-machine-licm --
 // hoisted out of the item loop, the constants of the normals' polynomials cost the kernel its registers -- and switched on
 // with BDF_K1_QUEUE=<waves per SIMD>): exactly the resident wave count is launched and every wave takes positions of `order`
@@ -1175,7 +1488,8 @@ struct PlanKey {
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
-    int glds, _padg;                  // 1: D = 32 with coded values, items of at most BDF_GLDS_MAX_OBS observations: rows gathered straight into LDS
+    int glds;                         // 1: D = 32 with coded values, items of at most BDF_GLDS_MAX_OBS observations: rows gathered straight into LDS
+    int fused4;                       // 1: ... and four jobs per wave (k_rows4) instead of one
     int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows_bundle + k_rows_fin) if the launch has at least this many
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
@@ -1192,6 +1506,8 @@ struct Plan {
     int32_t *order_dev = nullptr;
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
+    int32_t *wave_jobs_dev = nullptr; // k_rows4: four item numbers (of [split | direct], -1: none) per wave
+    int32_t n_waves4 = 0;
     bool glds = false;                // every item has at most BDF_GLDS_MAX_OBS observations and the launch is D = 32 with coded values
     uint32_t *ticket_dev = nullptr;   // queue-fed launch: the counter and what it stands at when the next launch begins
     uint32_t ticket_base = 0;
@@ -1449,6 +1765,24 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     plan.dev.order = plan.order_dev;
     plan.dev.decoupled = decoupled;
     plan.glds = key.glds != 0;
+    if (key.fused4) {
+        // four jobs per wave: the items by falling length dealt to the waves back and forth, so that every wave's four add up alike
+        bool ok = !decoupled;
+        std::vector<std::pair<int32_t, int32_t>> jobs;              // (observations, item number in [split | direct])
+        for (size_t i = 0; i < split.size(); i++) { jobs.push_back({split[i].count, (int32_t)i}); ok = ok && split[i].count <= BDF_GLDS_MAX_OBS; }
+        for (size_t i = 0; i < direct.size(); i++) { jobs.push_back({direct[i].count, (int32_t)(split.size() + i)}); ok = ok && direct[i].count <= BDF_GLDS_MAX_OBS; }
+        if (ok && !jobs.empty()) {
+            std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) { return x.first > y.first; });
+            const size_t W = (jobs.size() + 3) / 4;
+            std::vector<int32_t> wj(4 * W, -1);
+            for (size_t q = 0; q < jobs.size(); q++) {
+                const size_t g = q / W, r = q % W, wv = (g & 1) ? W - 1 - r : r;
+                wj[4 * wv + g] = jobs[q].second;
+            }
+            if ((rc = to_device(wj, &plan.wave_jobs_dev))) return rc;
+            plan.n_waves4 = (int32_t)W;
+        }
+    }
     return BDF_OK;
 }
 
@@ -1488,6 +1822,17 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
         }
         ctx->time_start = ctx->time_stop = nullptr;
         return BDF_OK;
+    }
+    if constexpr (DP == 32) {
+        if (plan.n_waves4 > 0 && coded && !dump) {
+            // four jobs per wave throughout (k_rows4)
+            const dim3 grid((unsigned)plan.n_waves4), block(64);
+            if (a.ready) hipExtLaunchKernelGGL(k_rows4<true>, grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p, (const int32_t *)plan.wave_jobs_dev, plan.n_waves4);
+            else hipExtLaunchKernelGGL(k_rows4<false>, grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p, (const int32_t *)plan.wave_jobs_dev, plan.n_waves4);
+            ctx->time_start = ctx->time_stop = nullptr;
+            BDF_HIP(hipGetLastError());
+            return BDF_OK;
+        }
     }
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
@@ -1576,6 +1921,7 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
             if (kv->second.lr_rows_dev) (void)hipFree(kv->second.lr_rows_dev);
             (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
             if (kv->second.ticket_dev) (void)hipFree(kv->second.ticket_dev);
+            if (kv->second.wave_jobs_dev) (void)hipFree(kv->second.wave_jobs_dev);
             if (kv->second.fin_dev) (void)hipFree(kv->second.fin_dev);
             if (kv->second.sys_dev) (void)hipFree(kv->second.sys_dev);
             if (kv->second.segs_dev) (void)hipFree(kv->second.segs_dev);
@@ -1649,10 +1995,12 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         bool matrix, coded;
         launch_kind(a, dump, matrix, coded);
         static const bool glds_on = getenv("BDF_K1_GLDS") && atoi(getenv("BDF_K1_GLDS")) != 0;      // (opt-in: bit-identical, 3 % faster alone, no gain in the iteration)
-        if (DP == 32 && a.D == 32 && coded && glds_on && !getenv("BDF_K1_DECOUPLE") && key.T <= 192) {
+        static const bool fused4_on = getenv("BDF_K1_FUSED4") && atoi(getenv("BDF_K1_FUSED4")) != 0;
+        if (DP == 32 && a.D == 32 && coded && (glds_on || fused4_on) && !getenv("BDF_K1_DECOUPLE") && key.T <= 192) {
             key.T = std::min(key.T, BDF_GLDS_MAX_OBS);
             key.Tp = std::min(key.Tp, key.T);
-            key.glds = 1;
+            if (fused4_on) { key.fused4 = 1; key.Tp = key.T; }
+            else key.glds = 1;
         }
     }
     // D <= 16, one two-mode relation with the lean gather and no per-observation baseline, an entity of many rows: its short

@@ -550,12 +550,13 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
                  Lam=Lam.cpu().numpy(), mu=mu.cpu().numpy())
     ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for variant in ("coded", "uncoded", "coded_lds"):
+    for variant in ("coded", "uncoded", "coded_lds") + (("four_per_wave",) if D == 32 else ()):
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npz")
             env = dict(os.environ)
             env.pop("BDF_K1_NO_CODED", None); env.pop("BDF_NO_CODES", None)
             env["BDF_K1_GLDS"] = "1" if variant == "coded_lds" else "0"
+            env["BDF_K1_FUSED4"] = "1" if variant == "four_per_wave" else "0"
             if variant == "uncoded":
                 env["BDF_K1_NO_CODED"] = "1"
             subprocess.run([sys.executable, "-c", code, f, str(D), str(n_values)], check=True, env=env, timeout=300)
@@ -563,6 +564,8 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
     for k in ("u", "v"):
         assert np.array_equal(got["coded"][k], got["uncoded"][k]), k
         assert np.array_equal(got["coded"][k], got["coded_lds"][k]), k
+        if "four_per_wave" in got:        # k_rows4: the same LDL' factorisation in another layout -- equal to rounding, not to the last bit
+            np.testing.assert_allclose(got["four_per_wave"][k], got["coded"][k], rtol=1e-9, atol=1e-11)
     g = got["coded"]
     dims = [300, 120]
     idx = O.index_build(g["ids"], dims)

@@ -45,6 +45,11 @@ for j, name in enumerate(("users", "movies")):
         x = f if sel is None else f[sel]
         d = x[:, b] - x[:, a]
         return f"{d.mean():8.0f} (p50 {np.median(d):6.0f} max {d.max():7d})"
+    if (s[:, 11:16] > 0).any():       # k_rows4's phase timers (cycles summed over the wave's trips): wait, LDS reads, issue, matrix instructions, flush
+        tr = np.maximum(s[:, 6], 1)
+        print("   k_rows4 phase timers per wave: trips %.1f; wait %.0f  reads %.0f  issue %.0f  mfma %.0f  flush %.0f (per trip: %.0f %.0f %.0f %.0f)" % (
+            s[:, 6].mean(), s[:, 11].mean(), s[:, 12].mean(), s[:, 13].mean(), s[:, 14].mean(), s[:, 15].mean(),
+            (s[:, 11] / tr).mean(), (s[:, 12] / tr).mean(), (s[:, 13] / tr).mean(), (s[:, 14] / tr).mean()))
     print("   start->acc     ", ph(0, 1))
     print("   acc->prior     ", ph(1, 3, ~split_fin) if (~split_fin).any() else "-")
     print("   prior->rng     ", ph(3, 4))
