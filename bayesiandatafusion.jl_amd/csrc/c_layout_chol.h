@@ -11,6 +11,9 @@
 #ifndef BDF_K1_WPB
 #define BDF_K1_WPB 4
 #endif
+#ifndef BDF_K1_WPB64
+#define BDF_K1_WPB64 1            // ... at D > 32: one (a wave's 18 KB of LDS come free with it: with two, a finished wave's slot idled until its partner ended -- C4 42.7 -> 39.1 ms)
+#endif
 #ifndef BDF_K1_WAVES32M
 #define BDF_K1_WAVES32M 6         // ... its variant for two-mode relations (78 registers)
 #endif
@@ -47,7 +50,7 @@ struct Geo {
     static constexpr int DB = DP / 16;                 // 16-wide blocks per dimension
     static constexpr int NB = DB * (DB + 1) / 2;       // lower block-triangle
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;  // doubles per partial slot
-    static constexpr int WPB = (DP == 64) ? 2 : BDF_K1_WPB;           // waves per workgroup
+    static constexpr int WPB = (DP == 64) ? BDF_K1_WPB64 : BDF_K1_WPB;           // waves per workgroup
     static constexpr int WAVES = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32 : 8);
     static constexpr int WAVES_MATRIX = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
     static constexpr int WAVES_CODED = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8);      // one two-mode relation, coded values

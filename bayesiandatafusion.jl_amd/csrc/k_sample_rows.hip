@@ -73,7 +73,7 @@
 #define SPAN_WAIT(t0) do { } while (0)
 #endif
 #ifdef BDF_K1_STAMPS
-#define STAMP(slot) do { if (lane == 0 && a.b_dump) ((unsigned long long *)a.b_dump)[wid * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define STAMP(slot) do { if (lane == 0 && a.b_dump && wid < 65536) ((unsigned long long *)a.b_dump)[wid * 16 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define STAMP(slot) do { } while (0)
 #endif
@@ -770,7 +770,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     STAMP(0);
     SPAN_BEGIN();
 #ifdef BDF_K1_STAMPS
-    if (lane == 0 && a.b_dump) {           // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID
+    if (lane == 0 && a.b_dump && wid < 65536) {           // where the wave runs: HW_ID (wave, SIMD, CU, SH, SE) and XCC_ID
         ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
             ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) );
         ((unsigned long long *)a.b_dump)[wid * 16 + 10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
@@ -1050,7 +1050,7 @@ __global__ __launch_bounds__(64, 2) void k_rows4(SampleArgs a, PlanDev p, const 
     const int64_t wid = w;                     // (diagnostic builds: the stamps' index)
     STAMP(0);
 #ifdef BDF_K1_STAMPS
-    if (lane == 0 && a.b_dump) {
+    if (lane == 0 && a.b_dump && wid < 65536) {
         ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
             ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) );
         ((unsigned long long *)a.b_dump)[wid * 16 + 10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
@@ -1263,7 +1263,7 @@ __global__ __launch_bounds__(64, 2) void k_rows4(SampleArgs a, PlanDev p, const 
         PH(ph_flush);
     }
 #ifdef BDF_K1_STAMPS
-    if (lane == 0 && a.b_dump) {
+    if (lane == 0 && a.b_dump && wid < 65536) {
         unsigned long long *d = (unsigned long long *)a.b_dump + wid * 16;
         d[11] = ph_wait; d[12] = ph_read; d[13] = ph_issue; d[14] = ph_mfma; d[15] = ph_flush; d[6] = U;
     }

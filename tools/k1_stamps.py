@@ -14,7 +14,12 @@ from bdf_amd import datasets
 from bdf_amd._lib import lib
 
 D = int(os.environ.get("D", "32"))
-rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
+if os.environ.get("DATA") == "c4":        # a C4-shaped relation (rows x cols x observations from C4_SIZES, default a twentieth of C4): D = 64 by default
+    D = int(os.environ.get("D", "64"))
+    nr, nc, nz = [int(x) for x in os.environ.get("C4_SIZES", "500000,50000,5000000").split(",")]
+    rd = datasets.c4_relation_data(B, nr, nc, nz)
+else:
+    rd, _ = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
 eng = B.GibbsEngine(rd, D, seed=1, device=0)
 if os.environ.get("ITEM"):           # observations per work item / per piece of a split row
     eng.ctx.set_item_size(int(os.environ["ITEM"]))
@@ -25,8 +30,10 @@ for i in range(1, 6):
 eng.sync()
 L = lib()
 L.bdf_debug_stamps.argtypes = [C.c_void_p, C.c_void_p, C.c_int]
-NW = 16384
+NW = 65536 if os.environ.get("DATA") == "c4" else 16384
 for j, name in enumerate(("users", "movies")):
+    if os.environ.get("DATA") == "c4" and j == 0:
+        continue          # (the users' launch has more waves than the stamp buffer holds)
     eng.ctx.set_sweep(10 + j)
     eng.sample_entity(j)
     eng.sync()
