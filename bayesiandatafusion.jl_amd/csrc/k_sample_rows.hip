@@ -1765,6 +1765,10 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     plan.dev.order = plan.order_dev;
     plan.dev.decoupled = decoupled;
     plan.glds = key.glds != 0;
+    // (a row of more than MAX_PIECES x the piece size has longer pieces than the LDS-direct gather's word buffer holds: such a
+    // launch keeps the register pipeline)
+    for (const Item &it : split) plan.glds = plan.glds && it.count <= BDF_GLDS_MAX_OBS;
+    for (const Item &it : direct) plan.glds = plan.glds && it.count <= BDF_GLDS_MAX_OBS;
     if (key.fused4) {
         // four jobs per wave: the items by falling length dealt to the waves back and forth, so that every wave's four add up alike
         bool ok = !decoupled;
