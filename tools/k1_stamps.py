@@ -57,6 +57,12 @@ for j, name in enumerate(("users", "movies")):
         print("   k_rows4 phase timers per wave: trips %.1f; wait %.0f  reads %.0f  issue %.0f  mfma %.0f  flush %.0f (per trip: %.0f %.0f %.0f %.0f)" % (
             s[:, 6].mean(), s[:, 11].mean(), s[:, 12].mean(), s[:, 13].mean(), s[:, 14].mean(), s[:, 15].mean(),
             (s[:, 11] / tr).mean(), (s[:, 12] / tr).mean(), (s[:, 13] / tr).mean(), (s[:, 14] / tr).mean()))
+    if (f[:, 6] > 0).any():           # (experiment builds: stamp 6 = the early normals drawn, stamp 7 = the wave got this item)
+        sel6 = f[:, 6] > 0
+        print("   stamp 6: start->normals", ph(0, 6, sel6), " normals->acc", ph(6, 1, sel6))
+    if (f[:, 7] > 0).any():
+        sel7 = f[:, 7] > 0
+        print("   stamp 7: got item->start", ph(7, 0, sel7))
     print("   start->acc     ", ph(0, 1))
     print("   acc->prior     ", ph(1, 3, ~split_fin) if (~split_fin).any() else "-")
     print("   prior->rng     ", ph(3, 4))
