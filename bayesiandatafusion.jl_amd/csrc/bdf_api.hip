@@ -78,6 +78,11 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
     c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
     c->fin_min_rows = getenv("BDF_K1_TWO_PHASE") ? atoll(getenv("BDF_K1_TWO_PHASE")) : -1;      // (off: measured slower than the one-kernel launch)
+    // K1c (k_rows_col.hip): on by default with pieces of at most 128 observations; BDF_K1_COL=0: off, BDF_K1_COL=<n>: that piece size
+    c->col_piece = getenv("BDF_K1_COL") ? atoi(getenv("BDF_K1_COL")) : 128;
+    if (c->col_piece == 1) c->col_piece = 128;
+    if (c->col_piece != 0) c->col_piece = std::min(4096, std::max(8, c->col_piece));
+    c->col_explicit = false;
     c->lr_T = nullptr; c->lr_vt = nullptr; c->lr_vt_bytes = 0; c->lr_mrows = nullptr; c->lr_mrows_bytes = 0;
     c->lr_key_fac = c->lr_key_Lambda = c->lr_key_mu = nullptr; c->lr_key_sweep = c->lr_key_tag = 0; c->lr_key_D = 0; c->lr_key_M = 0;
     {
@@ -198,6 +203,22 @@ extern "C" int bdf_ctx_set_two_phase(bdf_ctx *ctx, int64_t min_rows)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_set_two_phase: NULL context");
     ctx->fin_min_rows = min_rows;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_set_col_rows(bdf_ctx *ctx, int max_piece)
+{
+    BDF_REQUIRE(ctx && (max_piece == 0 || max_piece == -1 || (max_piece >= 8 && max_piece <= 4096)), BDF_ERR_ARG,
+                "bdf_ctx_set_col_rows: -1 (default), 0 (off) or 8..4096 observations per piece");
+    if (max_piece == -1) {            // the default again: BDF_K1_COL or 128, for launches whose item size the caller has not set
+        ctx->col_piece = getenv("BDF_K1_COL") ? atoi(getenv("BDF_K1_COL")) : 128;
+        if (ctx->col_piece == 1) ctx->col_piece = 128;
+        if (ctx->col_piece != 0) ctx->col_piece = std::min(4096, std::max(8, ctx->col_piece));
+        ctx->col_explicit = false;
+        return BDF_OK;
+    }
+    ctx->col_piece = max_piece;
+    ctx->col_explicit = true;
     return BDF_OK;
 }
 

@@ -43,6 +43,9 @@ struct bdf_ctx {
     int lr_max;                // longest row (observations) sampled that way at D > 16; -1: min(16, D / 2); 0: off
     int64_t lr_min_rows;       // ... and the smallest number of such rows in a launch for which it is used
     int64_t fin_min_rows;      // K1 at 16 < D <= 32: launches of at least this many rows run in two phases (k_rows<SYS> + k_rows_fin); < 0: never
+    int col_piece;             // K1c (k_rows_col.hip): one two-mode relation at 16 < D <= 32 four rows per wave in the column layout, rows cut
+                               // into pieces of at most this many observations; 0: off
+    bool col_explicit;         // ... set by the caller (bdf_ctx_set_col_rows): taken also when the caller chose K1's item size
     double *lr_T;              // Tf | Tb | Tm (64 x 64 each) | L' mu (64): the launch's constants (k_lr_prep)
     double *lr_mrows;          // per-row prior means transformed (L' mu_i, rows of DP doubles), grown on demand
     size_t lr_mrows_bytes;
@@ -373,4 +376,42 @@ struct bdf_fin_item {
 };
 int bdf_fin_launch(bdf_ctx *ctx, const SampleArgs &a, const bdf_fin_item *items, int64_t n_items, const double *slab, hipEvent_t e0, hipEvent_t e1);
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
+
+// ---- K1c (k_rows_col.hip): four rows per wave in the column layout ----------------------------------------------------
+struct ColJob {           // one lane row of one round
+    int32_t row;          // where the sample is written (the row's position in the factor matrix); -1: idle lane row
+    int32_t orig;         // the row's ORIGINAL id: keys its random stream
+    int64_t q_begin;      // first observation of the piece (index into the term's arrays)
+    int32_t count;        // observations of the piece
+    int32_t srow;         // a row that spans waves: its entry of the split-row table, else -1
+    int32_t slot;         // ... and this part's slot in the slab
+    int32_t flags;
+};
+#define COLF_LEADER 1     // the lane row that writes the sample of its group's row
+#define COLF_PAIR 2       // the lane row's sums are added to its neighbour's (lane ^ 16)
+#define COLF_QUAD 4       // ... and to the other half's (lane ^ 32)
+#define COLF_MULTI 8      // the round is one part of a row that spans waves
+struct ColSplit { int32_t slot_begin, n_slots; };
+struct ColPlanDev {
+    const ColJob *jobs;           // four per round, wave after wave
+    const int32_t *wave_round;    // wave w runs rounds wave_round[w] .. wave_round[w + 1] - 1
+    int32_t n_waves, _pad;
+    const ColSplit *rows;
+    double *partials;
+    int32_t *arrived;             // per split row: parts that have published (self-resetting)
+};
+struct bdf_row_ref { int32_t out, orig; int64_t qb, cnt; };
+struct bdf_col_plan {
+    ColJob *jobs_dev = nullptr;
+    int32_t *wave_round_dev = nullptr;
+    ColSplit *rows_dev = nullptr;
+    double *partials_dev = nullptr;
+    int32_t *arrived_dev = nullptr;
+    int32_t n_waves = 0, n_split_rows = 0;
+    int64_t n_rounds = 0;
+    double cost_max = 0.0, cost_min = 0.0;      // the planner's cost model: the heaviest and the lightest wave
+};
+int bdf_col_plan_build(bdf_ctx *ctx, const std::vector<bdf_row_ref> &rows, int T, int64_t slots, bdf_col_plan &plan);
+void bdf_col_plan_free(bdf_col_plan &plan);
+int bdf_col_launch(bdf_ctx *ctx, const SampleArgs &a, const bdf_col_plan &plan, int64_t M_other, hipEvent_t e0, hipEvent_t e1);
 int bdf_predict_plain(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors, double mean_value, double *out);   // rel_serial 0: every plan of the context

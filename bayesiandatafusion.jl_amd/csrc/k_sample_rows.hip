@@ -1491,6 +1491,8 @@ struct PlanKey {
     int glds;                         // 1: D = 32 with coded values, items of at most BDF_GLDS_MAX_OBS observations: rows gathered straight into LDS
     int fused4;                       // 1: ... and four jobs per wave (k_rows4) instead of one
     int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows_bundle + k_rows_fin) if the launch has at least this many
+    int col;                          // > 0: the rows of k_rows go to k_rows_col instead (four rows per wave, column layout), cut into pieces of at most this size
+    int col_slots;                    // ... dealt to at most this many waves
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
 };
 
@@ -1516,6 +1518,7 @@ struct Plan {
     double *sys_dev = nullptr;
     Item *segs_dev = nullptr;
     int32_t *wave_seg_dev = nullptr;
+    bdf_col_plan col;                 // the rows of k_rows_col (K1c)
 };
 
 struct PlanCache {
@@ -1568,8 +1571,10 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         two_phase = n_k1 >= std::max<int64_t>(key.fin_min, 1);
     }
     std::vector<const RowRef *> brows;
+    std::vector<bdf_row_ref> crows;
     for (const RowRef &rr : rows) {
         if (two_phase && row_is_k1(rr)) { brows.push_back(&rr); continue; }
+        if (key.col > 0 && row_is_k1(rr)) { crows.push_back(bdf_row_ref{rr.out, rr.orig, rr.qb[0], rr.cnt[0]}); continue; }
         const int32_t row = rr.out;
         int n_items = 0;
         for (int r = 0; r < key.n_terms; r++) n_items += (int)std::min<int64_t>((rr.cnt[r] + T - 1) / T, MAX_PIECES);
@@ -1718,6 +1723,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         for (int64_t i = head; i < total; i++) order[(size_t)i] = (int32_t)i;
     }
     int rc;
+    if (key.col > 0 && (rc = bdf_col_plan_build(ctx, crows, key.col, key.col_slots, plan.col))) return rc;
     while (small.size() % 4) small.push_back(SmallItem{-1, 0, 0, 0, 0});
     plan.n_small = (int64_t)small.size();
     if (!small.empty() && (rc = to_device(small, &plan.small_dev))) return rc;
@@ -1893,6 +1899,11 @@ extern "C" int bdf_rows_unfinished(bdf_ctx *ctx, int64_t *count)
     auto it = g_caches.find(ctx);
     if (it == g_caches.end()) return BDF_OK;
     for (auto &kv : it->second.plans) {
+        if (kv.second.col.n_split_rows > 0) {
+            std::vector<int32_t> hc((size_t)kv.second.col.n_split_rows);
+            BDF_HIP(hipMemcpy(hc.data(), kv.second.col.arrived_dev, hc.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+            for (int32_t v : hc) *count += v != 0;
+        }
         const int n = kv.second.dev.n_split_rows;
         if (n <= 0) continue;
         std::vector<int32_t> h((size_t)n);
@@ -1930,6 +1941,7 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
             if (kv->second.sys_dev) (void)hipFree(kv->second.sys_dev);
             if (kv->second.segs_dev) (void)hipFree(kv->second.segs_dev);
             if (kv->second.wave_seg_dev) (void)hipFree(kv->second.wave_seg_dev);
+            bdf_col_plan_free(kv->second.col);
             kv = plans.erase(kv);
         } else {
             ++kv;
@@ -2037,6 +2049,23 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     // bdf_ctx_set_two_phase's row count or more (environment BDF_K1_TWO_PHASE; negative: never)
     key.fin_min = (DP == 32 && a.D > 16 && !dump && !getenv("BDF_K1_DECOUPLE")) ? ctx->fin_min_rows : -1;
 
+    // 16 < D <= 32, one two-mode relation on the lean gather path without per-observation baselines: the rows four to a wave in
+    // the column layout (K1c, k_rows_col.hip; bdf_ctx_set_col_rows) -- unless the caller chose K1's item size or one of its variants
+    if (DP == 32 && a.D > 16 && !dump && ctx->col_piece > 0 && (ctx->col_explicit || ctx->item_auto) && a.n_terms == 1 && a.t[0].n_other == 1 &&
+        a.t[0].lean == 1 && a.t[0].linear == nullptr && key.fin_min < 0 && !key.glds && !key.fused4 && !getenv("BDF_K1_DECOUPLE") &&
+        !getenv("BDF_K1_GENERAL_KERNEL")) {
+        static int cus = 0;
+        if (!cus) {
+            hipDeviceProp_t prop;
+            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            cus = prop.multiProcessorCount;
+        }
+        static const int per_simd = getenv("BDF_COL_PER_SIMD") ? std::max(1, atoi(getenv("BDF_COL_PER_SIMD"))) : 2;
+        key.col = ctx->col_piece;
+        key.col_slots = std::max(1, cus - ctx->reserve_cus) * 4 * per_simd;
+        M_other = rels[0]->nint[1 - modes[0]];
+    }
+
     Plan *plan;
     {
         std::lock_guard<std::mutex> lock(g_cache_mutex);
@@ -2126,6 +2155,13 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         if (a.D <= 4) SMALL_LAUNCH(4); else if (a.D <= 8) SMALL_LAUNCH(8); else if (a.D <= 12) SMALL_LAUNCH(12); else SMALL_LAUNCH(16);
 #undef SMALL_LAUNCH
         BDF_HIP(hipGetLastError());
+        ctx->time_start = nullptr;
+        if (!more) { ctx->time_stop = nullptr; return BDF_OK; }
+    }
+    if (plan->col.n_waves > 0) {
+        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
+        int rc = bdf_col_launch(ctx, a, plan->col, M_other, ctx->time_start, more ? nullptr : ctx->time_stop);
+        if (rc) return rc;
         ctx->time_start = nullptr;
         if (!more) { ctx->time_stop = nullptr; return BDF_OK; }
     }

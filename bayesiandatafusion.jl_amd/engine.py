@@ -156,6 +156,11 @@ class Context:
         map, other sampled values"""
         check(lib().bdf_ctx_set_lowrank(self.handle, int(max_observations), int(min_rows)))
 
+    def set_col_rows(self, max_piece=-1):
+        """16 < D <= 32, one two-mode relation: the rows four to a wave in the column layout, cut into pieces of at most max_piece
+        observations (bdf_ctx_set_col_rows; 0: off -- the wave-per-row kernel; -1: the default, 128 unless the caller chose an item size)"""
+        check(lib().bdf_ctx_set_col_rows(self.handle, int(max_piece)))
+
     def set_two_phase(self, min_rows=1024):
         """16 < D <= 32: row launches of min_rows rows or more as two kernels -- accumulate every row's system, then factor,
         solve and draw four rows per wave (bdf_ctx_set_two_phase; negative: never)"""

@@ -123,6 +123,16 @@ int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows)
  * proved equal in mean and covariance to inv(P_i) b_i, inv(P_i)); max_observations = 0 restores the reference's map for
  * every row. */
 int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
+/* 16 < D <= 32, an entity of ONE two-mode relation without per-observation baselines (shared or per-row prior means): its rows are
+ * sampled FOUR TO A WAVE in a column-per-lane layout from the first observation to the draw (k_rows_col.hip, "K1c": 16 lanes and
+ * two columns per lane for each 32 x 32 system; sample_user_basic, src/sampling.jl:200-212 -- the SAME map from the row's
+ * normals to the sample as the wave-per-row kernel, equal to rounding: only the order of the floating-point sums differs).  A row
+ * of more than max_piece observations is cut into 2 or 4 equal pieces on neighbouring lane rows of one wave; a row of more than
+ * 4 max_piece observations spans waves.  The cut depends on the row's own length and max_piece only, so the values do not depend
+ * on the launch, the shard or the number of GPUs.  Default 128 (environment BDF_K1_COL: 0 = off, n = that piece size) for
+ * launches whose item size the caller has not set (bdf_ctx_set_item_size keeps the wave-per-row kernel); a call here with
+ * 8..4096 applies to every launch of the context, 0 turns it off, -1 restores the default. */
+int bdf_ctx_set_col_rows(bdf_ctx *ctx, int max_piece);
 /* (an experiment, OFF by default -- measured slower than the one-kernel launch)  16 < D <= 32: a row launch of
  * at least min_rows rows (environment BDF_K1_TWO_PHASE; negative, the default: never) runs as TWO
  * kernels -- the accumulation of every row's system (src/sampling.jl:205-207: Lambda_i's data part and its right-hand side) into a

@@ -13,7 +13,7 @@ if [ "$1" = build ]; then
     o=$tmp/$(basename ${f%.hip}).o
     extra=""
     case "$(basename $f)" in
-      k_sample_rows.hip) extra="$flags" ;;
+      k_sample_rows.hip|k_rows_col.hip) extra="$flags" ;;
       bdf_api.hip) case "$flags" in *BDF_K1_STAMPS*) extra="-DBDF_K1_STAMPS" ;; *BDF_K1_SPANS*) extra="-DBDF_K1_SPANS" ;; esac ;;
       k_hyper.hip) case "$flags" in *BDF_HYPER_STAMPS*) extra="-DBDF_HYPER_STAMPS" ;; esac ;;
     esac
