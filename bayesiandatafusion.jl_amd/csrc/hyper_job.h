@@ -39,6 +39,8 @@ struct NWArgs {
     const double *partial;
     int nblocks;
     double *sumU_w, *UUt_w;
+    int mean_ref;              // 1: mu through a second factorisation, chol(inv(Lambda) / beta_N)' z (the reference's map); 0: through the
+                               // factor of Lambda the Wishart draw holds (same law, no second factorisation: nw_draw)
 };
 
 // ---- stage 1: partial sums of rows [r0, r0 + HS_ROWS) by NW waves; red: (NW-1) * PSZ doubles of LDS -----------------------
@@ -172,7 +174,15 @@ __device__ __forceinline__ void hyper_scatter(int D, int e, double s, double *su
 //     mu   = mu_N + chol(inv(Lam) / beta_N)' z
 // Both "Cholesky factor of an inverse" steps come without forming the inverse (see k_hyper.hip): in index-reversed
 // coordinates (~)  W~ = L~ L~',  Z~ = L~^-T (J A),  Lam~ = Z~ Z~',  Lam~ = L2~ L2~',  mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N).
-// The two factorisations run on wave 0 in the accumulator layout (c_layout_chol.h), the rest on all threads.
+// The factorisations run on wave 0 in the accumulator layout (c_layout_chol.h), the rest on all threads.
+// Round 5 -- the mean WITHOUT the second factorisation (the default; a.mean_ref = 1 keeps the map above).  Lam = Z Z' with
+// Z = L_T A lower triangular, so Z^-T is a square root of inv(Lam) too, and  mu = mu_N + Z^-T z / sqrt(beta_N)  has the
+// reference's law N(mu_N, inv(beta_N Lam)) -- another function of the same D normals (oracle: orc_hyper_draw2, mean_map 1;
+// tests/test_oracle_known_answers.py proves mean and covariance).  In the reversed coordinates  Z~^-T = L~ (J A^-T):
+//     q = A^-T z   (A and z are the data-independent random part: wave 1 solves this while wave 0 factors W~)
+//     mu~ = mu_N~ + L~ (J q) / sqrt(beta_N)   (one product with the factor wave 0 has just made: wave 1, beside the solve for Z~)
+// which takes two dependent 32-step chains (the factorisation of Lam~ and its backward solve, ~7 us) off the iteration's
+// critical path.
 #ifdef BDF_HYPER_STAMPS
 #define HSTAMP(k) do { if (tid == 0 && a.params_out) ((unsigned long long *)a.params_out)[a.D + a.D * a.D + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -259,6 +269,30 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
         factor_sL(dv);
         s_rd[lane] = fast_rcp(dv);
         s_sq[lane] = dv * fast_rsqrt(dv);
+    } else if (wave == 1 && !a.mean_ref) {
+        // q = A^-T z by backward substitution over the Bartlett matrix (lower triangular; sA[i][c] = A[D-1-i][c], zero rows on the
+        // padding): lane c holds z_c - sum_(k > c) A_kc q_k; DP unconditional steps, natural row k = D - 1 - i (negative: padding, no-op)
+        double zi = (lane < D) ? a.draws[D * D + lane] : 0.0;
+        const double rai = (lane < D) ? fast_rcp(sA[(D - 1 - lane) * LD + lane]) : 1.0;
+        if constexpr (DP <= 32) {
+#pragma unroll
+            for (int i = 0; i < DP; i++) {
+                const int k = D - 1 - i;
+                const double qk = __shfl(zi * rai, k & 63);        // (lane k's entry is final when its turn comes)
+                const double aki = sA[i * LD + lane];
+                zi = (lane < k) ? fma(-aki, qk, zi) : zi;
+            }
+        } else {
+            // (D = 64: not unrolled -- the kernel's registers are the solve for Z~'s, 64 doubles per lane)
+#pragma unroll 1
+            for (int i = 0; i < DP; i++) {
+                const int k = D - 1 - i;
+                const double qk = __shfl(zi * rai, k & 63);
+                const double aki = sA[i * LD + lane];
+                zi = (lane < k) ? fma(-aki, qk, zi) : zi;
+            }
+        }
+        s_mu[lane] = (lane < D) ? zi * rai : 0.0;                   // q, natural order (s_mu is free until the mean is written)
     }
     __syncthreads();
     HSTAMP(2);
@@ -279,6 +313,34 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
         }
 #pragma unroll
         for (int i = 0; i < DP; i++) sA[i * LD + tid] = z[i];
+    } else if (wave == 1 && !a.mean_ref) {
+        // mu~ = mu_N~ + L~ v / sqrt(beta_N), v = J q; L~[i][k] = Lt[i][k] / sqrt(d_k) (k < i), L~[i][i] = sqrt(d_i): lane = row i
+        // (the padding's entries of the packed factor are zero, its pivots 1)
+        const int i = lane;
+        double acc4[4] = {0.0, 0.0, 0.0, 0.0};
+        if constexpr (DP <= 32) {
+#pragma unroll
+            for (int k = 0; k < DP - 1; k++) {
+                const int cb = GG::col_base(k), nr4 = GG::col_rows(k) / 4, r16 = GG::col_first(k);
+                const double l = (i > k && i < DP) ? tri[cb + (i & 3) * nr4 + (i - r16) / 4] : 0.0;
+                const double vk = (k < D) ? s_mu[(D - 1 - k) & 63] : 0.0;
+                acc4[k & 3] = fma(l * (s_rd[k] * s_sq[k]), vk, acc4[k & 3]);
+            }
+        } else {
+            double accs = 0.0;
+#pragma unroll 1
+            for (int k = 0; k < D - 1; k++) {
+                const typename GG::ColRT cr = GG::col_rt(k);
+                const double l = (i > k && i < DP) ? tri[cr.cbase + (i & 3) * cr.nr4 + (i >> 2) - cr.q] : 0.0;
+                accs = fma(l * (s_rd[k] * s_sq[k]), s_mu[D - 1 - k], accs);
+            }
+            acc4[0] = accs;
+        }
+        const double lv = (i < D) ? ((acc4[0] + acc4[1]) + (acc4[2] + acc4[3])) + s_sq[i] * s_mu[(D - 1 - i) & 63] : 0.0;
+        const double mu_c = s_muN[lane] + lv / sqrt(beta_N);
+        wave_sync();                                               // every lane has read q before the mean replaces it
+        if (i < D) a.mu_out[D - 1 - i] = mu_c;
+        s_mu[lane] = (i < D) ? mu_c : 0.0;                          // reversed: s_mu[c] = mu[D-1-c]
     }
     __syncthreads();
     HSTAMP(3);
@@ -315,8 +377,8 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     __syncthreads();
     HSTAMP(4);
 
-    // ---- mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
-    if (wave == 0) {
+    // ---- (the reference's map only) mu~ = mu_N~ + L2~^-T z~ / sqrt(beta_N), Lam~ = L2~ L2~'
+    if (wave == 0 && a.mean_ref) {
         double dv;
         const typename GG::ColRT cr = factor_sL(dv);
         const int ej = D - 1 - lane;

@@ -334,6 +334,8 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     a.ready = ctx->hyper_ready; a.ready_value = ctx->hyper_ready_value;
     ctx->hyper_ready = nullptr;
     a.partial = nullptr; a.nblocks = 0; a.sumU_w = a.UUt_w = nullptr;
+    static const int mean_ref = getenv("BDF_HYPER_MEAN") && !strcmp(getenv("BDF_HYPER_MEAN"), "reference");
+    a.mean_ref = mean_ref;
     if (ctx->hyper_partial) {
         // the partials of the bdf_hyper_sums call just before (same stream, fused mode): they live in the context's scratch
         BDF_REQUIRE(draws != nullptr && sumU == ctx->hyper_sumU && UUt == ctx->hyper_UUt, BDF_ERR_ARG,

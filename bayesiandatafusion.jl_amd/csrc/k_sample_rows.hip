@@ -2125,7 +2125,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         plan = &it->second;
     }
     if (plan->n_lr > 0) {
-        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
+        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct + plan->col.n_waves > 0;
         // the constants of the launch (L, the opposite factor transformed): once per entity launch -- a later chunk of the same
         // launch (same inputs, same iteration) finds them in the context
         const bool same = shard > 0 && ctx->lr_key_fac == (const void *)a.t[0].fac[0] && ctx->lr_key_Lambda == (const void *)a.Lambda &&
@@ -2141,7 +2141,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     if (plan->n_small > 0) {
         // the short rows first (most of the entity), then k_rows for the others; a caller's timing events and the hand-over of
         // the draw stay with k_rows when it has anything to do
-        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
+        const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct + plan->col.n_waves > 0;
         const dim3 grid((unsigned)((plan->n_small + 15) / 16)), block(256);
         hipEvent_t e0 = ctx->time_start, e1 = more ? nullptr : ctx->time_stop;
         const bool coded = a.t[0].packed != nullptr;

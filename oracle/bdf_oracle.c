@@ -581,8 +581,13 @@ int orc_hyper_params(int D, int64_t N, const double *U, const double *mu0, doubl
     return rc;
 }
 
-int orc_hyper_draw(int D, const double *mu_N, double beta_N, const double *T_N, double nu_N,
-                   uint64_t seed, uint32_t sweep, uint32_t entity_tag, double *mu, double *Lambda)
+/* mean_map 0: the reference's map, mu = mu_N + chol(inv(Lambda) / beta_N)' z (normal_wishart.jl:40 through Distributions' MvNormal).
+ * mean_map 1 (NOT the reference's function of z; the library's default since round 5): mu = mu_N + Z^-T z / sqrt(beta_N) with
+ * Z = L_T A the lower-triangular factor of Lambda = Z Z' that the Wishart draw already holds -- another square root of the same
+ * covariance inv(beta_N Lambda), so the same conditional law (tests/test_oracle_known_answers.py proves mean and covariance
+ * deterministically); it saves the device a second 32-step factorisation on the iteration's critical chain. */
+int orc_hyper_draw2(int D, const double *mu_N, double beta_N, const double *T_N, double nu_N,
+                    uint64_t seed, uint32_t sweep, uint32_t entity_tag, int mean_map, double *mu, double *Lambda)
 {
     size_t DD = (size_t)D * D;
     double *LT = (double *)malloc(sizeof(double) * DD * 5);
@@ -613,6 +618,19 @@ int orc_hyper_draw(int D, const double *mu_N, double beta_N, const double *T_N, 
             for (int k = 0; k < D; k++) s += Z[i + (size_t)k * D] * Z[j + (size_t)k * D];
             Lambda[i + (size_t)j * D] = s;
         }
+    if (mean_map == 1) {
+        /* Z' x = z by backward substitution (Z lower triangular with a positive diagonal), mu = mu_N + x / sqrt(beta_N) */
+        double z[ORC_MAX_D + 1], x[ORC_MAX_D + 1];
+        orc_normals(seed, sweep, P_NW_MEAN, entity_tag, 0, D, z);
+        for (int i = D - 1; i >= 0; i--) {
+            double s = z[i];
+            for (int k = i + 1; k < D; k++) s -= Z[k + (size_t)i * D] * x[k];
+            x[i] = s / Z[i + (size_t)i * D];
+        }
+        for (int i = 0; i < D; i++) mu[i] = mu_N[i] + x[i] / sqrt(beta_N);
+        free(LT);
+        return 0;
+    }
     /* mu ~ MvNormal(mu_N, inv(Symmetric(Lam)) ./ kappa) */
     rc = inv_lu(D, Lambda, cov);
     if (!rc) {
@@ -630,6 +648,12 @@ int orc_hyper_draw(int D, const double *mu_N, double beta_N, const double *T_N, 
     }
     free(LT);
     return rc;
+}
+
+int orc_hyper_draw(int D, const double *mu_N, double beta_N, const double *T_N, double nu_N,
+                   uint64_t seed, uint32_t sweep, uint32_t entity_tag, double *mu, double *Lambda)
+{
+    return orc_hyper_draw2(D, mu_N, beta_N, T_N, nu_N, seed, sweep, entity_tag, 0, mu, Lambda);
 }
 
 /* sample_lambda_beta (src/sampling.jl:136-142): Gamma(shape nux/2, scale 2 mux/nux) */

@@ -239,15 +239,22 @@ def hyper_params(U, mu0, b0, Tinv, nu):
     return mu_N, beta_N.value, T_N.T.copy(), nu_N.value
 
 
-def hyper_draw(mu_N, beta_N, T_N, nu_N, seed, sweep, entity_tag):
+# which map from the D mean normals to mu hyper_draw applies by default: "factor" -- through the factor Z of Lambda = Z Z' the Wishart
+# draw holds (the library's default since round 5; the same law as the reference's, another function of z) -- or "reference" --
+# chol(inv(Lambda) / beta_N)' z (normal_wishart.jl:40; the library with BDF_HYPER_MEAN=reference)
+HYPER_MEAN_MAP = "factor"
+
+
+def hyper_draw(mu_N, beta_N, T_N, nu_N, seed, sweep, entity_tag, mean_map=None):
     """rand(::NormalWishart) (normal_wishart.jl:38-42) -> mu (D), Lambda (D, D)"""
     mu_N = _f64(mu_N)
     D = len(mu_N)
     T = np.asfortranarray(_f64(T_N))
     mu = np.zeros(D)
     Lam = np.zeros((D, D))
-    rc = lib().orc_hyper_draw(D, _dp(mu_N), C.c_double(beta_N), T.ctypes.data_as(c_dp), C.c_double(nu_N),
-                              C.c_uint64(seed), C.c_uint32(sweep), C.c_uint32(entity_tag), _dp(mu), _dp(Lam))
+    mm = {"reference": 0, "factor": 1}[mean_map or HYPER_MEAN_MAP]
+    rc = lib().orc_hyper_draw2(D, _dp(mu_N), C.c_double(beta_N), T.ctypes.data_as(c_dp), C.c_double(nu_N),
+                               C.c_uint64(seed), C.c_uint32(sweep), C.c_uint32(entity_tag), C.c_int(mm), _dp(mu), _dp(Lam))
     if rc:
         raise np.linalg.LinAlgError("not positive definite")
     return mu, Lam.T.copy()

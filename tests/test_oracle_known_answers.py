@@ -103,7 +103,7 @@ def test_conditional_normal_wishart_parameters_and_draw(O):
     np.testing.assert_allclose(mu_N, mu_e, rtol=1e-13)
     T_e = np.linalg.inv(Tinv + NS + b0 * np.outer(mu0, mu0) - beta_N * np.outer(mu_e, mu_e))
     np.testing.assert_allclose(T_N, T_e, rtol=1e-10, atol=1e-14)
-    mu, Lam = O.hyper_draw(mu_N, beta_N, T_N, nu_N, 99, 4, 2)
+    mu, Lam = O.hyper_draw(mu_N, beta_N, T_N, nu_N, 99, 4, 2, mean_map="reference")
     A = np.zeros((D, D))
     for i in range(D):
         A[i, :i] = O.normals(99, 4, O.P_NW_NORMAL, 2, i, D)[:i]
@@ -112,6 +112,45 @@ def test_conditional_normal_wishart_parameters_and_draw(O):
     np.testing.assert_allclose(Lam, Z @ Z.T, rtol=1e-9, atol=1e-12)
     z = O.normals(99, 4, O.P_NW_MEAN, 2, 0, D)
     np.testing.assert_allclose(mu, mu_N + np.linalg.cholesky(np.linalg.inv(Lam) / beta_N) @ z, rtol=1e-9, atol=1e-12)
+
+
+@pytest.mark.parametrize("D", [1, 3, 10, 32, 64])
+def test_hyper_mean_through_the_wishart_factor_draws_the_reference_distribution(O, D):
+    """The library's default map from the D mean normals to mu (round 5; oracle: orc_hyper_draw2 with mean_map 1) is NOT the
+    reference's function of z -- rand(::NormalWishart) draws mu = mu_N + chol(inv(Lam) / beta_N)' z (normal_wishart.jl:40) -- but it
+    draws the SAME conditional distribution, deterministically checkable because both maps are affine in z: mu = mu_N + S z with
+    S S' = inv(beta_N Lam).  Here: (i) the oracle's two maps return the same Lambda (the mean map does not touch the Wishart draw);
+    (ii) each equals mu_N + S z for its own S, recomputed in numpy from the Bartlett matrix the streams give; (iii) both S S' equal
+    inv(beta_N Lam) to 1e-10 relative; (iv) the new S is Z^-T / sqrt(beta_N) with Z = chol(T_N)' A lower triangular, Lam = Z Z'."""
+    rng = np.random.default_rng(500 + D)
+    N = 50 + 3 * D
+    U = rng.standard_normal((N, D)) * 0.7 + 0.2
+    mu0 = rng.standard_normal(D) * 0.1
+    M = rng.standard_normal((D, D))
+    Tinv = M @ M.T / D + np.eye(D)
+    mu_N, beta_N, T_N, nu_N = O.hyper_params(U, mu0, 2.0, Tinv, float(D))
+    seed, sweep, tag = 4321, 17, 3
+    mu_ref, Lam_ref = O.hyper_draw(mu_N, beta_N, T_N, nu_N, seed, sweep, tag, mean_map="reference")
+    mu_fac, Lam_fac = O.hyper_draw(mu_N, beta_N, T_N, nu_N, seed, sweep, tag, mean_map="factor")
+    assert np.array_equal(Lam_ref, Lam_fac)
+    A = np.zeros((D, D))
+    for i in range(D):
+        A[i, :i] = O.normals(seed, sweep, O.P_NW_NORMAL, tag, i, D)[:i]
+        A[i, i] = np.sqrt(2.0 * O.gamma(seed, sweep, tag, i, 0.5 * (nu_N - i)))
+    Z = np.linalg.cholesky((T_N + T_N.T) / 2) @ A
+    assert np.allclose(Z, np.tril(Z)) and (np.diag(Z) > 0).all()
+    np.testing.assert_allclose(Lam_fac, Z @ Z.T, rtol=1e-9, atol=1e-12)
+    z = O.normals(seed, sweep, O.P_NW_MEAN, tag, 0, D)
+    cov = np.linalg.inv(beta_N * Lam_fac)
+    S_ref = np.linalg.cholesky((cov + cov.T) / 2)
+    S_fac = np.linalg.inv(Z).T / np.sqrt(beta_N)
+    scale = np.abs(cov).max()
+    np.testing.assert_allclose(S_ref @ S_ref.T, cov, rtol=0, atol=1e-10 * scale)
+    np.testing.assert_allclose(S_fac @ S_fac.T, cov, rtol=0, atol=1e-10 * scale)
+    np.testing.assert_allclose(mu_ref, mu_N + S_ref @ z, rtol=1e-8, atol=1e-10)
+    np.testing.assert_allclose(mu_fac, mu_N + S_fac @ z, rtol=1e-8, atol=1e-10)
+    if D > 1:
+        assert not np.allclose(mu_ref, mu_fac)          # two different functions of z
 
 
 def _reference_pattern():
