@@ -77,7 +77,6 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->small_min_rows = getenv("BDF_K1_SMALL_MIN_ROWS") ? atoll(getenv("BDF_K1_SMALL_MIN_ROWS")) : 8192;
     c->lr_max = getenv("BDF_LOWRANK") ? atoi(getenv("BDF_LOWRANK")) : -1;
     c->lr_min_rows = getenv("BDF_LOWRANK_MIN_ROWS") ? atoll(getenv("BDF_LOWRANK_MIN_ROWS")) : 8192;
-    c->fin_min_rows = getenv("BDF_K1_TWO_PHASE") ? atoll(getenv("BDF_K1_TWO_PHASE")) : -1;      // (off: measured slower than the one-kernel launch)
     // K1c (k_rows_col.hip): on by default with pieces of at most 128 observations; BDF_K1_COL=0: off, BDF_K1_COL=<n>: that piece size
     c->col_piece = getenv("BDF_K1_COL") ? atoi(getenv("BDF_K1_COL")) : 128;
     if (c->col_piece == 1) c->col_piece = 128;
@@ -196,13 +195,6 @@ extern "C" int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t m
                 "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..16");
     ctx->lr_max = max_observations;
     ctx->lr_min_rows = min_rows;
-    return BDF_OK;
-}
-
-extern "C" int bdf_ctx_set_two_phase(bdf_ctx *ctx, int64_t min_rows)
-{
-    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_set_two_phase: NULL context");
-    ctx->fin_min_rows = min_rows;
     return BDF_OK;
 }
 

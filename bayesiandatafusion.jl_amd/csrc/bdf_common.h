@@ -42,7 +42,6 @@ struct bdf_ctx {
     // k_rows_lr (k_rows_lr.hip): rows of few observations sampled by the low-rank map instead of the reference's
     int lr_max;                // longest row (observations) sampled that way at D > 16; -1: min(16, D / 2); 0: off
     int64_t lr_min_rows;       // ... and the smallest number of such rows in a launch for which it is used
-    int64_t fin_min_rows;      // K1 at 16 < D <= 32: launches of at least this many rows run in two phases (k_rows<SYS> + k_rows_fin); < 0: never
     int col_piece;             // K1c (k_rows_col.hip): one two-mode relation at 16 < D <= 32 four rows per wave in the column layout, rows cut
                                // into pieces of at most this many observations; 0: off
     bool col_explicit;         // ... set by the caller (bdf_ctx_set_col_rows): taken also when the caller chose K1's item size
@@ -366,15 +365,6 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *con
 int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded,
                   const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1);
 int bdf_lr_max_observations();
-// the finish of a two-phase row launch (k_rows_fin.hip): the rows' records (a multiple of 4, padded with row = -1) and the
-// slab of systems k_rows<SYS> left
-struct bdf_fin_item {
-    int32_t row;          // where the sample is written; -1: no row
-    int32_t orig;         // the row's original id (random stream)
-    int32_t sys;          // the row's slot in the slab
-    int32_t _pad;
-};
-int bdf_fin_launch(bdf_ctx *ctx, const SampleArgs &a, const bdf_fin_item *items, int64_t n_items, const double *slab, hipEvent_t e0, hipEvent_t e1);
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
 
 // ---- K1c (k_rows_col.hip): four rows per wave in the column layout ----------------------------------------------------

@@ -27,19 +27,6 @@
 #define BDF_K1_WAVES32C 7         // ... its variant for one two-mode relation with coded values (70 registers)
 #endif
 
-#ifndef BDF_K1_WAVES32G
-#define BDF_K1_WAVES32G 7         // ... its variant with the rows gathered straight into LDS (D = 32, coded values)
-#endif
-#ifndef BDF_K1_WAVES32S
-#define BDF_K1_WAVES32S 5         // the accumulate-only kernels of a two-phase launch: general,
-#endif
-#ifndef BDF_K1_WAVES32SM
-#define BDF_K1_WAVES32SM 6        // two-mode relations,
-#endif
-#ifndef BDF_K1_WAVES32SC
-#define BDF_K1_WAVES32SC 7        // one two-mode relation with coded values
-#endif
-
 namespace {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
@@ -54,10 +41,6 @@ struct Geo {
     static constexpr int WAVES = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32 : 8);
     static constexpr int WAVES_MATRIX = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32M : 8);     // the two-mode-only variant
     static constexpr int WAVES_CODED = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8);      // one two-mode relation, coded values
-    // the accumulate-only kernel of a two-phase launch (k_rows<SYS>: no factorisation, no normals; D <= 32 only)
-    static constexpr int WAVES_SYS = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32S : 8);
-    static constexpr int WAVES_SYS_MATRIX = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32SM : 8);
-    static constexpr int WAVES_SYS_CODED = (DP == 64) ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32SC : 8);
     __host__ __device__ static constexpr int blk(int I, int J) { return I * (I + 1) / 2 + J; }
     // packed factor in LDS: column k keeps rows col_first(k) = RG * (k / RG) .. DP-1, by row class:
     // entry i at col_base(k) + (i % 4) * col_rows(k) / 4 + (i - col_first(k)) / 4.  Columns are one double further apart

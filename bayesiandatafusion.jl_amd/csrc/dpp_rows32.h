@@ -2,8 +2,8 @@
 // lane j of a lane row holds COLUMNS j and 16 + j of the system in full (A0[i] = entry (i, j), A1[i] = entry (i, 16 + j); entry 32 of
 // each: the right-hand side) -- the unfinished part stays symmetric, so the multiplier of a column in step k is the lane's own
 // entry of row k: no transposition, no LDS.  The LDL' factorisation with the forward solve riding along as row 32 and the
-// backward solve are v_fmac_f64_dpp row_newbcast instructions (lane k % 16 of each lane row is the source of step k).  Shared by
-// k_rows_fin (k_rows_fin.hip: the finish of a two-kernel row launch) and k_rows4 (k_sample_rows.hip: four rows per wave throughout).
+// backward solve are v_fmac_f64_dpp row_newbcast instructions (lane k % 16 of each lane row is the source of step k).  Used by
+// k_rows_col (k_rows_col.hip: K1c, four rows per wave from the first observation on).
 #pragma once
 #include "dpp_rows16.h"
 
@@ -81,34 +81,4 @@ __device__ __forceinline__ void fin_backward(const double (&A0)[33], const doubl
     }
 }
 
-// the prior's image (the accumulator layout of the index-reversed Lambda, k_prior / prior_pack) added to a system already in
-// the registers, sixteen rows at a time (it is the same 6 KB for every wave: cache hits)
-template <int S, int I, int I1, bool POLLED>
-__device__ __forceinline__ void fin_prior16(double (&A)[33], const double *prior, int j)
-{
-    if constexpr (I < I1) {
-        const int o = sys_off<S, I>(j);
-        if constexpr (POLLED) A[I] += __hip_atomic_load(prior + o, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else A[I] += prior[o];
-        fin_prior16<S, I + 1, I1, POLLED>(A, prior, j);
-    }
-}
-template <int S, int I, int DR, bool POLLED>
-__device__ __forceinline__ void fin_prior(double (&A)[33], const double *prior, int j)
-{
-    if constexpr (I < DR) {
-        fin_prior16<S, I, (I + 16 < DR ? I + 16 : DR), POLLED>(A, prior, j);
-        asm volatile("" ::: "memory");
-        fin_prior<S, I + 16, DR, POLLED>(A, prior, j);
-    }
-}
-// a system staged in LDS in the partial-slot format, into the registers of the lanes that own it
-template <int S, int I, int DR>
-__device__ __forceinline__ void fin_from_lds(double (&A)[33], const double *stage, int j)
-{
-    if constexpr (I < DR) {
-        A[I] = stage[sys_off<S, I>(j)];
-        fin_from_lds<S, I + 1, DR>(A, stage, j);
-    }
-}
 }  // namespace

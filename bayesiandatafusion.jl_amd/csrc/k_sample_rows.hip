@@ -50,14 +50,10 @@
 #include <cstdlib>
 #include <map>
 #include <mutex>
-#include <queue>
 #include <utility>
 
 #ifndef BDF_CHOL_BLOCKED
 #define BDF_CHOL_BLOCKED 1        // the row's factorisation in 16-column panels: multipliers without an LDS round trip, trailing update on the matrix cores (c_layout_chol.h); 0: the plain right-looking variant
-#endif
-#ifndef BDF_K1_DEEP_MIN
-#define BDF_K1_DEEP_MIN 48        // D = 64: items of at least this many observations gather through three register sets (accumulate_deep); a huge value: off
 #endif
 #ifndef BDF_K1_KS
 #define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
@@ -78,17 +74,6 @@
 #define STAMP(slot) do { } while (0)
 #endif
 
-#ifdef BDF_EXP_NO_GATHER          // experiments (wrong results): the accumulation without its row gathers / without its matrix instructions
-#define BDF_EXP_NO_GATHER_V 1
-#else
-#define BDF_EXP_NO_GATHER_V 0
-#endif
-#ifdef BDF_EXP_NO_MFMA
-#define BDF_EXP_NO_MFMA_V 1
-#else
-#define BDF_EXP_NO_MFMA_V 0
-#endif
-
 namespace {
 
 
@@ -97,7 +82,7 @@ struct Item {             // one wave's accumulation work
     int32_t term;
     int64_t q_begin;      // first observation (index into the term's CSR arrays)
     int32_t count;        // observations in this item
-    int32_t slot;         // partial slot, or -1 for a direct row (k_rows_bundle: the job's slot in the slab)
+    int32_t slot;         // partial slot, or -1 for a direct row
     int32_t srow;         // index of the row in the split-row table (split items)
     int32_t orig;         // the row's ORIGINAL id: keys its random stream (== row unless the relation was created with a layout)
 };
@@ -115,13 +100,6 @@ struct PlanDev {
     double *partials;                            // n_split * PSZ doubles
     int32_t *arrived;                            // per split row: items that have published their partial (self-resetting)
     const int32_t *order;                        // launch order: wave w takes item order[w] of [split | direct]
-    int32_t decoupled, _pad;                     // 1: every row is accumulated by producer waves and finished by another wave
-    uint32_t *ticket;                            // queue-fed launch (k_rows_queue): the next position of `order`, counted on from
-    uint32_t ticket_base, _pad2;                 // (the launch's number: its parity picks the counter)
-    double *sys;                                 // two-phase launch (k_rows_bundle + k_rows_fin): one slot of PSZ doubles per job
-    const Item *segs;                            // ... the jobs (row or piece of a row: `slot` = its slot in the slab), wave by wave,
-    const int32_t *wave_seg;                     // wave w takes segs[wave_seg[w]] .. segs[wave_seg[w + 1] - 1]
-    int32_t n_bwaves, _pad3;
 };
 
 
@@ -305,9 +283,8 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     _Pragma("unroll") for (int k = 0; k < KS; k++)                                              \
         _Pragma("unroll") for (int m = 0; m < NO; m++)                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
-                w[S][k][m][I] = BDF_EXP_NO_GATHER_V ? (double)(int)(ix[S][k][m] & 255u) :                            \
-                                (WIDE ? *(const double *)(fac[m] + ((uint64_t)ix[S][k][m] * rowb + eoff[I]))           \
-                                     : *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I])));
+                w[S][k][m][I] = WIDE ? *(const double *)(fac[m] + ((uint64_t)ix[S][k][m] * rowb + eoff[I]))            \
+                                     : *(const double *)(fac[m] + (__umul24(ix[S][k][m], rowb) + eoff[I]));
 #define TRIP(t, C, X)                                                                           \
     {                                                                                           \
         LOAD_DATA(X)  /* unconditional (ids are clamped to the item): a branch here would cost exact waitcnts */ \
@@ -330,8 +307,7 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
             int b = 0;                                                                          \
             _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
                 _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
-                    if (BDF_EXP_NO_MFMA_V) acc[b][0] = fma(w_c[k][I], w_c[k][J], acc[b][0]);             \
-                    else acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
+                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0);     \
                     b++;                                                                        \
                 }                                                                               \
                 bpart[I] = fma(w_c[k][I], r, bpart[I]);                                         \
@@ -369,279 +345,20 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
     }
 }
 
-// ---- (experiments: -DBDF_K1_DEEP64, -DBDF_K1_DEEP32=n; neither is a gain) accumulate one LONG item at
-// D = DP (no padding), one other mode, shared baseline, through THREE register sets ----------------------------------------------
-// The two-set pipeline above has the factor rows of ONE trip in flight while a trip multiplies.  That is enough when the gathered
-// factor sits in the L2 (MovieLens) or when six or seven waves share a SIMD; at D = 64 two waves share it, and configuration
-// C4's item launch gathers 512-byte rows at random from a 5 GB factor matrix: every trip then waits out a whole HBM round trip
-// (~2.5 us for 8 observations = 0.5 us of matrix instructions; 12.5 M trips on 2,048 waves: 15 of the launch's 23 ms).  Here the
-// rows (and values) of trips t + 1 and t + 2 are in flight while trip t multiplies.  The loads complete in order, so the ids of a
-// trip are fetched two trips before its rows are (four before it multiplies): waiting for them then forces only loads that
-// are needed by then anyway.  (Four sets -- three trips in flight -- need more than the 256 registers two waves per SIMD leave.)
-template <int DP, bool WIDE, bool CODED = false>
-__device__ __forceinline__ void accumulate_deep(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
-                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
-{
-    static_assert(!CODED || !WIDE, "coded values: 32-bit row offsets");
-    constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB, KS = 2, NS = 3;
-    const TermDev &T = a.t[it.term];
-    const int j = lane & 15, h = lane >> 4;
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    double bpart[DB];
-    uint32_t eoff[DB];
-#pragma unroll
-    for (int I = 0; I < DB; I++) { bpart[I] = 0.0; eoff[I] = (uint32_t)(DP - 1 - (16 * I + j)) * 8u; }
-    const uint32_t n = (uint32_t)it.count, rowb = (uint32_t)DP * 8u;
-    const uint32_t ntrips = (n + 4 * KS - 1) / (4 * KS);
-    const char *ids = CODED ? (const char *)(T.packed + it.q_begin) : (const char *)(T.colidx + it.q_begin);
-    const char *fac = (const char *)T.fac[0], *vals = (const char *)(T.vals + it.q_begin);
-    const double mean = T.mean;
-    double tab_v = 0.0;
-    if (CODED && lane < BDF_K1_CODES) tab_v = T.table[lane] - mean;      // this wave's copy of the table: value - mean by code
-    uint32_t ix[NS][KS];
-    uint32_t cd[NS][KS];                  // CODED: the value codes of a set's observations (its ids' slot is reused before the trip multiplies)
-    double rr[NS][KS];
-    double w[NS][KS][DB];
-#define OBS(t, k) ((t) * (4 * KS) + KS * h + (k))
-#define LOAD_IDX(t, S)                                                                          \
-    {                                                                                           \
-        uint32_t o = OBS(t, 0);                                                                 \
-        o = (o < n ? o : n - 1) * 4u;                                                           \
-        const uint2 pi = *(const uint2 *)(ids + o);      /* (the arrays carry a spare entry) */  \
-        ix[S][0] = pi.x; ix[S][1] = pi.y;                                                       \
-    }
-#define LOAD_DATA(t, S)                                                                         \
-    {                                                                                           \
-        if (!CODED) {                                                                           \
-            uint32_t o = OBS(t, 0);                                                             \
-            o = (o < n ? o : n - 1) * 8u;                                                       \
-            const d2 pv = *(const d2 *)(vals + o);                                              \
-            rr[S][0] = pv[0]; rr[S][1] = pv[1];                                                 \
-        } else {                                                                                \
-            cd[S][0] = ix[S][0] >> 24; cd[S][1] = ix[S][1] >> 24;                               \
-        }                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
-            _Pragma("unroll") for (int I = 0; I < DB; I++)                                      \
-                w[S][k][I] = WIDE ? *(const double *)(fac + ((uint64_t)ix[S][k] * rowb + eoff[I]))      \
-                                  : *(const double *)(fac + (__umul24(ix[S][k], rowb) + eoff[I]));      \
-    }
-#define TRIP(t, C)                                                                              \
-    {                                                                                           \
-        LOAD_DATA((t) + 2, ((C) + 2) % NS)                                                      \
-        double w_c[KS][DB];                                                                     \
-        _Pragma("unroll") for (int k = 0; k < KS; k++)                                          \
-            _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = w[C][k][I];              \
-        if ((t) + 1 >= ntrips) {              /* the ragged last trip, and the empty ones behind it */ \
-            _Pragma("unroll") for (int k = 0; k < KS; k++) {                                    \
-                const bool valid = OBS(t, k) < n;                                               \
-                _Pragma("unroll") for (int I = 0; I < DB; I++) w_c[k][I] = valid ? w_c[k][I] : 0.0; \
-            }                                                                                   \
-        }                                                                                       \
-        _Pragma("unroll") for (int k = 0; k < KS; k++) {                                        \
-            const double r = CODED ? tab[cd[C][k]] : rr[C][k] - mean;                           \
-            int b = 0;                                                                          \
-            _Pragma("unroll") for (int I = 0; I < DB; I++) {                                    \
-                _Pragma("unroll") for (int J = 0; J <= I; J++) {                                \
-                    acc[b] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[k][I], w_c[k][J], acc[b], 0, 0, 0); \
-                    b++;                                                                        \
-                }                                                                               \
-                bpart[I] = fma(w_c[k][I], r, bpart[I]);                                         \
-            }                                                                                   \
-        }                                                                                       \
-        LOAD_IDX((t) + 4, ((C) + 1) % NS)                                                       \
-    }
-    LOAD_IDX(0u, 0)
-    LOAD_IDX(1u, 1)
-    LOAD_DATA(0u, 0)
-    LOAD_DATA(1u, 1)
-    LOAD_IDX(2u, 2)
-    LOAD_IDX(3u, 0)
-    if (CODED && lane < BDF_K1_CODES) const_cast<double *>(tab)[lane] = tab_v;
-    for (uint32_t t = 0; t < ntrips; t += 3) {
-        TRIP(t, 0)
-        TRIP(t + 1, 1)
-        TRIP(t + 2, 2)
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#undef LOAD_IDX
-#undef LOAD_DATA
-#undef TRIP
-#undef OBS
-    const double alpha = term_alpha(T);
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] *= alpha;
-#pragma unroll
-    for (int I = 0; I < DB; I++) {
-        double v = bpart[I] * alpha;
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        bred[I] = v;
-    }
-}
-
-// ---- accumulate one item, rows gathered STRAIGHT INTO LDS (D = DP = 32, one two-mode relation with coded values) ----------------
-// The register pipeline above has the factor rows of ONE trip in flight per wave (2 KB: two register sets are what 7 waves per
-// SIMD leave room for), and the accumulation runs at the rate that allows -- 26-31 us of the launch's 39 at MovieLens's size
-// whatever the balance of the waves, against 10 us of matrix-pipe time: 4.9 TB/s of gathered rows where the
-// gather alone reaches 14.5.  Here the rows never pass through vector registers on their way in: global_load_lds_dwordx4 writes
-// 64 lanes x 16 bytes = four 256-byte rows per instruction into a two-trip ring in the wave's LDS (the packed factor's space,
-// idle until the factorisation), and the matrix operands are read from there (ds_read_b64) when the trip multiplies.  TWO trips
-// (4 KB) are in flight per wave, the 16 registers of the two sets are gone (8 waves per SIMD), and the item's packed words
-// (ids + value codes, <= 160 observations: bdf_launch_sample_rows caps the item size) are fetched once, also by LDS-DMA.
-// LDS of the wave, bytes from `tri`: [0, 256) value table, [256, 896) packed words, [896, 4992) the ring (2 x 2 x 1 KB).
-// Same operands to the same matrix instructions in the same order as accumulate_lean<.., CODED>: bit-identical sums.
-#define BDF_GLDS_MAX_OBS 160
-__device__ __forceinline__ void glds16(unsigned voff, const void *sbase, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
-}
-__device__ __forceinline__ void glds4(unsigned voff, const void *sbase, unsigned lds_dst)
-{
-    unsigned keep;
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(voff), "s"(lds_dst), "s"(sbase) : "memory");
-}
-// R: trips in flight (ring slots of 2 KB; k_rows: 2 -- what the packed factor's space holds; k_rows4: BDF_K4_RING)
-template <int DP, int R = 2>
-__device__ __forceinline__ void accumulate_glds(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
-                                       double (&bred)[Geo<DP>::DB], double *tri)
-{
-    static_assert(DP == 32 && (R & (R - 1)) == 0 && R >= 2 && R <= 8, "LDS-direct gather: D = 32, a power-of-two ring");
-    constexpr int DB = 2, NB = 3;
-    const TermDev &T = a.t[it.term];
-    const int j = lane & 15, h = lane >> 4;
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    double bpart[DB] = {0.0, 0.0};
-    const uint32_t n = (uint32_t)it.count, ntrips = (n + 7) / 8;
-    // (wave-uniform by construction; the scalar-register operands of the LDS-DMA statements need the compiler to know it)
-    auto uniform = [](const void *q) {
-        const uint64_t v = (uint64_t)q;
-        return (const void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-    };
-    const void *fac = uniform((const void *)T.fac[0]);
-    const void *packed = uniform((const void *)(T.packed + it.q_begin));
-    const double mean = T.mean;
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)tri);
-    double *const tab = tri;
-    const uint2 *const idw = (const uint2 *)(tri + 32);          // pair p = observations 2p, 2p + 1 of the item
-    const double *const ring = tri + 112;
-    if (lane < BDF_K1_CODES) tab[lane] = T.table[lane] - mean;      // this wave's copy of the table: value - mean by code
-    // the item's packed words: word w (clamped to the item: positions past its end repeat the last observation) by lane w % 64
-    {
-        uint32_t w0 = (uint32_t)lane, w1 = w0 + 64, w2 = w0 + 128;
-        w0 = (w0 < n ? w0 : n - 1) * 4u; w1 = (w1 < n ? w1 : n - 1) * 4u; w2 = (w2 < n ? w2 : n - 1) * 4u;
-        glds4(w0, packed, lds0 + 256);
-        if (n > 64) glds4(w1, packed, lds0 + 512);
-        if (n > 128 && lane < 32) glds4(w2, packed, lds0 + 768);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    }
-    const unsigned chunk = (unsigned)j * 16u, ringb = lds0 + 896;
-    // gather trip tt (its 8 observations: lane group h takes observations 8 tt + 2 h + k in piece k) into ring slot tt & 1
-#define GLDS_TRIP(tt)                                                                            \
-    {                                                                                            \
-        const uint2 pw = idw[4 * (tt) + h];                                                      \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                       \
-        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + ((tt) & (unsigned)(R - 1)) * 2048u);          \
-        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + ((tt) & (unsigned)(R - 1)) * 2048u + 1024u);  \
-    }
-    GLDS_TRIP(0u)
-    if (ntrips > 1) GLDS_TRIP(1u)
-    if constexpr (R > 2) {
-        if (ntrips > 2) GLDS_TRIP(2u)
-        if (ntrips > 3) GLDS_TRIP(3u)
-    }
-    if constexpr (R > 4) {
-        if (ntrips > 4) GLDS_TRIP(4u)
-        if (ntrips > 5) GLDS_TRIP(5u)
-        if (ntrips > 6) GLDS_TRIP(6u)
-        if (ntrips > 7) GLDS_TRIP(7u)
-    }
-    const int eo0 = 31 - j, eo1 = 15 - j;                // natural index of reversed elements j, 16 + j
-    for (uint32_t t = 0; t < ntrips; t++) {
-        // trip t has landed: the R - 1 trips after it (as many as the item still has) may be in flight, two pieces each
-        {
-            const uint32_t m = ntrips - 1 - t < (uint32_t)(R - 1) ? ntrips - 1 - t : (uint32_t)(R - 1);
-            if (m == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (m == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (m == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (m == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (m == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (m == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (m == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        }
-        const double *sl = ring + (t & (unsigned)(R - 1)) * 256 + h * 32;
-        double w_c[2][DB];
-        w_c[0][0] = sl[eo0]; w_c[0][1] = sl[eo1];
-        w_c[1][0] = sl[128 + eo0]; w_c[1][1] = sl[128 + eo1];
-        const uint2 pw = idw[4 * t + h];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: the trip after next may land in it
-        if (t + R < ntrips) GLDS_TRIP(t + R)
-        if (t + 1 >= ntrips) {                                  // ragged last trip
-            const uint32_t o = 8 * t + 2 * (uint32_t)h;
-            if (!(o < n)) { w_c[0][0] = 0.0; w_c[0][1] = 0.0; }
-            if (!(o + 1 < n)) { w_c[1][0] = 0.0; w_c[1][1] = 0.0; }
-        }
-        const double r0 = tab[pw.x >> 24], r1 = tab[pw.y >> 24];
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][0], w_c[0][0], acc[0], 0, 0, 0);
-        bpart[0] = fma(w_c[0][0], r0, bpart[0]);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][0], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][1], acc[2], 0, 0, 0);
-        bpart[1] = fma(w_c[0][1], r0, bpart[1]);
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][0], w_c[1][0], acc[0], 0, 0, 0);
-        bpart[0] = fma(w_c[1][0], r1, bpart[0]);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][0], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][1], acc[2], 0, 0, 0);
-        bpart[1] = fma(w_c[1][1], r1, bpart[1]);
-    }
-#undef GLDS_TRIP
-    const double alpha = term_alpha(T);
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] *= alpha;
-#pragma unroll
-    for (int I = 0; I < DB; I++) {
-        double v = bpart[I] * alpha;
-        v += __shfl_xor(v, 16);
-        v += __shfl_xor(v, 32);
-        bred[I] = v;
-    }
-}
-
 // path and other-mode count are wave-uniform.  MATRIX: the kernel variant for launches whose terms are all two-mode
 // relations on the lean path -- without the tensor and general gathers the D <= 32 kernel needs 78 registers instead of
 // 92 (6 resident waves per SIMD instead of 5, and room beside 5 of them for a wave of the prediction update)
-template <int DP, bool MATRIX, bool CODED = false, bool GLDS = false>
+template <int DP, bool MATRIX, bool CODED = false>
 __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &it, int lane, d4 (&acc)[Geo<DP>::NB],
                                       double (&bred)[Geo<DP>::DB], const double *tab = nullptr)
 {
-    if constexpr (GLDS) {                    // ... at D = DP = 32 with items of at most BDF_GLDS_MAX_OBS observations (checked by the host)
-        accumulate_glds<DP>(a, it, lane, acc, bred, const_cast<double *>(tab));
-        return;
-    }
     if constexpr (CODED) {                   // one two-mode relation, lean gather, coded values (checked by the host)
-#ifdef BDF_K1_DEEP32
-        if (a.D == DP && it.count >= BDF_K1_DEEP32) { accumulate_deep<DP, false, true>(a, it, lane, acc, bred, tab); return; }
-#endif
         if (a.D == DP) accumulate_lean<DP, 1, true, false, true>(a, it, lane, acc, bred, tab);
         else accumulate_lean<DP, 1, false, false, true>(a, it, lane, acc, bred, tab);
         return;
     }
     const int no = a.t[it.term].n_other;
     if constexpr (DP == 64) {
-#ifdef BDF_K1_DEEP64
-        // (experiment, off: long items at D = 64 through the three-set pipeline -- configuration C4's item launch 23.6 ms with it,
-        // 23.5 without: that launch is bound by the FP64 pipe at two waves per SIMD, not by its gathers; 216 registers instead of 192)
-        if (a.D == DP && no == 1 && it.count >= BDF_K1_DEEP_MIN && a.t[it.term].lean != 0) {
-            if (a.t[it.term].lean == 2) accumulate_deep<DP, true>(a, it, lane, acc, bred);
-            else accumulate_deep<DP, false>(a, it, lane, acc, bred);
-            return;
-        }
-#endif
         if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
             if (a.D == DP) {
                 if (no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
@@ -756,7 +473,7 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
 // completes a row finishes that row (agent-scope release / acquire around a per-row arrival counter, placement
 // independent: cdna_hip_programming.md Guideline 16).  The remaining waves take one direct row each. -----------------------
 // One work item (index wi in [split items | direct items]) on one wave.
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool GLDS = false>
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
 __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev &p, const int64_t wid, const int lane, double *tri)
 {
     double *const tab = tri;          // CODED: the wave's value table (BDF_K1_CODES doubles) sits in the packed factor's space until the factorisation
@@ -783,25 +500,9 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     // a direct row's normals (lane c < D draws number D-1-c of the row's stream) are drawn BEFORE its gathers: the
     // Philox / Box-Muller arithmetic then runs under the matrix-pipe-bound accumulation instead of after it
     double z = 0.0;
-    const bool early_z = !DUMP && !is_split && !p.decoupled;
+    const bool early_z = !DUMP && !is_split;
     if (early_z && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
-    if (p.decoupled && !is_split) {
-        // finisher of a row whose items other waves accumulate (they were launched earlier and never wait): poll the
-        // row's arrival counter, bounded so that a bug cannot hang the device
-        const SplitRow sr = p.rows[it.srow];
-        int seen = 0;
-        for (int spin = 0; spin < (1 << 22); spin++) {
-            seen = __builtin_amdgcn_readfirstlane(__hip_atomic_load(p.arrived + it.srow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-            if (seen >= sr.n_slots) break;
-            __builtin_amdgcn_s_sleep(8);
-        }
-        if (seen < sr.n_slots && lane == 0) atomicOr_system(a.flag, 16);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
-        if (!DUMP && lane < D) z = bdf_normal(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, D - 1 - lane);
-        sum_partials<DP>(p, sr, lane, acc, bv);
-        STAMP(2);
-    } else if (it.count > 0) accumulate_any<DP, MATRIX, CODED, GLDS>(a, it, lane, acc, bv, tab);
+    if (it.count > 0) accumulate_any<DP, MATRIX, CODED>(a, it, lane, acc, bv, tab);
     else {
 #pragma unroll
         for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
@@ -828,7 +529,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         int old = 0;
         if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         old = __builtin_amdgcn_readfirstlane(old);
-        if (p.decoupled || old != sr.n_slots - 1) { SPAN_END(); return; }       // not the last item of the row (decoupled: never finishes)
+        if (old != sr.n_slots - 1) { SPAN_END(); return; }       // not the last item of the row
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) p.arrived[it.srow] = 0;                  // ready for the next launch
@@ -837,33 +538,6 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         sum_partials<DP>(p, sr, lane, acc, bv);
         STAMP(2);
     }
-#ifdef BDF_EXP_ACC_ONLY       // experiment: what the launch costs without the finish phase (the row's system goes to the slab instead)
-    {
-        double *dst = p.partials + (int64_t)(is_split ? it.slot : wid) * PSZ;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane] = acc[b][r];
-        if (lane < 16) {
-#pragma unroll
-            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane] = bv[I];
-        }
-        return;
-    }
-#endif
-#ifdef BDF_EXP_NO_PRIOR       // experiment: what the prior's loads cost (wrong results: 5 I instead of the prior's image)
-    if (true) {
-        int b = 0;
-#pragma unroll
-        for (int I = 0; I < DB; I++)
-#pragma unroll
-            for (int J = 0; J <= I; J++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) acc[b][r] += (I == J && h + 4 * r == j) ? 5.0 : 0.0;
-                b++;
-            }
-    } else
-#endif
     if (a.ready) {
         // launched without waiting for the hyperprior draw (bdf_gibbs_sweep: the draw runs on CUs this kernel never uses, so
         // it cannot be starved): poll its flag here, where the prior is first needed -- the gathers above have hidden most of
@@ -966,8 +640,8 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     SPAN_END();
 }
 
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false, bool GLDS = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, GLDS ? BDF_K1_WAVES32G : (CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES)))
+template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
+__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
 void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
@@ -976,385 +650,8 @@ void k_rows(SampleArgs a, PlanDev p)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct)
-        process_item<DP, DUMP, MATRIX, CODED, GLDS>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
 }
-
-// ---- two-phase launch, first kernel: EQUAL WORK PER WAVE ---------------------------------------------------------------------
-// The one-kernel launch gives every wave one item -- a row, or a piece of a long one -- and ends with its longest chain: 24
-// trips of gathers for a 192-observation row while the mean is 9 (the accumulation alone: 31 us of the launch's 39 at
-// MovieLens's size, against 10 us of matrix-pipe time).  Here a wave takes a BUNDLE of jobs: rows are cut into pieces of at
-// most the mean work per wave, the pieces and the whole rows are dealt to the waves longest first (build_plan), and every job
-// leaves its part of the row's system -- alpha S and alpha W r in the partial-slot format -- in its own slot of the slab.
-// The factorisation, the solves and the draw are k_rows_fin's (k_rows_fin.hip), four rows per wave.
-template <int DP, bool MATRIX, bool CODED = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_SYS_CODED : (MATRIX ? Geo<DP>::WAVES_SYS_MATRIX : Geo<DP>::WAVES_SYS))
-void k_rows_bundle(SampleArgs a, PlanDev p)
-{
-    using GG = Geo<DP>;
-    constexpr int WPB = GG::WPB, DB = GG::DB, NB = GG::NB, PSZ = GG::PSZ;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * BDF_K1_CODES];       // CODED: the wave's value table
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int w = (int)blockIdx.x * WPB + wave;
-    if (w >= p.n_bwaves) return;
-    const int s1 = p.wave_seg[w + 1];
-    for (int s = p.wave_seg[w]; s < s1; s++) {
-        // (the arguments, the lane and the wave number through an index the compiler cannot see through: kept live around the
-        // loop, what it derives from them would cost the kernel its registers)
-        int zero = 0, lane_i = lane, wave_i = wave;
-        asm volatile("" : "+s"(zero), "+v"(lane_i), "+s"(wave_i));
-        const SampleArgs &ai = (&a)[zero];
-        const PlanDev &pi = (&p)[zero];
-        const Item it = pi.segs[s];
-        d4 acc[NB];
-        double bv[DB];
-        accumulate_any<DP, MATRIX, CODED>(ai, it, lane_i, acc, bv, lds + wave_i * BDF_K1_CODES);
-        double *dst = pi.sys + (int64_t)it.slot * PSZ;
-#pragma unroll
-        for (int b = 0; b < NB; b++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) dst[(b * 4 + r) * 64 + lane_i] = acc[b][r];
-        if (lane_i < 16) {
-#pragma unroll
-            for (int I = 0; I < DB; I++) dst[NB * 4 * 64 + I * 16 + lane_i] = bv[I];
-        }
-        wave_sync();          // the next job's value table replaces this one's
-    }
-}
-
-// ---- FOUR ROWS PER WAVE THROUGHOUT (D = 32, one two-mode relation with coded values; environment BDF_K1_FUSED4=1) -----------
-// What the round's measurements say a launch of MovieLens's size is made of: ~10 us of accumulation at the
-// matrix pipe's rate and ~29 us of 32 x 32 factorisations, solves and their tails -- one per wave, ~800 vector instructions each in
-// the accumulator layout at a fifth of the lanes' rate.  k_rows_fin's finish needs 310 per row, but as a kernel of its own it pays
-// a slab (every row's system written and read back at 2 TB/s).  Here a wave takes FOUR jobs (rows, or pieces of long rows: at
-// most BDF_GLDS_MAX_OBS observations each), one for each of its 16-lane rows: it accumulates them one after the other on the
-// matrix cores (rows gathered straight into an LDS ring, BDF_K4_RING trips in flight: two waves per SIMD have no other latency
-// cover), passes each finished system through 6.4 KB of its own LDS into the two-columns-per-lane layout of dpp_rows32.h, and
-// then factors, solves and draws all four at once.  Pieces of long rows publish their partial sums to the slab exactly as
-// k_rows' split items do; the piece whose publication completes the row sums the partials in slot order and keeps the row.
-#ifndef BDF_K4_RING
-#define BDF_K4_RING 4
-#endif
-template <bool POLLED>
-__global__ __launch_bounds__(64, 2) void k_rows4(SampleArgs a, PlanDev p, const int32_t *wave_jobs, int n_waves)
-{
-    constexpr int DP = 32, DB = 2, NB = 3, PSZ = Geo<32>::PSZ, R = BDF_K4_RING, DR = 32;
-    // LDS of the wave (doubles): value table [0, 32) | the four jobs' packed words 4 x 80 | ring R x 256 | staging slot PSZ
-    __shared__ __attribute__((aligned(16))) double lds[32 + 320 + R * 256 + PSZ];
-    double *const tab = lds;
-    const uint2 *const idw = (const uint2 *)(lds + 32);
-    const double *const ring = lds + 352;
-    double *const stage = lds + 352 + R * 256;
-    const int lane = threadIdx.x & 63, j = lane & 15, h = lane >> 4;
-    const int w = (int)blockIdx.x;
-    if (w >= n_waves) return;
-    const int64_t wid = w;                     // (diagnostic builds: the stamps' index)
-    STAMP(0);
-#ifdef BDF_K1_STAMPS
-    if (lane == 0 && a.b_dump && wid < 65536) {
-        ((unsigned long long *)a.b_dump)[wid * 16 + 9] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 4) |
-            ((unsigned long long)__builtin_amdgcn_s_getreg((32 - 1) << 11 | 0 << 6 | 4) );
-        ((unsigned long long *)a.b_dump)[wid * 16 + 10] = __builtin_amdgcn_s_getreg((4 - 1) << 11 | 0 << 6 | 20);
-    }
-#endif
-    double A0[33], A1[33];
-#pragma unroll
-    for (int i = 0; i < 33; i++) { A0[i] = 0.0; A1[i] = 0.0; }
-    int my_row = -1;
-
-    // ---- the wave's four jobs as ONE stream of trips: the gathers run ahead across the jobs' boundaries ----
-    const TermDev &T = a.t[0];
-    auto uniform = [](const void *q) {
-        const uint64_t v = (uint64_t)q;
-        return (const void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) |
-                              (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v));
-    };
-    const void *fac = uniform((const void *)T.fac[0]);
-    const unsigned lds0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)lds);
-    const double mean = T.mean, alpha = term_alpha(T);
-    if (lane < BDF_K1_CODES) tab[lane] = T.table[lane] - mean;
-    int jw[4];                                 // item numbers (-1: none)
-    uint32_t jn[4], jt[4];                     // observations and trips of the four jobs
-    uint32_t U = 0;
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        jw[g] = __builtin_amdgcn_readfirstlane(wave_jobs[4 * w + g]);
-        int cnt = 0;
-        const void *packed = nullptr;
-        if (jw[g] >= 0) {
-            const Item &it = jw[g] < p.n_split ? p.split[jw[g]] : p.direct[jw[g] - p.n_split];
-            cnt = __builtin_amdgcn_readfirstlane(it.count);
-            packed = uniform((const void *)(T.packed + it.q_begin));
-        }
-        jn[g] = (uint32_t)cnt;
-        jt[g] = (jn[g] + 7) / 8;
-        U += jt[g];
-        if (cnt > 0) {
-            // the job's packed words: word w (clamped to the job: positions past its end repeat the last observation) by lane w % 64
-            const uint32_t n = jn[g];
-            uint32_t w0 = (uint32_t)lane, w1 = w0 + 64, w2 = w0 + 128;
-            w0 = (w0 < n ? w0 : n - 1) * 4u; w1 = (w1 < n ? w1 : n - 1) * 4u; w2 = (w2 < n ? w2 : n - 1) * 4u;
-            const unsigned dstb = lds0 + 256 + (unsigned)g * 640u;
-            glds4(w0, packed, dstb);
-            if (n > 64) glds4(w1, packed, dstb + 256);
-            if (n > 128 && lane < 32) glds4(w2, packed, dstb + 512);
-        }
-    }
-    // the normals of the row this lane row will hold -- if its job turns out to complete a row -- while the packed words arrive
-    const int D = a.D;
-    const int ec0 = D - 1 - j, ec1 = D - 17 - j;
-    const int n0 = ec0 >= 0 ? ec0 : 0, n1 = ec1 >= 0 ? ec1 : 0;
-    double z0 = 0.0, z1 = 0.0;
-    {
-        const int mywid = h == 0 ? jw[0] : (h == 1 ? jw[1] : (h == 2 ? jw[2] : jw[3]));
-        int orig_h = 0;
-        if (mywid >= 0) orig_h = (mywid < p.n_split ? p.split[mywid] : p.direct[mywid - p.n_split]).orig;
-        double ze = 0.0, zo = 0.0;
-        if (mywid >= 0 && 2 * j < D) bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)orig_h, (uint32_t)j, ze, zo);
-        const int base = lane & 48;
-        const double ze0 = __shfl(ze, base + (n0 >> 1)), zo0 = __shfl(zo, base + (n0 >> 1));
-        const double ze1 = __shfl(ze, base + (n1 >> 1)), zo1 = __shfl(zo, base + (n1 >> 1));
-        z0 = ec0 >= 0 ? ((n0 & 1) ? zo0 : ze0) : 0.0;
-        z1 = ec1 >= 0 ? ((n1 & 1) ? zo1 : ze1) : 0.0;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned chunk = (unsigned)j * 16u, ringb = lds0 + 352 * 8;
-    // issue side of the stream: trip (gi, ti) is the next to be gathered, into ring slot ui % R
-    int gi = 0;
-    uint32_t ti = 0, ui = 0;
-    while (gi < 4 && jt[gi == 0 ? 0 : (gi == 1 ? 1 : (gi == 2 ? 2 : 3))] == 0) gi++;
-#define JT(g) ((g) == 0 ? jt[0] : ((g) == 1 ? jt[1] : ((g) == 2 ? jt[2] : jt[3])))
-#define JN(g) ((g) == 0 ? jn[0] : ((g) == 1 ? jn[1] : ((g) == 2 ? jn[2] : jn[3])))
-#define JW(g) ((g) == 0 ? jw[0] : ((g) == 1 ? jw[1] : ((g) == 2 ? jw[2] : jw[3])))
-#define ISSUE_TRIP()                                                                              \
-    {                                                                                             \
-        const uint2 pw = idw[gi * 80 + 4 * (int)ti + h];                                          \
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                                        \
-        glds16(__umul24(pw.x, 256u) + chunk, fac, ringb + (ui & (unsigned)(R - 1)) * 2048u);          \
-        glds16(__umul24(pw.y, 256u) + chunk, fac, ringb + (ui & (unsigned)(R - 1)) * 2048u + 1024u);  \
-        ui++; ti++;                                                                               \
-        if (ti == JT(gi)) { ti = 0; gi++; while (gi < 4 && JT(gi) == 0) gi++; }                   \
-    }
-#pragma unroll 1
-    for (int q = 0; q < R; q++)
-        if (ui < U) ISSUE_TRIP()
-    // consume side
-    d4 acc[NB];
-    double bpart[DB] = {0.0, 0.0};
-#pragma unroll
-    for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-    const int eo0 = 31 - j, eo1 = 15 - j;
-    int gc = 0;
-    while (gc < 4 && JT(gc) == 0) gc++;
-    uint32_t tc = 0;
-#ifdef BDF_K1_STAMPS
-    unsigned long long ph_wait = 0, ph_read = 0, ph_issue = 0, ph_mfma = 0, ph_flush = 0, ph_t = __builtin_amdgcn_s_memtime();
-#define PH(x) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); x += now_ - ph_t; ph_t = now_; } while (0)
-#else
-#define PH(x) do { } while (0)
-#endif
-#pragma unroll 1
-    for (uint32_t uc = 0; uc < U; uc++) {
-        {
-            const uint32_t m = ui - 1 - uc;            // trips in flight behind this one (at most R - 1)
-            if (m == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            else if (m == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-            else if (m == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else if (m == 3) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-            else if (m == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (m == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            else if (m == 6) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-        }
-        PH(ph_wait);
-        const double *sl = ring + (uc & (unsigned)(R - 1)) * 256 + h * 32;
-        double w_c[2][DB];
-        w_c[0][0] = sl[eo0]; w_c[0][1] = sl[eo1];
-        w_c[1][0] = sl[128 + eo0]; w_c[1][1] = sl[128 + eo1];
-        const uint2 pw = idw[gc * 80 + 4 * (int)tc + h];
-        const double r0 = tab[pw.x >> 24], r1 = tab[pw.y >> 24];
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the slot has been read: a later trip may land in it
-        PH(ph_read);
-        if (ui < U) ISSUE_TRIP()
-        PH(ph_issue);
-        const uint32_t ntr = JT(gc);
-        const bool last = tc + 1 == ntr;
-        if (last) {                                             // ragged last trip of the job
-            const uint32_t o = 8 * tc + 2 * (uint32_t)h, n = JN(gc);
-            if (!(o < n)) { w_c[0][0] = 0.0; w_c[0][1] = 0.0; }
-            if (!(o + 1 < n)) { w_c[1][0] = 0.0; w_c[1][1] = 0.0; }
-        }
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][0], w_c[0][0], acc[0], 0, 0, 0);
-        bpart[0] = fma(w_c[0][0], r0, bpart[0]);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][0], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[0][1], w_c[0][1], acc[2], 0, 0, 0);
-        bpart[1] = fma(w_c[0][1], r0, bpart[1]);
-        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][0], w_c[1][0], acc[0], 0, 0, 0);
-        bpart[0] = fma(w_c[1][0], r1, bpart[0]);
-        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][0], acc[1], 0, 0, 0);
-        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(w_c[1][1], w_c[1][1], acc[2], 0, 0, 0);
-        bpart[1] = fma(w_c[1][1], r1, bpart[1]);
-        tc++;
-#ifdef BDF_K1_STAMPS
-        asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[1]), "v"(acc[2]));      // (the matrix instructions have issued)
-#endif
-        PH(ph_mfma);
-        if (!last) continue;
-        // ---- the job is complete: its system to this wave's lane row gc (pieces of long rows through the slab first) ----
-        const int g = gc, widj = JW(gc);
-        tc = 0; gc++;
-        while (gc < 4 && JT(gc) == 0) gc++;
-        const bool is_split = widj < p.n_split;
-        const Item it = is_split ? p.split[widj] : p.direct[widj - p.n_split];
-        double bv[DB];
-#pragma unroll
-        for (int b = 0; b < NB; b++) acc[b] *= alpha;
-#pragma unroll
-        for (int I = 0; I < DB; I++) {
-            double v = bpart[I] * alpha;
-            v += __shfl_xor(v, 16);
-            v += __shfl_xor(v, 32);
-            bv[I] = v;
-            bpart[I] = 0.0;
-        }
-        bool has = true;
-        if (is_split) {
-            double *dst = p.partials + (int64_t)it.slot * PSZ;
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    __hip_atomic_store(dst + (b * 4 + r) * 64 + lane, acc[b][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (lane < 16) {
-#pragma unroll
-                for (int I = 0; I < DB; I++)
-                    __hip_atomic_store(dst + NB * 4 * 64 + I * 16 + lane, bv[I], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            const SplitRow sr = p.rows[it.srow];
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            int old = 0;
-            if (lane == 0) old = __hip_atomic_fetch_add(p.arrived + it.srow, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            old = __builtin_amdgcn_readfirstlane(old);
-            if (old != sr.n_slots - 1) has = false;                 // not the last piece of the row: this lane row stays empty
-            else {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                if (lane == 0) p.arrived[it.srow] = 0;              // ready for the next launch
-                sum_partials<DP>(p, sr, lane, acc, bv);
-            }
-        }
-        if (has) {
-#pragma unroll
-            for (int b = 0; b < NB; b++)
-#pragma unroll
-                for (int r = 0; r < 4; r++) stage[(b * 4 + r) * 64 + lane] = acc[b][r];
-            if (lane < 16) { stage[NB * 4 * 64 + lane] = bv[0]; stage[NB * 4 * 64 + 16 + lane] = bv[1]; }
-            wave_sync();
-            if (h == g) {
-                fin_from_lds<0, 0, DR>(A0, stage, j);
-                fin_from_lds<1, 0, DR>(A1, stage, j);
-                A0[32] = stage[NB * 4 * 64 + j];
-                A1[32] = stage[NB * 4 * 64 + 16 + j];
-                my_row = it.row;
-            }
-            wave_sync();
-        }
-#pragma unroll
-        for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
-        PH(ph_flush);
-    }
-#ifdef BDF_K1_STAMPS
-    if (lane == 0 && a.b_dump && wid < 65536) {
-        unsigned long long *d = (unsigned long long *)a.b_dump + wid * 16;
-        d[11] = ph_wait; d[12] = ph_read; d[13] = ph_issue; d[14] = ph_mfma; d[15] = ph_flush; d[6] = U;
-    }
-#endif
-#undef PH
-#undef ISSUE_TRIP
-    // jobs without observations (rows of none): their systems are the prior alone
-#pragma unroll
-    for (int g = 0; g < 4; g++) {
-        if (jw[g] >= 0 && jn[g] == 0) {
-            const Item &it = jw[g] < p.n_split ? p.split[jw[g]] : p.direct[jw[g] - p.n_split];
-            if (h == g) my_row = it.row;
-        }
-    }
-#undef JT
-#undef JN
-#undef JW
-    // ---- the four systems: normals, prior, LDL' with the forward solve, backward solve (k_rows_fin's finish) ----
-    STAMP(1);
-    const bool live = my_row >= 0;
-    const int64_t pb = a.mu_is_matrix && live ? (int64_t)my_row * D : 0;
-    if constexpr (POLLED) {
-        int spins = 0;
-        while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }
-        }
-        A0[32] += ec0 >= 0 ? __hip_atomic_load(a.prior_b + pb + n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-        A1[32] += ec1 >= 0 ? __hip_atomic_load(a.prior_b + pb + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
-    } else {
-        A0[32] += ec0 >= 0 ? a.prior_b[pb + n0] : 0.0;
-        A1[32] += ec1 >= 0 ? a.prior_b[pb + n1] : 0.0;
-    }
-    STAMP(3);
-    fin_prior<0, 0, DR, POLLED>(A0, a.prior_c, j);
-    fin_prior<1, 0, DR, POLLED>(A1, a.prior_c, j);
-    STAMP(4);
-    double d0 = 1.0, d1 = 1.0;
-    fin_factor<DR, 0>(A0, A1, d0, d1, j);
-    STAMP(5);
-    if (live && ((ec0 >= 0 && !(d0 > 0.0)) || (ec1 >= 0 && !(d1 > 0.0)))) atomicOr_system(a.flag, 1);      // not positive definite
-    const double rd0 = fast_rcp(d0), rd1 = fast_rcp(d1);
-    double y0 = fma(z0, fast_rsqrt(d0), A0[32] * rd0), y1 = fma(z1, fast_rsqrt(d1), A1[32] * rd1);
-    fin_backward<DR - 1>(A0, A1, y0, y1, rd0, rd1, j);
-    if (live && ec0 >= 0) a.out[(int64_t)my_row * D + ec0] = y0;
-    if (live && ec1 >= 0) a.out[(int64_t)my_row * D + ec1] = y1;
-    STAMP(8);
-}
-
-// Queue-fed launch (an experiment, DESIGN.md section 4, K1: built with -DBDF_K1_QUEUE_BUILD -mllvm -disable-machine-licm --
-// hoisted out of the item loop, the constants of the normals' polynomials cost the kernel its registers -- and switched on
-// with BDF_K1_QUEUE=<waves per SIMD>): exactly the resident wave count is launched and every wave takes positions of `order`
-// from a global counter until they run out.  The results are the one-item-per-wave launch's to the last bit: split rows are
-// summed in slot order whoever finishes them.
-#ifdef BDF_K1_QUEUE_BUILD
-template <int DP, bool DUMP, bool MATRIX, bool CODED = false>
-__global__ __launch_bounds__(64 * Geo<DP>::WPB, CODED ? Geo<DP>::WAVES_CODED : (MATRIX ? Geo<DP>::WAVES_MATRIX : Geo<DP>::WAVES))
-void k_rows_queue(SampleArgs a, PlanDev p)
-{
-    using GG = Geo<DP>;
-    constexpr int WPB = GG::WPB;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint32_t total = (uint32_t)p.n_split + (uint32_t)p.n_direct;
-    // the first item of a wave is its own number (7,000 waves drawing from one counter at once are served one after the other,
-    // ~9 ns each: the launch took 177 us that way); later ones come from the counter of this launch's parity, which the
-    // launch before left at zero -- wave 0 zeroes the other one for the launch after
-    uint32_t *const ctr = p.ticket + 16 * (p.ticket_base & 1u);
-    if (blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(p.ticket + 16 * ((p.ticket_base & 1u) ^ 1u), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t n_waves = gridDim.x * WPB;
-    uint32_t t = blockIdx.x * WPB + wave;
-    for (;;) {
-        if (t >= total) break;
-        // the arguments are read again for every item (an index the compiler cannot see through): kept live around the loop they
-        // would cost the kernel its registers
-        int zero = 0;
-        asm volatile("" : "+s"(zero));
-        const SampleArgs &ai = (&a)[zero];
-        const PlanDev &pi = (&p)[zero];
-        int lane_i = lane, wave_i = wave;                  // (and nothing derived from the lane or the wave number either)
-        asm volatile("" : "+v"(lane_i), "+s"(wave_i));
-        process_item<DP, DUMP, MATRIX, CODED>(ai, pi, pi.order[t], lane_i, lds + wave_i * GG::WAVE_LDS);
-        // a look before the draw: once the items have run out the waves leave without touching the counter
-        if ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) + n_waves >= total) break;
-        t = 0;
-        if (lane == 0) t = __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + n_waves;
-        t = __builtin_amdgcn_readfirstlane(t);
-        wave_sync();          // the next item's value table goes where this item's packed factor was
-    }
-}
-#endif
 
 // ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
 // At D <= 16 a row of ten observations costs the wave-per-row kernel ~570 vector and ~340 scalar instructions, nearly all of
@@ -1488,9 +785,6 @@ struct PlanKey {
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
-    int glds;                         // 1: D = 32 with coded values, items of at most BDF_GLDS_MAX_OBS observations: rows gathered straight into LDS
-    int fused4;                       // 1: ... and four jobs per wave (k_rows4) instead of one
-    int64_t fin_min;                  // >= 0: the rows of k_rows in two phases (k_rows_bundle + k_rows_fin) if the launch has at least this many
     int col;                          // > 0: the rows of k_rows go to k_rows_col instead (four rows per wave, column layout), cut into pieces of at most this size
     int col_slots;                    // ... dealt to at most this many waves
     bool operator<(const PlanKey &o) const { return memcmp(this, &o, sizeof(PlanKey)) < 0; }
@@ -1508,16 +802,6 @@ struct Plan {
     int32_t *order_dev = nullptr;
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
-    int32_t *wave_jobs_dev = nullptr; // k_rows4: four item numbers (of [split | direct], -1: none) per wave
-    int32_t n_waves4 = 0;
-    bool glds = false;                // every item has at most BDF_GLDS_MAX_OBS observations and the launch is D = 32 with coded values
-    uint32_t *ticket_dev = nullptr;   // queue-fed launch: the counter and what it stands at when the next launch begins
-    uint32_t ticket_base = 0;
-    bdf_fin_item *fin_dev = nullptr;  // two-phase launch: the rows of k_rows_fin (a multiple of 4), the jobs of k_rows_bundle wave by
-    int64_t n_fin = 0;                // wave, and the slab with a slot per job
-    double *sys_dev = nullptr;
-    Item *segs_dev = nullptr;
-    int32_t *wave_seg_dev = nullptr;
     bdf_col_plan col;                 // the rows of k_rows_col (K1c)
 };
 
@@ -1546,16 +830,14 @@ struct RowRef {
     int64_t cnt[BDF_MAX_TERMS];
 };
 
-int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, bool lr_on, int64_t bundle_waves, Plan &plan)
+int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows, int psz, bool lr_on, Plan &plan)
 {
     const int T = key.T;
     std::vector<Item> direct, split;
     std::vector<SmallItem> small, lr;
     std::vector<SplitRow> srows;
-    static const int decoupled = getenv("BDF_K1_DECOUPLE") ? atoi(getenv("BDF_K1_DECOUPLE")) : 0;
-    // two-phase launch (16 < D <= 32): the rows that neither k_rows_small nor the low-rank sampler takes go to k_rows_bundle +
-    // k_rows_fin when there are at least key.fin_min of them
     auto row_total = [&](const RowRef &rr) { int64_t n = 0; for (int r = 0; r < key.n_terms; r++) n += rr.cnt[r]; return n; };
+    // a row that neither k_rows_small nor the low-rank sampler takes
     auto row_is_k1 = [&](const RowRef &rr) {
         int nz = 0;
         for (int r = 0; r < key.n_terms; r++) nz += rr.cnt[r] > 0;
@@ -1564,16 +846,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         if (nz <= 1 && lr_on && n <= key.lr) return false;
         return true;
     };
-    bool two_phase = false;
-    if (key.fin_min >= 0 && !decoupled) {
-        int64_t n_k1 = 0;
-        for (const RowRef &rr : rows) n_k1 += row_is_k1(rr);
-        two_phase = n_k1 >= std::max<int64_t>(key.fin_min, 1);
-    }
-    std::vector<const RowRef *> brows;
     std::vector<bdf_row_ref> crows;
     for (const RowRef &rr : rows) {
-        if (two_phase && row_is_k1(rr)) { brows.push_back(&rr); continue; }
         if (key.col > 0 && row_is_k1(rr)) { crows.push_back(bdf_row_ref{rr.out, rr.orig, rr.qb[0], rr.cnt[0]}); continue; }
         const int32_t row = rr.out;
         int n_items = 0;
@@ -1587,7 +861,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
             n_items = 0;
             for (int r = 0; r < key.n_terms; r++) n_items += (int)std::min<int64_t>((rr.cnt[r] + Tp - 1) / Tp, MAX_PIECES);
         }
-        if (n_items <= 1 && !decoupled) {
+        if (n_items <= 1) {
             Item it{row, 0, 0, 0, -1, -1, rr.orig};
             for (int r = 0; r < key.n_terms; r++)
                 if (rr.cnt[r] > 0) { it.term = r; it.q_begin = rr.qb[r]; it.count = (int32_t)rr.cnt[r]; }
@@ -1595,12 +869,6 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
             else if (lr_on && it.count <= key.lr) lr.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
             else direct.push_back(it);
         } else {
-            if (n_items == 0) {          // all-split mode, empty row: one empty item so that the row has a slot
-                split.push_back(Item{row, 0, 0, 0, (int32_t)split.size(), (int32_t)srows.size(), rr.orig});
-                srows.push_back(SplitRow{row, (int32_t)split.size() - 1, 1, 0});
-                if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});
-                continue;
-            }
             SplitRow sr{row, (int32_t)split.size(), n_items, 0};
             for (int r = 0; r < key.n_terms; r++) {
                 const int64_t beg = rr.qb[r], n = rr.cnt[r];
@@ -1613,114 +881,20 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
             }
             srows.push_back(sr);
         }
-        if (decoupled) direct.push_back(Item{row, 0, 0, 0, -2, (int32_t)srows.size() - 1, rr.orig});      // the row's finisher
-    }
-    // two-phase launch: jobs (whole rows, pieces of the long ones; one slot of the slab each) dealt to bundle_waves waves so
-    // that every wave has the same number of trips (8 observations) plus a trip's worth per job for its start and its store
-    std::vector<bdf_fin_item> fin;
-    std::vector<Item> segs;
-    std::vector<int32_t> wave_seg;
-    if (two_phase) {
-        auto trips_of = [](int64_t n) { return (n + 7) / 8; };
-        int64_t total = 0;
-        for (const RowRef *rr : brows)
-            for (int r = 0; r < key.n_terms; r++) total += trips_of(rr->cnt[r]) + (rr->cnt[r] > 0);
-        const int64_t nw = std::max<int64_t>(1, std::min<int64_t>(bundle_waves, total));
-        static const double slack = getenv("BDF_K1_BUNDLE_SLACK") ? atof(getenv("BDF_K1_BUNDLE_SLACK")) : 1.0;
-        const int64_t cap = std::max<int64_t>(2, (int64_t)(slack * (double)((total + nw - 1) / nw)));       // trips per job at most
-        struct Job { int64_t trips; int32_t seg; };
-        std::vector<Job> jobs;
-        for (const RowRef *rr : brows) {
-            bdf_fin_item fi{rr->out, rr->orig, (int32_t)segs.size(), 0};
-            for (int r = 0; r < key.n_terms; r++) {
-                const int64_t n = rr->cnt[r];
-                if (n <= 0) continue;
-                const int64_t t = trips_of(n), pieces = (t + cap - 1) / cap;
-                for (int64_t q = 0; q < pieces; q++) {
-                    // equal pieces, cut at multiples of a trip
-                    const int64_t t0 = t * q / pieces, t1 = t * (q + 1) / pieces;
-                    const int64_t b0 = rr->qb[r] + 8 * t0, b1 = rr->qb[r] + std::min<int64_t>(8 * t1, n);
-                    jobs.push_back(Job{t1 - t0, (int32_t)segs.size()});
-                    segs.push_back(Item{rr->out, r, b0, (int32_t)(b1 - b0), (int32_t)segs.size(), -1, rr->orig});
-                    fi._pad++;                   // (the row's number of slots)
-                }
-            }
-            fin.push_back(fi);
-        }
-        for (bdf_fin_item &fi : fin)
-            if (fi._pad == 0) fi.sys = (int32_t)segs.size();          // no observations: the slab's last slot, all zeros
-        // the rows of one finish wave go through as many rounds of slot sums as the longest of them has slots: like with like
-        std::stable_sort(fin.begin(), fin.end(), [](const bdf_fin_item &x, const bdf_fin_item &y) { return x._pad > y._pad; });
-        while (fin.size() % 4) fin.push_back(bdf_fin_item{-1, 0, 0, 0});
-        // longest job first, each to the wave with the least work so far
-        std::stable_sort(jobs.begin(), jobs.end(), [](const Job &x, const Job &y) { return x.trips > y.trips; });
-        std::vector<std::vector<int32_t>> bins((size_t)nw);
-        std::priority_queue<std::pair<int64_t, int64_t>, std::vector<std::pair<int64_t, int64_t>>, std::greater<std::pair<int64_t, int64_t>>> heap;
-        for (int64_t w = 0; w < nw; w++) heap.push({0, w});
-        for (const Job &j : jobs) {
-            auto top = heap.top();
-            heap.pop();
-            bins[(size_t)top.second].push_back(j.seg);
-            heap.push({top.first + j.trips + 1, top.second});
-        }
-        // the slab's slots stay numbered by row (a row's slots are neighbours); the waves' job lists are a permutation
-        std::vector<Item> ordered;
-        wave_seg.push_back(0);
-        for (int64_t w = 0; w < nw; w++) {
-            for (int32_t sg : bins[(size_t)w]) ordered.push_back(segs[(size_t)sg]);
-            wave_seg.push_back((int32_t)ordered.size());
-        }
-        segs.swap(ordered);
     }
     // launch order.  The items are listed longest first (split pieces, then rows by falling observation count); waves
     // that share a SIMD should be at different phases (the gather/MFMA phase of one under the factorisation of another),
     // so neighbours in launch order should differ in length: a fixed stride permutation of the sorted list.
     const int64_t total = (int64_t)split.size() + (int64_t)direct.size();
     std::vector<int32_t> order((size_t)total);
-    if (decoupled) {
-        // producers in list order; the finisher of row r a fixed number of producer launches after r's last producer, so
-        // that it normally finds the row complete and the resident waves are a mix of gathering and factorising ones
-        static const int64_t lag = getenv("BDF_K1_LAG") ? atoll(getenv("BDF_K1_LAG")) : 2048;
-        size_t pos = 0, next_f = 0;
-        const int64_t nP = (int64_t)split.size();
-        for (int64_t i = 0; i < nP; i++) {
-            order[pos++] = (int32_t)i;
-            while (next_f < srows.size() && srows[next_f].slot_begin + srows[next_f].n_slots - 1 + lag <= i)
-                order[pos++] = (int32_t)(nP + (int64_t)next_f++);
-        }
-        while (next_f < srows.size()) order[pos++] = (int32_t)(nP + (int64_t)next_f++);
-    } else {
-        static const int mode = getenv("BDF_K1_ORDER") ? atoi(getenv("BDF_K1_ORDER")) : 1;
+    {
         auto gcd = [](int64_t x, int64_t y) { while (y) { int64_t t = x % y; x = y; y = t; } return x; };
-        auto stride_of = [&](int64_t n) {
-            int64_t st = 1;
-            if (n > 2) {
-                st = (int64_t)(0.6180339887 * (double)n) | 1;
-                while (gcd(st, n) != 1) st += 2;
-            }
-            return st;
-        };
-        // mode 2 (experiment, BDF_K1_ORDER=2): a launch with more waves than the device holds at once starts its last waves
-        // only when slots come free, a third to a half into the launch; make those the LIGHTEST rows -- the `slots` heaviest
-        // items in the stride order, then the rest by falling length.  (Alone: the pair of launches 86.0 -> 83.4 us; inside
-        // the iteration: no change -- the iteration is not paced by the launches' tails.)
-        int64_t head = total;
-        if (mode == 2) {
-            static const int64_t slots_env = getenv("BDF_K1_SLOTS") ? atoll(getenv("BDF_K1_SLOTS")) : 0;
-            int64_t slots = slots_env;
-            if (slots <= 0) {
-                hipDeviceProp_t prop;
-                int dev = 0;
-                BDF_HIP(hipGetDevice(&dev));
-                BDF_HIP(hipGetDeviceProperties(&prop, dev));
-                const int per_simd = key.DP == 64 ? BDF_K1_WAVES64 : (key.DP == 32 ? BDF_K1_WAVES32C : 8);
-                slots = (int64_t)(prop.multiProcessorCount - ctx->reserve_cus) * 4 * per_simd;
-            }
-            if (total > slots && total < 2 * slots) head = slots;
+        int64_t stride = 1;
+        if (total > 2) {
+            stride = (int64_t)(0.6180339887 * (double)total) | 1;
+            while (gcd(stride, total) != 1) stride += 2;
         }
-        const int64_t stride = (mode >= 1) ? stride_of(head) : 1;
-        for (int64_t i = 0; i < head; i++) order[(size_t)i] = (int32_t)((i * stride) % head);
-        for (int64_t i = head; i < total; i++) order[(size_t)i] = (int32_t)i;
+        for (int64_t i = 0; i < total; i++) order[(size_t)i] = (int32_t)((i * stride) % total);
     }
     int rc;
     if (key.col > 0 && (rc = bdf_col_plan_build(ctx, crows, key.col, key.col_slots, plan.col))) return rc;
@@ -1740,59 +914,18 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
         (rc = to_device(srows, &plan.rows_dev)) || (rc = to_device(order, &plan.order_dev)))
         return rc;
-#ifdef BDF_EXP_ACC_ONLY
-    BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>((split.size() + direct.size()) * (size_t)psz * sizeof(double), 8)));
-#else
     BDF_HIP(hipMalloc((void **)&plan.partials_dev, std::max<size_t>(split.size() * (size_t)psz * sizeof(double), 8)));
-#endif
     BDF_HIP(hipMalloc((void **)&plan.arrived_dev, std::max<size_t>(srows.size() * sizeof(int32_t), 8)));
     // on the launch stream: hipMemset runs on the NULL stream and returns before the device has done it, and a kernel on a
     // non-blocking stream does not wait for it -- the first launch of a new plan could have its counters zeroed under it
     // (a split row then never finds its last piece: the row keeps its old content)
     BDF_HIP(hipMemsetAsync(plan.arrived_dev, 0, std::max<size_t>(srows.size() * sizeof(int32_t), 8), ctx->stream));
-    plan.n_fin = (int64_t)fin.size();
-    if (!fin.empty()) {
-        if ((rc = to_device(fin, &plan.fin_dev)) || (rc = to_device(segs, &plan.segs_dev)) || (rc = to_device(wave_seg, &plan.wave_seg_dev))) return rc;
-        BDF_HIP(hipMalloc((void **)&plan.sys_dev, (segs.size() + 1) * (size_t)psz * sizeof(double)));
-        BDF_HIP(hipMemsetAsync(plan.sys_dev + segs.size() * (size_t)psz, 0, (size_t)psz * sizeof(double), ctx->stream));
-        plan.dev.sys = plan.sys_dev;
-        plan.dev.segs = plan.segs_dev;
-        plan.dev.wave_seg = plan.wave_seg_dev;
-        plan.dev.n_bwaves = (int32_t)wave_seg.size() - 1;
-    }
-    BDF_HIP(hipMalloc((void **)&plan.ticket_dev, 128));
-    BDF_HIP(hipMemsetAsync(plan.ticket_dev, 0, 128, ctx->stream));
-    plan.dev.ticket = plan.ticket_dev;
     plan.dev.direct = plan.direct_dev; plan.dev.n_direct = (int32_t)direct.size();
     plan.dev.split = plan.split_dev;   plan.dev.n_split = (int32_t)split.size();
     plan.dev.rows = plan.rows_dev;     plan.dev.n_split_rows = (int32_t)srows.size();
     plan.dev.partials = plan.partials_dev;
     plan.dev.arrived = plan.arrived_dev;
     plan.dev.order = plan.order_dev;
-    plan.dev.decoupled = decoupled;
-    plan.glds = key.glds != 0;
-    // (a row of more than MAX_PIECES x the piece size has longer pieces than the LDS-direct gather's word buffer holds: such a
-    // launch keeps the register pipeline)
-    for (const Item &it : split) plan.glds = plan.glds && it.count <= BDF_GLDS_MAX_OBS;
-    for (const Item &it : direct) plan.glds = plan.glds && it.count <= BDF_GLDS_MAX_OBS;
-    if (key.fused4) {
-        // four jobs per wave: the items by falling length dealt to the waves back and forth, so that every wave's four add up alike
-        bool ok = !decoupled;
-        std::vector<std::pair<int32_t, int32_t>> jobs;              // (observations, item number in [split | direct])
-        for (size_t i = 0; i < split.size(); i++) { jobs.push_back({split[i].count, (int32_t)i}); ok = ok && split[i].count <= BDF_GLDS_MAX_OBS; }
-        for (size_t i = 0; i < direct.size(); i++) { jobs.push_back({direct[i].count, (int32_t)(split.size() + i)}); ok = ok && direct[i].count <= BDF_GLDS_MAX_OBS; }
-        if (ok && !jobs.empty()) {
-            std::stable_sort(jobs.begin(), jobs.end(), [](const std::pair<int32_t, int32_t> &x, const std::pair<int32_t, int32_t> &y) { return x.first > y.first; });
-            const size_t W = (jobs.size() + 3) / 4;
-            std::vector<int32_t> wj(4 * W, -1);
-            for (size_t q = 0; q < jobs.size(); q++) {
-                const size_t g = q / W, r = q % W, wv = (g & 1) ? W - 1 - r : r;
-                wj[4 * wv + g] = jobs[q].second;
-            }
-            if ((rc = to_device(wj, &plan.wave_jobs_dev))) return rc;
-            plan.n_waves4 = (int32_t)W;
-        }
-    }
     return BDF_OK;
 }
 
@@ -1815,71 +948,14 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
     PlanDev p = plan.dev;
     bool matrix, coded;
     launch_kind(a, dump, matrix, coded);
-    if (plan.n_fin > 0 && !dump) {
-        // two phases (16 < D <= 32): equal bundles of jobs accumulate every row's system into the slab, then k_rows_fin
-        // factors, solves and draws four rows per wave.  The caller's start event rides on the first kernel, its stop event
-        // on the second.
-        if constexpr (DP == 32) {
-            if (p.n_bwaves > 0) {
-                const dim3 grid((unsigned)((p.n_bwaves + WPB - 1) / WPB)), block(64 * WPB);
-                auto kern = coded ? k_rows_bundle<DP, true, true> : (matrix ? k_rows_bundle<DP, true, false> : k_rows_bundle<DP, false, false>);
-                hipExtLaunchKernelGGL(kern, grid, block, 0, ctx->stream, ctx->time_start, nullptr, 0, a, p);
-                BDF_HIP(hipGetLastError());
-                ctx->time_start = nullptr;
-            }
-            int rc = bdf_fin_launch(ctx, a, plan.fin_dev, plan.n_fin, plan.sys_dev, ctx->time_start, ctx->time_stop);
-            if (rc) return rc;
-        }
-        ctx->time_start = ctx->time_stop = nullptr;
-        return BDF_OK;
-    }
-    if constexpr (DP == 32) {
-        if (plan.n_waves4 > 0 && coded && !dump) {
-            // four jobs per wave throughout (k_rows4)
-            const dim3 grid((unsigned)plan.n_waves4), block(64);
-            if (a.ready) hipExtLaunchKernelGGL(k_rows4<true>, grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p, (const int32_t *)plan.wave_jobs_dev, plan.n_waves4);
-            else hipExtLaunchKernelGGL(k_rows4<false>, grid, block, 0, ctx->stream, ctx->time_start, ctx->time_stop, 0, a, p, (const int32_t *)plan.wave_jobs_dev, plan.n_waves4);
-            ctx->time_start = ctx->time_stop = nullptr;
-            BDF_HIP(hipGetLastError());
-            return BDF_OK;
-        }
-    }
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
-        dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
-        // BDF_K1_QUEUE=w: exactly w waves per SIMD of the row stream's CUs are launched and pull their items from a counter
-#ifdef BDF_K1_QUEUE_BUILD
-        static const int queue = getenv("BDF_K1_QUEUE") ? atoi(getenv("BDF_K1_QUEUE")) : 0;
-#else
-        constexpr int queue = 0;
-#endif
-        static int cus = 0;
-        if (queue > 0 && !cus) {
-            hipDeviceProp_t prop;
-            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
-            cus = prop.multiProcessorCount;
-        }
-        const int64_t slots_wg = queue > 0 ? (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * queue / WPB : 0;
-        const bool queued = queue > 0 && !dump && !p.decoupled && (int64_t)grid.x > slots_wg;
-        if (queued) {
-            grid.x = (unsigned)slots_wg;
-            p.ticket_base = plan.ticket_base++;          // (its parity picks the counter)
-        }
+        const dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
         auto kern = dump ? (matrix ? k_rows<DP, true, true> : k_rows<DP, true, false>)
                          : (coded ? k_rows<DP, false, true, true> : (matrix ? k_rows<DP, false, true> : k_rows<DP, false, false>));
-        if constexpr (DP == 32) {
-            // D = 32 with coded values and items of at most BDF_GLDS_MAX_OBS observations (the plan was built that way): the
-            // rows gathered straight into LDS
-            if (coded && plan.glds) kern = k_rows<DP, false, true, true, true>;
-        }
         // start / stop events (bdf_ctx_time_next_rows) ride on the dispatch packet itself: the kernel's own begin and end,
         // no marker packets around it
-        static const unsigned lds_pad = getenv("BDF_K1_LDS_PAD") ? (unsigned)atoi(getenv("BDF_K1_LDS_PAD")) : 0u;      // experiment: fewer resident waves
-#ifdef BDF_K1_QUEUE_BUILD
-        if (queued)
-            kern = coded ? k_rows_queue<DP, false, true, true> : (matrix ? k_rows_queue<DP, false, true> : k_rows_queue<DP, false, false>);
-#endif
-        hipExtLaunchKernelGGL(kern, grid, block, lds_pad, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
+        hipExtLaunchKernelGGL(kern, grid, block, 0, ctx->stream, dump ? nullptr : ctx->time_start, dump ? nullptr : ctx->time_stop, 0, a, p);
         if (!dump) ctx->time_start = ctx->time_stop = nullptr;
         BDF_HIP(hipGetLastError());
     }
@@ -1935,12 +1011,6 @@ void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial)
             if (kv->second.lr_dev) (void)hipFree(kv->second.lr_dev);
             if (kv->second.lr_rows_dev) (void)hipFree(kv->second.lr_rows_dev);
             (void)hipFree(kv->second.partials_dev); (void)hipFree(kv->second.arrived_dev); (void)hipFree(kv->second.order_dev);
-            if (kv->second.ticket_dev) (void)hipFree(kv->second.ticket_dev);
-            if (kv->second.wave_jobs_dev) (void)hipFree(kv->second.wave_jobs_dev);
-            if (kv->second.fin_dev) (void)hipFree(kv->second.fin_dev);
-            if (kv->second.sys_dev) (void)hipFree(kv->second.sys_dev);
-            if (kv->second.segs_dev) (void)hipFree(kv->second.segs_dev);
-            if (kv->second.wave_seg_dev) (void)hipFree(kv->second.wave_seg_dev);
             bdf_col_plan_free(kv->second.col);
             kv = plans.erase(kv);
         } else {
@@ -1993,31 +1063,13 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         // hundreds of waves per resident slot has no such tail, and every piece costs a partial sum written to the slab and read
         // back (21 KB at D = 64: the 540,000 pieces of configuration C4's item launch moved 22 GB): larger items there -- about
         // sixteen waves per slot, between the default and 2048 observations (the same for every shard of the launch).
-        static int cus = 0;
-        if (!cus) {
-            hipDeviceProp_t prop;
-            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
-            cus = prop.multiProcessorCount;
-        }
+        // (a NOMINAL slot count -- 256 CUs -- not the device's or the stream's: the cut of a row, and with it the order of its
+        // floating-point sums, must not depend on the CU count or on BDF_RESERVE_CUS)
         int64_t nnz_launch = 0;
         for (int r = 0; r < a.n_terms; r++) nnz_launch += rels[r]->idx[modes[r]].own_nnz;
-        const int64_t slots = (int64_t)std::max(1, cus - ctx->reserve_cus) * 4 * (DP == 64 ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8));
+        const int64_t slots = (int64_t)256 * 4 * (DP == 64 ? BDF_K1_WAVES64 : (DP == 32 ? BDF_K1_WAVES32C : 8));
         const int64_t t = std::min<int64_t>(2048, (nnz_launch / (slots * 16) + 63) / 64 * 64);
         if (t > key.T) { key.T = (int)t; key.Tp = (int)(t * 2 / 3); }
-    }
-    // D = 32, one two-mode relation with coded values, environment BDF_K1_GLDS=1: the rows gathered straight into LDS
-    // (accumulate_glds) -- the item's packed words sit in the wave's LDS too, which caps an item at BDF_GLDS_MAX_OBS observations
-    {
-        bool matrix, coded;
-        launch_kind(a, dump, matrix, coded);
-        static const bool glds_on = getenv("BDF_K1_GLDS") && atoi(getenv("BDF_K1_GLDS")) != 0;      // (opt-in: bit-identical, 3 % faster alone, no gain in the iteration)
-        static const bool fused4_on = getenv("BDF_K1_FUSED4") && atoi(getenv("BDF_K1_FUSED4")) != 0;
-        if (DP == 32 && a.D == 32 && coded && (glds_on || fused4_on) && !getenv("BDF_K1_DECOUPLE") && key.T <= 192) {
-            key.T = std::min(key.T, BDF_GLDS_MAX_OBS);
-            key.Tp = std::min(key.Tp, key.T);
-            if (fused4_on) { key.fused4 = 1; key.Tp = key.T; }
-            else key.glds = 1;
-        }
     }
     // D <= 16, one two-mode relation with the lean gather and no per-observation baseline, an entity of many rows: its short
     // rows four to a wave (k_rows_small).  bdf_ctx_set_small_rows: the longest row taken that way (default 48 observations,
@@ -2028,7 +1080,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         const int64_t small_rows = ctx->small_min_rows;
         const int64_t n_rows_all = rels[0]->sharded ? (int64_t)rels[0]->idx[modes[0]].own_orig.size() : (int64_t)rels[0]->idx[modes[0]].order.size();
         if (DP == 16 && !dump && small_max > 0 && a.n_terms == 1 && a.t[0].lean == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr &&
-            !getenv("BDF_K1_DECOUPLE") && n_rows_all >= small_rows)
+            n_rows_all >= small_rows)
             key.small = std::min(small_max, ctx->item_size);
     }
 
@@ -2036,8 +1088,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     // by the low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
     // the longest such row, -1 = min(15, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
     int64_t M_other = 0;
-    if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr &&
-        !getenv("BDF_K1_DECOUPLE")) {
+    if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr) {
         const int other = 1 - modes[0];
         M_other = rels[0]->nint[other];
         key.lr = std::min(std::min(ctx->lr_max < 0 ? a.D / 2 : ctx->lr_max, bdf_lr_max_observations()), ctx->item_size);
@@ -2045,15 +1096,11 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         key.lr_other = ctx->lr_min_rows > 0 ? rels[0]->dims[other] : 0;          // (min_rows = 0, a test hook: whenever the entity has such a row)
     }
 
-    // 16 < D <= 32: accumulate and finish as two kernels (k_rows_bundle + k_rows_fin, four rows per wave) for launches of
-    // bdf_ctx_set_two_phase's row count or more (environment BDF_K1_TWO_PHASE; negative: never)
-    key.fin_min = (DP == 32 && a.D > 16 && !dump && !getenv("BDF_K1_DECOUPLE")) ? ctx->fin_min_rows : -1;
-
     // 16 < D <= 32, one two-mode relation on the lean gather path without per-observation baselines: the rows four to a wave in
-    // the column layout (K1c, k_rows_col.hip; bdf_ctx_set_col_rows) -- unless the caller chose K1's item size or one of its variants
+    // the column layout (K1c, k_rows_col.hip; bdf_ctx_set_col_rows) -- unless the caller chose K1's item size or its general variant
+    static const bool no_col = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;          // (test hook: k_rows' general variant)
     if (DP == 32 && a.D > 16 && !dump && ctx->col_piece > 0 && (ctx->col_explicit || ctx->item_auto) && a.n_terms == 1 && a.t[0].n_other == 1 &&
-        a.t[0].lean == 1 && a.t[0].linear == nullptr && key.fin_min < 0 && !key.glds && !key.fused4 && !getenv("BDF_K1_DECOUPLE") &&
-        !getenv("BDF_K1_GENERAL_KERNEL")) {
+        a.t[0].lean == 1 && a.t[0].linear == nullptr && !no_col) {
         static int cus = 0;
         if (!cus) {
             hipDeviceProp_t prop;
@@ -2110,15 +1157,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
                 lr_on = cnt >= key.lr_min && 2 * cnt >= key.lr_other;
             }
             Plan np;
-            // two-phase launch: as many bundles as the row stream's CUs hold waves of the accumulate kernel at once
-            int64_t bundle_waves = 0;
-            if (key.fin_min >= 0) {
-                hipDeviceProp_t prop;
-                BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
-                static const int per_simd = getenv("BDF_K1_BUNDLE_WAVES") ? atoi(getenv("BDF_K1_BUNDLE_WAVES")) : BDF_K1_WAVES32SC;
-                bundle_waves = (int64_t)std::max(1, prop.multiProcessorCount - ctx->reserve_cus) * 4 * per_simd;
-            }
-            int rc = build_plan(ctx, key, rows, psz, lr_on, bundle_waves, np);
+            int rc = build_plan(ctx, key, rows, psz, lr_on, np);
             if (rc) return rc;
             it = cache.plans.emplace(key, np).first;
         }
@@ -2160,7 +1199,10 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     }
     if (plan->col.n_waves > 0) {
         const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct > 0;
-        int rc = bdf_col_launch(ctx, a, plan->col, M_other, ctx->time_start, more ? nullptr : ctx->time_stop);
+        static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: ids and values instead of the packed words
+        SampleArgs ac = a;
+        if (no_coded) ac.t[0].packed = nullptr;
+        int rc = bdf_col_launch(ctx, ac, plan->col, M_other, ctx->time_start, more ? nullptr : ctx->time_stop);
         if (rc) return rc;
         ctx->time_start = nullptr;
         if (!more) { ctx->time_stop = nullptr; return BDF_OK; }

@@ -161,11 +161,6 @@ class Context:
         observations (bdf_ctx_set_col_rows; 0: off -- the wave-per-row kernel; -1: the default, 128 unless the caller chose an item size)"""
         check(lib().bdf_ctx_set_col_rows(self.handle, int(max_piece)))
 
-    def set_two_phase(self, min_rows=1024):
-        """16 < D <= 32: row launches of min_rows rows or more as two kernels -- accumulate every row's system, then factor,
-        solve and draw four rows per wave (bdf_ctx_set_two_phase; negative: never)"""
-        check(lib().bdf_ctx_set_two_phase(self.handle, int(min_rows)))
-
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
 

@@ -133,13 +133,6 @@ int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
  * launches whose item size the caller has not set (bdf_ctx_set_item_size keeps the wave-per-row kernel); a call here with
  * 8..4096 applies to every launch of the context, 0 turns it off, -1 restores the default. */
 int bdf_ctx_set_col_rows(bdf_ctx *ctx, int max_piece);
-/* (an experiment, OFF by default -- measured slower than the one-kernel launch)  16 < D <= 32: a row launch of
- * at least min_rows rows (environment BDF_K1_TWO_PHASE; negative, the default: never) runs as TWO
- * kernels -- the accumulation of every row's system (src/sampling.jl:205-207: Lambda_i's data part and its right-hand side) into a
- * slab, then the factorisation, solves and draw (src/sampling.jl:208-211) FOUR ROWS PER WAVE (k_rows_fin.hip: 16 lanes and two
- * columns per lane for each 32 x 32 system).  The same map from the row's normals to the sample as the one-kernel launch (the
- * LDL' factorisation of the same matrix), equal to rounding; the order of the floating-point sums differs. */
-int bdf_ctx_set_two_phase(bdf_ctx *ctx, int64_t min_rows);
 /* parity hook: which gather path the row kernel takes.  0 = chosen by the sizes (default; env BDF_GATHER=general|wide sets the
  * initial value), 1 = the general path (any number of modes, per-observation baselines), 2 = the lean path with 64-bit row
  * offsets (num_latent > 32; what a factor matrix of 4 GiB or more needs, e.g. 10M rows at D = 64).  Same values on every path. */

@@ -190,10 +190,11 @@ def test_whole_iterations_match_oracle(B, O, with_feat, use_ff):
 
 
 @pytest.mark.parametrize("D", [24, 32])
-def test_whole_iterations_two_phase_rows_match_oracle(B, O, monkeypatch, D):
-    """the native iteration with the two-kernel row launch forced (BDF_K1_TWO_PHASE=1: k_rows<SYS> + k_rows_fin, the finish kernel
-    polling for the hyperprior's draw): three whole iterations with entity side information against the oracle"""
-    monkeypatch.setenv("BDF_K1_TWO_PHASE", "1")
+def test_whole_iterations_col_rows_small_pieces_match_oracle(B, O, monkeypatch, D):
+    """the native iteration with K1c's pieces cut small (BDF_K1_COL=8: rows on two and four lane rows, rows that span waves, the
+    kernel polling for the hyperprior's draw, per-row prior means): three whole iterations with entity side information against
+    the oracle"""
+    monkeypatch.setenv("BDF_K1_COL", "8")
     monkeypatch.setenv("BDF_LOWRANK", "0")
     rng = np.random.default_rng(80 + D)
     N1, N2, nnz = 150, 70, 4000

@@ -511,8 +511,9 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
     8-bit value code in one word, the value from a table in LDS, seven resident waves at D <= 32; up to 32 distinct values,
     33 fall back to the plain two-mode variant.  Same arithmetic: the rows equal the uncoded variant's (BDF_K1_NO_CODED, read
     once per process: a child) to the last bit, and the oracle's to tolerance.  Rows of 0 .. 900 observations: whole rows,
-    ragged last trips, split rows.  At D = 32 the coded variant has a second form, the rows gathered straight into LDS
-    (accumulate_glds, BDF_K1_GLDS=1: items of at most 160 observations -- every child runs with that item size): the same bits again."""
+    ragged last trips, split rows.  At 16 < D <= 32 the same pair once more through K1c (k_rows_col.hip, pieces of 48: the packed
+    word and the table in global memory against ids and values): bit-identical to each other, equal to the wave-per-row kernel to
+    rounding."""
     import subprocess, sys, textwrap, tempfile
     code = textwrap.dedent('''
         import ctypes as C, numpy as np, sys
@@ -532,6 +533,7 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
         ctx = B.Context(seed=11)
         ctx.set_item_size(160)
         ctx.set_piece_size(128)
+        ctx.set_col_rows(int(sys.argv[4]))
         dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
         ft = [ctx.tensor(rng.standard_normal((d, D)) * 0.4) for d in dims]
         A = rng.standard_normal((D, D)); Lam = ctx.tensor(A @ A.T / D + np.eye(D)); mu = ctx.tensor(rng.standard_normal(D))
@@ -550,22 +552,21 @@ def test_coded_values_variant_is_bit_identical(B, O, ctx, D, n_values):
                  Lam=Lam.cpu().numpy(), mu=mu.cpu().numpy())
     ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     got = {}
-    for variant in ("coded", "uncoded", "coded_lds") + (("four_per_wave",) if D == 32 else ()):
+    for variant in ("coded", "uncoded") + (("col_coded", "col_uncoded") if 16 < D <= 32 else ()):
         with tempfile.TemporaryDirectory() as td:
             f = os.path.join(td, "o.npz")
             env = dict(os.environ)
             env.pop("BDF_K1_NO_CODED", None); env.pop("BDF_NO_CODES", None)
-            env["BDF_K1_GLDS"] = "1" if variant == "coded_lds" else "0"
-            env["BDF_K1_FUSED4"] = "1" if variant == "four_per_wave" else "0"
-            if variant == "uncoded":
+            if variant.endswith("uncoded"):
                 env["BDF_K1_NO_CODED"] = "1"
-            subprocess.run([sys.executable, "-c", code, f, str(D), str(n_values)], check=True, env=env, timeout=300)
+            subprocess.run([sys.executable, "-c", code, f, str(D), str(n_values), "48" if variant.startswith("col") else "0"], check=True,
+                           env=env, timeout=300)
             got[variant] = dict(np.load(f))
     for k in ("u", "v"):
         assert np.array_equal(got["coded"][k], got["uncoded"][k]), k
-        assert np.array_equal(got["coded"][k], got["coded_lds"][k]), k
-        if "four_per_wave" in got:        # k_rows4: the same LDL' factorisation in another layout -- equal to rounding, not to the last bit
-            np.testing.assert_allclose(got["four_per_wave"][k], got["coded"][k], rtol=1e-9, atol=1e-11)
+        if "col_coded" in got:        # K1c: the same LDL' factorisation in another layout -- equal to rounding, not to the last bit
+            assert np.array_equal(got["col_coded"][k], got["col_uncoded"][k]), k
+            np.testing.assert_allclose(got["col_coded"][k], got["coded"][k], rtol=1e-9, atol=1e-11)
     g = got["coded"]
     dims = [300, 120]
     idx = O.index_build(g["ids"], dims)
@@ -854,89 +855,3 @@ def test_lowrank_row_moments(B, O, ctx, D, n):
     exp1 = O.sample_row_lowrank(D, [ot], 3, mu, Lam, O.lowrank_normals(SEED, 1, 1, 3, D, n))
     np.testing.assert_allclose(draws[3], exp1, rtol=1e-8, atol=1e-9)
     dr.close()
-
-
-@pytest.mark.parametrize("D", [17, 20, 24, 27, 30, 32])
-@pytest.mark.parametrize("coded", [True, False])
-def test_two_phase_rows_against_oracle(B, O, ctx, D, coded):
-    """The two-kernel row launch (16 < D <= 32: k_rows<SYS> leaves every row's system in a slab, k_rows_fin factors, solves and draws
-    FOUR ROWS PER WAVE) against the CPU ORACLE (sample_user_basic, sampling.jl:200-212) on the same normals at 1e-8: rows of 0 / 1 /
-    15 / 16 / 17 / 150 / 700 observations (whole rows and rows cut into pieces: item size 64), a row count that is no multiple of
-    four, ratings (coded ids) and continuous values, shared and per-row prior means, both modes; and against the one-kernel launch
-    (the same LDL' factorisation of the same matrix: equal to rounding)."""
-    rng = np.random.default_rng(900 + D)
-    dims = [203, 90]
-    deg = rng.integers(0, 120, dims[0])
-    deg[:10] = [0, 1, 15, 16, 17, 32, 150, 700, 64, 65]
-    rows = np.repeat(np.arange(1, dims[0] + 1), deg)
-    ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
-    vals = rng.integers(1, 6, len(rows)).astype(np.float64) if coded else rng.random(len(rows)) * 4 + 1
-    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
-    facs = [rng.standard_normal((d, D)) * 0.5 for d in dims]
-    ft = [ctx.tensor(f) for f in facs]
-    A = rng.standard_normal((D, D))
-    Lam = A @ A.T / D + np.eye(D)
-    alpha, mean = 1.7, float(vals.mean())
-    idx = O.index_build(ids, dims)
-    ctx.set_lowrank(0, 0)
-    ctx.set_item_size(64)
-    try:
-        for mode0 in (0, 1):
-            N = dims[mode0]
-            mu = rng.standard_normal(D)
-            mu_rows = rng.standard_normal((N, D))
-            terms = _dev_terms(B, ctx, [(dr, mode0, alpha, mean, [None if k == mode0 else ft[k] for k in (0, 1)], None)])
-            ot = O.Term(ids, vals, dims, mode0, alpha, mean, [None if k == mode0 else facs[k] for k in (0, 1)], index=idx)
-            Lam_t = ctx.tensor(Lam)
-            for per_row in (False, True):
-                m = mu_rows if per_row else mu
-                mu_t = ctx.tensor(m)
-                ctx.set_sweep(6)
-                got = {}
-                for two in (1, -1):
-                    ctx.set_two_phase(two)
-                    out_t = ctx.zeros(N, D)
-                    _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 4, out_t)
-                    got[two] = out_t.cpu().numpy()
-                exp = O.sample_rows(D, N, [ot], m, Lam, SEED, 6, 4)
-                assert np.isfinite(got[1]).all()
-                np.testing.assert_allclose(got[1], exp, rtol=1e-8, atol=1e-9)
-                np.testing.assert_allclose(got[1], got[-1], rtol=1e-10, atol=1e-11)
-                assert ctx.rows_unfinished() == 0
-    finally:
-        ctx.set_two_phase(1024)
-        ctx.set_lowrank(-1, 8192)
-        ctx.set_item_size(0)
-    dr.close()
-
-
-def test_two_phase_tensor_multi_relation_mu_matrix_linear(B, O, ctx):
-    """the general accumulate-only kernel of the two-kernel launch: a 3-mode relation (Hadamard gather, sampling.jl:215-234) and a
-    2-mode relation sharing the entity (sum over relations, :270-283: several items per row, summed through the slab), per-row
-    prior means (macau.jl:104) and linear_values (:273), D = 20, against the oracle"""
-    D = 20
-    rng = np.random.default_rng(55)
-    dimsA, dimsB = [23, 9, 6], [23, 14]
-    idsA, valsA, facsA, Lam, mu = _problem(rng, dimsA, 700, D)
-    idsB, valsB, facsB, _, _ = _problem(rng, dimsB, 300, D)
-    facsB[0] = facsA[0]
-    linB = rng.standard_normal(len(valsB))
-    mu_mat = rng.standard_normal((23, D))
-    drA, drB = B.DeviceRelation(ctx, B.IndexedDF((idsA, valsA), dimsA)), B.DeviceRelation(ctx, B.IndexedDF((idsB, valsB), dimsB))
-    fA = [ctx.tensor(f) for f in facsA]
-    fB = [fA[0], ctx.tensor(facsB[1])]
-    lin_t = ctx.tensor(linB)
-    terms = _dev_terms(B, ctx, [(drA, 0, 2.0, 0.1, [None, fA[1], fA[2]], None), (drB, 0, 0.7, -0.3, [None, fB[1]], lin_t)])
-    Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu_mat)
-    ctx.set_two_phase(1)
-    try:
-        ctx.set_sweep(9)
-        out_t = ctx.zeros(23, D)
-        _run_rows(B, ctx, D, 23, terms, mu_t, Lam_t, 2, out_t)
-        oA = O.Term(idsA, valsA, dimsA, 0, 2.0, 0.1, [None, facsA[1], facsA[2]])
-        oB = O.Term(idsB, valsB, dimsB, 0, 0.7, -0.3, [None, facsB[1]], linear_values=linB)
-        exp = O.sample_rows(D, 23, [oA, oB], mu_mat, Lam, SEED, 9, 2)
-        np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
-    finally:
-        ctx.set_two_phase(1024)
-    drA.close(); drB.close()

@@ -354,13 +354,13 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
             elif name is not None:
                 res[name][m.group(1).split(" ")[0]] = int(m.group(2))
     assert res, "no csrc/*.o.res: build with __graft_entry__.build() (make)"
-    hot = {k: v for k, v in res.items() if re.search(r"6k_rowsILi|k_hyper_sampleILi|k_hyper_partialILi|9k_predictILi|k_spmm_rm|k_dense_", k)}
+    hot = {k: v for k, v in res.items() if re.search(r"6k_rowsILi|10k_rows_colILi|k_hyper_sampleILi|k_hyper_chainILi|k_hyper_partialILi|9k_predictILi|k_spmm_rm|k_dense_", k)}
     assert len(hot) >= 20, sorted(res)
     for k, v in hot.items():
         assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256 and v.get("VGPRs Spill".split(" ")[0], 0) >= 0, (k, v)
     occ = {k: v["Occupancy"] for k, v in hot.items()}
-    k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dELb0EEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values, rows through registers>
-    assert occ[k.replace("ELb0EEEv", "ELb1EEEv") % (32, 1, 1)] >= 7       # ... with the rows gathered straight into LDS (D = 32): the bench's kernel
+    k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dEEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values>
+    assert occ["_ZN12_GLOBAL__N_110k_rows_colILi32ELb1EEEv10SampleArgs10ColPlanDevj"] >= 2       # K1c at D = 32: the bench's kernel
     assert occ[k % (32, 1, 1)] >= 7       # one two-mode relation with coded values (ratings), D <= 32
     assert occ[k % (32, 1, 0)] >= 6       # two-mode variant, D <= 32
     assert occ[k % (32, 0, 0)] >= 5
@@ -483,7 +483,7 @@ def test_no_dpp_read_inside_a_hazard_window():
     spec.loader.exec_module(mod)
     import glob
     files = sorted(glob.glob(os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc", "*.s")))
-    assert {os.path.basename(f) for f in files} >= {"k_sample_rows.s", "k_rows_lr.s", "k_rows_fin.s", "k_hyper.s", "k_block.s"}, "build with __graft_entry__.build() (make)"
+    assert {os.path.basename(f) for f in files} >= {"k_sample_rows.s", "k_rows_lr.s", "k_rows_col.s", "k_hyper.s", "k_block.s"}, "build with __graft_entry__.build() (make)"
     total = 0
     for f in files:
         bad, n = mod.check(f)
