@@ -102,9 +102,12 @@ def _shards_items_map(eng, j, D, rows_checked, mu_is_matrix=False, tol=1e-8):
         ctx.sync()
         return out.cpu().numpy()
 
-    assert np.all(np.isfinite(rows(1)))           # (with the automatic item size)
-    ctx.set_item_size(192)           # (explicit: the comparisons below are between launches of known item sizes)
+    auto = rows(1)                   # (the automatic item size: at 16 < D <= 32 a single two-mode relation takes K1c, k_rows_col.hip)
+    assert np.all(np.isfinite(auto))
+    assert np.array_equal(auto, rows(3)), "union of three shards differs from the unsharded launch (default dispatch)"
+    ctx.set_item_size(192)           # (explicit: the comparisons below are between launches of known item sizes, all through k_rows)
     a = rows(1)
+    np.testing.assert_allclose(auto, a, rtol=tol, atol=tol)
     assert np.array_equal(a, rows(2)), "union of two shards differs from the unsharded launch"
     ctx.set_item_size(64)
     b = rows(1)
@@ -124,7 +127,44 @@ def _shards_items_map(eng, j, D, rows_checked, mu_is_matrix=False, tol=1e-8):
     return a
 
 
+# ---- C2: BPMF MovieLens-1M, D = 32 (BASELINE.json configs[1], the headline) at FULL size against the oracle chain ------
+def test_c2_full_size_whole_iterations_match_oracle(B, O):
+    """The bench's workload itself -- MovieLens-1M, 500,209 training ratings, D = 32, default dispatch (K1c for both entities,
+    hyperprior chains, the native iteration) -- two whole iterations, every one of the 9,992 sampled rows and both (mu, Lambda)
+    against the oracle's chain (src/macau.jl:80-140, sampling.jl:116-127, 200-212) at 1e-6."""
+    from bdf_amd import datasets
+    from bdf_amd.engine import GibbsEngine
+    rd, source = datasets.movielens_relation_data(B, ntest=500_000, seed=1, alpha=1.5, class_cut=2.5)
+    D = 32
+    eng = GibbsEngine(rd, D, seed=11)
+    assert eng.native
+    for i in (1, 2):
+        eng.sweep(i)
+    eng.sync()
+    assert eng.ctx.rows_unfinished() == 0
+    _compare(rd, *oracle_macau(O, rd, D, 11, 2, True), tol=1e-6)
+    eng.close()
+
+
 # ---- C3: Macau MovieLens + dense user side information 6040 x 500, D = 32 ---------------------------------------------
+@pytest.mark.parametrize("use_ff", [True, False])
+def test_c3_full_size_one_iteration_matches_oracle(B, O, use_ff):
+    """C3 at its full size (MovieLens + dense F 6040 x 500 i.i.d., D = 32): one whole native iteration -- uhat, rows with per-row
+    prior means, hyperprior with the feature terms, the beta update by the direct solve / by CG (parallel_cg.jl:63-94), lambda_beta --
+    against the oracle.  beta at 1e-5 (CG columns stop at the reference's own tolerance, eps * numF)."""
+    from bdf_amd import datasets
+    from bdf_amd.engine import GibbsEngine
+    rd, source = datasets.c3_relation_data(B, "iid")
+    D = 32
+    eng = GibbsEngine(rd, D, seed=7, compute_ff_size=6500 if use_ff else 0)
+    assert eng.native and rd.entities[0].use_FF is use_ff
+    eng.sweep(1)
+    eng.sync()
+    eng.sync_host_scalars()          # (lambda_beta back to the Entity: macau() does this at its end)
+    _compare(rd, *oracle_macau(O, rd, D, 7, 1, use_ff), tol=1e-6)
+    eng.close()
+
+
 @pytest.mark.parametrize("use_ff", [True, False])
 def test_c3_reduced_whole_iterations_match_oracle(B, O, use_ff):
     """C3's structure at a size the oracle finishes in seconds: dense features with numF = 96 > 64 (the FF path's blocked
@@ -244,6 +284,64 @@ def test_c4_reduced_whole_iterations_match_oracle(B, O):
         eng.sweep(i)
     eng.sync()
     _compare(rd, *oracle_macau(O, rd, D, 13, 2, True), tol=1e-6)
+    eng.close()
+
+
+def test_c4_dispatch_whole_iterations_match_oracle(B, O):
+    """C4's DEFAULT dispatch end to end at a size the oracle sweeps in seconds: 12,000 users of ~10 observations (more than the 8,192
+    rows from which the low-rank sampler is taken, and more than half the items' count) x 300 items, D = 64, 64-bit gather offsets
+    forced as the full size needs: the users' rows of at most 16 observations through K1-lr (k_rows_lr4<64> + k_rowmat<64> +
+    k_lr_prep<64>), the longer ones and the items through k_rows<64>, inside the native iteration -- two whole iterations against
+    the oracle dispatching the same way (lowrank = {users: 16})."""
+    from bdf_amd import datasets
+    from bdf_amd.engine import GibbsEngine
+    rd = datasets.c4_relation_data(B, 12_000, 300, 120_000, test_fraction=0.0)
+    D = 64
+    cnt = np.bincount(rd.relations[0].data.ids[:, 0] - 1, minlength=12_000)
+    assert (cnt <= 16).sum() >= 10_000 and (cnt > 16).sum() >= 100
+    eng = GibbsEngine(rd, D, seed=13)
+    eng.ctx.set_gather(2)
+    for i in range(1, 3):
+        eng.sweep(i)
+    eng.sync()
+    assert eng.ctx.rows_unfinished() == 0
+    _compare(rd, *oracle_macau(O, rd, D, 13, 2, True, lowrank={0: 16}), tol=1e-6)
+    eng.close()
+
+
+def test_c4_full_size_properties(B):
+    """C4 at its REAL size -- 10M x 1M, 100M observations (1 % held out), D = 64, the default dispatch (K1-lr for 9.7M users,
+    k_rows<64> with 64-bit offsets for the rest and the items): after two sweeps every sampled row is finite, no split row is left
+    unfinished, and for both entities the union of two shards equals the unsharded launch bit for bit.  ~16 GiB of device memory
+    plus two 5 GB outputs: skipped on a device with less than 40 GiB free."""
+    import torch
+    from bdf_amd import datasets
+    from bdf_amd._lib import check, lib
+    from bdf_amd.engine import GibbsEngine
+    free, _ = torch.cuda.mem_get_info()
+    if free < 40 * 2 ** 30:
+        pytest.skip("less than 40 GiB of device memory free")
+    rd = datasets.c4_relation_data(B)
+    D = 64
+    eng = GibbsEngine(rd, D, seed=5)
+    for i in (1, 2):
+        eng.sweep(i)
+    eng.sync()
+    ctx = eng.ctx
+    assert ctx.rows_unfinished() == 0
+    ctx.set_sweep(9)
+    for j in (1, 0):
+        st, terms = eng.ent[j], eng._terms(j)
+        assert bool(torch.isfinite(st.sample).all())
+        full, halves = ctx.zeros(st.N, D), ctx.zeros(st.N, D)
+        check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, _p(st.mu), 0, _p(st.Lambda), st.tag, 0, 1, _p(full), None))
+        for sh in range(2):
+            check(lib().bdf_sample_rows(ctx.handle, D, st.N, 1, terms, _p(st.mu), 0, _p(st.Lambda), st.tag, sh, 2, _p(halves), None))
+        ctx.sync()
+        assert bool(torch.isfinite(full).all())
+        assert torch.equal(full, halves), f"entity {j}: union of two shards differs from the unsharded launch"
+        del full, halves
+    assert ctx.rows_unfinished() == 0
     eng.close()
 
 
