@@ -12,6 +12,7 @@
 //   lambda_beta ~ Gamma                                sample_lambda_beta, src/sampling.jl:136-142
 #include "bdf_common.h"
 #include "wave_linalg.h"
+#include "dpp_rows16.h"
 #include <algorithm>
 #include <cmath>
 
@@ -348,6 +349,68 @@ __global__ __launch_bounds__(256) void k_spmm_rm(int64_t m, int ncol, const int6
     }
 }
 
+// The same product for up to 32 columns taken in pairs (C5: D = 32, 5 M nonzeros; the kernel above ran 149 us per product there,
+// 0.05 of what its bytes cost at the HBM rate -- four 8-byte gathers in flight per lane, one dependent round trip after the
+// other).  SIXTEEN lanes per row, 16 bytes per lane (a 256-byte row of B is one instruction of the lane row), four rows per wave,
+// sixteen rows per workgroup; a row's column indices come sixteen at a time -- lane l of the lane row loads index l of the chunk,
+// one coalesced read -- and are handed round by DPP row broadcasts, and all (up to) sixteen gathers of a chunk are issued before
+// the first is used: 256 bytes x 16 x 4 rows = 16 KB in flight per wave.  Same sums in the same order as k_spmm_rm (entry q of
+// the row after entry q - 1): the two kernels agree to the last bit.
+typedef double spd2 __attribute__((ext_vector_type(2)));
+template <int J>
+__device__ __forceinline__ void spmm_gather16(spd2 (&g)[16], int32_t myi, int left, const double *__restrict__ B, int64_t ldb, int c, bool cv)
+{
+    if constexpr (J < 16) {
+        const int32_t ij = (int32_t)row_bcast_u32<J>((uint32_t)myi);
+        g[J] = (cv && J < left) ? *(const spd2 *)(B + (int64_t)ij * ldb + c) : spd2{0.0, 0.0};
+        spmm_gather16<J + 1>(g, myi, left, B, ldb, c, cv);
+    }
+}
+template <bool HASV, int J>
+__device__ __forceinline__ void spmm_acc16(const spd2 (&g)[16], double myv, int left, double &a0, double &a1)
+{
+    if constexpr (J < 16) {
+        const double w = HASV ? row_bcast_f64<J>(myv) : (J < left ? 1.0 : 0.0);
+        a0 = fma(w, g[J][0], a0);
+        a1 = fma(w, g[J][1], a1);
+        spmm_acc16<HASV, J + 1>(g, myv, left, a0, a1);
+    }
+}
+template <bool HASV>
+__global__ __launch_bounds__(256) void k_spmm_rm16(int64_t m, int ncol, const int64_t *__restrict__ rowptr,
+                                                   const int32_t *__restrict__ colind, const double *__restrict__ vals,
+                                                   const double *__restrict__ B, int64_t ldb, double *__restrict__ Y, int64_t ldy,
+                                                   const double *__restrict__ bias, double *__restrict__ Y2, const int *skip)
+{
+    if (skip && *skip == 0) return;
+    const int l = threadIdx.x & 15;
+    const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+    const bool rv = r < m;                       // (every lane stays: the broadcasts run over whole lane rows)
+    const int64_t beg = rv ? rowptr[r] : 0, end = rv ? rowptr[r + 1] : 0;
+    const int c = 2 * l;
+    const bool cv = c < ncol;
+    double a0 = 0.0, a1 = 0.0;
+    // (the longest row of the wave sets the trip count: wave-uniform, the DPP instructions never sit under a divergent branch)
+    int64_t nq = end - beg;
+    nq = max(nq, __shfl_xor(nq, 16));
+    nq = max(nq, __shfl_xor(nq, 32));
+    nq = __builtin_amdgcn_readfirstlane((int)nq);
+    for (int64_t o = 0; o < nq; o += 16) {
+        const int64_t q = beg + o + l;
+        const int left = (int)min((int64_t)16, end - beg - o);          // entries of this lane row's chunk (<= 0: none)
+        const int32_t myi = q < end ? colind[q] : 0;
+        double myv = 0.0;
+        if (HASV) myv = q < end ? vals[q] : 0.0;
+        spd2 g[16];
+        spmm_gather16<0>(g, myi, left, B, ldb, c, cv);
+        spmm_acc16<HASV, 0>(g, myv, left, a0, a1);
+    }
+    if (rv && cv) {
+        *(spd2 *)(Y + r * ldy + c) = spd2{a0, a1};
+        if (Y2) *(spd2 *)(Y2 + r * ldy + c) = spd2{a0 + bias[c], a1 + bias[c + 1]};
+    }
+}
+
 // out[i*ncol + c] = in[i*irs + c*ics]  (32 x 32 tiles through LDS: coalesced on both sides for a column-major `in`)
 __global__ __launch_bounds__(256) void k_to_rowmajor(int64_t n, int ncol, const double *__restrict__ in, int64_t irs, int64_t ics,
                                                      double *__restrict__ out, const int *skip)
@@ -416,6 +479,16 @@ int spmm(bdf_ctx *ctx, const SpmmArgs &s)
         }
         if (!y_rm) { Y = ty; ldy = s.ncol; }
     }
+    // up to 32 columns in pairs, rows 16-byte aligned: sixteen lanes per row, sixteen gathers of 16 bytes in flight per lane
+    static const bool wide_ok = !(getenv("BDF_SPMM_WIDE") && atoi(getenv("BDF_SPMM_WIDE")) == 0);
+    const bool wide = wide_ok && s.ncol >= 2 && s.ncol <= 32 && s.ncol % 2 == 0 && ldb % 2 == 0 && ldy % 2 == 0 && ((uintptr_t)B & 15) == 0 &&
+                      ((uintptr_t)Y & 15) == 0 && (!(y_rm && s.Y2) || (((uintptr_t)s.Y2 & 15) == 0));
+    if (wide) {
+        if (s.vals) hipLaunchKernelGGL(k_spmm_rm16<true>, dim3((unsigned)((s.m + 15) / 16)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind,
+                                       s.vals, B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
+        else hipLaunchKernelGGL(k_spmm_rm16<false>, dim3((unsigned)((s.m + 15) / 16)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind,
+                                s.vals, B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
+    } else
     hipLaunchKernelGGL(k_spmm_rm, dim3((unsigned)((s.m + 7) / 8)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind, s.vals,
                        B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
     if (!y_rm)
