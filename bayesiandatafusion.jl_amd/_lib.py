@@ -177,6 +177,9 @@ _SIGS = {
     "bdf_comm_unique_id": (C.c_int, [C.c_void_p]),
     "bdf_comm_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_char_p, C.POINTER(C.c_void_p)]),
     "bdf_comm_create_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "bdf_comm_enable_peer": (C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p, C.c_size_t]),
+    "bdf_comm_disable_peer": (C.c_int, [C.c_void_p]),
+    "bdf_comm_peer_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bdf_comm_destroy": (C.c_int, [C.c_void_p]),
     "bdf_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "bdf_allgather_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, C.c_int]),
@@ -191,6 +194,8 @@ _SIGS = {
     "bdf_gibbs_sweep": (C.c_int, [C.c_void_p, C.c_uint32, C.c_int]),
     "bdf_gibbs_current": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int)]),
     "bdf_gibbs_time_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]),
+    "bdf_gibbs_span_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p]),
+    "bdf_ctx_span_next_rows": (C.c_int, [C.c_void_p, C.c_void_p]),
     "bdf_gibbs_sync": (C.c_int, [C.c_void_p]),
     "bdf_gibbs_rows_only": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32]),
     "bdf_gibbs_warm_device": (C.c_int, [C.c_void_p, C.c_double]),

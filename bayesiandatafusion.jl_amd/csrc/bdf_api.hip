@@ -56,6 +56,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->time_start = c->time_stop = nullptr;
     c->time_h_start = c->time_h_stop = nullptr;
     c->sweep_host = 0;
+    c->rows_span = nullptr;
     c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr; c->hyper_ready_value = 0;
     c->warnings = 0;
     c->reserve_cus = 0;
@@ -195,6 +196,16 @@ extern "C" int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t m
                 "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..16");
     ctx->lr_max = max_observations;
     ctx->lr_min_rows = min_rows;
+    return BDF_OK;
+}
+
+// slot (dev, 64 x 2 uint64): every pair set to {~0, 0} by the caller; the next K1c launch of this context leaves {earliest start,
+// latest end} of its waves w = s mod 64 in pair s, in ticks of the 100 MHz clock the XCDs share (s_memrealtime): min / max over the
+// pairs = the launch's duration without events around it
+extern "C" int bdf_ctx_span_next_rows(bdf_ctx *ctx, void *slot_dev)
+{
+    BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_span_next_rows: NULL context");
+    ctx->rows_span = (unsigned long long *)slot_dev;
     return BDF_OK;
 }
 
@@ -718,6 +729,8 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     if (prior_pack && !mu_is_matrix) { a.prior_b = prior_pack; a.prior_c = prior_pack + D; }
     if (ctx->rows_ready && prior_pack && !mu_is_matrix) { a.ready = ctx->rows_ready; a.ready_want = ctx->rows_ready_want; }
     ctx->rows_ready = nullptr;
+    a.span = ctx->rows_span;
+    ctx->rows_span = nullptr;
 #ifdef BDF_K1_SPANS
     {   // diagnostic build only: a ring of 1024 launches x 8192 waves x {start, end, wait} (bdf_debug_spans)
         extern unsigned long long *g_bdf_span_buf;

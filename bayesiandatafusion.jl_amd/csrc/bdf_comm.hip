@@ -7,8 +7,23 @@
 // Transport: RCCL (ncclAllGather over xGMI), resolved with dlopen at the first use so that the library loads on hosts
 // without RCCL; or a host callback (test rigs with several ranks on one GPU, where RCCL refuses to run: the block is staged
 // through host memory and the caller's function -- e.g. a gloo all-gather -- does the exchange).
+//
+// LARGE exchanges -- bdf_comm_enable_peer: DIRECT ALL-PAIRS COPIES.  RCCL's all-gather is a ring: every byte crosses P - 1
+// links one after the other, and a ring uses one of a GPU's seven xGMI links at a time -- configuration C4's 5.12 GB user
+// factor (640 MB per rank on 8 GPUs) takes ~29 ms that way.  MI355X's xGMI is point-to-point, all pairs
+// connected: every rank can PULL its P - 1 missing blocks from their owners at once, one copy per link: 640 MB per link,
+// ~4.2 ms.  The ranks are processes: each exports the allocation its block lives in (hipIpcGetMemHandle), opens its peers'
+// (hipIpcOpenMemHandle, cached per handle), and an exchange is P - 1 concurrent device-to-device copies on P - 1 streams.
+// What orders them is the HOST: a rank's rows are complete (stream synchronised) before it tells its peers so -- the control
+// message, 88 bytes per rank through the caller's host all-gather, doubles as the barrier -- and its copies are complete before
+// it returns, so a rank that has entered exchange k + 1 has finished reading exchange k: an owner may overwrite a block once
+// it has passed the next exchange's barrier, which the rotation of an entity's three sample buffers guarantees by a wide margin.
+// The price is a host round trip per exchange (~0.1 ms): taken for exchanges of peer_min_bytes per rank or more (default
+// 4 MiB: C4's, not MovieLens's); smaller ones stay on the stream-ordered transport above.  UNMEASURED on several GPUs (the
+// pool has one-GPU boxes); exercised by two processes on one GPU (tests/test_gpu_macau.py).
 #include "bdf_common.h"
 #include <dlfcn.h>
+#include <unistd.h>
 
 namespace {
 struct NcclId { char internal[128]; };
@@ -57,7 +72,71 @@ struct bdf_comm {
     hipStream_t stream;              // the exchange runs here
     hipEvent_t ev_rows, ev_done;
     std::vector<char> hsend, hrecv;
+    // direct all-pairs copies for large exchanges (bdf_comm_enable_peer)
+    bdf_exchange_fn peer_cb = nullptr;
+    void *peer_user = nullptr;
+    size_t peer_min_bytes = 0;
+    std::vector<hipStream_t> pstreams;                       // one per peer
+    std::vector<std::pair<std::vector<char>, void *>> opened; // (peer rank byte + handle bytes) -> mapped base
+    int64_t peer_exchanges = 0, peer_bytes = 0;
 };
+
+namespace {
+struct PeerMsg {
+    hipIpcMemHandle_t handle;       // the allocation the block lives in
+    uint64_t offset;                // of the exchanged region's start inside it
+    uint64_t bytes;                 // per rank (checked: every rank exchanges the same amount)
+    uint64_t pid;                   // (a peer in the SAME process -- never in production -- uses the pointer itself)
+    uint64_t region;
+};
+
+// in-place all-gather of `bytes` per rank at region + r * bytes by direct copies from the owners' mappings
+int peer_allgather(bdf_ctx *ctx, bdf_comm *c, char *region, size_t bytes)
+{
+    BDF_HIP(hipStreamSynchronize(ctx->stream));              // my block is complete
+    void *base = nullptr;
+    size_t asize = 0;
+    BDF_HIP(hipMemGetAddressRange((hipDeviceptr_t *)&base, &asize, (hipDeviceptr_t)region));
+    PeerMsg mine;
+    memset(&mine, 0, sizeof(mine));
+    BDF_HIP(hipIpcGetMemHandle(&mine.handle, base));
+    mine.offset = (uint64_t)(region - (char *)base);
+    mine.bytes = (uint64_t)bytes;
+    mine.pid = (uint64_t)getpid();
+    mine.region = (uint64_t)(uintptr_t)region;
+    std::vector<PeerMsg> all((size_t)c->world);
+    int rc = c->peer_cb(c->peer_user, &mine, all.data(), sizeof(PeerMsg));      // control message + barrier
+    BDF_REQUIRE(rc == 0, BDF_ERR_HIP, "bdf_comm (peer copies): the host exchange function returned %d", rc);
+    int k = 0;
+    for (int p = 0; p < c->world; p++) {
+        if (p == c->rank) continue;
+        const PeerMsg &m = all[(size_t)p];
+        BDF_REQUIRE(m.bytes == (uint64_t)bytes, BDF_ERR_ARG, "bdf_comm (peer copies): rank %d exchanges %llu bytes, this rank %llu", p,
+                    (unsigned long long)m.bytes, (unsigned long long)bytes);
+        const char *src = nullptr;
+        if (m.pid == mine.pid) src = (const char *)(uintptr_t)m.region;          // same process: its pointer is valid here
+        else {
+            std::vector<char> key(1 + sizeof(hipIpcMemHandle_t));
+            key[0] = (char)p;
+            memcpy(key.data() + 1, &m.handle, sizeof(hipIpcMemHandle_t));
+            void *pbase = nullptr;
+            for (auto &o : c->opened)
+                if (o.first == key) { pbase = o.second; break; }
+            if (!pbase) {
+                BDF_HIP(hipIpcOpenMemHandle(&pbase, m.handle, hipIpcMemLazyEnablePeerAccess));
+                c->opened.emplace_back(key, pbase);
+            }
+            src = (const char *)pbase + m.offset;
+        }
+        BDF_HIP(hipMemcpyAsync(region + (size_t)p * bytes, src + (size_t)p * bytes, bytes, hipMemcpyDeviceToDevice, c->pstreams[(size_t)k]));
+        k++;
+    }
+    for (int q = 0; q < k; q++) BDF_HIP(hipStreamSynchronize(c->pstreams[(size_t)q]));      // my reads are complete before I enter the next barrier
+    c->peer_exchanges++;
+    c->peer_bytes += (int64_t)bytes * (c->world - 1);
+    return BDF_OK;
+}
+}  // namespace
 
 extern "C" int bdf_comm_unique_id(void *id_out)
 {
@@ -116,12 +195,44 @@ extern "C" int bdf_comm_create_host(bdf_ctx *ctx, int rank, int world, bdf_excha
     return BDF_OK;
 }
 
+// Large exchanges by direct all-pairs copies (the header of this file).  fn: the caller's HOST all-gather (the control
+// messages and the barrier); min_bytes: exchanges of at least this much per rank take it.  Local: no collective here.
+extern "C" int bdf_comm_enable_peer(bdf_comm *c, bdf_exchange_fn fn, void *user, size_t min_bytes)
+{
+    BDF_REQUIRE(c && fn, BDF_ERR_ARG, "bdf_comm_enable_peer: NULL argument");
+    BDF_HIP(hipSetDevice(c->ctx->device));
+    while ((int)c->pstreams.size() < c->world - 1) {
+        hipStream_t st;
+        BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+        c->pstreams.push_back(st);
+    }
+    c->peer_cb = fn; c->peer_user = user; c->peer_min_bytes = min_bytes;
+    return BDF_OK;
+}
+
+extern "C" int bdf_comm_disable_peer(bdf_comm *c)
+{
+    BDF_REQUIRE(c, BDF_ERR_ARG, "bdf_comm_disable_peer: NULL argument");
+    c->peer_cb = nullptr;
+    return BDF_OK;
+}
+
+// exchanges made by direct copies so far, and the bytes this rank pulled
+extern "C" int bdf_comm_peer_stats(const bdf_comm *c, int64_t *exchanges, int64_t *bytes)
+{
+    BDF_REQUIRE(c && exchanges && bytes, BDF_ERR_ARG, "bdf_comm_peer_stats: NULL argument");
+    *exchanges = c->peer_exchanges; *bytes = c->peer_bytes;
+    return BDF_OK;
+}
+
 extern "C" int bdf_comm_destroy(bdf_comm *c)
 {
     if (!c) return BDF_OK;
     (void)hipSetDevice(c->ctx->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     if (c->nccl && g_rccl.destroy) g_rccl.destroy(c->nccl);
+    for (auto &o : c->opened) (void)hipIpcCloseMemHandle(o.second);
+    for (hipStream_t st : c->pstreams) { (void)hipStreamSynchronize(st); (void)hipStreamDestroy(st); }
     if (c->ev_rows) (void)hipEventDestroy(c->ev_rows);
     if (c->ev_done) (void)hipEventDestroy(c->ev_done);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -148,6 +259,7 @@ extern "C" int bdf_allgather_rows(bdf_ctx *ctx, bdf_comm *c, int D, int64_t N, d
     const size_t count = (size_t)cmax * (size_t)D;                         // doubles per rank
     double *region = sample + (size_t)chunk * (size_t)c->world * count;
     if (count == 0 || (c->world == 1 && !c->nccl)) return BDF_OK;
+    if (c->peer_cb && c->world > 1 && count * sizeof(double) >= c->peer_min_bytes) return peer_allgather(ctx, c, (char *)region, count * sizeof(double));
     if (c->nccl) {       // (a one-rank RCCL communicator still goes through ncclAllGather: the call path is exercised on one GPU)
         BDF_HIP(hipEventRecord(c->ev_rows, ctx->stream));
         BDF_HIP(hipStreamWaitEvent(c->stream, c->ev_rows, 0));
@@ -173,6 +285,7 @@ extern "C" int bdf_allgather_block(bdf_ctx *ctx, bdf_comm *c, void *buf, size_t 
     BDF_REQUIRE(ctx && c && buf, BDF_ERR_ARG, "bdf_allgather_block: NULL argument");
     if (bytes == 0 || (c->world == 1 && !c->nccl)) return BDF_OK;
     char *b = (char *)buf;
+    if (c->peer_cb && c->world > 1 && bytes >= c->peer_min_bytes) return peer_allgather(ctx, c, b, bytes);
     if (c->nccl) {
         BDF_HIP(hipEventRecord(c->ev_rows, ctx->stream));
         BDF_HIP(hipStreamWaitEvent(c->stream, c->ev_rows, 0));

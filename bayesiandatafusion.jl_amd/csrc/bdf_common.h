@@ -61,6 +61,7 @@ struct bdf_ctx {
     bool item_auto;            // K1: neither was set by the caller: large launches take larger items (bdf_launch_sample_rows)
     int gather_mode;           // K1 parity hook: 0 auto, 1 general gather path, 2 lean path with 64-bit row offsets (D > 32)
     hipEvent_t time_start, time_stop;      // bdf_ctx_time_next_rows: attached to the next row-kernel dispatch, then cleared
+    unsigned long long *rows_span;         // bdf_ctx_span_next_rows: SampleArgs::span of the next row launch, then cleared
     const uint32_t *rows_ready;            // (library-internal) SampleArgs::ready of the next row launch, then cleared
     uint32_t rows_ready_want;
     uint32_t *hyper_ready;                 // (library-internal) word the next bdf_hyper_sample sets to hyper_ready_value once its pack is written, then cleared
@@ -358,6 +359,9 @@ struct SampleArgs {
     // the non-coherent caches
     const uint32_t *ready;
     uint32_t ready_want, _pad4;
+    // nullable (bdf_ctx_span_next_rows): {start of the launch's first wave, end of its last} in s_memrealtime ticks (the 100 MHz
+    // clock the XCDs share), by one atomic min / max per wave -- a launch's duration without events around it (k_rows_col only)
+    unsigned long long *span;  // (64 shards of {start, end}: wave w uses shard w % 64)
 };
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,

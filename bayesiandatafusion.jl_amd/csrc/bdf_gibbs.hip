@@ -36,6 +36,7 @@ struct bdf_gibbs {
         // repeat or restart (a repeated number would let the poll pass while the draw is still writing the pack)
         uint32_t epoch = 0;
         hipEvent_t t_start = nullptr, t_stop = nullptr;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
+        unsigned long long *span = nullptr;                  // bdf_gibbs_span_rows: SampleArgs::span of the next row launch of this entity
     };
     std::vector<Ent> ent;
     bdf_pairs *test;
@@ -582,6 +583,13 @@ extern "C" int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *
     return BDF_OK;
 }
 
+extern "C" int bdf_gibbs_span_rows(bdf_gibbs *g, int entity, void *slot_dev)
+{
+    BDF_REQUIRE(g && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_span_rows: bad entity");
+    g->ent[(size_t)entity].span = (unsigned long long *)slot_dev;
+    return BDF_OK;
+}
+
 extern "C" int bdf_gibbs_current(const bdf_gibbs *g, int entity, int *buffer)
 {
     BDF_REQUIRE(g && buffer && entity >= 0 && entity < (int)g->ent.size(), BDF_ERR_ARG, "bdf_gibbs_current: bad argument");
@@ -679,6 +687,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         const int nch = e.terms[0].rel->chunks;                    // 1 unless the relations were created with a layout
         for (int c = 0; c < nch; c++) {
             R->time_start = (c == 0) ? E.t_start : nullptr;
+            R->rows_span = E.span;
             R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
             if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.epoch; }
             if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
@@ -691,6 +700,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             BDF_HIP(hipEventRecord(done, R->stream));
         }
         E.t_start = E.t_stop = nullptr;
+        E.span = nullptr;
         E.cur = nxt;
         BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
         static const bool fuse_sums = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);

@@ -622,6 +622,7 @@ class GibbsEngine:
         self._test_pairs = None
         self._train_pairs = None
         self._test_opts = None
+        self.k1_spans = None      # bench.py: (tensor n x 2 of uint64 ticks as int64, [entity per used slot]) -- device-side launch spans (k1_span_begin)
         self.k1_events = None     # bench.py: list of (entity, KernelTimer) of the timed K1 launches
         self.k1_event_every = 1   # ... of every n-th sweep
         self._k1_sweep = 0
@@ -914,9 +915,38 @@ class GibbsEngine:
             check(lib().bdf_gibbs_set_test(self.gibbs, test.handle, eom, r.model.mean_value, lo, hi, class_cut, _ptr(test.stats)))
             self._test_opts = opts
 
+    def k1_span_begin(self, n):
+        """the next n row launches of the native iteration leave {first wave's start, last wave's end} (100 MHz ticks) in a device
+        buffer (bdf_gibbs_span_rows: K1c launches only) -- their durations with no event packets around them"""
+        t = torch.zeros(n, 64, 2, dtype=torch.int64, device=self.ctx.device)      # (64 shards per launch: wave w uses shard w % 64)
+        t[:, :, 0] = -1                    # (uint64 all ones: the kernel takes an atomic min)
+        torch.cuda.synchronize(self.ctx.device)
+        self.k1_spans = (t, [])
+
+    def k1_span_result(self):
+        """-> [(entity, microseconds)] of the launches that recorded a span"""
+        if self.k1_spans is None:
+            return []
+        self.sync()
+        t, ents = self.k1_spans
+        self.k1_spans = None
+        h = t.cpu().numpy().view(np.uint64)
+        out = []
+        for k, j in enumerate(ents):
+            used = h[k, :, 1] > 0
+            if used.any():
+                out.append((j, (int(h[k, used, 1].max()) - int(h[k, used, 0].min())) / 100.0))
+        return out
+
     def sweep(self, i, predict_phase=None):
         """iteration i without reporting (native: with the prediction update of `predict_phase` on the registered test pairs)"""
         self._k1_sweep = i
+        if self.native and self.k1_spans is not None:
+            t, ents = self.k1_spans
+            for j in range(len(self.ent)):
+                if len(ents) < t.shape[0]:
+                    check(lib().bdf_gibbs_span_rows(self.gibbs, j, C.c_void_p(t[len(ents)].data_ptr())))
+                    ents.append(j)
         if self.native:
             timed = self.k1_events is not None and i % self.k1_event_every == 0
             if timed:
@@ -1132,8 +1162,49 @@ class Comm:
         else:
             self.transport = "host transport with a gloo all-gather behind it (test rig: several ranks on one GPU)"
             self._host_transport(ctx, rank, world, on_device=False)
+        self._enable_peer(ctx, rank, world, on_device=dist.get_backend() == "nccl")
 
-    def _host_transport(self, ctx, rank, world, on_device):
+    def _enable_peer(self, ctx, rank, world, on_device):
+        """large exchanges (>= BDF_COMM_PEER_MIN_BYTES per rank, default 4 MiB) by direct all-pairs copies over IPC mappings
+        (bdf_comm_enable_peer) -- after a collective self-test: every rank pulls a small block from every other one and checks it;
+        if any rank fails (no peer access, IPC refused) all of them stay on the communicator's own transport.  BDF_COMM_PEER=0: off."""
+        import torch.distributed as dist
+        self.peer_min_bytes = None
+        if world <= 1 or os.environ.get("BDF_COMM_PEER", "1") == "0":
+            return
+        self._peer_cb = _lib.EXCHANGE_FN(self._make_exchange(ctx, world, on_device))
+        min_bytes = int(os.environ.get("BDF_COMM_PEER_MIN_BYTES", str(4 << 20)))
+        err = ""
+        try:
+            check(lib().bdf_comm_enable_peer(self.handle, self._peer_cb, None, 0))
+            probe = torch.full((world, 64), -1.0, dtype=torch.float64, device=ctx.device)
+            probe[rank] = float(rank + 1)
+            torch.cuda.synchronize(ctx.device)
+            check(lib().bdf_allgather_block(ctx.handle, self.handle, C.c_void_p(probe.data_ptr()), 64 * 8))
+            torch.cuda.synchronize(ctx.device)
+            want = torch.arange(1, world + 1, dtype=torch.float64, device=ctx.device)[:, None].expand(world, 64)
+            if not torch.equal(probe, want):
+                err = "the self-test's blocks did not arrive"
+        except Exception as e:          # noqa: BLE001 -- agreed on below
+            err = f"{type(e).__name__}: {e}"
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=ctx.device if on_device else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0:
+            lib().bdf_comm_disable_peer(self.handle)
+            if err:
+                print(f"[bdf] rank {rank}: direct peer copies are off ({err})", file=sys.stderr, flush=True)
+            return
+        check(lib().bdf_comm_enable_peer(self.handle, self._peer_cb, None, min_bytes))
+        self.peer_min_bytes = min_bytes
+        self.transport += (f"; exchanges of >= {min_bytes} bytes per rank by direct all-pairs peer copies over IPC mappings "
+                           f"(bdf_comm_enable_peer: one copy per xGMI link at once instead of the ring)")
+
+    def peer_stats(self):
+        n, b = C.c_int64(0), C.c_int64(0)
+        check(lib().bdf_comm_peer_stats(self.handle, C.byref(n), C.byref(b)))
+        return n.value, b.value
+
+    def _make_exchange(self, ctx, world, on_device):
         import torch.distributed as dist
 
         def exchange(user, send, recv, nbytes):
@@ -1149,7 +1220,10 @@ class Comm:
                 return 0
             except Exception:        # noqa: BLE001 -- reported through the library's error code
                 return 1
-        self._cb = _lib.EXCHANGE_FN(exchange)
+        return exchange
+
+    def _host_transport(self, ctx, rank, world, on_device):
+        self._cb = _lib.EXCHANGE_FN(self._make_exchange(ctx, world, on_device))
         check(lib().bdf_comm_create_host(ctx.handle, rank, world, self._cb, None, C.byref(self.handle)))
 
     def close(self):

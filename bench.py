@@ -188,7 +188,9 @@ def c3_block(B, datasets, D, device, sweeps=20):
         eng.sync()
         dt = (time.perf_counter() - t0) / sweeps
         it = eng.ent[0].cg_iters.cpu().numpy()
+        b3 = sum(eng.k1_algorithmic_bytes(j) for j in range(len(eng.ent))) + (2 * int(it.max()) + 3) * 6040 * 500 * 8
         out[key] = {"ms_per_sweep": round(1e3 * dt, 4), "sweeps_per_s": round(1.0 / dt, 1), "native_iteration": bool(eng.native),
+                    "roofline": config_roofline("c3_" + key, b3, 1e3 * dt),
                     "solver": "direct: F'F = Q diag(s) Q' once, beta = Q ((Q' rhs) ./ (s + lambda)) per iteration" if ff_size else "conjugate gradients (compute_ff_size=0)",
                     "cg_iterations_last_sweep": [int(it.min()), int(it.max())]}
         eng.close()
@@ -223,6 +225,7 @@ def mref_block(B, device, cpu):
         bytes_sweep = sum(eng.k1_algorithmic_bytes(j) for j in (0, 1))
         blk = {"ms_per_sweep": round(1e3 * dt, 3), "sweeps_per_s": round(1.0 / dt, 2), "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
                "algorithmic_tb_per_s": round(bytes_sweep / dt / 1e12, 3),
+               "roofline": config_roofline(f"mref_d{D}", bytes_sweep, 1e3 * dt),
                # rows drawn by the low-rank sampler (same conditional distribution as the reference's map, other values: DESIGN 4)
                "lowrank_rows": [eng.lowrank_rows(j) for j in (0, 1)]}
         train_ids, train_vals = np.asarray(rel.data.ids), np.asarray(rel.data.values, dtype=np.float64)
@@ -290,7 +293,9 @@ def pin_to_quiet_core(share, shares):
         return None, None
 
 
-TRAFFIC_JSON = "profiles/r04_hbm_traffic.json"
+TRAFFIC_JSON = "profiles/r05_hbm_traffic.json"
+PMC_JSON = "profiles/r05_pmc_k_rows.json"
+CONFIG_KERNELS_JSON = "profiles/r05_config_kernels.json"
 
 
 def k1_source_sha1():
@@ -298,7 +303,7 @@ def k1_source_sha1():
     wave_linalg.h, c_layout_chol.h, include/bdf.h, ...): the identity of the code the PMC passes profiled"""
     import re
     csrc = os.path.join(ROOT, "bayesiandatafusion.jl_amd", "csrc")
-    seen, todo = {}, [os.path.join(csrc, "k_sample_rows.hip")]
+    seen, todo = {}, [os.path.join(csrc, "k_sample_rows.hip"), os.path.join(csrc, "k_rows_col.hip")]
     while todo:
         f = os.path.normpath(todo.pop())
         if f in seen:
@@ -328,6 +333,41 @@ def recorded_traffic():
         return d["k1_traffic_bytes_per_launch"]["hbm_bytes_fetch_doubled"], TRAFFIC_JSON + " (rocprofv3 --pmc passes of this workload on this kernel source; not measured by this run)"
     except (OSError, KeyError, ValueError):
         return None, None
+
+
+def recorded_pipe(launch_us):
+    """FP64-pipe occupancy of the headline row kernel from the committed counter passes (tools/profile_round_r05.sh; NOT measured by
+    this run, returned only for the kernel source they ran on): SQ_ACTIVE_INST_VALU (quad-cycles summed over the SIMDs) and
+    SQ_VALU_MFMA_BUSY_CYCLES per launch, over 1,024 SIMDs x the launch's cycles at 2.4 GHz."""
+    try:
+        d = json.load(open(os.path.join(ROOT, PMC_JSON)))
+        if d.get("k1_source_sha1") != k1_source_sha1():
+            return None
+        k = next(v for kk, v in d["kernels"].items() if "k_rows_col" in kk)
+        valu = 4.0 * k["SQ_ACTIVE_INST_VALU"]["mean"]
+        mfma = k.get("SQ_VALU_MFMA_BUSY_CYCLES", {"mean": 0.0})["mean"]
+        cyc = launch_us * 1e-6 * 2.4e9 * 1024
+        return {"valu_busy_cycles_per_launch": round(valu), "mfma_busy_cycles_per_launch": round(mfma),
+                "valu_instructions_per_launch": round(k["SQ_INSTS_VALU"]["mean"]) if "SQ_INSTS_VALU" in k else None,
+                "frac": round((valu + mfma) / cyc, 3), "of": "1,024 SIMDs x launch duration x 2.4 GHz", "source": PMC_JSON + " (not measured by this run)"}
+    except (OSError, KeyError, ValueError, StopIteration):
+        return None
+
+
+def config_roofline(name, bytes_sweep, ms_per_sweep, extra=None):
+    """`roofline` of one of the other configurations: algorithmic bytes of the row launches per sweep over the measured
+    sweep, against the HBM peak; the dominant kernel and its rocprofv3 average from the committed profile of that configuration
+    (profiles/r05_config_kernels.json, written by tools/profile_round_r05.sh: not measured by this run)"""
+    r = {"bound": "hbm", "achieved": round(bytes_sweep / 1e9 / (ms_per_sweep / 1e3), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(bytes_sweep / 1e9 / (ms_per_sweep / 1e3) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sweep": int(bytes_sweep),
+         "traffic": None}
+    try:
+        r["dominant_kernel"] = dict(json.load(open(os.path.join(ROOT, CONFIG_KERNELS_JSON)))[name], source=CONFIG_KERNELS_JSON + " (not measured by this run)")
+    except (OSError, KeyError, ValueError):
+        r["dominant_kernel"] = None
+    if extra:
+        r.update(extra)
+    return r
 
 
 def main():
@@ -496,17 +536,30 @@ def main():
     rmse = float(np.sqrt(float(sse.item()) / n_test_total))
 
     # K1 roofline: the launches timed inside the timed region, then further sweeps (every launch timed) up to the minimum
+    # (i) device-side spans: first wave's start to last wave's end of every row launch (s_memrealtime, K1c only), no event packets
+    it = args.warmup + args.steps
+    span_us = []
+    if eng.native and args.k1_min_launches > 0:
+        eng.k1_span_begin(args.k1_min_launches)
+        for _ in range((args.k1_min_launches + len(eng.ent) - 1) // len(eng.ent)):
+            it += 1
+            eng.sweep(it, 2)
+        span_us = eng.k1_span_result()
+    # (ii) HIP events on the kernels' dispatch packets (every K1 variant; the events themselves lengthen the launch)
     eng.k1_events = []
     eng.k1_event_every = 1
-    it = args.warmup + args.steps
-    while len(eng.k1_events) < args.k1_min_launches and it < args.warmup + args.steps + 2000:
+    t_ev = time.perf_counter()
+    it_ev0 = it
+    while len(eng.k1_events) < args.k1_min_launches and it < it_ev0 + 2000:
         it += 1
         eng.sweep(it, 2)
     eng.sync()
     k1_ms = sum(t.elapsed_us() for (_, t) in eng.k1_events) / 1e3
     k1_bytes = sum(eng.k1_algorithmic_bytes(j) for (j, _) in eng.k1_events) / max(world, 1)
     n_launch = max(len(eng.k1_events), 1)
-    achieved = (k1_bytes / 1e9) / (k1_ms / 1e3) if k1_ms > 0 else 0.0
+    launch_us_events = 1e3 * k1_ms / n_launch
+    launch_us = (sum(u for _, u in span_us) / len(span_us)) if span_us else launch_us_events
+    achieved = (k1_bytes / n_launch / 1e9) / (launch_us / 1e6) if launch_us > 0 else 0.0
     eng.k1_events = None
     traffic, traffic_source = recorded_traffic() if (world == 1 and replicas == 1 and D == 32) else (None, None)
     # the same kernel with nothing beside it: back-to-back launches alternating the entities on the row stream, wall clock (one
@@ -567,8 +620,14 @@ def main():
             "value_without_device_warmup": None if value_cold is None else round(value_cold, 3),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel": "k_rows (k_sample_rows.hip)", "launches_timed": n_launch,
-                         "avg_launch_us": round(1e3 * k1_ms / n_launch, 2),
+                         "kernel": "k_rows_col (k_rows_col.hip: K1c) when D in 17..32, else k_rows (k_sample_rows.hip)", "launches_timed": n_launch,
+                         # avg_launch_us: first wave's start to last wave's end of the launch, stamped BY THE KERNEL (s_memrealtime, one
+                         # atomic min / max per wave: bdf_gibbs_span_rows) on sweeps after the timed region -- what rocprofv3 reports as
+                         # the kernel's duration, with no event packets around the dispatch; by_events: HIP events riding on the dispatch
+                         # packets (what rounds 1-4 quoted: the events lengthen the launch by a few us)
+                         "avg_launch_us": round(launch_us, 2), "avg_launch_us_timer": "in-kernel s_memrealtime span" if span_us else "HIP events",
+                         "launches_spanned": len(span_us), "avg_launch_us_by_events": round(launch_us_events, 2),
+                         "fp64_pipe": recorded_pipe(launch_us),
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch),
                          "avg_launch_us_alone": None if alone_us is None else round(alone_us, 2),
                          "frac_alone": None if alone_us is None else round((k1_bytes / n_launch / 1e9) / (alone_us / 1e6) / HBM_PEAK_GBS, 4)},
@@ -609,8 +668,13 @@ def main():
             if dist is not None:
                 dist.all_reduce(sse4)
             bytes_sweep = sum(eng4.k1_algorithmic_bytes(j) for j in range(2))
+            rmse4 = float(np.sqrt(float(sse4.item()) / max(n4, 1)))
+            mp4 = float(np.sqrt(np.mean((np.asarray(rel4.test_vec.values) - rel4.model.mean_value) ** 2)))
             c4.update({"sweeps_per_s": round(args.c4_sweeps / el4, 3), "ms_per_sweep": round(1e3 * el4 / args.c4_sweeps, 3),
-                       "test_rmse": round(float(np.sqrt(float(sse4.item()) / max(n4, 1))), 5),
+                       "roofline": config_roofline("c4", bytes_sweep, 1e3 * el4 / args.c4_sweeps),
+                       "test_rmse": round(rmse4, 5),
+                       # (a chain this short has not left its start: above the mean predictor the figure says nothing about the model)
+                       "test_rmse_above_mean_predictor": bool(rmse4 > mp4),
                        # what the held-out RMSE is to be read against: the spread of the held-out values = the RMSE of predicting
                        # their mean, and the generator's noise floor sqrt(0.5^2 + 1/12) (rounded N(., 0.5)); after only
                        # c4-sweeps + c4-sweeps sweeps the chain is still near the first (profiles/r04_c4_quality.json: the same
@@ -621,6 +685,8 @@ def main():
                        "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
                        "algorithmic_tb_per_s": round(bytes_sweep / (el4 / args.c4_sweeps) / 1e12, 3),
                        "lowrank_rows": [eng4.lowrank_rows(j) for j in range(2)],
+                       "exchange": None if eng4.comm is None else dict(zip(("peer_exchanges", "peer_bytes_pulled_per_rank"), eng4.comm.peer_stats()),
+                                                                      transport=eng4.comm.transport),
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
             eng4.close()
@@ -661,7 +727,21 @@ def main():
             if dist is not None:
                 dist.all_reduce(sse5)
             it5 = eng5.ent[0].cg_iters.cpu().numpy()
-            c5.update({"sweeps_per_s": round(args.c5_sweeps / el5, 2), "ms_per_sweep": round(1e3 * el5 / args.c5_sweeps, 3),
+            bytes5 = sum(eng5.k1_algorithmic_bytes(j) for j in range(len(eng5.ent)))
+            # the beta update's sparse products: 2 per CG iteration (F p, F' t) + 3 (right-hand side, uhat, ...): gathered bytes =
+            # nonzeros x 8 D per product; HBM-minimal = indices + the two dense operands once
+            nnzF, nA5, nF5 = z5["nA"] * z5["feat_per_row"], z5["nA"], z5["n_feat"]
+            n_prod = 2 * int(it5.max()) + 3
+            gathered = n_prod * nnzF * 8 * 32
+            minimal = n_prod * (nnzF * 4 + (nA5 + nF5) * 8 * 32)
+            ms5 = 1e3 * el5 / args.c5_sweeps
+            c5.update({"sweeps_per_s": round(args.c5_sweeps / el5, 2), "ms_per_sweep": round(ms5, 3),
+                       "roofline": config_roofline("c5", bytes5 + minimal, ms5, {
+                           "sparse_products_per_sweep": n_prod, "gathered_bytes_per_product": nnzF * 8 * 32,
+                           "hbm_minimal_bytes_per_product": nnzF * 4 + (nA5 + nF5) * 8 * 32,
+                           "note": "the sweep is its sparse products (k_spmm_rm16): gathered rows of a 12.8 / 25.6 MB dense operand come from the "
+                                   "Infinity Cache (a 4 MiB XCD L2 holds a third / a sixth of it), whose gather rate (8.6 TB/s, MI355X_MICROARCH.md) "
+                                   "is the bound the product runs at; `achieved` prices the HBM-minimal bytes"}),
                        "test_rmse": round(float(np.sqrt(float(sse5.item()) / max(n5, 1))), 5), "value_std": round(info5["value_std"], 4),
                        "noise": info5["noise"], "native_iteration": bool(eng5.native),
                        "cg_iterations_last_sweep": [int(it5.min()), int(it5.max())], "beta_columns_per_rank": -(-32 // world)})

@@ -133,6 +133,12 @@ int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
  * launches whose item size the caller has not set (bdf_ctx_set_item_size keeps the wave-per-row kernel); a call here with
  * 8..4096 applies to every launch of the context, 0 turns it off, -1 restores the default. */
 int bdf_ctx_set_col_rows(bdf_ctx *ctx, int max_piece);
+/* measurement: slot (dev, 64 pairs of uint64, each set to {~0, 0} by the caller) receives per pair s {earliest start, latest end}
+ * of the waves w = s mod 64 of the NEXT K1c launch of the context, in ticks of the 100 MHz clock the XCDs share (s_memrealtime; one
+ * atomic min / max per wave, sharded: one word would serialise two thousand waves): min / max over the pairs = the launch's
+ * duration with no event packets around it.  bdf_gibbs_span_rows: the same for the next launch of an entity inside
+ * bdf_gibbs_sweep. */
+int bdf_ctx_span_next_rows(bdf_ctx *ctx, void *slot_dev);
 /* parity hook: which gather path the row kernel takes.  0 = chosen by the sizes (default; env BDF_GATHER=general|wide sets the
  * initial value), 1 = the general path (any number of modes, per-observation baselines), 2 = the lean path with 64-bit row
  * offsets (num_latent > 32; what a factor matrix of 4 GiB or more needs, e.g. 10M rows at D = 64).  Same values on every path. */
@@ -378,6 +384,18 @@ typedef int (*bdf_exchange_fn)(void *user, const void *send, void *recv, size_t 
 int bdf_comm_create_host(bdf_ctx *ctx, int rank, int world, bdf_exchange_fn fn, void *user, bdf_comm **out);
 int bdf_comm_destroy(bdf_comm *comm);
 int bdf_comm_size(const bdf_comm *comm, int *rank, int *world);
+/* LARGE exchanges by DIRECT ALL-PAIRS COPIES over the point-to-point xGMI links instead of RCCL's ring -- the GPU-side answer to
+ * the reference shipping the whole sample matrix to every worker (src/sampling.jl:155-171): every rank exports the allocation its
+ * block lives in (hipIpcGetMemHandle), opens its peers', and an exchange of bytes_per_rank >= min_bytes is world - 1 concurrent
+ * device-to-device copies, one per link, pulled from the owners' mappings (configuration C4 on 8 GPUs: 640 MB per link per users'
+ * half-sweep, ~4.2 ms, where a ring moves 7 x 640 MB through one link after the other).  `fn` is the host's all-gather (as for
+ * bdf_comm_create_host): it carries the 88-byte control message per rank and is the barrier that orders the copies; such an
+ * exchange is synchronous for the host (~0.1 ms), which is why small exchanges keep the communicator's own transport.  Added to a
+ * communicator of either kind; bdf_comm_disable_peer takes it off again (collectively: every rank or none).  Exchanges made this
+ * way and the bytes this rank pulled: bdf_comm_peer_stats.  Unmeasured on several GPUs; tested with two processes on one. */
+int bdf_comm_enable_peer(bdf_comm *comm, bdf_exchange_fn fn, void *user, size_t min_bytes);
+int bdf_comm_disable_peer(bdf_comm *comm);
+int bdf_comm_peer_stats(const bdf_comm *comm, int64_t *exchanges, int64_t *bytes_pulled);
 /* Exchange of chunk `chunk` of the N x D factor matrix `sample` (dev; N = chunks * world * cmax rows, the layout above): an
  * in-place all-gather of the ranks' blocks (ncclAllGather), ordered after the work enqueued so far on ctx's stream, run on
  * the communicator's own stream -- the row kernel of the next chunk runs beside it.  bdf_allgather_join: ctx's stream waits
@@ -489,6 +507,7 @@ int bdf_gibbs_recorded(const bdf_gibbs *g, int entity, int *hyper, int *beta);
 int bdf_gibbs_set_recorded(bdf_gibbs *g, int entity, int hyper, int beta);
 /* measurement: (start, stop) events ride on the dispatch of entity's next row kernel (bdf_ctx_time_next_rows) */
 int bdf_gibbs_time_rows(bdf_gibbs *g, int entity, void *start, void *stop);
+int bdf_gibbs_span_rows(bdf_gibbs *g, int entity, void *slot_dev);      /* bdf_ctx_span_next_rows for the next row launch of `entity` */
 int bdf_gibbs_sync(bdf_gibbs *g);     /* waits for the three streams; errors as bdf_ctx_sync */
 
 /* ---- synthetic sparse relation of configuration C4 (host-only, needs no GPU) ---------------------------------------

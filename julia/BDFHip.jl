@@ -330,6 +330,17 @@ function set_comm!(g::Gibbs, m::Comm)
     g.comm = m                        # the native object keeps the pointer: keep the communicator alive with it
     nothing
 end
+"""large exchanges by direct all-pairs copies over IPC mappings (bdf_comm_enable_peer).  `fn`: a `@cfunction` pointer to the host's
+all-gather, `(user::Ptr{Cvoid}, send::Ptr{Cvoid}, recv::Ptr{Cvoid}, bytes::Csize_t) -> Cint` (e.g. a remotecall round over the
+workers): it carries the control messages and orders the copies"""
+enable_peer!(m::Comm, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL, min_bytes::Integer=4 << 20) =
+    check(ccall((:bdf_comm_enable_peer, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), m.h, fn, user, min_bytes))
+disable_peer!(m::Comm) = check(ccall((:bdf_comm_disable_peer, lib), Cint, (Ptr{Cvoid},), m.h))
+function peer_stats(m::Comm)
+    n = Ref{Int64}(0); b = Ref{Int64}(0)
+    check(ccall((:bdf_comm_peer_stats, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), m.h, n, b))
+    return n[], b[]
+end
 "in-place exchange of chunk `chunk` (0-based) of the D x N sample matrix between the ranks, then `allgather_join!` (bdf_allgather_rows / _join)"
 allgather_rows!(c::Context, m::Comm, D, N, sample::DevArray, chunk::Integer, chunks::Integer) =
     check(ccall((:bdf_allgather_rows, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Int64, Ptr{Cvoid}, Cint, Cint), c.h, m.h, D, N, sample.p, chunk, chunks))

@@ -516,7 +516,9 @@ def test_two_ranks_match_one(B):
     """bench.py's N > 1 path (rows shared out by bdf_layout_build, every rank holding its rows' observations only, in-place
     exchange of the sampled rows inside bdf_gibbs_sweep, test ratings split over the ranks, RMSE all-reduced) gives the chain
     of the single-process run of the same workload.  Two ranks on the one GPU of the box: RCCL needs a GPU per rank, so the
-    exchange goes through the library's host transport with a gloo all-gather behind it (BDF_DIST_BACKEND=gloo)."""
+    small exchanges go through the library's host transport with a gloo all-gather behind it (BDF_DIST_BACKEND=gloo) -- and the
+    large ones (the C4-shaped block's 5 MB per rank) by DIRECT PEER COPIES over IPC mappings (bdf_comm_enable_peer: two processes
+    on one GPU can open each other's allocations), the transport the 8-GPU design needs for C4's 5 GB user factor."""
     import json
     import subprocess
     import sys
@@ -542,6 +544,8 @@ def test_two_ranks_match_one(B):
     assert "error" not in d2["c4"] and "error" not in d1["c4"], (d2["c4"], d1["c4"])
     assert d2["c4"]["n_gpus"] == 2 and d2["c4"]["scaling"] == "strong"
     assert abs(d2["c4"]["test_rmse"] - d1["c4"]["test_rmse"]) < 1e-4, (d2["c4"], d1["c4"])
+    ex = d2["c4"]["exchange"]
+    assert "peer copies" in ex["transport"] and ex["peer_exchanges"] >= 10 and ex["peer_bytes_pulled_per_rank"] >= 10 * 5_000_000, ex
     # and the C5-shaped block (a shared entity with two relations and binary sparse features, beta's columns split over the ranks)
     assert "error" not in d2["c5"] and "error" not in d1["c5"], (d2["c5"], d1["c5"])
     assert d2["c5"]["n_gpus"] == 2 and d2["c5"]["beta_columns_per_rank"] == 16 and d2["c5"]["native_iteration"] and d1["c5"]["native_iteration"]

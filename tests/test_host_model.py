@@ -442,7 +442,7 @@ def test_julia_binding_covers_every_product_export():
         "bdf_comm_create_host", "bdf_comm_size",                                                     # the one-GPU test rig's transport
         "bdf_ctx_set_gather", "bdf_row_system", "bdf_normals", "bdf_philox", "bdf_rows_unfinished",  # parity hooks
         "bdf_event_create", "bdf_event_destroy", "bdf_event_elapsed_us", "bdf_ctx_time_next_rows", "bdf_ctx_time_next_hyper",
-        "bdf_gibbs_time_rows", "bdf_gibbs_rows_only", "bdf_gibbs_contexts", "bdf_gibbs_recorded", "bdf_gibbs_set_recorded",   # measurement
+        "bdf_ctx_span_next_rows", "bdf_gibbs_span_rows", "bdf_comm_peer_stats", "bdf_gibbs_time_rows", "bdf_gibbs_rows_only", "bdf_gibbs_contexts", "bdf_gibbs_recorded", "bdf_gibbs_set_recorded",   # measurement
         "bdf_synth_ratings",                                                                         # the bench's generator
     }
     unbound = [n for n in exports if (":" + n) not in jl and n not in not_needed]
