@@ -884,7 +884,7 @@ __device__ __forceinline__ void cg_grid_sync(unsigned *bar, unsigned target, int
         int spins = 0;
         while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
             __builtin_amdgcn_s_sleep(1);
-            if (++spins > (1 << 25)) { atomicOr_system(flag, 16); break; }       // bounded: a bug must not hang the device
+            if (++spins > (1 << 21)) { atomicOr_system(flag, 16); break; }       // bounded (~0.2 s): a workgroup that is not resident must not hang the device
         }
     }
     __syncthreads();
@@ -1411,7 +1411,24 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
     // a small resident operator: the whole solve in one launch (k_cg_resident; BDF_CG_RESIDENT=0: the two launches per iteration)
     static const bool resident_ok = !(getenv("BDF_CG_RESIDENT") && atoi(getenv("BDF_CG_RESIDENT")) == 0);
-    const bool resident = resident_ok && use_ff && numF <= 512 && D <= 32 && D <= (numF + 15) / 16;
+    bool resident = resident_ok && use_ff && numF <= 512 && D <= 32 && D <= (numF + 15) / 16;
+    if (resident) {
+        // its workgroups hand over through a counter they all poll: ALL ceil(numF / 16) of them must be resident at once.  One
+        // workgroup per CU is what the kernel's registers and LDS allow for certain (asked of the runtime below), so the stream
+        // needs that many CUs: not the reserved hyperprior stream (a handful of CUs), and the row context's CUs minus the
+        // reserved ones.  (A caller-supplied CU-masked stream the library cannot see is covered by the spin bound: flag 16.)
+        static int cus = 0, occ32 = -1, occ16 = -1;
+        if (!cus) {
+            hipDeviceProp_t prop;
+            BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+            cus = prop.multiProcessorCount;
+            BDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ16, k_cg_resident<1>, 256, 0));
+            BDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ32, k_cg_resident<2>, 256, 0));
+        }
+        const int avail = ctx->on_reserved ? 0 : std::max(0, cus - ctx->reserve_cus);
+        const int per_cu = std::min(1, D <= 16 ? occ16 : occ32);
+        resident = (int64_t)per_cu * avail >= (numF + 15) / 16;
+    }
     if (resident && !ctx->cg_bar) BDF_HIP(hipMalloc((void **)&ctx->cg_bar, sizeof(unsigned)));
     hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol, resident ? ctx->cg_bar : (unsigned *)nullptr);
     BDF_HIP(hipGetLastError());
