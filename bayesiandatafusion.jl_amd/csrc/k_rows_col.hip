@@ -492,15 +492,36 @@ int bdf_col_plan_build(bdf_ctx *ctx, const std::vector<bdf_row_ref> &rows, int T
     plan.n_waves = 0;
     plan.n_split_rows = (int32_t)splits.size();
     if (rounds.empty()) return BDF_OK;
-    // ONE ROUND PER WAVE, costliest first: the launch has more waves than the device holds at once and the hardware's dispatcher
-    // hands the later, lighter ones to whichever SIMD comes free -- which balances the SIMDs whatever the placement (with a CU
-    // mask the shader engines hold different numbers of CUs and still receive the same share of the first generation of workgroups:
-    // rounds dealt to exactly the resident wave count ended 1.5 x the mean wave's time after the launch began)
+    // ONE ROUND PER WAVE.  Two waves share a SIMD (250 registers each), and the older of the two takes the issue slots it wants: a
+    // heavy round beside a medium one runs at a lone wave's pace while its partner crawls (stamps: 430 against 900 cycles per
+    // observation step).  The dispatcher deals single-wave workgroups round-robin -- wave w and wave w + (SIMDs) meet on one SIMD
+    // (1,024 apart on the whole chip, 896 in the shader engines a CU mask has taken a CU from) -- so the ORDER of the waves decides
+    // who shares: costliest first paired the heaviest round with the median one and the median with the lightest (SIMD totals of
+    // 194 against 76 observation steps on MovieLens; the launch ended with the first kind).  Here the first S2 waves hold the
+    // heavier rounds and the next S2 bring the lighter ones LIGHTEST FIRST, so that wave w's partner is its complement and every
+    // SIMD gets about the same sum.  S2 = 896, the SHORTER of the two distances, whatever the stream's CUs (the order must not
+    // depend on them): with 1,024 the waves 896 .. 1,023 -- still heavy -- became the partners of the heaviest ones in the masked
+    // shader engines and the launch took 41 us instead of 37 on the row stream's 248 CUs; with 896 a partner is at worst 128
+    // places -- a few observation steps -- from the exact complement, under either mask: 33.1 / 34.9 us (users' / movies' launch
+    // alone, all CUs; 33.2 / 35.2 on 248) against 35.4 / 37.9 costliest-first (profiles/r05_k1c_wave_order.txt).  With fewer rounds
+    // than 2 S2 the heaviest run alone; rounds beyond 2 S2 follow costliest first and take whichever slot comes free.
     (void)slots;
     const int64_t nw = (int64_t)rounds.size();
-    std::vector<int32_t> idx(rounds.size());
-    for (size_t i = 0; i < idx.size(); i++) idx[i] = (int32_t)i;
-    std::stable_sort(idx.begin(), idx.end(), [&](int32_t x, int32_t y) { return rounds[(size_t)x].cost > rounds[(size_t)y].cost; });
+    std::vector<int32_t> rank(rounds.size());
+    for (size_t i = 0; i < rank.size(); i++) rank[i] = (int32_t)i;
+    std::stable_sort(rank.begin(), rank.end(), [&](int32_t x, int32_t y) { return rounds[(size_t)x].cost > rounds[(size_t)y].cost; });
+    static const int64_t S2 = getenv("BDF_COL_PAIR_DISTANCE") ? std::max<int64_t>(0, atoll(getenv("BDF_COL_PAIR_DISTANCE"))) : 896;
+    std::vector<int32_t> idx;
+    idx.reserve(rounds.size());
+    if (S2 == 0 || nw <= S2) idx = rank;                       // (0: the plain costliest-first order)
+    else {
+        const int64_t two = std::min<int64_t>(nw, 2 * S2);      // the rounds of the first two generations: ranks 0 .. two - 1
+        const int64_t P = two - S2, A = S2 - P;                 // P pairs; the A heaviest alone
+        for (int64_t i = 0; i < P; i++) idx.push_back(rank[(size_t)(A + i)]);
+        for (int64_t i = 0; i < A; i++) idx.push_back(rank[(size_t)i]);
+        for (int64_t i = 0; i < P; i++) idx.push_back(rank[(size_t)(two - 1 - i)]);
+        for (int64_t i = two; i < nw; i++) idx.push_back(rank[(size_t)i]);
+    }
     std::vector<ColJob> jobs;
     std::vector<int32_t> wave_round;
     jobs.reserve(rounds.size() * 4);
@@ -509,8 +530,8 @@ int bdf_col_plan_build(bdf_ctx *ctx, const std::vector<bdf_row_ref> &rows, int T
         for (int q = 0; q < 4; q++) jobs.push_back(rounds[(size_t)i].job[q]);
         wave_round.push_back((int32_t)(jobs.size() / 4));
     }
-    plan.cost_max = rounds[(size_t)idx.front()].cost;
-    plan.cost_min = rounds[(size_t)idx.back()].cost;
+    plan.cost_max = rounds[(size_t)rank.front()].cost;
+    plan.cost_min = rounds[(size_t)rank.back()].cost;
     plan.n_waves = (int32_t)nw;
     BDF_HIP(hipMalloc((void **)&plan.jobs_dev, jobs.size() * sizeof(ColJob)));
     BDF_HIP(hipMemcpy(plan.jobs_dev, jobs.data(), jobs.size() * sizeof(ColJob), hipMemcpyHostToDevice));
