@@ -134,59 +134,35 @@ __device__ __forceinline__ void col_slot_load(double (&A0)[33], double (&A1)[33]
 // the prior's image (the accumulator-layout image of the index-reversed Lambda: prior_pack / k_prior) for the lane's two columns,
 // every load in flight at once -- a batch of sixteen at a time cost a round 12 k cycles, a quarter of its life.  SC: agent-scope
 // loads (the pack was written by a hyperprior draw this launch did not wait for: past the CU's non-coherent L1).
-// entries E0 .. E1-1 of the lane's two columns (entry e < DR: row e of column j, else row e - DR of column 16 + j): loaded, then added
-template <int DR, int E, int E1, bool SC>
-__device__ __forceinline__ void col_prior_load(double (&P)[24], int k, const double *prior, int j)
+// The prior's image (768 doubles at D <= 32) into the wave's LDS by LDS-DMA: six instructions of 64 lanes x 16 bytes, no vector
+// registers, past the CU's L1 (sc1: the pack may be the hyperprior draw's of a moment ago).  Issued at the START of a round when
+// the draw is already there -- it lands under the accumulation -- and read back with ds_read when the round adds the prior:
+// 66 agent-scope loads in three dependent batches were 3.9 k cycles of every round (stamps), a twelfth of its life.
+__device__ __forceinline__ void col_prior_dma(const double *image, unsigned lds_dst, int lane)
 {
-    if constexpr (E < E1) {
-        constexpr int S = E < DR ? 0 : 1, I = E < DR ? E : E - DR;
-        if constexpr (SC) P[E1 - 1 - E] = __hip_atomic_load(prior + sys_off<S, I>(j), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else P[E1 - 1 - E] = prior[sys_off<S, I>(j)];
-        col_prior_load<DR, E + 1, E1, SC>(P, k, prior, j);
+    const void *sbase = (const void *)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((uint64_t)image >> 32)) << 32) |
+                                       (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uint64_t)image));
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const unsigned voff = (unsigned)k * 1024u + (unsigned)lane * 16u;
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 sc1\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(voff), "s"(lds_dst + (unsigned)k * 1024u), "s"(sbase) : "memory");
     }
 }
-template <int DR, int E, int E1>
-__device__ __forceinline__ void col_prior_add(double (&A0)[33], double (&A1)[33], const double (&P)[24], double alpha)
+template <int S, int I, int DR>
+__device__ __forceinline__ void col_prior_lds(double (&A)[33], const double *img, double alpha, int j)
 {
-    if constexpr (E < E1) {
-        if constexpr (E < DR) A0[E] = fma(alpha, A0[E], P[E1 - 1 - E]); else A1[E - DR] = fma(alpha, A1[E - DR], P[E1 - 1 - E]);
-        col_prior_add<DR, E + 1, E1>(A0, A1, P, alpha);
+    if constexpr (I < DR) {
+        A[I] = fma(alpha, A[I], img[sys_off<S, I>(j)]);
+        col_prior_lds<S, I + 1, DR>(A, img, alpha, j);
     }
-}
-template <int DR, int E0, bool SC>
-__device__ __forceinline__ void col_prior_batches(double (&A0)[33], double (&A1)[33], const double *prior, double alpha, int j)
-{
-    // (batches of 22: all 2 DR loads in flight at once would need more registers than two waves per SIMD leave; sixteen at a time
-    // cost a round 12 k cycles, a quarter of its life)
-    if constexpr (E0 < 2 * DR) {
-        constexpr int E1 = E0 + 22 < 2 * DR ? E0 + 22 : 2 * DR;
-        double P[24];
-        col_prior_load<DR, E0, E1, SC>(P, 0, prior, j);
-        col_prior_add<DR, E0, E1>(A0, A1, P, alpha);
-        asm volatile("" ::: "memory");
-        col_prior_batches<DR, E1, SC>(A0, A1, prior, alpha, j);
-    }
-}
-// P~ = alpha S~ + Lambda~, b~ = alpha W r + Lambda mu.  SC: agent-scope loads (the pack was written by a hyperprior draw this launch
-// did not wait for: past the CU's non-coherent L1)
-template <int DR, bool SC>
-__device__ __forceinline__ void col_prior(double (&A0)[33], double (&A1)[33], const double *prior, const double *pb, int n0, int n1, bool ok1,
-                                          double alpha, int j)
-{
-    double b0, b1;
-    if constexpr (SC) {
-        b0 = __hip_atomic_load(pb + n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        b1 = __hip_atomic_load(pb + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else { b0 = pb[n0]; b1 = pb[n1]; }
-    col_prior_batches<DR, 0, SC>(A0, A1, prior, alpha, j);
-    A0[32] = fma(alpha, A0[32], b0);
-    A1[32] = ok1 ? fma(alpha, A1[32], b1) : 0.0;
 }
 
 template <int DR, bool FULL>
 __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in, ColPlanDev p_in, uint32_t fac_bytes)
 {
-    __shared__ double lds[4 * 272];                // block (1,0) of the four systems on its way to block (0,1)
+    __shared__ __attribute__((aligned(16))) double lds[4 * 272 + 768];      // block (1,0) of the four systems on its way to block (0,1) | the prior's image
     const int w = blockIdx.x;
     if (w >= p_in.n_waves) return;
     const int r_end = p_in.wave_round[w + 1];
@@ -217,6 +193,12 @@ __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in,
         const ColJob jb = p.jobs[(int64_t)rd * 4 + g];
         const bool live = jb.row >= 0;
         const int n = live ? jb.count : 0;
+        // the prior's image on its way into LDS under the accumulation, if the draw is there already (a launch that did not wait
+        // for it: one look at its flag, no spinning here)
+        const unsigned lds_img = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(size_t)(__attribute__((address_space(3))) double *)(lds + 4 * 272));
+        bool have_prior = true;
+        if (a.ready) have_prior = __builtin_amdgcn_readfirstlane((int)((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) >= 0)) != 0;
+        if (have_prior) col_prior_dma(a.prior_c, lds_img, lane);
         // ---- accumulate: S~ (blocks (0,0), (1,0), (1,1)) and W r ----
         double A0[33], A1[33];
 #pragma unroll
@@ -352,18 +334,26 @@ __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in,
         CSTAMP(st_mid);
         // ---- P~ = alpha S~ + Lambda~, b~ = alpha W r + Lambda mu: the prior pack (polled for when the launch did not wait for the draw) ----
         const double alpha = term_alpha(T);
-        if (a.ready) {
+        if (!have_prior) {
             int spins = 0;
             while ((int32_t)(__hip_atomic_load(a.ready, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.ready_want) < 0) {
                 __builtin_amdgcn_s_sleep(16);
                 if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }
             }
+            col_prior_dma(a.prior_c, lds_img, lane);
         }
         {
             const double *pb = a.prior_b + (a.mu_is_matrix && live ? (int64_t)jb.row * D : 0);
-            // (agent-scope loads also when the launch did wait for the draw: a second copy of this code with plain loads costs the
-            // kernel 88 spilled registers)
-            col_prior<DR, true>(A0, A1, a.prior_c, pb, n0, n1, ok1, alpha, j);
+            const double b0 = __hip_atomic_load(pb + n0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const double b1 = __hip_atomic_load(pb + n1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the image has landed (nothing else orders a ds_read behind an LDS-DMA)
+            wave_sync();
+            const double *img = lds + 4 * 272;
+            col_prior_lds<0, 0, DR>(A0, img, alpha, j);
+            col_prior_lds<1, 0, DR>(A1, img, alpha, j);
+            A0[32] = fma(alpha, A0[32], b0);
+            A1[32] = ok1 ? fma(alpha, A1[32], b1) : 0.0;
+            wave_sync();                                           // (the next round's image goes to the same place)
         }
 #ifdef BDF_K1_STAMPS
         asm volatile("s_nop 0" :: "v"(A0[0]), "v"(A0[31]), "v"(A1[0]), "v"(A1[31]));
