@@ -134,16 +134,22 @@ int streams_overlap(hipStream_t a, hipStream_t b, bool *yes)
 // used (torch: allocator pools per stream, events recorded on it) beyond the life of the context that ran on it, and
 // destroying it under them crashes at the framework's own teardown.  Slot k of (device, reserve, role) is always the same
 // stream, so later engines of a process pick the same streams as the first.
-int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t *out)
+// low_priority: a stream of the lowest priority the device offers, on ALL CUs (the runtime has no call that gives a stream both
+// a CU mask and a priority) -- for work that should only take the slots the row kernels leave free.
+int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t *out, bool low_priority = false)
 {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int>, hipStream_t> pool;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_tuple(device, reserve, reserved ? 1 : 0, slot);
+    const auto key = std::make_tuple(device, low_priority ? -1 : reserve, reserved ? 1 : 0, slot);
     auto it = pool.find(key);
     if (it != pool.end()) { *out = it->second; return BDF_OK; }
     hipStream_t st;
-    if (reserve <= 0) {
+    if (low_priority) {
+        int least = 0, greatest = 0;
+        BDF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        BDF_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least));
+    } else if (reserve <= 0) {
         BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     } else {
         hipDeviceProp_t prop;
@@ -159,14 +165,14 @@ int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t 
     return BDF_OK;
 }
 
-int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bool reserved, bdf_ctx **out)
+int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bool reserved, bdf_ctx **out, bool low_priority = false)
 {
     // a few candidate streams; the first that overlaps with the row stream and with every stream in `apart`
     bdf_ctx *fallback = nullptr;
     for (int attempt = 0; attempt < 8; attempt++) {
         hipStream_t st;
         // slot 0 of the unreserved role is the row stream itself
-        int rc = pooled_stream(main->device, main->reserve_cus, reserved, attempt + 1, &st);
+        int rc = pooled_stream(main->device, main->reserve_cus, reserved, attempt + 1, &st, low_priority);
         if (rc) return rc;
         if (st == main->stream) continue;
         bool taken = false;
@@ -252,7 +258,8 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     g->n_pred = 0; g->comm = nullptr; g->ready_dev = nullptr; g->polling = false;
     g->debug = false; g->host_wait_us = g->host_enqueue_us = 0.0; g->n_sweeps = 0;
     int rc;
-    if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
+    static const bool pred_low = getenv("BDF_PRED_PRIORITY") && !strcmp(getenv("BDF_PRED_PRIORITY"), "low");
+    if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred, pred_low))) { bdf_gibbs_destroy(g); return rc; }
     g->ready_dev = nullptr;
     g->polling = rows_ctx->reserve_cus > 0 && g->hyper->on_reserved && !getenv("BDF_NO_POLL");
     if (g->polling) {
