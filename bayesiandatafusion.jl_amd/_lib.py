@@ -145,6 +145,7 @@ _SIGS = {
     "bdf_ctx_set_small_rows": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "bdf_ctx_set_lowrank": (C.c_int, [C.c_void_p, C.c_int, C.c_int64]),
     "bdf_ctx_set_col_rows": (C.c_int, [C.c_void_p, C.c_int]),
+    "bdf_ctx_rows_dispatch": (C.c_int, [C.c_void_p, C.c_uint32, C.POINTER(C.c_int64)]),
     "bdf_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
     "bdf_pairs_destroy": (C.c_int, [C.c_void_p]),
     "bdf_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),

@@ -67,6 +67,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->hyper_chain = false; c->hyper_count = nullptr; c->hyper_chain_draws = nullptr;
     c->cg_gen = 0;
     c->cg_bar = nullptr;
+    c->rows_dispatch = nullptr;
     c->scratch = nullptr;
     c->scratch2 = nullptr;
     c->scratch2_bytes = 0;
@@ -107,6 +108,7 @@ extern "C" int bdf_ctx_destroy(bdf_ctx *ctx)
     if (ctx->cg_status) hipHostFree((void *)ctx->cg_status);
     if (ctx->cg_part) hipFree(ctx->cg_part);
     if (ctx->cg_bar) hipFree(ctx->cg_bar);
+    delete ctx->rows_dispatch;
     if (ctx->hyper_count) hipFree(ctx->hyper_count);
     if (ctx->lr_T) hipFree(ctx->lr_T);
     if (ctx->lr_vt) hipFree(ctx->lr_vt);
@@ -206,6 +208,16 @@ extern "C" int bdf_ctx_span_next_rows(bdf_ctx *ctx, void *slot_dev)
 {
     BDF_REQUIRE(ctx, BDF_ERR_ARG, "bdf_ctx_span_next_rows: NULL context");
     ctx->rows_span = (unsigned long long *)slot_dev;
+    return BDF_OK;
+}
+
+extern "C" int bdf_ctx_rows_dispatch(const bdf_ctx *ctx, uint32_t entity_tag, int64_t out[6])
+{
+    BDF_REQUIRE(ctx && out, BDF_ERR_ARG, "bdf_ctx_rows_dispatch: NULL argument");
+    BDF_REQUIRE(ctx->rows_dispatch && ctx->rows_dispatch->count(entity_tag), BDF_ERR_ARG,
+                "bdf_ctx_rows_dispatch: no row launch under entity_tag %u on this context", entity_tag);
+    const std::array<int64_t, 7> &r = ctx->rows_dispatch->at(entity_tag);
+    for (int k = 0; k < 6; k++) out[k] = r[(size_t)k + 1];
     return BDF_OK;
 }
 

@@ -1,5 +1,7 @@
 // bdf_common.h -- internal declarations shared by the HIP translation units of libbdf_hip.so
 #pragma once
+#include <map>
+#include <array>
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <cstdint>
@@ -85,6 +87,8 @@ struct bdf_ctx {
     double *cg_part;                    // partial dot products of the chunked CG step (k_cg_long_*), allocated at first use
     uint32_t cg_gen;
     unsigned *cg_bar;                   // the hand-over counter of the one-launch CG solve (k_cg_resident), allocated at first use
+    // bdf_ctx_rows_dispatch: per entity tag {iteration number, rows by K1-lr, K1s, K1c, K1, K1's items, K1c's waves} of the latest launch
+    std::map<uint32_t, std::array<int64_t, 7>> *rows_dispatch;
 };
 
 int bdf_scratch(bdf_ctx *ctx, size_t bytes, void **out);

@@ -803,6 +803,7 @@ struct Plan {
     double *partials_dev = nullptr;
     int32_t *arrived_dev = nullptr;
     bdf_col_plan col;                 // the rows of k_rows_col (K1c)
+    int64_t rows_lr = 0, rows_small = 0, rows_col = 0, rows_k1 = 0;      // how the plan's rows are shared out (bdf_ctx_rows_dispatch)
 };
 
 struct PlanCache {
@@ -898,6 +899,8 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     }
     int rc;
     if (key.col > 0 && (rc = bdf_col_plan_build(ctx, crows, key.col, key.col_slots, plan.col))) return rc;
+    plan.rows_lr = (int64_t)lr.size(); plan.rows_small = (int64_t)small.size(); plan.rows_col = (int64_t)crows.size();
+    plan.rows_k1 = (int64_t)direct.size() + (int64_t)srows.size();
     while (small.size() % 4) small.push_back(SmallItem{-1, 0, 0, 0, 0});
     plan.n_small = (int64_t)small.size();
     if (!small.empty() && (rc = to_device(small, &plan.small_dev))) return rc;
@@ -1086,7 +1089,7 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
 
     // D > 16, one two-mode relation without per-observation baselines (shared or per-row prior means): the rows of few observations
     // by the low-rank sampler (k_rows_lr.hip; bdf_ctx_set_lowrank, environment BDF_LOWRANK:
-    // the longest such row, -1 = min(15, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
+    // the longest such row, -1 = min(16, D / 2), 0 = off) -- when there are enough of them (decided when the plan is built)
     int64_t M_other = 0;
     if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr) {
         const int other = 1 - modes[0];
@@ -1162,6 +1165,14 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
             it = cache.plans.emplace(key, np).first;
         }
         plan = &it->second;
+    }
+    {
+        // bdf_ctx_rows_dispatch: the chunks / shards of one iteration's launch of the entity add up
+        if (!ctx->rows_dispatch) ctx->rows_dispatch = new std::map<uint32_t, std::array<int64_t, 7>>();
+        std::array<int64_t, 7> &rdsp = (*ctx->rows_dispatch)[a.entity_tag];
+        if (rdsp[0] != (int64_t)a.sweep + 1) rdsp = {(int64_t)a.sweep + 1, 0, 0, 0, 0, 0, 0};
+        rdsp[1] += plan->rows_lr; rdsp[2] += plan->rows_small; rdsp[3] += plan->rows_col; rdsp[4] += plan->rows_k1;
+        rdsp[5] += (int64_t)plan->dev.n_split + plan->dev.n_direct; rdsp[6] += plan->col.n_waves;
     }
     if (plan->n_lr > 0) {
         const bool more = (int64_t)plan->dev.n_split + plan->dev.n_direct + plan->col.n_waves > 0;

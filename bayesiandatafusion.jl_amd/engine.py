@@ -151,7 +151,7 @@ class Context:
         check(lib().bdf_ctx_set_small_rows(self.handle, int(max_observations), int(min_rows)))
 
     def set_lowrank(self, max_observations=-1, min_rows=8192):
-        """D > 16: rows of at most max_observations observations (-1: min(15, D / 2); 0: off) by the low-rank sampler when a
+        """D > 16: rows of at most max_observations observations (-1: min(16, D / 2); 0: off) by the low-rank sampler when a
         launch has min_rows such rows or more (bdf_ctx_set_lowrank) -- the same conditional distribution as the reference's
         map, other sampled values"""
         check(lib().bdf_ctx_set_lowrank(self.handle, int(max_observations), int(min_rows)))
@@ -160,6 +160,14 @@ class Context:
         """16 < D <= 32, one two-mode relation: the rows four to a wave in the column layout, cut into pieces of at most max_piece
         observations (bdf_ctx_set_col_rows; 0: off -- the wave-per-row kernel; -1: the default, 128 unless the caller chose an item size)"""
         check(lib().bdf_ctx_set_col_rows(self.handle, int(max_piece)))
+
+    def rows_dispatch(self, entity_tag):
+        """how the latest row launch under entity_tag was dispatched on this context (bdf_ctx_rows_dispatch): a dict of rows by
+        the low-rank sampler, k_rows_small, K1c and k_rows, k_rows' work items and K1c's waves; None before the first launch"""
+        out = (C.c_int64 * 6)()
+        if lib().bdf_ctx_rows_dispatch(self.handle, int(entity_tag), out) != 0:
+            return None
+        return dict(zip(("lowrank", "small", "col", "k1", "k1_items", "col_waves"), (int(x) for x in out)))
 
     def set_piece_size(self, observations):
         check(lib().bdf_ctx_set_piece_size(self.handle, int(observations)))
@@ -739,11 +747,18 @@ class GibbsEngine:
             b += r.data.nnz() * ((4 + 8 * D) * (len(r.entities) - 1) + 8)
         return b
 
+    def rows_dispatch(self, j):
+        """how the library dispatched entity j's latest row launch (Context.rows_dispatch); None before the first iteration"""
+        return self.ctx.rows_dispatch(self.ent[j].tag)
+
     def lowrank_rows(self, j):
-        """rows of entity j the library draws with the low-rank sampler (k_rows_lr.hip) instead of the reference's map: the rule
-        of bdf_launch_sample_rows restated for reports -- D > 16, one two-mode relation, no side information on the relation
-        (the entity's own is fine: per-row prior means), rows of at most min(16, D / 2) observations (BDF_LOWRANK), at least 8,192 of them (BDF_LOWRANK_MIN_ROWS)
-        and at least half as many as the opposite entity has rows"""
+        """rows of entity j the library draws with the low-rank sampler (k_rows_lr.hip) instead of the reference's map -- the
+        library's own count for the latest launch (bdf_ctx_rows_dispatch); before the first iteration: the rule of
+        bdf_launch_sample_rows restated from the environment (D > 16, one two-mode relation, no side information on the relation,
+        rows of at most min(16, D / 2) observations, at least 8,192 of them and at least half as many as the opposite entity has rows)"""
+        got = self.rows_dispatch(j)
+        if got is not None:
+            return got["lowrank"]
         en, st, D = self.data.entities[j], self.ent[j], self.D
         lr = int(os.environ.get("BDF_LOWRANK", "-1"))
         lr = min(16, D // 2) if lr < 0 else min(lr, 16)

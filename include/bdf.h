@@ -133,6 +133,12 @@ int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows);
  * launches whose item size the caller has not set (bdf_ctx_set_item_size keeps the wave-per-row kernel); a call here with
  * 8..4096 applies to every launch of the context, 0 turns it off, -1 restores the default. */
 int bdf_ctx_set_col_rows(bdf_ctx *ctx, int max_piece);
+/* report: how the most recent bdf_sample_rows launch of the entity with this entity_tag (all its chunks / shards since the tag's
+ * previous iteration number) was dispatched on this context -- out[0] rows drawn by the low-rank sampler (k_rows_lr.hip, a
+ * different map from the normals than sample_user_basic's, src/sampling.jl:200-212), out[1] rows by k_rows_small (D <= 16),
+ * out[2] rows by k_rows_col (K1c), out[3] rows by the wave-per-row kernel k_rows, out[4] its work items (pieces included),
+ * out[5] K1c's waves.  BDF_ERR_ARG if the context has launched no rows under that tag. */
+int bdf_ctx_rows_dispatch(const bdf_ctx *ctx, uint32_t entity_tag, int64_t out[6]);
 /* measurement: slot (dev, 64 pairs of uint64, each set to {~0, 0} by the caller) receives per pair s {earliest start, latest end}
  * of the waves w = s mod 64 of the NEXT K1c launch of the context, in ticks of the 100 MHz clock the XCDs share (s_memrealtime; one
  * atomic min / max per wave, sharded: one word would serialise two thousand waves): min / max over the pairs = the launch's

@@ -53,6 +53,12 @@ set_small_rows!(c::Context, max_obs, min_rows) = check(ccall((:bdf_ctx_set_small
 set_lowrank!(c::Context, max_obs=-1, min_rows=8192) = check(ccall((:bdf_ctx_set_lowrank, lib), Cint, (Ptr{Cvoid}, Cint, Int64), c.h, max_obs, min_rows))
 # 16 < D <= 32: row launches of at least `min_rows` rows as two kernels (accumulate, then factor / solve / draw four rows per wave); negative: never
 set_col_rows!(c::Context, max_piece=-1) = check(ccall((:bdf_ctx_set_col_rows, lib), Cint, (Ptr{Cvoid}, Cint), c.h, max_piece))
+# how the latest row launch under `entity_tag` was dispatched: rows by K1-lr, K1s, K1c, K1; K1's items; K1c's waves
+function rows_dispatch(c::Context, entity_tag::Integer)
+    out = zeros(Int64, 6)
+    check(ccall((:bdf_ctx_rows_dispatch, lib), Cint, (Ptr{Cvoid}, UInt32, Ptr{Int64}), c.h, UInt32(entity_tag), out))
+    return out
+end
 set_piece_size!(c::Context, piece) = check(ccall((:bdf_ctx_set_piece_size, lib), Cint, (Ptr{Cvoid}, Cint), c.h, piece))
 # a row context on a library-owned stream that leaves `reserve_cus` CUs (0, 8, 16, ...) free, and side contexts that really
 # run beside it -- on the reserved CUs (`reserved = true`: the hyperprior's small kernels) or on the others

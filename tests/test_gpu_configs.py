@@ -437,6 +437,12 @@ def test_macau_with_side_information_and_lowrank_rows_match_oracle(B, O):
         eng.sweep(i)
     eng.sync()
     eng.sync_host_scalars()
+    # what the library itself says it did (bdf_ctx_rows_dispatch), against the rule restated above and the relation's degrees
+    deg = np.bincount(ids[:, 0] - 1, minlength=N1)
+    d0, d1 = eng.rows_dispatch(0), eng.rows_dispatch(1)
+    assert d0["lowrank"] == int((deg <= 12).sum()) == eng.lowrank_rows(0)
+    assert d0["lowrank"] + d0["small"] + d0["col"] + d0["k1"] == N1 and d0["small"] == 0
+    assert d1["lowrank"] == 0 and d1["col"] + d1["k1"] == N2 and eng.lowrank_rows(1) == 0
     _compare(rd, *oracle_macau(O, rd, D, 31, 2, True, lowrank={0: 12}), tol=1e-6)
     eng.close()
 
