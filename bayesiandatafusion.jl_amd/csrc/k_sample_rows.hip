@@ -1112,6 +1112,19 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         }
         static const int per_simd = getenv("BDF_COL_PER_SIMD") ? std::max(1, atoi(getenv("BDF_COL_PER_SIMD"))) : 2;
         key.col = ctx->col_piece;
+        if (!ctx->col_explicit) {
+            // A row of more than 4 T observations SPANS waves: every part writes its 6.4 KB of sums through to the slab and the part
+            // that arrives last adds them, slot after slot -- ~25 us of a wave's slot per part when thousands of them are in flight
+            // (profiles/r05_k1c_piece_size.txt: 1,000 rows of 15,000 observations, the reference's benchmark shape, 2.7 ms at
+            // T = 128 in 30,000 parts, 0.70 ms at T = 1,024 in 4,000; 4,000 rows of 3,000: 0.73 -> 0.44 ms).  Small pieces are
+            // for launches of ONE generation of waves (MovieLens: the heaviest wave is the launch's tail); a launch with many
+            // waves per slot takes larger ones: about eight waves' worth of observations per slot of a NOMINAL 2,048 (not the
+            // device's or the stream's: the cut of a row must not depend on them), from the WHOLE entity's count -- the same on
+            // every shard, chunk and rank -- between the default and 2,048.
+            const int64_t nnz_entity = (int64_t)rels[0]->idx[modes[0]].rowptr.back();
+            const int64_t t = std::min<int64_t>(2048, (nnz_entity / (2048 * 8) + 63) / 64 * 64);
+            if (t > key.col) key.col = (int)t;
+        }
         key.col_slots = std::max(1, cus - ctx->reserve_cus) * 4 * per_simd;
         M_other = rels[0]->nint[1 - modes[0]];
     }
