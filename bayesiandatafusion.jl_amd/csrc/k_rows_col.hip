@@ -397,12 +397,6 @@ ColJob idle_job() { return ColJob{-1, 0, 0, 0, -1, 0, 0}; }
 
 }  // namespace
 
-int bdf_col_max_piece()
-{
-    static const int t = getenv("BDF_COL_T") ? std::max(8, atoi(getenv("BDF_COL_T"))) : 64;
-    return t;
-}
-
 int bdf_col_plan_build(bdf_ctx *ctx, const std::vector<bdf_row_ref> &rows, int T, int64_t slots, bdf_col_plan &plan)
 {
     std::vector<Round> rounds;
@@ -420,7 +414,12 @@ int bdf_col_plan_build(bdf_ctx *ctx, const std::vector<bdf_row_ref> &rows, int T
                               (int32_t)(COLF_PAIR | COLF_QUAD | (q == 0 ? COLF_LEADER : 0) | (srow >= 0 ? COLF_MULTI : 0))};
             lmax = std::max(lmax, (int32_t)(p1 - p0));
         }
-        R.cost = COL_C_OBS * lmax + 2 * COL_C_FOLD + (srow >= 0 ? COL_C_PART + fin_share : COL_C_FIN);
+        // (a part of a spanning row is ranked ABOVE what the model gives it: the part that arrives last pays the whole finish, the slab's
+        // round trips and the slots' sums, and as the YOUNGER wave of its SIMD -- 900 cycles per observation step against the older
+        // wave's 430 -- it was the launch's tail; ranked among the heavy rounds it is dispatched first and runs as the older one:
+        // users' launch alone 31.9 -> 29.9 us, movies' 33.9 -> 32.9, the iteration +2.5 %: profiles/r05_k1c_part_cost.txt)
+        static const double part_extra = getenv("BDF_COL_PART_COST") ? atof(getenv("BDF_COL_PART_COST")) : 3000.0;
+        R.cost = COL_C_OBS * lmax + 2 * COL_C_FOLD + (srow >= 0 ? COL_C_PART + fin_share + part_extra : COL_C_FIN);
         rounds.push_back(R);
     };
     for (const bdf_row_ref &rr : rows) {
