@@ -184,7 +184,10 @@ __device__ __forceinline__ void hyper_scatter(int D, int e, double s, double *su
 // which takes two dependent 32-step chains (the factorisation of Lam~ and its backward solve, ~7 us) off the iteration's
 // critical path.
 #ifdef BDF_HYPER_STAMPS
-#define HSTAMP(k) do { if (tid == 0 && a.params_out) ((unsigned long long *)a.params_out)[a.D + a.D * a.D + (k)] = __builtin_amdgcn_s_memtime(); } while (0)
+// diagnostic build: phase stamps of the LAST draw into a module-scope array (s_memrealtime, 100 MHz; bdf_debug_hyper_stamps) --
+// 0..6 nw_draw's phases, 8 the chain's last workgroup at its start, 9 when the partial sums and the draws have arrived
+__device__ unsigned long long g_hstamps[16];
+#define HSTAMP(k) do { if (tid == 0) g_hstamps[(k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define HSTAMP(k) do { } while (0)
 #endif

@@ -145,12 +145,21 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     if (pb < c.nblocks) {
         const int64_t r0 = (int64_t)pb * c.rows_per_block;
         const int64_t r1 = r0 + c.rows_per_block < c.N ? r0 + c.rows_per_block : c.N;
+#ifdef BDF_HYPER_STAMPS
+        if (threadIdx.x == 0 && (pb == 0 || pb == c.nblocks - 1)) g_hstamps[pb == 0 ? 10 : 12] = __builtin_amdgcn_s_memrealtime();
+#endif
         hyper_partial<DP, 4>(c.D, c.N, c.sample, c.uhat, r0, r1, c.partial + (int64_t)pb * HGeo<DP>::PSZ, lds, threadIdx.x);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this lane's write-through stores of the partial have completed
         __syncthreads();
+#ifdef BDF_HYPER_STAMPS
+        if (threadIdx.x == 0 && (pb == 0 || pb == c.nblocks - 1)) g_hstamps[pb == 0 ? 11 : 13] = __builtin_amdgcn_s_memrealtime();
+#endif
         if (threadIdx.x == 0) __hip_atomic_fetch_add(c.count, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
     }
+#ifdef BDF_HYPER_STAMPS
+    if (threadIdx.x == 0) g_hstamps[8] = __builtin_amdgcn_s_memrealtime();
+#endif
     if (threadIdx.x == 0) {
         int spins = 0;
         while (__hip_atomic_load(c.count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < (unsigned)(c.nblocks + c.ndraw)) {
@@ -161,6 +170,9 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     }
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+#ifdef BDF_HYPER_STAMPS
+    if (threadIdx.x == 0) g_hstamps[9] = __builtin_amdgcn_s_memrealtime();
+#endif
     nw_draw<DP>(a, lds, threadIdx.x, 256);
     if (a.ready) {
         __threadfence();
@@ -374,3 +386,12 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
     BDF_HIP(hipGetLastError());
     return BDF_OK;
 }
+
+#ifdef BDF_HYPER_STAMPS
+extern "C" int bdf_debug_hyper_stamps(unsigned long long *host16)
+{
+    BDF_HIP(hipDeviceSynchronize());
+    BDF_HIP(hipMemcpyFromSymbol(host16, HIP_SYMBOL(g_hstamps), sizeof(unsigned long long) * 16));
+    return BDF_OK;
+}
+#endif
