@@ -20,7 +20,8 @@ struct HGeo {
     static constexpr int PSZ = NB * 4 * 64 + DB * 16;      // doubles per partial: C-layout blocks, then the column sums
     static constexpr int LD = DP + 1;
     // LDS of nw_draw (doubles): sL | sA | tri | s_muN s_mu s_rd s_sq
-    static constexpr int NW_LDS = 2 * DP * LD + Geo<DP>::TRI_D + 4 * 64;
+    // LDS of nw_draw (doubles): sL | sA | tri | s_muN s_mu s_rd s_sq | (DP <= 32) the summed U U' and column sums
+    static constexpr int NW_LDS = 2 * DP * LD + Geo<DP>::TRI_D + 4 * 64 + (DP <= 32 ? DP * LD + 64 : 0);
 };
 
 struct NWArgs {
@@ -204,6 +205,86 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     const int D = a.D;
     const double beta_N = a.b0 + a.N;
     HSTAMP(0);
+    bool head_done = false;
+    if constexpr (DP <= 32) {
+        if (a.partial && nthreads == 256) {
+            // The chain's head in one pass (D <= 32, 256 threads, the sums' partials supplied): EVERY load the head needs is issued
+            // before the first use -- the sixteen partials of each of the thread's elements (written through by other CUs: ~1.5 us a
+            // round trip), its entries of Tinv, mu0 and the Bartlett matrix -- and the summed U U' / column sums go to LDS as well
+            // as to sumU / UUt, so that mu_N and W~ are built from LDS instead of from global memory this workgroup has just written
+            // (three dependent round trips: 6.3 of the chain's 27 us).  Same sums in the same order, same W.
+            constexpr int PSZ = HGeo<DP>::PSZ, NE = (PSZ + 255) / 256, NW = DP * DP / 256;
+            double *sUU = s_sq + 64, *s_sum = sUU + DP * LD;
+            double c[NE][16];
+#pragma unroll
+            for (int t = 0; t < NE; t++) {
+                const int e = tid + 256 * t;
+#pragma unroll
+                for (int q = 0; q < 16; q++) c[t][q] = (q < a.nblocks && e < PSZ) ? a.partial[(int64_t)q * PSZ + e] : 0.0;
+            }
+            double tinv[NW], m_lo[NW], m_hi[NW], dr[NW];
+#pragma unroll
+            for (int t = 0; t < NW; t++) {
+                const int e = tid + 256 * t, i = e / DP, cc = e % DP;
+                const int ei = D - 1 - i, ej = D - 1 - cc;
+                const bool ok = ei >= 0 && ej >= 0;
+                const int lo = ok ? (ei < ej ? ei : ej) : 0, hi = ok ? (ei < ej ? ej : ei) : 0;
+                tinv[t] = a.Tinv[lo + (int64_t)hi * D]; m_lo[t] = a.mu0[lo]; m_hi[t] = a.mu0[hi];
+                dr[t] = (ei >= 0 && cc < D) ? a.draws[ei * D + cc] : 0.0;
+            }
+            const double mu0_e = (tid < 64 && D - 1 - tid >= 0) ? a.mu0[D - 1 - tid] : 0.0;
+#pragma unroll
+            for (int t = 0; t < NE; t++) {
+#pragma unroll
+                for (int off = 8; off >= 1; off >>= 1)
+#pragma unroll
+                    for (int q = 0; q < off; q++) c[t][q] += c[t][q + off];
+            }
+#pragma unroll
+            for (int t = 0; t < NE; t++) {
+                const int e = tid + 256 * t;
+                if (e < PSZ) {
+                    const double v = c[t][0];
+                    hyper_scatter<DP>(D, e, v, a.sumU_w, a.UUt_w);
+                    constexpr int NBv = HGeo<DP>::NB;
+                    if (e < NBv * 4 * 64) {
+                        const int b = e >> 8, r = (e >> 6) & 3, l = e & 63;
+                        int I = 0;
+                        while ((I + 1) * (I + 2) / 2 <= b) I++;
+                        const int J = b - I * (I + 1) / 2;
+                        const int row = 16 * I + (l >> 4) + 4 * r, col = 16 * J + (l & 15);
+                        sUU[row * LD + col] = v;
+                        if (I != J) sUU[col * LD + row] = v;
+                    } else s_sum[e - NBv * 4 * 64] = v;
+                }
+            }
+            if (D < DP)
+                for (int e = tid; e < GG::TRI_D; e += nthreads) tri[e] = 0.0;
+            __syncthreads();
+            if (tid < 64) {
+                const int e = D - 1 - tid;
+                s_muN[tid] = (e >= 0) ? (a.b0 * mu0_e + s_sum[e]) / beta_N : 0.0;      // reversed: s_muN[c] = mu_N[D-1-c]
+            }
+            __syncthreads();
+#pragma unroll
+            for (int t = 0; t < NW; t++) {
+                const int e = tid + 256 * t, i = e / DP, cc = e % DP;
+                const int ei = D - 1 - i, ej = D - 1 - cc;
+                double w = (i == cc) ? 1.0 : 0.0;
+                if (ei >= 0 && ej >= 0) {
+                    const int lo = ei < ej ? ei : ej, hi = ei < ej ? ej : ei;
+                    w = tinv[t] + sUU[lo * LD + hi] + a.b0 * m_lo[t] * m_hi[t] - beta_N * s_muN[D - 1 - lo] * s_muN[D - 1 - hi];
+                    if (a.params_out) a.params_out[D + ei + (int64_t)ej * D] = w;
+                }
+                sL[i * LD + cc] = w;
+                sA[i * LD + cc] = dr[t];                                              // sA[i][c] = A[D-1-i][c]
+            }
+            if (a.params_out && tid < DP && D - 1 - tid >= 0) a.params_out[D - 1 - tid] = s_muN[tid];
+            __syncthreads();
+            head_done = true;
+        }
+    }
+    if (!head_done) {
     if (a.partial) {
         // stage 2 of the sums (k_hyper_final's order: chain q = partial q, then the butterfly 8, 4, 2, 1); all loads of an
         // element in flight together
@@ -243,6 +324,7 @@ __device__ __forceinline__ void nw_draw(const NWArgs &a, double *lds, int tid, i
     }
     if (a.params_out && tid < DP && D - 1 - tid >= 0) a.params_out[D - 1 - tid] = s_muN[tid];
     __syncthreads();
+    }
     HSTAMP(1);
 
     // the factorisation of the matrix in sL on wave 0; pivots' reciprocals and square roots to s_rd / s_sq
