@@ -175,8 +175,9 @@ def c3_block(B, datasets, D, device, sweeps=20):
     rows, hyperpriors with the feature terms, beta); the direct solve and the forced conjugate gradients"""
     out = {"workload": f"Macau MovieLens-1M + dense user side information 6040 x 500 (iid N(0,1), seed 4242), D={D}, 5 + {sweeps} sweeps, "
                        f"no prediction update; ms per sweep"}
-    for ff_size, key in ((6500, "ff"), (0, "cg")):
-        rd, _ = datasets.c3_relation_data(B, "iid")
+    # (cg_correlated: SURVEY M-C3's second feature matrix, Z W + 0.1 E with 20 dominant directions -- the conditioning CG feels)
+    for ff_size, key, kind in ((6500, "ff", "iid"), (0, "cg", "iid"), (0, "cg_correlated", "correlated")):
+        rd, _ = datasets.c3_relation_data(B, kind)
         eng = B.GibbsEngine(rd, D, seed=1, device=device, compute_ff_size=ff_size)
         eng.warm_device(30.0)
         for i in range(1, 6):
@@ -190,7 +191,8 @@ def c3_block(B, datasets, D, device, sweeps=20):
         it = eng.ent[0].cg_iters.cpu().numpy()
         b3 = sum(eng.k1_algorithmic_bytes(j) for j in range(len(eng.ent))) + (2 * int(it.max()) + 3) * 6040 * 500 * 8
         out[key] = {"ms_per_sweep": round(1e3 * dt, 4), "sweeps_per_s": round(1.0 / dt, 1), "native_iteration": bool(eng.native),
-                    "roofline": config_roofline("c3_" + key, b3, 1e3 * dt),
+                    "roofline": config_roofline("c3_" + ("cg" if key.startswith("cg") else key), b3, 1e3 * dt),
+                    "features": "iid N(0,1), seed 4242" if kind == "iid" else "correlated: Z W + 0.1 E, Z 6040 x 20 (seeds 4243 / 4244)",
                     "solver": "direct: F'F = Q diag(s) Q' once, beta = Q ((Q' rhs) ./ (s + lambda)) per iteration" if ff_size else "conjugate gradients (compute_ff_size=0)",
                     "cg_iterations_last_sweep": [int(it.min()), int(it.max())]}
         eng.close()
@@ -386,6 +388,7 @@ def main():
                     help="engine set-up before the first warm-up step: full iterations whose results are discarded (the chain's state is "
                          "put back bit for bit), for this long; brings the device to its working state; 0 = none")
     ap.add_argument("--no-c4", action="store_true", help="skip the strong-scaling measurement on configuration C4")
+    ap.add_argument("--no-c4-uniform", action="store_true", help="skip configuration C4's uniform-column variant (SURVEY M-C4)")
     ap.add_argument("--no-c3", action="store_true", help="skip the C3 block (Macau with dense side information; one GPU only)")
     ap.add_argument("--no-mref", action="store_true", help="skip the block on the reference's own benchmark shape (one GPU only)")
     ap.add_argument("--no-c5", action="store_true", help="skip the C5 block (3-mode tensor + matrix sharing an entity with binary sparse "
@@ -638,13 +641,13 @@ def main():
     del eng, rd, rel, test
 
     # ---- strong scaling on configuration C4 ---------------------------------------------------------------------------------
-    if not args.no_c4:
+    def c4_variant(zipf_offset, columns, with_cpu):
         c4 = {"workload": f"synthetic {args.c4_rows} x {args.c4_cols}, {args.c4_nnz} observations (1% held out), BPMF D={args.c4_latent}, "
-                          f"alpha=2, {args.c4_sweeps}+{args.c4_sweeps} sweeps (SURVEY M-C4: bdf_synth_ratings seed 777, Zipf-like columns)",
+                          f"alpha=2, {args.c4_sweeps}+{args.c4_sweeps} sweeps (SURVEY M-C4: bdf_synth_ratings seed 777, {columns} columns)",
               "n_gpus": world, "scaling": "strong"}
         try:
             t0 = time.time()
-            rd4 = datasets.c4_relation_data(B, args.c4_rows, args.c4_cols, args.c4_nnz)
+            rd4 = datasets.c4_relation_data(B, args.c4_rows, args.c4_cols, args.c4_nnz, zipf_offset=zipf_offset)
             t_gen = time.time() - t0
             rel4 = rd4.relations[0]
             t0 = time.time()
@@ -690,14 +693,23 @@ def main():
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
             eng4.close()
-            if not args.no_cpu_baseline and world == 1:         # (the CPU figures: one process only, as the main line's)
+            if with_cpu and not args.no_cpu_baseline and world == 1:         # (the CPU figures: one process only, as the main line's)
                 del eng4, test4
                 c4["cpu_baseline"] = c4_cpu_baseline(rel4, args.c4_latent)
         except Exception as e:      # noqa: BLE001 -- the BASELINE metric above must still be reported
             c4["error"] = f"{type(e).__name__}: {e}"
             print(f"[bench] rank {rank}: the C4 block failed: {c4['error']}", file=sys.stderr, flush=True)
+        return c4
+
+    if not args.no_c4:
+        c4 = c4_variant(100.0, "Zipf-like", True)
         if out is not None:
             out["c4"] = c4
+        # SURVEY M-C4's other column law: uniform columns (every item ~100 observations), same sizes, no CPU leg
+        if not args.no_c4_uniform:
+            c4u = c4_variant(0.0, "uniform", False)
+            if out is not None:
+                out["c4_uniform"] = c4u
     # ---- configuration C5: tensor + matrix sharing an entity with binary sparse features (strong scaling) -------------------
     if not args.no_c5:
         z5 = dict(zip(("nA", "nB", "nC", "nT", "n1", "n2", "n_feat", "feat_per_row"),
