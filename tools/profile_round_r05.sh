@@ -67,7 +67,7 @@ done
 cp $(find /tmp/c5prof -name "*kernel_stats.csv" | head -1) $out/c5_kernel_stats.csv
 (cd /tmp && rm -rf /tmp/mr && BDF_RESERVE_CUS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/mr -- python3 $R/tools/mref_probe.py > $out/mref_prof.txt 2>&1)
 cp $(find /tmp/mr -name "*kernel_stats.csv" | head -1) $out/mref_kernel_stats.csv
-(cd /tmp && rm -rf /tmp/c4prof && BDF_RESERVE_CUS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4prof -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-c3 --no-c5 --no-mref --k1-min-launches 0 > $out/c4_prof.txt 2>&1)
+(cd /tmp && rm -rf /tmp/c4prof && BDF_RESERVE_CUS=0 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/c4prof -- python3 $R/bench.py --steps 4 --warmup 4 --no-cpu-baseline --no-c3 --no-c5 --no-mref --no-c4-uniform --k1-min-launches 0 > $out/c4_prof.txt 2>&1)
 cp $(find /tmp/c4prof -name "*kernel_stats.csv" | head -1) $out/c4_kernel_stats.csv
 python3 - <<PY
 import csv, json
@@ -89,5 +89,9 @@ json.dump(out, open("$out/config_kernels.json", "w"), indent=1)
 print(json.dumps(out, indent=1))
 PY
 python3 tools/k1_alone.py > $out/k1_alone.txt 2>&1
+BDF_RESERVE_CUS=8 python3 tools/k1_alone.py 2>&1 | grep "K1 alone\|launches only" | sed 's/^/[248 CUs] /' >> $out/k1_alone.txt
+# ---- a timeline of steady-state iterations (kernel trace of every launch; the profiler's teardown may crash after the output is written)
+(cd /tmp && rm -rf /tmp/tl && rocprofv3 --kernel-trace --output-format csv -d /tmp/tl -- python3 $R/bench.py --steps 100 --warmup 100 --k1-min-launches 0 $B > $out/timeline_bench.log 2>&1)
+python3 tools/timeline_dump.py $(find /tmp/tl -name "*kernel_trace.csv" | head -1) 4 20 > $out/timeline.txt 2>&1
 python3 tools/kstats.py $out/kernel_stats.csv 500 8
 tail -4 $out/k1_alone.txt
