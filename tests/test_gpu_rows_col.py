@@ -107,3 +107,47 @@ def test_col_rows_shards_repeats_and_default_piece(B, O, ctx):
         ctx.set_col_rows(-1)
         ctx.set_lowrank(-1, 8192)
     dr.close()
+
+
+def test_col_rows_piece_size_follows_the_entity_and_not_the_shard(B, O, ctx):
+    """An entity of many observations takes larger pieces (bdf_launch_sample_rows: its observation count over 8 x 2,048 nominal slots,
+    between 128 and 2,048) -- here 600 rows of 4,200 observations at D = 30, 2.5 M in all: T = 192, every row spans waves in six parts.
+    The cut comes from the WHOLE entity's count: three shards write the bits of one launch, and the library reports the dispatch
+    (bdf_ctx_rows_dispatch).  Against the oracle at 1e-8."""
+    D = 30
+    rng = np.random.default_rng(4200)
+    dims = [600, 9000]
+    per = 4200
+    rows = np.repeat(np.arange(1, dims[0] + 1), per)
+    cols = np.concatenate([np.sort(rng.choice(dims[1], per, replace=False)) + 1 for _ in range(dims[0])])
+    ids = np.stack([rows, cols], axis=1).astype(np.int64)
+    vals = rng.random(len(rows))
+    dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), dims))
+    facs = [rng.standard_normal((d, D)) * 0.3 for d in dims]
+    ft = [ctx.tensor(f) for f in facs]
+    A = rng.standard_normal((D, D))
+    Lam, mu = A @ A.T / D + np.eye(D), rng.standard_normal(D)
+    alpha, mean = 1.3, float(vals.mean())
+    N = dims[0]
+    terms = _dev_terms(B, ctx, [(dr, 0, alpha, mean, [None, ft[1]], None)])
+    ot = O.Term(ids, vals, dims, 0, alpha, mean, [None, facs[1]])
+    Lam_t, mu_t = ctx.tensor(Lam), ctx.tensor(mu)
+    ctx.set_lowrank(0, 0)
+    try:
+        ctx.set_sweep(5)
+        one = ctx.zeros(N, D)
+        _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 9, one)
+        d = ctx.rows_dispatch(9)
+        assert d["col"] == N and d["k1"] == 0
+        T = (len(rows) // (2048 * 8) + 63) // 64 * 64
+        assert T == 192 and d["col_waves"] == N * -(-per // (4 * T))
+        parts = ctx.zeros(N, D)
+        for s in range(3):
+            _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 9, parts, shard=s, n_shards=3)
+        exp = O.sample_rows(D, N, [ot], mu, Lam, SEED, 5, 9)
+        np.testing.assert_allclose(one.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+        assert np.array_equal(one.cpu().numpy(), parts.cpu().numpy())
+        assert ctx.rows_unfinished() == 0
+    finally:
+        ctx.set_lowrank(-1, 8192)
+    dr.close()
