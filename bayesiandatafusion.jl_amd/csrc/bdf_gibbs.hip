@@ -23,7 +23,6 @@
 
 struct bdf_gibbs {
     bdf_ctx *rows, *hyper, *pred;        // rows: the caller's context; hyper / pred: owned (own streams)
-    bdf_ctx *hyper2 = nullptr;           // nullable: a second hyperprior stream on the same reserved CUs, for the odd entities (bdf_gibbs_create)
     int D;
     struct Ent {
         bdf_gibbs_entity d;
@@ -135,22 +134,16 @@ int streams_overlap(hipStream_t a, hipStream_t b, bool *yes)
 // used (torch: allocator pools per stream, events recorded on it) beyond the life of the context that ran on it, and
 // destroying it under them crashes at the framework's own teardown.  Slot k of (device, reserve, role) is always the same
 // stream, so later engines of a process pick the same streams as the first.
-// low_priority: a stream of the lowest priority the device offers, on ALL CUs (the runtime has no call that gives a stream both
-// a CU mask and a priority) -- for work that should only take the slots the row kernels leave free.
-int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t *out, bool low_priority = false)
+int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t *out)
 {
     static std::mutex mu;
     static std::map<std::tuple<int, int, int, int>, hipStream_t> pool;
     std::lock_guard<std::mutex> lock(mu);
-    const auto key = std::make_tuple(device, low_priority ? -1 : reserve, reserved ? 1 : 0, slot);
+    const auto key = std::make_tuple(device, reserve, reserved ? 1 : 0, slot);
     auto it = pool.find(key);
     if (it != pool.end()) { *out = it->second; return BDF_OK; }
     hipStream_t st;
-    if (low_priority) {
-        int least = 0, greatest = 0;
-        BDF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        BDF_HIP(hipStreamCreateWithPriority(&st, hipStreamNonBlocking, least));
-    } else if (reserve <= 0) {
+    if (reserve <= 0) {
         BDF_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     } else {
         hipDeviceProp_t prop;
@@ -166,14 +159,14 @@ int pooled_stream(int device, int reserve, bool reserved, int slot, hipStream_t 
     return BDF_OK;
 }
 
-int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bool reserved, bdf_ctx **out, bool low_priority = false)
+int make_side_ctx(bdf_ctx *main, const std::vector<bdf_ctx *> &apart, bool reserved, bdf_ctx **out)
 {
     // a few candidate streams; the first that overlaps with the row stream and with every stream in `apart`
     bdf_ctx *fallback = nullptr;
     for (int attempt = 0; attempt < 8; attempt++) {
         hipStream_t st;
         // slot 0 of the unreserved role is the row stream itself
-        int rc = pooled_stream(main->device, main->reserve_cus, reserved, attempt + 1, &st, low_priority);
+        int rc = pooled_stream(main->device, main->reserve_cus, reserved, attempt + 1, &st);
         if (rc) return rc;
         if (st == main->stream) continue;
         bool taken = false;
@@ -259,21 +252,9 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
     g->n_pred = 0; g->comm = nullptr; g->ready_dev = nullptr; g->polling = false;
     g->debug = false; g->host_wait_us = g->host_enqueue_us = 0.0; g->n_sweeps = 0;
     int rc;
-    static const bool pred_low = getenv("BDF_PRED_PRIORITY") && !strcmp(getenv("BDF_PRED_PRIORITY"), "low");
-    if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred, pred_low))) { bdf_gibbs_destroy(g); return rc; }
+    if ((rc = make_side_ctx(rows_ctx, {}, true, &g->hyper)) || (rc = make_side_ctx(rows_ctx, {g->hyper}, false, &g->pred))) { bdf_gibbs_destroy(g); return rc; }
     g->ready_dev = nullptr;
     g->polling = rows_ctx->reserve_cus > 0 && g->hyper->on_reserved && !getenv("BDF_NO_POLL");
-    // BDF_HYPER_STREAMS=2: a second hyperprior stream for the odd entities (same reserved CUs).  One stream carries an entity's chain
-    // behind the previous entity's: ~32 us of kernel plus ~9.5 us from one chain's end to the next one's start is 42 us of stream
-    // per chain, 84 per iteration of two entities -- as much as the two row launches with the prediction update beside them
-    // (profiles/r05_timeline.txt).  With a stream of its own an entity's chain starts ~12 us after its rows end and is ready before
-    // its next row launch starts -- and the iteration is no faster (11.4-11.8 k sweeps/s against 11.9 k): the row launches
-    // themselves are what is left (34 + 40 us of kernel and two gaps of 5-6 us).  Off by default.
-    static const int hyper_streams = getenv("BDF_HYPER_STREAMS") ? atoi(getenv("BDF_HYPER_STREAMS")) : 1;
-    if (hyper_streams >= 2 && n_entities >= 2 && g->hyper->on_reserved && !getenv("BDF_NO_POLL")) {
-        if ((rc = make_side_ctx(rows_ctx, {g->hyper, g->pred}, true, &g->hyper2))) { bdf_gibbs_destroy(g); return rc; }
-        if (g->hyper2 && (!g->hyper2->on_reserved || g->hyper2->stream == g->hyper->stream)) { bdf_ctx_destroy(g->hyper2); g->hyper2 = nullptr; }
-    }
     if (g->polling) {
         bool conc = false;
         if ((rc = streams_concurrent(rows_ctx->stream, g->hyper->stream, &conc))) { bdf_gibbs_destroy(g); return rc; }
@@ -320,7 +301,6 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
     if (g->rel_sse) (void)hipFree(g->rel_sse);
     if (g->pred) bdf_ctx_destroy(g->pred);
     if (g->hyper) bdf_ctx_destroy(g->hyper);
-    if (g->hyper2) bdf_ctx_destroy(g->hyper2);
     delete g;
     return BDF_OK;
 }
@@ -573,7 +553,6 @@ extern "C" int bdf_gibbs_warm_device(bdf_gibbs *g, double milliseconds)
     }
     BDF_HIP(hipStreamSynchronize(R->stream));
     R->sweep_host = g->hyper->sweep_host = g->pred->sweep_host = keep;
-    if (g->hyper2) g->hyper2->sweep_host = keep;
     return rc;
 }
 
@@ -625,7 +604,6 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     const int D = g->D, n = (int)g->ent.size();
     int rc;
     R->sweep_host = H->sweep_host = P->sweep_host = sweep;
-    if (g->hyper2) g->hyper2->sweep_host = sweep;
     // The row kernels of the NEXT sweep overwrite the buffers that held the rows of sweep - 2, which the prediction update of
     // sweep - 2 reads.  The HOST waits here until an update of some sweeps ago has completed (normally it has, long ago): the
     // device then needs no wait for the prediction stream anywhere, and the host never runs more than a few prediction updates
@@ -675,9 +653,6 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
     for (int j = 0; j < n; j++) {
         auto &E = g->ent[(size_t)j];
         const bdf_gibbs_entity &e = E.d;
-        // the odd entities' chains on the second hyperprior stream (when the chain's launch makes its own random part: nothing of
-        // an entity's chain then depends on another entity's; one rank)
-        bdf_ctx *const H = (g->hyper2 && draws_in_chain && !g->comm && (j & 1)) ? g->hyper2 : g->hyper;
         // (mu, Lambda) of the previous iteration: an event wait, or -- draws on reserved CUs -- the row kernel polls for it
         // (with side information the prior mean is a matrix, computed here from mu: nothing to poll for)
         // (several ranks: event waits unless BDF_POLL_WITH_COMM is set -- the draws of an iteration depend on nothing the rows of
@@ -768,11 +743,6 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
             const auto &O = g->ent[(size_t)g->test_entity[k]];
             fac[k] = O.d.sample[O.cur];
         }
-        // (BDF_PRED_DELAY_US: the update held back by a one-wave timer kernel, so that its workgroups come when the next row launch
-        // is resident and take the slots its first waves leave -- a 126-register wave of the update on a SIMD keeps a second
-        // 240-register wave of K1c off it)
-        static const long long pred_delay = getenv("BDF_PRED_DELAY_US") ? atoll(getenv("BDF_PRED_DELAY_US")) * 100 : 0;
-        if (pred_delay > 0) hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, P->stream, pred_delay);
         // (phase 3, set-up only: the same kernel on the same pairs, statistics of this sample into stats_dev, no running state)
         if ((rc = predict_phase == 3 ? bdf_predict_sse(P, g->test, D, fac, g->test_mean, nullptr, g->stats_dev)
                                      : bdf_predict_update(P, g->test, D, fac, g->test_mean, predict_phase, g->clamp_lo, g->clamp_hi, g->class_cut, g->stats_dev)))
@@ -795,6 +765,5 @@ extern "C" int bdf_gibbs_sync(bdf_gibbs *g)
     BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_sync: NULL argument");
     int rc;
     if ((rc = bdf_ctx_sync(g->pred)) || (rc = bdf_ctx_sync(g->hyper))) return rc;
-    if (g->hyper2 && (rc = bdf_ctx_sync(g->hyper2))) return rc;
     return bdf_ctx_sync(g->rows);
 }
