@@ -159,6 +159,10 @@ struct bdf_feat {
     // CSR (rows) and CSC (= CSR of F') so that neither product needs atomics
     int64_t *rowptr_dev; int32_t *colind_dev; double *rvals_dev;
     int64_t *colptr_dev; int32_t *rowind_dev; double *cvals_dev;
+    // column panels of the sparse products (k_feat.hip, spmm): entries of row r with a column in panel p are
+    // [panel_ptr[p * rows + r], panel_ptr[(p + 1) * rows + r]) -- NULL when the operand is small or a row's entries are not in column order
+    int64_t *panel_fwd_dev; int n_panels_fwd;      // F   (rows m, panels over the n columns)
+    int64_t *panel_tr_dev; int n_panels_tr;        // F'  (rows n, panels over the m columns)
     double *FF_dev;       // n x n (F'F), built on first use_ff
     int32_t *row_ids_dev; // nullable (bdf_feat_set_row_ids): original id of every row of F, keys the rows' noise streams
     double *chol_ws;      // workspace of the blocked direct solve (k_chol.hip), allocated on first use

@@ -315,7 +315,11 @@ struct SpmmArgs {
     const double *B; int64_t brs, bcs;
     double *Y; int64_t yrs, ycs;
     const double *bias; double *Y2;
+    const int64_t *panel_ptr = nullptr; int n_panels = 0;     // column panels of the sparse operand (bdf_feat::panel_*), or none
 };
+
+// rows of B per column panel: 3 MiB of a 32-column operand (a 4 MiB XCD L2 keeps the panel beside the streams of the launch)
+#define BDF_SPMM_PANEL_ROWS 12288
 
 // B(i,c) at B[i*ldb + c], Y(r,c) at Y[r*ldy + c].  32 lanes walk the columns, 8 rows per block; the row's nonzeros four at a
 // time (independent gathers), accumulated in order (the result does not depend on the unrolling).
@@ -380,30 +384,40 @@ template <bool HASV>
 __global__ __launch_bounds__(256) void k_spmm_rm16(int64_t m, int ncol, const int64_t *__restrict__ rowptr,
                                                    const int32_t *__restrict__ colind, const double *__restrict__ vals,
                                                    const double *__restrict__ B, int64_t ldb, double *__restrict__ Y, int64_t ldy,
-                                                   const double *__restrict__ bias, double *__restrict__ Y2, const int *skip)
+                                                   const double *__restrict__ bias, double *__restrict__ Y2, const int *skip,
+                                                   const int64_t *__restrict__ pb, const int64_t *__restrict__ pe, int first)
 {
     if (skip && *skip == 0) return;
     const int l = threadIdx.x & 15;
     const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
     const bool rv = r < m;                       // (every lane stays: the broadcasts run over whole lane rows)
-    const int64_t beg = rv ? rowptr[r] : 0, end = rv ? rowptr[r + 1] : 0;
+    // pb / pe: this launch takes the row's entries [pb[r], pe[r]) -- one column panel of the operand -- and carries the row's running
+    // sums on from Y unless it is the first panel (the entries of a row in column order: the same sums in the same order as one pass)
+    const int64_t beg = rv ? (pb ? pb[r] : rowptr[r]) : 0, end = rv ? (pb ? pe[r] : rowptr[r + 1]) : 0;
     const int c = 2 * l;
     const bool cv = c < ncol;
     double a0 = 0.0, a1 = 0.0;
+    if (!first && rv && cv) { const spd2 y = *(const spd2 *)(Y + r * ldy + c); a0 = y[0]; a1 = y[1]; }
     // (the longest row of the wave sets the trip count: wave-uniform, the DPP instructions never sit under a divergent branch)
     int64_t nq = end - beg;
     nq = max(nq, __shfl_xor(nq, 16));
     nq = max(nq, __shfl_xor(nq, 32));
     nq = __builtin_amdgcn_readfirstlane((int)nq);
+    // (the NEXT chunk's indices -- and values -- are loaded before this chunk's gathers are issued: a chunk then costs one dependent
+    // round trip, its gathers, instead of two)
+    int32_t myi = beg + l < end ? colind[beg + l] : 0;
+    double myv = 0.0;
+    if (HASV) myv = beg + l < end ? vals[beg + l] : 0.0;
     for (int64_t o = 0; o < nq; o += 16) {
-        const int64_t q = beg + o + l;
         const int left = (int)min((int64_t)16, end - beg - o);          // entries of this lane row's chunk (<= 0: none)
-        const int32_t myi = q < end ? colind[q] : 0;
-        double myv = 0.0;
-        if (HASV) myv = q < end ? vals[q] : 0.0;
+        const int64_t qn = beg + o + 16 + l;
+        const int32_t nxi = qn < end ? colind[qn] : 0;
+        double nxv = 0.0;
+        if (HASV) nxv = qn < end ? vals[qn] : 0.0;
         spd2 g[16];
         spmm_gather16<0>(g, myi, left, B, ldb, c, cv);
         spmm_acc16<HASV, 0>(g, myv, left, a0, a1);
+        myi = nxi; myv = nxv;
     }
     if (rv && cv) {
         *(spd2 *)(Y + r * ldy + c) = spd2{a0, a1};
@@ -484,10 +498,23 @@ int spmm(bdf_ctx *ctx, const SpmmArgs &s)
     const bool wide = wide_ok && s.ncol >= 2 && s.ncol <= 32 && s.ncol % 2 == 0 && ldb % 2 == 0 && ldy % 2 == 0 && ((uintptr_t)B & 15) == 0 &&
                       ((uintptr_t)Y & 15) == 0 && (!(y_rm && s.Y2) || (((uintptr_t)s.Y2 & 15) == 0));
     if (wide) {
-        if (s.vals) hipLaunchKernelGGL(k_spmm_rm16<true>, dim3((unsigned)((s.m + 15) / 16)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind,
-                                       s.vals, B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
-        else hipLaunchKernelGGL(k_spmm_rm16<false>, dim3((unsigned)((s.m + 15) / 16)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind,
-                                s.vals, B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
+        // a gathered operand of several L2 sizes: one launch per COLUMN PANEL of it (3 MiB: every XCD's L2 holds the panel its workgroups
+        // gather from, 23 TB/s of 16-byte lanes instead of the Infinity Cache's 8.6), the rows' running sums carried through Y
+        static const bool panels_ok = !(getenv("BDF_SPMM_PANELS") && atoi(getenv("BDF_SPMM_PANELS")) == 0);
+        static const int max_panels = getenv("BDF_SPMM_MAX_PANELS") ? atoi(getenv("BDF_SPMM_MAX_PANELS")) : 64;
+        const int np = (panels_ok && s.panel_ptr && s.n_panels >= 2 && s.n_panels <= max_panels &&
+                        (size_t)s.kin * s.ncol * sizeof(double) >= ((size_t)8 << 20)) ? s.n_panels : 1;
+        const dim3 grid((unsigned)((s.m + 15) / 16));
+        for (int p = 0; p < np; p++) {
+            const int64_t *pb = np > 1 ? s.panel_ptr + (size_t)p * s.m : nullptr, *pe = np > 1 ? s.panel_ptr + (size_t)(p + 1) * s.m : nullptr;
+            const bool last = p == np - 1;
+            const double *bias = (last && y_rm) ? s.bias : nullptr;
+            double *Y2 = (last && y_rm) ? s.Y2 : nullptr;
+            if (s.vals) hipLaunchKernelGGL(k_spmm_rm16<true>, grid, dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind, s.vals, B, ldb, Y, ldy,
+                                           bias, Y2, ctx->skip_flag, pb, pe, p == 0 ? 1 : 0);
+            else hipLaunchKernelGGL(k_spmm_rm16<false>, grid, dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind, s.vals, B, ldb, Y, ldy,
+                                    bias, Y2, ctx->skip_flag, pb, pe, p == 0 ? 1 : 0);
+        }
     } else
     hipLaunchKernelGGL(k_spmm_rm, dim3((unsigned)((s.m + 7) / 8)), dim3(256), 0, ctx->stream, s.m, s.ncol, s.rowptr, s.colind, s.vals,
                        B, ldb, Y, ldy, y_rm ? s.bias : nullptr, y_rm ? s.Y2 : nullptr, ctx->skip_flag);
@@ -517,6 +544,7 @@ int feat_apply(bdf_ctx *ctx, const bdf_feat *f, bool transpose, const double *B,
     s.colind = transpose ? f->rowind_dev : f->colind_dev;
     s.vals = f->kind == 1 ? (transpose ? f->cvals_dev : f->rvals_dev) : nullptr;
     s.B = B; s.brs = brs; s.bcs = bcs; s.Y = Y; s.yrs = yrs; s.ycs = ycs; s.bias = bias; s.Y2 = Y2;
+    s.panel_ptr = transpose ? f->panel_tr_dev : f->panel_fwd_dev; s.n_panels = transpose ? f->n_panels_tr : f->n_panels_fwd;
     return spmm(ctx, s);
 }
 
@@ -1261,12 +1289,35 @@ int create_sparse(bdf_ctx *ctx, int64_t m, int64_t n, int64_t nnz, const int32_t
     f->ctx = ctx; f->kind = vals ? 1 : 2; f->m = m; f->n = n; f->nnz = nnz;
     std::vector<int64_t> ptr; std::vector<int32_t> ind; std::vector<double> v;
     int rc;
+    // column panels (spmm): where each row's entries cross a multiple of BDF_SPMM_PANEL_ROWS columns -- only when every row's entries
+    // are in column order (the panels must keep the order of the row's sum) and the operand is large enough to be worth it
+    auto panels = [&](int64_t nmajor, int64_t nminor, int64_t **dev, int *np_out) -> int {
+        const int64_t P = (nminor + BDF_SPMM_PANEL_ROWS - 1) / BDF_SPMM_PANEL_ROWS;
+        *dev = nullptr; *np_out = 0;
+        if (P < 2 || P > 64 || (size_t)(P + 1) * nmajor * sizeof(int64_t) > ((size_t)256 << 20)) return BDF_OK;
+        std::vector<int64_t> pp((size_t)(P + 1) * nmajor);
+        for (int64_t r = 0; r < nmajor; r++) {
+            int64_t q = ptr[(size_t)r];
+            const int64_t e = ptr[(size_t)r + 1];
+            for (int64_t k = q + 1; k < e; k++)
+                if (ind[(size_t)k] < ind[(size_t)k - 1]) return BDF_OK;           // not in column order: one pass
+            for (int64_t p = 0; p <= P; p++) {
+                while (q < e && ind[(size_t)q] < p * BDF_SPMM_PANEL_ROWS) q++;
+                pp[(size_t)p * nmajor + r] = (p == P) ? e : q;
+            }
+        }
+        int rc2 = upload_vec(pp, dev);
+        if (!rc2) *np_out = (int)P;
+        return rc2;
+    };
     build(rows, cols, m, ptr, ind, v);
     if ((rc = upload_vec(ptr, &f->rowptr_dev)) || (rc = upload_vec(ind, &f->colind_dev))) return rc;
     if (vals && (rc = upload_vec(v, &f->rvals_dev))) return rc;
+    if ((rc = panels(m, n, &f->panel_fwd_dev, &f->n_panels_fwd))) return rc;
     build(cols, rows, n, ptr, ind, v);
     if ((rc = upload_vec(ptr, &f->colptr_dev)) || (rc = upload_vec(ind, &f->rowind_dev))) return rc;
     if (vals && (rc = upload_vec(v, &f->cvals_dev))) return rc;
+    if ((rc = panels(n, m, &f->panel_tr_dev, &f->n_panels_tr))) return rc;
     guard.f = nullptr;
     *out = f;
     return BDF_OK;
@@ -1310,6 +1361,7 @@ extern "C" int bdf_feat_destroy(bdf_feat *f)
     hipStreamSynchronize(f->ctx->stream);
     hipFree(f->dense_dev); hipFree(f->rowptr_dev); hipFree(f->colind_dev); hipFree(f->rvals_dev);
     hipFree(f->colptr_dev); hipFree(f->rowind_dev); hipFree(f->cvals_dev); hipFree(f->FF_dev); hipFree(f->chol_ws);
+    hipFree(f->panel_fwd_dev); hipFree(f->panel_tr_dev);
     hipFree(f->row_ids_dev); hipFree(f->gather_dev);
     if (f->eig_Q) { hipFree(f->eig_Q->dense_dev); delete f->eig_Q; }
     hipFree(f->eig_s); hipFree(f->eig_y);

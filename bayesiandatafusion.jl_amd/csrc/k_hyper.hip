@@ -196,7 +196,13 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     // the caller enqueues the draw next and lets it add the partials (bdf_gibbs_sweep): at most 16 of them, for entities small
     // enough that 16 workgroups read them quickly
     const bool fuse = fuse_asked && N <= 16384;
-    const int64_t rpb = HS_ROWS * ((chunks + (fuse ? 15 : 2047)) / (fuse ? 16 : 2048));
+    static const bool one_launch_ = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
+    // the one-launch chain (k_hyper_chain): its workgroups -- the draws' (D^2 + D entries, 256 each), the partial sums', the last one --
+    // should all be resident at once on the stream's CUs (two workgroups of 255 registers per CU: 16 on the 8 reserved CUs), or the
+    // partial sums take two rounds and the last workgroup gets its slot when the first round ends (9.3 us of the chain at D = 32)
+    const int wg_slots = 2 * (ctx->on_reserved && ctx->reserve_cus > 0 ? ctx->reserve_cus : 8);
+    const int max_part = (fuse && one_launch_) ? std::max(8, std::min(16, wg_slots - 1 - (D * D + D + 255) / 256)) : 16;
+    const int64_t rpb = HS_ROWS * ((chunks + (fuse ? max_part - 1 : 2047)) / (fuse ? max_part : 2048));
     const int nblocks = (int)std::max<int64_t>(1, (N + rpb - 1) / rpb);
     const int DP = D <= 16 ? 16 : (D <= 32 ? 32 : 64);
     const int psz = DP == 16 ? HGeo<16>::PSZ : (DP == 32 ? HGeo<32>::PSZ : HGeo<64>::PSZ);
@@ -204,7 +210,7 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     int rc = bdf_scratch(ctx, (size_t)nblocks * psz * sizeof(double), &scratch);
     if (rc) return rc;
     double *part = (double *)scratch;
-    static const bool one_launch = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
+    const bool one_launch = one_launch_;
     if (fuse && one_launch) {
         // left to the bdf_hyper_sample that follows: one launch for the whole chain (k_hyper_chain)
         ctx->hyper_chain = true;
