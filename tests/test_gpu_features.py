@@ -323,3 +323,37 @@ def test_cg_one_launch_solve_matches_the_two_launch_solve_and_the_oracle(B, O, N
     # the oracle's literal cg_AtA on the same right-hand side (two products with F per iteration): same solution to the solver's tolerance
     beta_o, _, _ = O.sample_beta(O.Feat.from_dense(a["F"]), a["sample"], a["mu"], a["Lam"], 0.6, False, None, 77, 4, 3)
     np.testing.assert_allclose(a["beta_tight"].reshape(D, numF).T, beta_o, rtol=1e-6, atol=1e-8)
+
+
+@pytest.mark.parametrize("kind", ["bin", "csr"])
+def test_sparse_products_in_column_panels(B, ctx, kind):
+    """A gathered operand of 8 MiB and more is taken in column panels (k_feat.hip, spmm: 12,288 rows of it per launch, the rows'
+    running sums carried through the output) -- 40,000 x 40,000 with 24 entries per row, 32 columns: four panels in both
+    directions.  Against scipy at 1e-12 (sparsebin_csr.jl:49-63 / sparse_csr.jl semantics); and the same matrix given with every
+    row's entries in a shuffled order -- which the library takes in ONE pass: the panels must keep the order of a row's sum, so an
+    operand whose rows are not in column order is not panelled -- gives the same values to rounding."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    m = n = 40_000
+    per = 24
+    rows = np.repeat(np.arange(m), per)
+    cols = np.concatenate([np.sort(rng.choice(n, per, replace=False)) for _ in range(m)])
+    vals = np.ones(len(rows)) if kind == "bin" else rng.standard_normal(len(rows))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(m, n))
+    def make(r, c, v):
+        if kind == "bin":
+            return B.FeatOperator(ctx, B.SparseBinMatrix(m, n, r + 1, c + 1))
+        return B.FeatOperator(ctx, B.sparse_csr(r + 1, c + 1, v, m, n))
+    op = make(rows, cols, vals)
+    X = rng.standard_normal((n, 32))
+    Y = rng.standard_normal((m, 32))
+    fwd = _from_colmajor(op.mul(_colmajor(ctx, X)))
+    tr = _from_colmajor(op.mul(_colmajor(ctx, Y), transpose=True))
+    np.testing.assert_allclose(fwd, A @ X, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(tr, A.T @ Y, rtol=1e-12, atol=1e-12)
+    # the same matrix, every row's entries in a shuffled order: one pass (no panels), the same values to rounding
+    perm = np.concatenate([r0 + rng.permutation(per) for r0 in range(0, m * per, per)])
+    op2 = make(rows[perm], cols[perm], vals[perm])
+    fwd2 = _from_colmajor(op2.mul(_colmajor(ctx, X)))
+    np.testing.assert_allclose(fwd2, fwd, rtol=1e-12, atol=1e-12)
+    op.close(); op2.close()
