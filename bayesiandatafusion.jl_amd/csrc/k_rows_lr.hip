@@ -132,39 +132,57 @@ __global__ __launch_bounds__(64) void k_lr_prep(int D, const double *Lambda, con
 
 // ---- Y = X T for rows of D doubles (X, Y row-major with leading dimension D; T: DP x DP row-major, zero-padded), on the
 // matrix cores.  A tile is 16 rows; the DB = DP / 16 waves of a tile each take one 16-column block of the result and keep
-// their block of T in registers; the contraction runs over d = kk DP/4 + s (lane row kk, k-step s), so that a lane reads
-// DP/4 consecutive doubles of its row.  rows == nullptr: rows 0 .. n_rows-1; else the listed rows (entries < 0: none).
-// In place (Y == X) is allowed: every wave of a tile has read the tile before any of them writes (workgroup barrier).
+// their block of T in registers; the contraction runs over d = kk DP/4 + s (lane row kk, k-step s).  rows == nullptr: rows
+// 0 .. n_rows-1; else the listed rows (entries < 0: none).  In place (Y == X) is allowed: every wave of a tile has read the tile
+// before any of them writes (workgroup barrier).
+// The tile comes through LDS: its waves load it ONCE between them, 64 consecutive doubles per instruction (a lane reading the 128
+// bytes of its own row's quarter -- the operand layout -- touched 64 cache lines per instruction, eight instructions per line, in
+// every one of the tile's waves: configuration C4's back-transform of 9.75 M rows moved its 10 GB at 3 TB/s), and every wave reads
+// its operands back from there; the next tile's loads are in flight under this tile's matrix instructions and stores.
 template <int DP>
 __global__ __launch_bounds__(256) void k_rowmat(const double *X, double *Y, const double *__restrict__ T, int D, int ldy, const int32_t *__restrict__ rows,
                                                 int64_t n_rows, int64_t n_iters)
 {
-    constexpr int DB = DP / 16, KQ = DP / 4, TPW = 4 / DB;
+    constexpr int DB = DP / 16, KQ = DP / 4, TPW = 4 / DB, LDT = DP + 2;
+    __shared__ __attribute__((aligned(16))) double tile[TPW][16 * LDT];
+    __shared__ int64_t tile_rows[TPW][16];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i = lane & 15, kk = lane >> 4;
     const int sub = wave / DB, cb = wave % DB;
     double b[KQ];
 #pragma unroll
     for (int s = 0; s < KQ; s++) b[s] = T[(kk * KQ + s) * DP + 16 * cb + i];
-    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
-        const int64_t r = (it * TPW + sub) * 16 + i;
-        int64_t row = -1;
-        if (r < n_rows) row = rows ? (int64_t)rows[r] : r;
-        double a[KQ];
-        if (row >= 0) {
-            const double *src = X + row * D + kk * KQ;
-            if (D == DP) {
+    // this wave's share of its tile's loads: rows cb * 16 / DB .. of the tile, 64 consecutive doubles per instruction
+    int trow[4], tcol[4];
 #pragma unroll
-                for (int s = 0; s < KQ; s += 2) { const d2 v = *(const d2 *)(src + s); a[s] = v[0]; a[s + 1] = v[1]; }
-            } else {
+    for (int q = 0; q < 4; q++) {
+        const int E = cb * (16 / DB) * DP + q * 64 + lane;
+        trow[q] = E / DP; tcol[q] = E % DP;
+    }
+    auto tile_row = [&](int64_t it, int r16) -> int64_t {
+        const int64_t r = (it * TPW + sub) * 16 + r16;
+        return (it < n_iters && r < n_rows) ? (rows ? (int64_t)rows[r] : r) : -1;
+    };
+    auto tile_load = [&](double (&g)[4], int64_t it) {
 #pragma unroll
-                for (int s = 0; s < KQ; s++) a[s] = (kk * KQ + s < D) ? src[s] : 0.0;
-            }
-        } else {
-#pragma unroll
-            for (int s = 0; s < KQ; s++) a[s] = 0.0;
+        for (int q = 0; q < 4; q++) {
+            const int64_t row = tile_row(it, trow[q]);
+            g[q] = (row >= 0 && tcol[q] < D) ? X[row * D + tcol[q]] : 0.0;
         }
-        __syncthreads();
+    };
+    double g[4];
+    tile_load(g, blockIdx.x);
+    for (int64_t it = blockIdx.x; it < n_iters; it += gridDim.x) {
+        const int64_t myrow = tile_row(it, i);
+#pragma unroll
+        for (int q = 0; q < 4; q++) tile[sub][trow[q] * LDT + tcol[q]] = g[q];
+        if (cb == 0 && kk == 0) tile_rows[sub][i] = myrow;
+        __syncthreads();                               // the tile is in LDS: every global read of it has completed (in place: before any write)
+        tile_load(g, it + gridDim.x);                  // the next tile's rows, under this tile's matrix instructions
+        double a[KQ];
+        const double *src = &tile[sub][i * LDT + kk * KQ];
+#pragma unroll
+        for (int s = 0; s < KQ; s += 2) { const d2 v = *(const d2 *)(src + s); a[s] = v[0]; a[s + 1] = v[1]; }
         d4 acc = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
         for (int s = 0; s < KQ; s++) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[s], b[s], acc, 0, 0, 0);
@@ -172,9 +190,10 @@ __global__ __launch_bounds__(256) void k_rowmat(const double *X, double *Y, cons
         const int col = 16 * cb + i;
 #pragma unroll
         for (int rr = 0; rr < 4; rr++) {
-            const int64_t rowm = __shfl((long long)row, kk + 4 * rr);
+            const int64_t rowm = tile_rows[sub][kk + 4 * rr];
             if (rowm >= 0 && col < ldy) Y[rowm * ldy + col] = acc[rr];       // (columns D .. ldy-1: zeros, T is zero-padded)
         }
+        __syncthreads();                               // every wave has read the tile from LDS: the next one may be written
     }
 }
 

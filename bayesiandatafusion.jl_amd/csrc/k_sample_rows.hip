@@ -910,6 +910,10 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         std::stable_sort(lr.begin(), lr.end(), [](const SmallItem &x, const SmallItem &y) { return x.count > y.count; });
         std::vector<int32_t> lr_rows(lr.size());
         for (size_t i = 0; i < lr.size(); i++) lr_rows[i] = lr[i].row;
+        // (the positions in ASCENDING order: they are what the dense passes over the rows walk -- the back-transform x = L^-T q and
+        // the per-row prior means -- and a pass over rows in the sampler's order, longest first, reads and writes 512-byte rows at
+        // random: configuration C4's back-transform of 9.75 M rows moved its 10 GB at 3 TB/s)
+        std::sort(lr_rows.begin(), lr_rows.end());
         while (lr.size() % 4) lr.push_back(SmallItem{-1, 0, 0, 0, 0});      // four rows per wave
         plan.n_lr_padded = (int64_t)lr.size();
         if ((rc = to_device(lr, &plan.lr_dev)) || (rc = to_device(lr_rows, &plan.lr_rows_dev))) return rc;
