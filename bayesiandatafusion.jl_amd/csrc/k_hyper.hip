@@ -26,7 +26,9 @@ __global__ __launch_bounds__(HS_THREADS) void k_hyper_partial(int D, int64_t N, 
                                                                const double *__restrict__ uhat, double *__restrict__ partial)
 {
     __shared__ double red[3 * HGeo<DP>::PSZ];
-    __builtin_amdgcn_s_setprio(3);      // small and on the sweep's critical path, usually beside a chip-filling K1 launch
+    // small and on the sweep's critical path, usually beside a chip-filling K1 launch: ahead of it at the issue port -- but not the sums
+    // of a large entity (thousands of workgroups beside the other entity's rows: they would only take the rows' issue slots)
+    if (gridDim.x <= 64) __builtin_amdgcn_s_setprio(3);
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     const int64_t r1 = r0 + rows_per_block < N ? r0 + rows_per_block : N;
     hyper_partial<DP, 4>(D, N, sample, uhat, r0, r1, partial + (int64_t)blockIdx.x * HGeo<DP>::PSZ, red, threadIdx.x);
