@@ -194,8 +194,8 @@ extern "C" int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_
 
 extern "C" int bdf_ctx_set_lowrank(bdf_ctx *ctx, int max_observations, int64_t min_rows)
 {
-    BDF_REQUIRE(ctx && max_observations >= -1 && max_observations <= 16 && min_rows >= 0, BDF_ERR_ARG,
-                "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..16");
+    BDF_REQUIRE(ctx && max_observations >= -1 && max_observations <= 32 && min_rows >= 0, BDF_ERR_ARG,
+                "bdf_ctx_set_lowrank: max_observations must be -1 (default), 0 (off) or 1..32");
     ctx->lr_max = max_observations;
     ctx->lr_min_rows = min_rows;
     return BDF_OK;

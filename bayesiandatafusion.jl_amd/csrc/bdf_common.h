@@ -374,9 +374,10 @@ struct SampleArgs {
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump);
-int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded,
+int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded, int64_t n32_padded,
                   const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1);
 int bdf_lr_max_observations();
+int bdf_lr32_max_observations();
 void bdf_plans_release(bdf_ctx *ctx, uint64_t rel_serial);
 
 // ---- K1c (k_rows_col.hip): four rows per wave in the column layout ----------------------------------------------------

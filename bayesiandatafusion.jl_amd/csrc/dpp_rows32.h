@@ -24,6 +24,20 @@ __device__ __forceinline__ int sys_off(int j)
     }
 }
 
+// ---- a rank-1 update v v' of the three stored blocks (0,0), (1,0), (1,1): lane j holds v0 = v_j and v1 = v_(16+j) (k_rows_col: an observation;
+// k_rows_lr32: an element of the two observations a lane streams) ----
+template <int DR, int I>
+__device__ __forceinline__ void col_rank1(double (&A0)[33], double (&A1)[33], double v0, double v1)
+{
+    if constexpr (I < 16) {
+        if constexpr (I == 0) fm1<0>(A0[0], v0, v0); else fm1_run<I>(A0[I], v0, v0);      // (i, j)      += v_i v_j
+        if constexpr (16 + I < DR) {
+            fm1_run<I>(A0[16 + I], v1, v0);                                               // (16+i, j)   += v_(16+i) v_j
+            fm1_run<I>(A1[16 + I], v1, v1);                                               // (16+i,16+j) += v_(16+i) v_(16+j)
+        }
+        col_rank1<DR, I + 1>(A0, A1, v0, v1);
+    }
+}
 // rows I .. DR-1 and the extra row 32 of step k = 16 S + K: A_s[I] -= A[I][k] * A[k][c_s] / d_k
 template <int DR, int S, int K, int I, bool FIRST>
 __device__ __forceinline__ void fin_elim(double (&A0)[33], double (&A1)[33], double nm0, double nm1)

@@ -47,19 +47,6 @@
 
 namespace {
 
-// ---- one observation: the rank-1 update of the three stored blocks and of the right-hand side -------------------------
-template <int DR, int I>
-__device__ __forceinline__ void col_rank1(double (&A0)[33], double (&A1)[33], double v0, double v1)
-{
-    if constexpr (I < 16) {
-        if constexpr (I == 0) fm1<0>(A0[0], v0, v0); else fm1_run<I>(A0[I], v0, v0);      // (i, j)      += v_i v_j
-        if constexpr (16 + I < DR) {
-            fm1_run<I>(A0[16 + I], v1, v0);                                               // (16+i, j)   += v_(16+i) v_j
-            fm1_run<I>(A1[16 + I], v1, v1);                                               // (16+i,16+j) += v_(16+i) v_(16+j)
-        }
-        col_rank1<DR, I + 1>(A0, A1, v0, v1);
-    }
-}
 // K: the observation's position in its chunk of 16 (lane K of the lane row holds its value minus the mean)
 template <int DR, int K>
 __device__ __forceinline__ void col_obs(double (&A0)[33], double (&A1)[33], double v0, double v1, double r)

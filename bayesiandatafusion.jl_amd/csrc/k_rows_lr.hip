@@ -31,6 +31,7 @@
 #include "wave_linalg.h"
 #include "c_layout_chol.h"
 #include "dpp_rows16.h"
+#include "dpp_rows32.h"
 
 namespace {
 
@@ -497,6 +498,128 @@ __global__ __launch_bounds__(256, 3) void k_rows_lr4(LrArgs a, const LrItem *__r
     else lr4_body<DP, 16>(a, it, j);
 }
 
+// ---- ROWS OF 17 .. 32 OBSERVATIONS (D > 32): four rows per wave still, a lane row per entity row, lane b of it taking observations b
+// AND 16 + b -- the 32 x 32 Gram system in K1c's layout (dpp_rows32.h: lane b holds columns b and 16 + b).  The two rows of Vt stream
+// through registers eight elements at a time; every ELEMENT d is one rank-1 update of the three stored blocks (col_rank1: 48 fmac_dpp)
+// and of Wt' e0 (the system's extra row); block (0,1) is block (1,0)'s transpose through LDS; G = I + alpha Wt' Wt, rho rides along
+// through K1c's LDL' (fin_factor) and backward solve (fin_backward: tau); q = e0 + alpha Wt tau takes the element-major second read.
+// Normals: u as k_rows_lr4; delta_a = pair DP / 2 + a / 2, element a % 2 (orc_lowrank_normals' assignment for every a).
+template <int DP, int C, int U>
+__device__ __forceinline__ void lr32_gram_el(double (&A0)[33], double (&A1)[33], const double (&e0)[DP / 16], const double (&W0c)[8], const double (&W1c)[8])
+{
+    if constexpr (U < 8) {
+        const double w0 = W0c[U], w1 = W1c[U];
+        col_rank1<32, 0>(A0, A1, w0, w1);                                // G[., b] += wt_d[.] wt_d[b], G[., 16 + b] += wt_d[.] wt_d[16 + b]
+        constexpr int d = 8 * C + U;
+        fm1_run<d % 16>(A0[32], e0[d / 16], w0);                         // (Wt' e0)_b      += e0_d wt_d[b]
+        fm1_run<d % 16>(A1[32], e0[d / 16], w1);                         // (Wt' e0)_(16+b) += e0_d wt_d[16 + b]
+        lr32_gram_el<DP, C, U + 1>(A0, A1, e0, W0c, W1c);
+    }
+}
+template <int DP, int C>
+__device__ __forceinline__ void lr32_gram(double (&A0)[33], double (&A1)[33], const double (&e0)[DP / 16], double (&W0)[2][8], double (&W1)[2][8],
+                                          const d2 *rowp0, const d2 *rowp1)
+{
+    if constexpr (C < DP / 8) {
+        lr32_gram_el<DP, C, 0>(A0, A1, e0, W0[C & 1], W1[C & 1]);
+        if constexpr (C + 2 < DP / 8) { lr4_load<(C & 1), C + 2>(W0, rowp0); lr4_load<(C & 1), C + 2>(W1, rowp1); }
+        lr32_gram<DP, C + 1>(A0, A1, e0, W0, W1, rowp0, rowp1);
+    }
+}
+template <int DP, int A0I>
+__device__ __forceinline__ void lr32_phase_c(double (&q)[DP / 16], uint32_t idw0, uint32_t idw1, const double *vt, int j, double tau0, double tau1)
+{
+    if constexpr (A0I < 32) {
+        double wc[4][DP / 16];
+        if constexpr (A0I < 16) { lr4_cgather<DP, A0I, 0>(wc, idw0, vt, j); lr4_cfma<DP, A0I, 0>(q, wc, tau0); }
+        else { lr4_cgather<DP, A0I - 16, 0>(wc, idw1, vt, j); lr4_cfma<DP, A0I - 16, 0>(q, wc, tau1); }
+        lr32_phase_c<DP, A0I + 4>(q, idw0, idw1, vt, j, tau0, tau1);
+    }
+}
+
+template <int DP>
+__global__ __launch_bounds__(256, 2) void k_rows_lr32(LrArgs a, const LrItem *__restrict__ items, int64_t n_items)
+{
+    constexpr int DB = DP / 16, NR = DP / 32;
+    __shared__ double lds[4 * 4 * 272];                   // block (1,0) of the four systems of each wave on its way to block (0,1)
+    const int lane = threadIdx.x & 63, j = lane & 15, g = lane >> 4, wave = threadIdx.x >> 6;
+    const int64_t w = (int64_t)blockIdx.x * 4 + wave;
+    if (w * 4 >= n_items) return;
+    const LrItem it = items[w * 4 + g];
+    const bool live = it.row >= 0;
+    const int D = a.D, n = live ? it.count : 0;
+    const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
+    uint32_t idw0 = (uint32_t)a.zero_row, idw1 = (uint32_t)a.zero_row;
+    double rv0 = 0.0, rv1 = 0.0;
+    if (j < n) { idw0 = (uint32_t)a.colidx[it.q_begin + j]; rv0 = a.vals[it.q_begin + j] - a.mean; }
+    if (16 + j < n) { idw1 = (uint32_t)a.colidx[it.q_begin + 16 + j]; rv1 = a.vals[it.q_begin + 16 + j] - a.mean; }
+    const d2 *rowp0 = (const d2 *)(a.vt + (int64_t)idw0 * DP), *rowp1 = (const d2 *)(a.vt + (int64_t)idw1 * DP);
+    double W0[2][8], W1[2][8];
+    lr4_load<0, 0>(W0, rowp0); lr4_load<0, 0>(W1, rowp1);
+    lr4_load<1, 1>(W0, rowp0); lr4_load<1, 1>(W1, rowp1);
+    // the normals under the first loads
+    double e0[DB];
+#pragma unroll
+    for (int r = 0; r < NR; r++) {
+        double z0, z1;
+        bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(j + 16 * r), z0, z1);
+        const double *mrow = a.mt + (live ? (int64_t)it.row * a.mt_stride : 0);
+        e0[2 * r] = mrow[32 * r + j] + z0;
+        e0[2 * r + 1] = mrow[32 * r + 16 + j] + z1;
+    }
+    double dl0, dl1;
+    {
+        double z0, z1;
+        bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(DP / 2 + (j >> 1)), z0, z1);
+        dl0 = (j & 1) ? z1 : z0;
+        bdf_normal_pair(a.seed, a.sweep, BDF_P_ROW, a.entity_tag, (uint64_t)(uint32_t)it.orig, (uint32_t)(DP / 2 + 8 + (j >> 1)), z0, z1);
+        dl1 = (j & 1) ? z1 : z0;
+    }
+    double A0[33], A1[33];
+#pragma unroll
+    for (int i = 0; i < 33; i++) { A0[i] = 0.0; A1[i] = 0.0; }
+    asm volatile("s_nop 1" ::: "memory");              // (e0 is a DPP source below: written by the vector adds just above)
+    lr32_gram<DP, 0>(A0, A1, e0, W0, W1, rowp0, rowp1);
+    // block (0,1) = block (1,0)': lane j's entry (i, 16 + j) is lane i's entry (16 + j, i)
+    {
+        double *tl = lds + (wave * 4 + g) * 272;
+#pragma unroll
+        for (int r = 0; r < 16; r++) tl[r * 17 + j] = A0[16 + r];
+        wave_sync();
+#pragma unroll
+        for (int i = 0; i < 16; i++) A1[i] = tl[j * 17 + i];
+        wave_sync();
+    }
+    // G = I + alpha Wt' Wt on n x n, identity outside; rho = r - Wt' e0 - delta / sqrt(alpha) as the extra row
+    const double rsa = fast_rsqrt(alpha);
+    const double rho0 = (j < n) ? rv0 - A0[32] - dl0 * rsa : 0.0, rho1 = (16 + j < n) ? rv1 - A1[32] - dl1 * rsa : 0.0;
+#pragma unroll
+    for (int i = 0; i < 32; i++) {
+        const double id0 = (i == j) ? 1.0 : 0.0, id1 = (i == 16 + j) ? 1.0 : 0.0;
+        A0[i] = (i < n && j < n) ? fma(alpha, A0[i], id0) : id0;
+        A1[i] = (i < n && 16 + j < n) ? fma(alpha, A1[i], id1) : id1;
+    }
+    A0[32] = rho0; A1[32] = rho1;
+    asm volatile("s_nop 1" ::: "memory");              // (the matrix rows are DPP sources in the factorisation)
+    double d0 = 1.0, d1 = 1.0;
+    fin_factor<32, 0>(A0, A1, d0, d1, j);
+    if (live && ((j < n && !(d0 > 0.0)) || (16 + j < n && !(d1 > 0.0)))) atomicOr_system(a.flag, 1);
+    const double rd0 = fast_rcp(d0), rd1 = fast_rcp(d1);
+    double tau0 = A0[32] * rd0, tau1 = A1[32] * rd1;
+    fin_backward<31>(A0, A1, tau0, tau1, rd0, rd1, j);
+    // q = e0 + alpha Wt tau: the rows once more, element-major (the padding's observations are the zero row, their tau is 0)
+    double q[DB];
+#pragma unroll
+    for (int k = 0; k < DB; k++) q[k] = 0.0;
+    asm volatile("s_nop 1" ::: "memory");              // (tau is a DPP source below)
+    lr32_phase_c<DP, 0>(q, idw0, idw1, a.vt, j, tau0, tau1);
+    if (live) {
+#pragma unroll
+        for (int k = 0; k < DB; k++)
+            if (16 * k + j < D) a.out[(int64_t)it.row * D + 16 * k + j] = fma(alpha, q[k], e0[k]);
+    }
+}
+
 int lr_buffers(bdf_ctx *ctx, size_t vt_bytes, size_t mrows_bytes)
 {
     if (!ctx->lr_T) BDF_HIP(hipMalloc((void **)&ctx->lr_T, (size_t)(3 * 64 * 64 + 64) * sizeof(double)));
@@ -520,8 +643,8 @@ int lr_buffers(bdf_ctx *ctx, size_t vt_bytes, size_t mrows_bytes)
 }
 
 template <int DP>
-int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, const int32_t *rows_dev,
-                bool transform, hipEvent_t e0, hipEvent_t e1)
+int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *items, int64_t n_items, int64_t n_padded, int64_t n32_padded,
+                const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1)
 {
     const int D = a.D;
     double *Tf = ctx->lr_T, *Tb = Tf + 64 * 64, *Tm = Tb + 64 * 64, *mt = Tm + 64 * 64;
@@ -547,10 +670,19 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
     la.alpha = a.t[0].alpha; la.alpha_dev = a.t[0].alpha_dev; la.mean = a.t[0].mean; la.seed = a.seed; la.sweep = a.sweep; la.entity_tag = a.entity_tag;
     la.D = D; la._pad = 0; la.flag = a.flag;
     static const bool wave_per_row = getenv("BDF_LR_WAVE") != nullptr;        // the wave-per-row kernel instead (rows of at most 15 observations)
-    if (wave_per_row)
-        hipExtLaunchKernelGGL((k_rows_lr<DP>), dim3((unsigned)((n_items + 3) / 4)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_items);
-    else
-        hipExtLaunchKernelGGL((k_rows_lr4<DP>), dim3((unsigned)((n_padded + 15) / 16)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_padded);
+    // items: n_padded records of rows of at most 16 observations, then n32_padded of rows of 17 .. 32 (D > 32 only); n_items rows in all
+    if (n_padded > 0) {
+        if (wave_per_row)
+            hipExtLaunchKernelGGL((k_rows_lr<DP>), dim3((unsigned)((n_padded + 3) / 4)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_padded);
+        else
+            hipExtLaunchKernelGGL((k_rows_lr4<DP>), dim3((unsigned)((n_padded + 15) / 16)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la, (const LrItem *)items, n_padded);
+        e0 = nullptr;
+    }
+    if constexpr (DP == 64) {
+        if (n32_padded > 0)
+            hipExtLaunchKernelGGL((k_rows_lr32<DP>), dim3((unsigned)((n32_padded + 15) / 16)), dim3(256), 0, ctx->stream, e0, nullptr, 0, la,
+                                  (const LrItem *)items + n_padded, n32_padded);
+    }
     const int64_t iters = (n_items + 16 * TPW - 1) / (16 * TPW);
     hipExtLaunchKernelGGL((k_rowmat<DP>), dim3((unsigned)std::min<int64_t>(iters, 4096)), dim3(256), 0, ctx->stream, nullptr, e1, 0, (const double *)a.out, a.out,
                           (const double *)Tb, D, D, rows_dev, n_items, iters);
@@ -566,14 +698,16 @@ int lr_launch_t(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, const void *
 // opposite factor's M_other rows transformed into the context's buffer (false: both are still valid from the previous chunk
 // of the same entity launch).  rows_dev: the rows' positions (n_items int32).
 int bdf_lr_launch(bdf_ctx *ctx, const SampleArgs &a, int64_t M_other, int64_t n_rows_entity, const void *items, int64_t n_items, int64_t n_padded,
-                  const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1)
+                  int64_t n32_padded, const int32_t *rows_dev, bool transform, hipEvent_t e0, hipEvent_t e1)
 {
     const int DP = a.D <= 32 ? 32 : 64;
     int rc = lr_buffers(ctx, ((size_t)M_other + 2) * DP * sizeof(double),         // rows of DP doubles, the zero row, slack
                         a.mu_is_matrix ? (size_t)n_rows_entity * DP * sizeof(double) : 0);
     if (rc) return rc;
-    if (DP == 32) return lr_launch_t<32>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);
-    return lr_launch_t<64>(ctx, a, M_other, items, n_items, n_padded, rows_dev, transform, e0, e1);
+    if (DP == 32) return lr_launch_t<32>(ctx, a, M_other, items, n_items, n_padded, 0, rows_dev, transform, e0, e1);
+    return lr_launch_t<64>(ctx, a, M_other, items, n_items, n_padded, n32_padded, rows_dev, transform, e0, e1);
 }
 
 int bdf_lr_max_observations() { return getenv("BDF_LR_WAVE") ? 15 : 16; }
+// ... and with the two-observations-per-lane kernel (k_rows_lr32, D > 32)
+int bdf_lr32_max_observations() { return getenv("BDF_LR_WAVE") || (getenv("BDF_LR32") && atoi(getenv("BDF_LR32")) == 0) ? 0 : 32; }

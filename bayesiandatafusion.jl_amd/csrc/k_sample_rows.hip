@@ -784,6 +784,7 @@ struct PlanKey {
     int shard, n_shards;
     int small;                        // > 0: rows of at most this many observations go to k_rows_small (four rows per wave)
     int lr;                           // > 0: rows of at most this many observations go to k_rows_lr (the low-rank sampler, k_rows_lr.hip)
+    int lr32;                         // > lr: rows of lr + 1 .. lr32 observations too (k_rows_lr32: two observations per lane, D > 32)
     int64_t lr_min, lr_other;         // ... if the launch has at least lr_min of them, and at least half as many as the opposite entity has rows
     int col;                          // > 0: the rows of k_rows go to k_rows_col instead (four rows per wave, column layout), cut into pieces of at most this size
     int col_slots;                    // ... dealt to at most this many waves
@@ -796,7 +797,8 @@ struct Plan {
     int64_t n_small = 0;              // entries of small_dev (a multiple of 4)
     SmallItem *lr_dev = nullptr;      // the rows of the low-rank sampler (same record), and their positions for the back-transform
     int32_t *lr_rows_dev = nullptr;
-    int64_t n_lr = 0, n_lr_padded = 0;
+    int64_t n_lr = 0, n_lr_padded = 0;   // rows of the low-rank sampler in all; records of the rows of at most key.lr observations (a multiple of 4)
+    int64_t n_lr32_padded = 0;           // ... and of the rows of key.lr + 1 .. key.lr32 observations, behind them in lr_dev
     Item *direct_dev = nullptr, *split_dev = nullptr;
     SplitRow *rows_dev = nullptr;
     int32_t *order_dev = nullptr;
@@ -835,7 +837,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
 {
     const int T = key.T;
     std::vector<Item> direct, split;
-    std::vector<SmallItem> small, lr;
+    std::vector<SmallItem> small, lr, lr32;
     std::vector<SplitRow> srows;
     auto row_total = [&](const RowRef &rr) { int64_t n = 0; for (int r = 0; r < key.n_terms; r++) n += rr.cnt[r]; return n; };
     // a row that neither k_rows_small nor the low-rank sampler takes
@@ -844,7 +846,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
         for (int r = 0; r < key.n_terms; r++) nz += rr.cnt[r] > 0;
         const int64_t n = row_total(rr);
         if (nz <= 1 && key.small > 0 && n <= key.small) return false;
-        if (nz <= 1 && lr_on && n <= key.lr) return false;
+        if (nz <= 1 && lr_on && n <= std::max(key.lr, key.lr32)) return false;
         return true;
     };
     std::vector<bdf_row_ref> crows;
@@ -868,6 +870,7 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
                 if (rr.cnt[r] > 0) { it.term = r; it.q_begin = rr.qb[r]; it.count = (int32_t)rr.cnt[r]; }
             if (key.small > 0 && it.count <= key.small) small.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
             else if (lr_on && it.count <= key.lr) lr.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
+            else if (lr_on && it.count <= key.lr32) lr32.push_back(SmallItem{row, rr.orig, it.q_begin, it.count, 0});
             else direct.push_back(it);
         } else {
             SplitRow sr{row, (int32_t)split.size(), n_items, 0};
@@ -899,23 +902,30 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     }
     int rc;
     if (key.col > 0 && (rc = bdf_col_plan_build(ctx, crows, key.col, key.col_slots, plan.col))) return rc;
-    plan.rows_lr = (int64_t)lr.size(); plan.rows_small = (int64_t)small.size(); plan.rows_col = (int64_t)crows.size();
+    plan.rows_lr = (int64_t)lr.size() + (int64_t)lr32.size(); plan.rows_small = (int64_t)small.size(); plan.rows_col = (int64_t)crows.size();
     plan.rows_k1 = (int64_t)direct.size() + (int64_t)srows.size();
     while (small.size() % 4) small.push_back(SmallItem{-1, 0, 0, 0, 0});
     plan.n_small = (int64_t)small.size();
     if (!small.empty() && (rc = to_device(small, &plan.small_dev))) return rc;
-    plan.n_lr = (int64_t)lr.size();
-    if (!lr.empty()) {
+    plan.n_lr = (int64_t)lr.size() + (int64_t)lr32.size();
+    if (plan.n_lr > 0) {
         // longest first: the waves of a workgroup then have rows of like length
-        std::stable_sort(lr.begin(), lr.end(), [](const SmallItem &x, const SmallItem &y) { return x.count > y.count; });
-        std::vector<int32_t> lr_rows(lr.size());
-        for (size_t i = 0; i < lr.size(); i++) lr_rows[i] = lr[i].row;
+        auto by_count = [](const SmallItem &x, const SmallItem &y) { return x.count > y.count; };
+        std::stable_sort(lr.begin(), lr.end(), by_count);
+        std::stable_sort(lr32.begin(), lr32.end(), by_count);
+        std::vector<int32_t> lr_rows;
+        lr_rows.reserve((size_t)plan.n_lr);
+        for (const SmallItem &x : lr) lr_rows.push_back(x.row);
+        for (const SmallItem &x : lr32) lr_rows.push_back(x.row);
         // (the positions in ASCENDING order: they are what the dense passes over the rows walk -- the back-transform x = L^-T q and
         // the per-row prior means -- and a pass over rows in the sampler's order, longest first, reads and writes 512-byte rows at
-        // random: configuration C4's back-transform of 9.75 M rows moved its 10 GB at 3 TB/s)
+        // random)
         std::sort(lr_rows.begin(), lr_rows.end());
         while (lr.size() % 4) lr.push_back(SmallItem{-1, 0, 0, 0, 0});      // four rows per wave
+        while (lr32.size() % 4) lr32.push_back(SmallItem{-1, 0, 0, 0, 0});
         plan.n_lr_padded = (int64_t)lr.size();
+        plan.n_lr32_padded = (int64_t)lr32.size();
+        lr.insert(lr.end(), lr32.begin(), lr32.end());
         if ((rc = to_device(lr, &plan.lr_dev)) || (rc = to_device(lr_rows, &plan.lr_rows_dev))) return rc;
     }
     if ((rc = to_device(direct, &plan.direct_dev)) || (rc = to_device(split, &plan.split_dev)) ||
@@ -1098,7 +1108,9 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
     if (DP > 16 && !dump && ctx->lr_max != 0 && a.n_terms == 1 && a.t[0].n_other == 1 && a.t[0].linear == nullptr) {
         const int other = 1 - modes[0];
         M_other = rels[0]->nint[other];
-        key.lr = std::min(std::min(ctx->lr_max < 0 ? a.D / 2 : ctx->lr_max, bdf_lr_max_observations()), ctx->item_size);
+        const int lr_want = ctx->lr_max < 0 ? a.D / 2 : ctx->lr_max;
+        key.lr = std::min(std::min(lr_want, bdf_lr_max_observations()), ctx->item_size);
+        key.lr32 = DP == 64 ? std::min(std::min(lr_want, bdf_lr32_max_observations()), ctx->item_size) : 0;       // (> key.lr: rows of 17 .. 32 observations too)
         key.lr_min = std::max<int64_t>(ctx->lr_min_rows, 1);
         key.lr_other = ctx->lr_min_rows > 0 ? rels[0]->dims[other] : 0;          // (min_rows = 0, a test hook: whenever the entity has such a row)
     }
@@ -1198,7 +1210,8 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         const bool same = shard > 0 && ctx->lr_key_fac == (const void *)a.t[0].fac[0] && ctx->lr_key_Lambda == (const void *)a.Lambda &&
                           ctx->lr_key_mu == (const void *)a.mu && ctx->lr_key_sweep == a.sweep && ctx->lr_key_tag == a.entity_tag &&
                           ctx->lr_key_D == a.D && ctx->lr_key_M == M_other;
-        int rc = bdf_lr_launch(ctx, a, M_other, rels[0]->nint[modes[0]], plan->lr_dev, plan->n_lr, plan->n_lr_padded, plan->lr_rows_dev, !same, ctx->time_start, more ? nullptr : ctx->time_stop);
+        int rc = bdf_lr_launch(ctx, a, M_other, rels[0]->nint[modes[0]], plan->lr_dev, plan->n_lr, plan->n_lr_padded, plan->n_lr32_padded, plan->lr_rows_dev, !same,
+                               ctx->time_start, more ? nullptr : ctx->time_stop);
         if (rc) return rc;
         ctx->lr_key_fac = a.t[0].fac[0]; ctx->lr_key_Lambda = a.Lambda; ctx->lr_key_mu = a.mu; ctx->lr_key_sweep = a.sweep;
         ctx->lr_key_tag = a.entity_tag; ctx->lr_key_D = a.D; ctx->lr_key_M = M_other;

@@ -151,7 +151,7 @@ class Context:
         check(lib().bdf_ctx_set_small_rows(self.handle, int(max_observations), int(min_rows)))
 
     def set_lowrank(self, max_observations=-1, min_rows=8192):
-        """D > 16: rows of at most max_observations observations (-1: min(16, D / 2); 0: off) by the low-rank sampler when a
+        """D > 16: rows of at most max_observations observations (-1: D / 2 up to 16, up to 32 at D > 32; 0: off) by the low-rank sampler when a
         launch has min_rows such rows or more (bdf_ctx_set_lowrank) -- the same conditional distribution as the reference's
         map, other sampled values"""
         check(lib().bdf_ctx_set_lowrank(self.handle, int(max_observations), int(min_rows)))
@@ -755,13 +755,14 @@ class GibbsEngine:
         """rows of entity j the library draws with the low-rank sampler (k_rows_lr.hip) instead of the reference's map -- the
         library's own count for the latest launch (bdf_ctx_rows_dispatch); before the first iteration: the rule of
         bdf_launch_sample_rows restated from the environment (D > 16, one two-mode relation, no side information on the relation,
-        rows of at most min(16, D / 2) observations, at least 8,192 of them and at least half as many as the opposite entity has rows)"""
+        rows of at most min(16, D / 2) observations (D > 32: min(32, D / 2)), at least 8,192 of them and at least half as many as the opposite entity has rows)"""
         got = self.rows_dispatch(j)
         if got is not None:
             return got["lowrank"]
         en, st, D = self.data.entities[j], self.ent[j], self.D
         lr = int(os.environ.get("BDF_LOWRANK", "-1"))
-        lr = min(16, D // 2) if lr < 0 else min(lr, 16)
+        cap = 32 if D > 32 else 16
+        lr = min(cap, D // 2) if lr < 0 else min(lr, cap)
         if D <= 16 or lr == 0 or len(en.relations) != 1 or len(en.relations[0].entities) != 2:
             return 0
         r = en.relations[0]

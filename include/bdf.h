@@ -114,7 +114,8 @@ int bdf_ctx_set_piece_size(bdf_ctx *ctx, int observations);
  * BDF_K1_SMALL_MIN_ROWS); max_observations 0 turns it off.  Same sample up to the order of the floating-point sums. */
 int bdf_ctx_set_small_rows(bdf_ctx *ctx, int max_observations, int64_t min_rows);
 /* D > 16, an entity of one two-mode relation (shared or per-row prior means): rows of at most max_observations observations (at most
- * 16; -1 = min(16, num_latent / 2), the default; 0 = off; environment BDF_LOWRANK) are drawn by the LOW-RANK SAMPLER
+ * 16 at num_latent <= 32, 32 above -- rows of 17 .. 32 observations two to a lane, k_rows_lr32; -1 = num_latent / 2 up to that, the
+ * default; 0 = off; environment BDF_LOWRANK) are drawn by the LOW-RANK SAMPLER
  * (k_rows_lr.hip) when a launch has at least min_rows of them (default 8192, BDF_LOWRANK_MIN_ROWS) and at least half as many as
  * the opposite entity has rows (min_rows = 0: whenever there is such a row).  It replaces sample_user_basic (src/sampling.jl:200-212) for those rows by another map from
  * standard normals to the SAME conditional distribution N(inv(P_i) b_i, inv(P_i)): D + n normals of the row's stream and an

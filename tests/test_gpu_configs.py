@@ -291,21 +291,23 @@ def test_c4_dispatch_whole_iterations_match_oracle(B, O):
     """C4's DEFAULT dispatch end to end at a size the oracle sweeps in seconds: 12,000 users of ~10 observations (more than the 8,192
     rows from which the low-rank sampler is taken, and more than half the items' count) x 300 items, D = 64, 64-bit gather offsets
     forced as the full size needs: the users' rows of at most 16 observations through K1-lr (k_rows_lr4<64> + k_rowmat<64> +
-    k_lr_prep<64>), the longer ones and the items through k_rows<64>, inside the native iteration -- two whole iterations against
-    the oracle dispatching the same way (lowrank = {users: 16})."""
+    k_lr_prep<64>), those of 17 .. 32 through k_rows_lr32<64> (two observations per lane), the longer ones and the items through
+    k_rows<64>, inside the native iteration -- two whole iterations against the oracle dispatching the same way
+    (lowrank = {users: 32})."""
     from bdf_amd import datasets
     from bdf_amd.engine import GibbsEngine
     rd = datasets.c4_relation_data(B, 12_000, 300, 120_000, test_fraction=0.0)
     D = 64
     cnt = np.bincount(rd.relations[0].data.ids[:, 0] - 1, minlength=12_000)
-    assert (cnt <= 16).sum() >= 10_000 and (cnt > 16).sum() >= 100
+    assert (cnt <= 16).sum() >= 10_000 and (cnt > 16).sum() >= 100 and (cnt > 32).sum() == 0
     eng = GibbsEngine(rd, D, seed=13)
     eng.ctx.set_gather(2)
     for i in range(1, 3):
         eng.sweep(i)
     eng.sync()
     assert eng.ctx.rows_unfinished() == 0
-    _compare(rd, *oracle_macau(O, rd, D, 13, 2, True, lowrank={0: 16}), tol=1e-6)
+    assert eng.rows_dispatch(0)["lowrank"] == 12_000          # every user: at most 16 by k_rows_lr4, 17 .. 32 by k_rows_lr32
+    _compare(rd, *oracle_macau(O, rd, D, 13, 2, True, lowrank={0: 32}), tol=1e-6)
     eng.close()
 
 

@@ -755,9 +755,10 @@ def test_lowrank_rows_against_oracle(B, O, ctx, D):
     deg = rng.integers(0, 18, dims[0])
     deg[:10] = [0, 1, 2, 4, 5, 14, 15, 16, 40, 250]
     deg[10:14] = [17, 8, 9, 12]
+    deg[14:22] = [18, 24, 31, 32, 33, 20, 29, 64]       # D > 32: rows of 17 .. 32 observations by k_rows_lr32 (two observations per lane)
     rows = np.repeat(np.arange(1, dims[0] + 1), deg)
     ids = np.stack([rows, rng.integers(1, dims[1] + 1, len(rows))], axis=1).astype(np.int64)
-    lr = min(16, D // 2)
+    lr = min(32 if D > 32 else 16, D // 2)
     idx = O.index_build(ids, dims)
     Am = rng.standard_normal((D, D))
     Lam = Am @ Am.T / D + np.eye(D)
