@@ -292,6 +292,11 @@ def test_argument_errors(B, ctx):
     with pytest.raises(B.BoundsError):
         B.DeviceRelation(ctx, type("X", (), {"dims": [2, 2], "values": np.ones(1), "ids": np.asfortranarray(np.array([[3, 1]])),
                                              "nnz": lambda self: 1})())
+    # the low-rank sampler's longest row: -1 (default), 0 (off), 1 .. 32 (above 16 only D > 32 has a kernel for; clamped otherwise)
+    assert lib().bdf_ctx_set_lowrank(ctx.handle, 33, 0) == -1 and lib().bdf_ctx_set_lowrank(ctx.handle, -2, 0) == -1
+    assert lib().bdf_ctx_set_lowrank(ctx.handle, 32, 0) == 0 and lib().bdf_ctx_set_lowrank(ctx.handle, -1, 8192) == 0
+    # no row launch under a tag yet: the dispatch report says so
+    assert ctx.rows_dispatch(123456) is None
     dr.close()
 
 
