@@ -66,6 +66,13 @@ struct bdf_ctx {
     unsigned long long *rows_span;         // bdf_ctx_span_next_rows: SampleArgs::span of the next row launch, then cleared
     const uint32_t *rows_ready;            // (library-internal) SampleArgs::ready of the next row launch, then cleared
     uint32_t rows_ready_want;
+    // (library-internal, bdf_gibbs_sweep) the rows' hand-over to the hyperprior chain WITHOUT an event: when the next bdf_sample_rows is
+    // one k_rows_col launch, every wave of it -- its rows written through, the stores drained -- adds 1 to shard (wave % 64) of these
+    // 64 words (16 words apart), and rows_done_added says how many will; else rows_done_added stays -1 and the caller uses the event
+    uint32_t *rows_done;
+    int64_t rows_done_added;
+    const uint32_t *hyper_wait;            // (library-internal) ... and the next one-launch chain (k_hyper_chain) polls their sum for this target
+    uint32_t hyper_wait_target;
     uint32_t *hyper_ready;                 // (library-internal) word the next bdf_hyper_sample sets to hyper_ready_value once its pack is written, then cleared
     uint32_t hyper_ready_value;
     hipEvent_t time_h_start, time_h_stop;  // bdf_ctx_time_next_hyper: start of the next sums kernel, end of the next draw kernel
@@ -370,7 +377,12 @@ struct SampleArgs {
     // nullable (bdf_ctx_span_next_rows): {start of the launch's first wave, end of its last} in s_memrealtime ticks (the 100 MHz
     // clock the XCDs share), by one atomic min / max per wave -- a launch's duration without events around it (k_rows_col only)
     unsigned long long *span;  // (64 shards of {start, end}: wave w uses shard w % 64)
+    // nullable (bdf_gibbs_sweep, k_rows_col only): 64 counters, 16 words apart; a wave that has written its rows (write-through, drained)
+    // adds 1 to counter (wave % 64): what the hyperprior chain polls instead of waiting for the launch's completion event
+    uint32_t *done;
 };
+#define BDF_DONE_SHARDS 64
+#define BDF_DONE_STRIDE 16         // words between two shards
 
 int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a, const bdf_rel *const *rels, const int *modes, int shard,
                            int n_shards, bool dump);

@@ -35,6 +35,10 @@ struct bdf_gibbs {
         // entity's next row launch polls for.  Private and strictly increasing -- NOT the caller's sweep number, which may
         // repeat or restart (a repeated number would let the poll pass while the draw is still writing the pack)
         uint32_t epoch = 0;
+        // the rows' hand-over to the chain by counter (no event): the sum the 64 words of done_dev reach when every row launch of
+        // this entity enqueued so far has completed (wraps; compared as a difference)
+        uint32_t *done_dev = nullptr;
+        uint32_t done_target = 0;
         hipEvent_t t_start = nullptr, t_stop = nullptr;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
         unsigned long long *span = nullptr;                  // bdf_gibbs_span_rows: SampleArgs::span of the next row launch of this entity
     };
@@ -278,6 +282,14 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
         if (E.d.feat) BDF_HIP(hipEventCreateWithFlags(&E.ev_beta, hipEventDisableTiming));
     }
     for (int k = 0; k < 3; k++) BDF_HIP(hipEventCreateWithFlags(&g->ev_pred[k], hipEventDisableTiming));
+    if (g->polling && !getenv("BDF_NO_COUNTER_HANDOVER")) {
+        const size_t bytes = (size_t)BDF_DONE_SHARDS * BDF_DONE_STRIDE * sizeof(uint32_t);
+        for (int j = 0; j < n_entities; j++) {
+            BDF_HIP(hipMalloc((void **)&g->ent[(size_t)j].done_dev, bytes));
+            BDF_HIP(hipMemsetAsync(g->ent[(size_t)j].done_dev, 0, bytes, rows_ctx->stream));
+        }
+        BDF_HIP(hipStreamSynchronize(rows_ctx->stream));
+    }
     guard.g = nullptr;
     *out = g;
     return BDF_OK;
@@ -294,6 +306,7 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
         if (E.ev_rows) (void)hipEventDestroy(E.ev_rows);
         if (E.ev_hyper) (void)hipEventDestroy(E.ev_hyper);
         if (E.ev_beta) (void)hipEventDestroy(E.ev_beta);
+        if (E.done_dev) (void)hipFree(E.done_dev);
     }
     for (int k = 0; k < 3; k++)
         if (g->ev_pred[k]) (void)hipEventDestroy(g->ev_pred[k]);
@@ -685,24 +698,38 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         // the completion event rides on the row kernel's dispatch (a caller-supplied timing pair takes its place)
         hipEvent_t done = E.t_stop ? E.t_stop : E.ev_rows;
         const int nch = e.terms[0].rel->chunks;                    // 1 unless the relations were created with a layout
+        // The hand-over to the entity's hyperprior chain.  By default an event on the row kernel's dispatch and a wait on the
+        // hyperprior stream -- which costs that stream ~10 us per chain even when the event completed long before, and the row
+        // stream ~1.7 us per launch.  When the chain is the one-launch kind and runs on reserved CUs (the schedule in which the
+        // row kernels poll for the draw), the chain is enqueued AT ONCE instead and its partial-sum workgroups poll a counter
+        // the row waves add to when their rows are in memory (SampleArgs::done; k_rows_col only -- a launch that takes another
+        // kernel reports -1 and gets the event).  No cycle: the rows of iteration t poll for the draw of t - 1, enqueued before.
+        const bool counter = E.done_dev && draws_in_chain && g->polling && !g->comm && !e.feat && nch == 1 && !E.t_stop;
+        const bool pred_waits = j == n - 1 && g->test && predict_phase >= 0;
+        bool by_counter = false;
         for (int c = 0; c < nch; c++) {
             R->time_start = (c == 0) ? E.t_start : nullptr;
             R->rows_span = E.span;
-            R->time_stop = (c == nch - 1 && !g->comm) ? done : nullptr;
+            R->time_stop = (c == nch - 1 && !g->comm && !(counter && !pred_waits)) ? done : nullptr;
             if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.epoch; }
+            if (counter) R->rows_done = E.done_dev;
             if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
                                       e.sample[nxt], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr)))
                 return rc;
+            if (counter && R->rows_done_added >= 0) { by_counter = true; E.done_target += (uint32_t)R->rows_done_added; }
             if (g->comm && (rc = bdf_allgather_rows(R, g->comm, D, e.N, e.sample[nxt], c, nch))) return rc;
         }
         if (g->comm) {
             if ((rc = bdf_allgather_join(R, g->comm))) return rc;       // the row stream continues after the last chunk's exchange
             BDF_HIP(hipEventRecord(done, R->stream));
+        } else if (counter && !pred_waits && !by_counter) {
+            BDF_HIP(hipEventRecord(done, R->stream));                   // (the launch took another kernel: the event after all)
         }
         E.t_start = E.t_stop = nullptr;
         E.span = nullptr;
         E.cur = nxt;
-        BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
+        if (by_counter) { H->hyper_wait = E.done_dev; H->hyper_wait_target = E.done_target; }
+        else BDF_HIP(hipStreamWaitEvent(H->stream, done, 0));
         static const bool fuse_sums = !(getenv("BDF_HYPER_FUSE") && atoi(getenv("BDF_HYPER_FUSE")) == 0);
         H->hyper_fuse = fuse_sums;        // small entities: the draw adds the sums' partials itself (one launch fewer)
         // side information: U = sample - uhat, T^-1 = WI + beta' beta lambda_beta with the beta of the previous iteration

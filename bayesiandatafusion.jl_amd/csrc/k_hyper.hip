@@ -120,6 +120,10 @@ struct ChainArgs {
     // ndraw > 0: the first ndraw workgroups make the data-independent random part (k_hyper_draws' entries, 256 per workgroup)
     // into draws_out -- beside the partial sums instead of in a launch of their own on the same stream
     int ndraw; double nu_N; uint64_t seed; uint32_t sweep, tag; double *draws_out;
+    // nullable: the launch was NOT ordered behind the rows' launch; the sums' workgroups wait until the 64 counters the row waves add to
+    // (SampleArgs::done) sum to rows_target (bdf_gibbs_sweep: no event, no stream wait -- a wait for another stream's event costs the
+    // waiting stream ~10 us even when the event completed long before)
+    const uint32_t *rows_done; uint32_t rows_target; int *flag;
 };
 template <int DP>
 __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
@@ -147,6 +151,21 @@ __global__ __launch_bounds__(256) void k_hyper_chain(ChainArgs c, NWArgs a)
     if (pb < c.nblocks) {
         const int64_t r0 = (int64_t)pb * c.rows_per_block;
         const int64_t r1 = r0 + c.rows_per_block < c.N ? r0 + c.rows_per_block : c.N;
+        if (c.rows_done) {
+            if (threadIdx.x < 64) {
+                int spins = 0;
+                for (;;) {
+                    uint32_t v = __hip_atomic_load(c.rows_done + BDF_DONE_STRIDE * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+                    if ((int32_t)(v - c.rows_target) >= 0) break;
+                    __builtin_amdgcn_s_sleep(8);
+                    if (++spins > (1 << 22)) { if (threadIdx.x == 0) atomicOr_system(c.flag, 16); break; }      // bounded: a bug must not hang the device
+                }
+            }
+            __syncthreads();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
 #ifdef BDF_HYPER_STAMPS
         if (threadIdx.x == 0 && (pb == 0 || pb == c.nblocks - 1)) g_hstamps[pb == 0 ? 10 : 12] = __builtin_amdgcn_s_memrealtime();
 #endif
@@ -373,6 +392,8 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
         c.D = ctx->hyper_chain_D; c.N = ctx->hyper_chain_N; c.rows_per_block = ctx->hyper_chain_rpb; c.sample = ctx->hyper_chain_sample;
         c.uhat = ctx->hyper_chain_uhat; c.partial = const_cast<double *>(a.partial); c.count = ctx->hyper_count; c.nblocks = a.nblocks;
         c.ndraw = 0; c.nu_N = 0.0; c.seed = 0; c.sweep = 0; c.tag = 0; c.draws_out = nullptr;
+        c.rows_done = ctx->hyper_wait; c.rows_target = ctx->hyper_wait_target; c.flag = ctx->flag_dev;
+        ctx->hyper_wait = nullptr;
         if (ctx->hyper_chain_draws) {
             BDF_REQUIRE(ctx->hyper_chain_draws == draws, BDF_ERR_ARG, "bdf_hyper_sample: the chain's draws go to another buffer than the one the draw reads");
             c.ndraw = (D * D + D + 255) / 256; c.nu_N = nu + (double)N; c.seed = ctx->seed; c.sweep = ctx->sweep_host; c.tag = entity_tag;
@@ -387,6 +408,7 @@ extern "C" int bdf_hyper_sample(bdf_ctx *ctx, int D, int64_t N, const double *su
         BDF_HIP(hipGetLastError());
         return BDF_OK;
     }
+    BDF_REQUIRE(!ctx->hyper_wait, BDF_ERR_ARG, "bdf_hyper_sample: a hand-over by counter needs the one-launch chain");
     if (D <= 16) hipExtLaunchKernelGGL(k_hyper_sample<16>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else if (D <= 32) hipExtLaunchKernelGGL(k_hyper_sample<32>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);
     else hipExtLaunchKernelGGL(k_hyper_sample<64>, dim3(1), dim3(256), 0, ctx->stream, nullptr, ctx->time_h_stop, 0, a);

@@ -354,10 +354,17 @@ __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in,
         const double rd0 = fast_rcp(d0), rd1 = fast_rcp(d1);
         double y0 = fma(z0, fast_rsqrt(d0), A0[32] * rd0), y1 = fma(z1, fast_rsqrt(d1), A1[32] * rd1);
         fin_backward<DR - 1>(A0, A1, y0, y1, rd0, rd1, j);
-        if (lead) a.out[(int64_t)jb.row * D + ec0] = y0;
-        if (lead && ok1) a.out[(int64_t)jb.row * D + ec1] = y1;
+        // (write-through: with a.done the hyperprior's sums read the rows while this launch is still running, from CUs behind other L2s)
+        if (lead) __hip_atomic_store(a.out + ((int64_t)jb.row * D + ec0), y0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lead && ok1) __hip_atomic_store(a.out + ((int64_t)jb.row * D + ec1), y1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         CSTAMP(st_fin);
     }
+    }
+    if (a_in.done) {
+        // this wave's rows are in memory (write-through stores, drained): one more wave of the launch done -- what the entity's
+        // hyperprior chain polls for (k_hyper_chain) instead of waiting for the launch's completion event
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (threadIdx.x == 0) __hip_atomic_fetch_add(a_in.done + BDF_DONE_STRIDE * (w & (BDF_DONE_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     if (a_in.span && threadIdx.x == 0) atomicMax(a_in.span + 2 * (w & 63) + 1, (unsigned long long)__builtin_amdgcn_s_memrealtime());
 #ifdef BDF_K1_STAMPS
