@@ -219,9 +219,11 @@ extern "C" int bdf_hyper_sums(bdf_ctx *ctx, int D, int64_t N, const double *samp
     const bool fuse = fuse_asked && N <= 16384;
     static const bool one_launch_ = !(getenv("BDF_HYPER_CHAIN") && atoi(getenv("BDF_HYPER_CHAIN")) == 0);
     // the one-launch chain (k_hyper_chain): its workgroups -- the draws' (D^2 + D entries, 256 each), the partial sums', the last one --
-    // should all be resident at once on the stream's CUs (two workgroups of 255 registers per CU: 16 on the 8 reserved CUs), or the
-    // partial sums take two rounds and the last workgroup gets its slot when the first round ends (9.3 us of the chain at D = 32)
-    const int wg_slots = 2 * (ctx->on_reserved && ctx->reserve_cus > 0 ? ctx->reserve_cus : 8);
+    // should all be resident at once on the stream's CUs (two workgroups of 255 registers per CU), or the partial sums take two
+    // rounds and the last workgroup gets its slot when the first round ends (9.3 us of the chain at D = 32).  The count comes from a
+    // NOMINAL 16 slots (8 reserved CUs), not from the context's: the number of partials decides the order of the sums, and the
+    // sampled values must not depend on BDF_RESERVE_CUS or the CU count (k_sample_rows.hip's rule for the rows' cuts)
+    const int wg_slots = 16;
     const int max_part = (fuse && one_launch_) ? std::max(8, std::min(16, wg_slots - 1 - (D * D + D + 255) / 256)) : 16;
     const int64_t rpb = HS_ROWS * ((chunks + (fuse ? max_part - 1 : 2047)) / (fuse ? max_part : 2048));
     const int nblocks = (int)std::max<int64_t>(1, (N + rpb - 1) / rpb);

@@ -234,6 +234,7 @@ __global__ __launch_bounds__(256, 6) void k_rows_lr(LrArgs a, const LrItem *__re
     double *st = lds + wave * LG::WAVE_LDS, *tri = st + LG::STAGE;
     const int j = lane & 15, h = lane >> 4;
     const LrItem it = items[w];
+    if (it.row < 0) return;             // (the list is padded to a multiple of four with row = -1 records: k_rows_lr4's idle lane rows)
     const int D = a.D, n = it.count;
     const double alpha = a.alpha_dev ? *a.alpha_dev : a.alpha;
 

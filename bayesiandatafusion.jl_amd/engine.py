@@ -747,6 +747,15 @@ class GibbsEngine:
             b += r.data.nnz() * ((4 + 8 * D) * (len(r.entities) - 1) + 8)
         return b
 
+    def k1_algorithmic_flops(self, j):
+        """flops of one K1 launch over all rows of entity j by the reference's map (sampling.jl:200-212):
+        nnz*(D(D+1) + 2D) [+ nnz*D*(n_modes-2) Hadamard] + N*(D^3/3 + 3D^2)"""
+        en, st, D = self.data.entities[j], self.ent[j], self.D
+        f = st.n_real * (D ** 3 / 3.0 + 3 * D * D)
+        for r in en.relations:
+            f += r.data.nnz() * (D * (D + 1) + 2 * D + D * max(len(r.entities) - 2, 0))
+        return f
+
     def rows_dispatch(self, j):
         """how the library dispatched entity j's latest row launch (Context.rows_dispatch); None before the first iteration"""
         return self.ctx.rows_dispatch(self.ent[j].tag)

@@ -191,7 +191,8 @@ def c3_block(B, datasets, D, device, sweeps=20):
         it = eng.ent[0].cg_iters.cpu().numpy()
         b3 = sum(eng.k1_algorithmic_bytes(j) for j in range(len(eng.ent))) + (2 * int(it.max()) + 3) * 6040 * 500 * 8
         out[key] = {"ms_per_sweep": round(1e3 * dt, 4), "sweeps_per_s": round(1.0 / dt, 1), "native_iteration": bool(eng.native),
-                    "roofline": config_roofline("c3_" + ("cg" if key.startswith("cg") else key), b3, 1e3 * dt),
+                    "roofline": config_roofline("c3_" + ("cg" if key.startswith("cg") else key), b3, 1e3 * dt,
+                                                flops_sweep=sum(eng.k1_algorithmic_flops(j) for j in range(len(eng.ent))) + (2 * int(it.max()) + 3) * 2.0 * 6040 * 500 * D),
                     "features": "iid N(0,1), seed 4242" if kind == "iid" else "correlated: Z W + 0.1 E, Z 6040 x 20 (seeds 4243 / 4244)",
                     "solver": "direct: F'F = Q diag(s) Q' once, beta = Q ((Q' rhs) ./ (s + lambda)) per iteration" if ff_size else "conjugate gradients (compute_ff_size=0)",
                     "cg_iterations_last_sweep": [int(it.min()), int(it.max())]}
@@ -227,7 +228,7 @@ def mref_block(B, device, cpu):
         bytes_sweep = sum(eng.k1_algorithmic_bytes(j) for j in (0, 1))
         blk = {"ms_per_sweep": round(1e3 * dt, 3), "sweeps_per_s": round(1.0 / dt, 2), "algorithmic_gb_per_sweep": round(bytes_sweep / 1e9, 2),
                "algorithmic_tb_per_s": round(bytes_sweep / dt / 1e12, 3),
-               "roofline": config_roofline(f"mref_d{D}", bytes_sweep, 1e3 * dt),
+               "roofline": config_roofline(f"mref_d{D}", bytes_sweep, 1e3 * dt, flops_sweep=sum(eng.k1_algorithmic_flops(j) for j in (0, 1))),
                # rows drawn by the low-rank sampler (same conditional distribution as the reference's map, other values: DESIGN 4)
                "lowrank_rows": [eng.lowrank_rows(j) for j in (0, 1)]}
         train_ids, train_vals = np.asarray(rel.data.ids), np.asarray(rel.data.values, dtype=np.float64)
@@ -295,9 +296,10 @@ def pin_to_quiet_core(share, shares):
         return None, None
 
 
-TRAFFIC_JSON = "profiles/r05_hbm_traffic.json"
-PMC_JSON = "profiles/r05_pmc_k_rows.json"
-CONFIG_KERNELS_JSON = "profiles/r05_config_kernels.json"
+TRAFFIC_JSON = "profiles/r06_hbm_traffic.json"
+PMC_JSON = "profiles/r06_pmc_k_rows.json"
+CONFIG_KERNELS_JSON = "profiles/r06_config_kernels.json"
+FP64_PEAK_TFLOPS = 78.6            # MI355X fp64 vector = matrix peak (the matrix and the vector instructions share the pipe)
 
 
 def k1_source_sha1():
@@ -356,13 +358,24 @@ def recorded_pipe(launch_us):
         return None
 
 
-def config_roofline(name, bytes_sweep, ms_per_sweep, extra=None):
-    """`roofline` of one of the other configurations: algorithmic bytes of the row launches per sweep over the measured
-    sweep, against the HBM peak; the dominant kernel and its rocprofv3 average from the committed profile of that configuration
-    (profiles/r05_config_kernels.json, written by tools/profile_round_r05.sh: not measured by this run)"""
-    r = {"bound": "hbm", "achieved": round(bytes_sweep / 1e9 / (ms_per_sweep / 1e3), 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-         "frac": round(bytes_sweep / 1e9 / (ms_per_sweep / 1e3) / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sweep": int(bytes_sweep),
-         "traffic": None}
+def config_roofline(name, bytes_sweep, ms_per_sweep, extra=None, flops_sweep=None):
+    """`roofline` of one of the other configurations: algorithmic bytes (and flops) of the row launches per sweep over
+    the measured sweep.  The roof that binds is the one SURVEY 8d derives from the arithmetic intensity against the ridge
+    78.6 TF / 8 TB/s = 9.8 flop/B: HBM below it (C2, C3, M-ref: 4.4-6 flop/B), the fp64 pipe above (C4: 17.7); both figures are
+    given.  The dominant kernel and its rocprofv3 average come from the committed profile of that configuration
+    (CONFIG_KERNELS_JSON, written by tools/profile_round_r06.sh: not measured by this run)."""
+    gbs = bytes_sweep / 1e9 / (ms_per_sweep / 1e3)
+    r = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+         "frac": round(gbs / HBM_PEAK_GBS, 4), "algorithmic_bytes_per_sweep": int(bytes_sweep), "traffic": None}
+    if flops_sweep:
+        tf = flops_sweep / 1e12 / (ms_per_sweep / 1e3)
+        ai = flops_sweep / max(bytes_sweep, 1)
+        r.update({"algorithmic_flops_per_sweep": int(flops_sweep), "flop_per_byte": round(ai, 2),
+                  "hbm_gbs": round(gbs, 2), "hbm_frac": round(gbs / HBM_PEAK_GBS, 4),
+                  "fp64_tflops": round(tf, 2), "fp64_frac": round(tf / FP64_PEAK_TFLOPS, 4)})
+        if ai > FP64_PEAK_TFLOPS * 1e3 / HBM_PEAK_GBS:          # above the ridge: the fp64 pipe is the roof (SURVEY 8d)
+            r.update({"bound": "fp64", "achieved": round(tf, 2), "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(tf / FP64_PEAK_TFLOPS, 4),
+                      "note": "flops by the reference's map (sampling.jl:200-212: D^2 n + D^3/3 per row); the low-rank sampler does fewer for short rows"})
     try:
         r["dominant_kernel"] = dict(json.load(open(os.path.join(ROOT, CONFIG_KERNELS_JSON)))[name], source=CONFIG_KERNELS_JSON + " (not measured by this run)")
     except (OSError, KeyError, ValueError):
@@ -400,6 +413,8 @@ def main():
     ap.add_argument("--c4-nnz", type=int, default=100_000_000)
     ap.add_argument("--c4-latent", type=int, default=64)
     ap.add_argument("--c4-sweeps", type=int, default=5, help="warm-up and timed sweeps of the C4 measurement (5 + 5: SURVEY M-C4)")
+    ap.add_argument("--dump-state", default="", help="(tests) PREFIX: every rank leaves every entity's sample (the reference's row order), mu and "
+                                                     "Lambda of the main workload and of the C4 / C5 blocks in PREFIX.<block>.rank<r>.npz")
     ap.add_argument("--rendezvous-only", action="store_true",
                     help="test hook: every rank joins the process group, all-reduces its rank, rank 0 prints it; no GPU is touched")
     args = ap.parse_args()
@@ -472,6 +487,18 @@ def main():
         """the test pairs this rank predicts: a contiguous slice"""
         return np.arange(n * rank // world, n * (rank + 1) // world)
 
+    def dump_state(engine, block):
+        if not args.dump_state:
+            return
+        st = {}
+        for j, e in enumerate(engine.ent):
+            st[f"S{j}"] = e.host("sample")          # D x N, the reference's row order whatever the layout
+            st[f"mu{j}"] = e.host("mu")
+            st[f"Lam{j}"] = e.host("Lambda")
+            if getattr(e, "numF", 0):
+                st[f"beta{j}"] = e.host("beta")
+        np.savez(f"{args.dump_state}.{block}.rank{rank}.npz", **st)
+
     # ---- the BASELINE metric: MovieLens (N > 1: N stacked units) ------------------------------------------------------------
     D = args.num_latent
     replicas = args.replicas if args.replicas > 0 else world
@@ -537,6 +564,7 @@ def main():
     if dist is not None:
         dist.all_reduce(sse)                       # every rank holds the squared error of its share of the test ratings
     rmse = float(np.sqrt(float(sse.item()) / n_test_total))
+    dump_state(eng, "main")
 
     # K1 roofline: the launches timed inside the timed region, then further sweeps (every launch timed) up to the minimum
     # (i) device-side spans: first wave's start to last wave's end of every row launch (s_memrealtime, K1c only), no event packets
@@ -559,9 +587,11 @@ def main():
     eng.sync()
     k1_ms = sum(t.elapsed_us() for (_, t) in eng.k1_events) / 1e3
     k1_bytes = sum(eng.k1_algorithmic_bytes(j) for (j, _) in eng.k1_events) / max(world, 1)
+    k1_flops = sum(eng.k1_algorithmic_flops(j) for (j, _) in eng.k1_events) / max(world, 1)
     n_launch = max(len(eng.k1_events), 1)
     launch_us_events = 1e3 * k1_ms / n_launch
     launch_us = (sum(u for _, u in span_us) / len(span_us)) if span_us else launch_us_events
+    pipe = recorded_pipe(launch_us)
     achieved = (k1_bytes / n_launch / 1e9) / (launch_us / 1e6) if launch_us > 0 else 0.0
     eng.k1_events = None
     traffic, traffic_source = recorded_traffic() if (world == 1 and replicas == 1 and D == 32) else (None, None)
@@ -630,7 +660,15 @@ def main():
                          # packets (what rounds 1-4 quoted: the events lengthen the launch by a few us)
                          "avg_launch_us": round(launch_us, 2), "avg_launch_us_timer": "in-kernel s_memrealtime span" if span_us else "HIP events",
                          "launches_spanned": len(span_us), "avg_launch_us_by_events": round(launch_us_events, 2),
-                         "fp64_pipe": recorded_pipe(launch_us),
+                         "fp64_pipe": pipe,
+                         # the same as scalars (what a parser that keeps only numbers and strings sees): the FP64 pipe's busy share of the
+                         # launch from the committed counters, the launch's flops by the reference's map against the 78.6 TF peak, and the
+                         # counters' HBM traffic over the algorithmic bytes (<< 1: the gathered factor is L2-resident, nothing re-read)
+                         "fp64_valu_busy_frac": None if pipe is None else pipe["frac"],
+                         "fp64_flops_frac": round(k1_flops / n_launch / (launch_us * 1e-6) / (FP64_PEAK_TFLOPS * 1e12), 4),
+                         "traffic_over_algorithmic": None if traffic is None else round(traffic / (k1_bytes / n_launch), 3),
+                         "counters_schedule": "the committed PMC passes ran with BDF_RESERVE_CUS=0 BDF_NO_POLL=1 (rocprofv3 serialises the streams; CU-masked "
+                                              "streams crash its teardown): all 1,024 SIMDs, event hand-overs -- the launch time they are divided by is this run's",
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch),
                          "avg_launch_us_alone": None if alone_us is None else round(alone_us, 2),
                          "frac_alone": None if alone_us is None else round((k1_bytes / n_launch / 1e9) / (alone_us / 1e6) / HBM_PEAK_GBS, 4)},
@@ -674,7 +712,7 @@ def main():
             rmse4 = float(np.sqrt(float(sse4.item()) / max(n4, 1)))
             mp4 = float(np.sqrt(np.mean((np.asarray(rel4.test_vec.values) - rel4.model.mean_value) ** 2)))
             c4.update({"sweeps_per_s": round(args.c4_sweeps / el4, 3), "ms_per_sweep": round(1e3 * el4 / args.c4_sweeps, 3),
-                       "roofline": config_roofline("c4", bytes_sweep, 1e3 * el4 / args.c4_sweeps),
+                       "roofline": config_roofline("c4", bytes_sweep, 1e3 * el4 / args.c4_sweeps, flops_sweep=sum(eng4.k1_algorithmic_flops(j) for j in range(2))),
                        "test_rmse": round(rmse4, 5),
                        # (a chain this short has not left its start: above the mean predictor the figure says nothing about the model)
                        "test_rmse_above_mean_predictor": bool(rmse4 > mp4),
@@ -692,6 +730,7 @@ def main():
                                                                       transport=eng4.comm.transport),
                        "chunks": eng4.layouts[0].chunks, "generate_s": round(t_gen, 1), "setup_s": round(t_setup, 1),
                        "device_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2)})
+            dump_state(eng4, "c4" if zipf_offset else "c4_uniform")
             eng4.close()
             if with_cpu and not args.no_cpu_baseline and world == 1:         # (the CPU figures: one process only, as the main line's)
                 del eng4, test4
@@ -757,6 +796,7 @@ def main():
                        "test_rmse": round(float(np.sqrt(float(sse5.item()) / max(n5, 1))), 5), "value_std": round(info5["value_std"], 4),
                        "noise": info5["noise"], "native_iteration": bool(eng5.native),
                        "cg_iterations_last_sweep": [int(it5.min()), int(it5.max())], "beta_columns_per_rank": -(-32 // world)})
+            dump_state(eng5, "c5")
             eng5.close()
             del eng5, test5, rd5, rel5
         except Exception as e:      # noqa: BLE001

@@ -51,7 +51,8 @@ set_item_size!(c::Context, item) = check(ccall((:bdf_ctx_set_item_size, lib), Ci
 set_small_rows!(c::Context, max_obs, min_rows) = check(ccall((:bdf_ctx_set_small_rows, lib), Cint, (Ptr{Cvoid}, Cint, Int64), c.h, max_obs, min_rows))
 # rows of few observations by the low-rank sampler (same distribution as sample_user_basic, other values); max_obs = 0: off
 set_lowrank!(c::Context, max_obs=-1, min_rows=8192) = check(ccall((:bdf_ctx_set_lowrank, lib), Cint, (Ptr{Cvoid}, Cint, Int64), c.h, max_obs, min_rows))
-# 16 < D <= 32: row launches of at least `min_rows` rows as two kernels (accumulate, then factor / solve / draw four rows per wave); negative: never
+# 16 < D <= 32, one two-mode relation: the rows four to a wave in the column layout (K1c, k_rows_col.hip), cut into pieces of at most `max_piece`
+# observations; 0: off (the wave-per-row kernel), -1: the default again (128, larger for entities of many observations)
 set_col_rows!(c::Context, max_piece=-1) = check(ccall((:bdf_ctx_set_col_rows, lib), Cint, (Ptr{Cvoid}, Cint), c.h, max_piece))
 # how the latest row launch under `entity_tag` was dispatched: rows by K1-lr, K1s, K1c, K1; K1's items; K1c's waves
 function rows_dispatch(c::Context, entity_tag::Integer)

@@ -189,6 +189,44 @@ def test_whole_iterations_match_oracle(B, O, with_feat, use_ff):
         assert math.isclose(rd.entities[0].lambda_beta, lb, rel_tol=1e-6)
 
 
+def test_hyper_reference_mean_map_matches_oracle(B, O, tmp_path):
+    """BDF_HYPER_MEAN=reference (a process-wide switch: a fresh process, tests/env_probe.py): the reference's own map from the mean
+    normals to mu, chol(inv(Lambda) / beta_N)' z (/root/reference/src/normal_wishart.jl:38-42), on the device -- two whole native
+    iterations at D = 32 (K1c rows, the one-launch hyperprior chain) against the oracle's chain with mean_map="reference"; and the
+    values DIFFER from the default map's (the same law, another function of z)."""
+    import os, subprocess, sys
+    from env_probe import macau_problem
+    seed, N1, N2, nnz, D, iters = 31, 140, 90, 5000, 32, 2
+    out = str(tmp_path / "ref.npz")
+    env = dict(os.environ)
+    env.update({"BDF_HYPER_MEAN": "reference", "BDF_LOWRANK": "0"})
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_probe.py"), "macau", out] +
+                       [str(x) for x in (seed, N1, N2, nnz, D, iters)], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    got = np.load(out)
+    ids, vals = macau_problem(seed, N1, N2, nnz)
+    N = [N1, N2]
+    mean = float(vals.mean())
+    res = {}
+    for mm in ("reference", "factor"):
+        S = [np.zeros((N1, D)), np.zeros((N2, D))]
+        mu = [np.zeros(D), np.zeros(D)]
+        Lam = [5.0 * np.eye(D), 5.0 * np.eye(D)]
+        for it in range(1, iters + 1):
+            for j in (0, 1):
+                t = O.Term(ids, vals, N, j, 2.0, mean, [None if k == j else S[k] for k in (0, 1)])
+                S[j] = O.sample_rows(D, N[j], [t], mu[j], Lam[j], 77, it, j + 1)
+                mu_N, beta_N, T_N, nu_N = O.hyper_params(S[j], np.zeros(D), 2.0, np.eye(D), float(D))
+                mu[j], Lam[j] = O.hyper_draw(mu_N, beta_N, T_N, nu_N, 77, it, j + 1, mean_map=mm)
+        res[mm] = (S, mu, Lam)
+    S, mu, Lam = res["reference"]
+    for j in (0, 1):
+        np.testing.assert_allclose(got[f"S{j}"], S[j], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[f"mu{j}"], mu[j], rtol=1e-6, atol=1e-7)
+        np.testing.assert_allclose(got[f"Lam{j}"], Lam[j], rtol=1e-6, atol=1e-7)
+    assert not np.allclose(got["mu0"], res["factor"][1][0], rtol=1e-3, atol=1e-4)
+
+
 @pytest.mark.parametrize("D", [24, 32])
 def test_whole_iterations_col_rows_small_pieces_match_oracle(B, O, monkeypatch, D):
     """the native iteration with K1c's pieces cut small (BDF_K1_COL=8: rows on two and four lane rows, rows that span waves, the
@@ -512,7 +550,7 @@ def test_movielens_d32_full_size_properties(B):
     eng.close()
 
 
-def test_two_ranks_match_one(B):
+def test_two_ranks_match_one(B, tmp_path):
     """bench.py's N > 1 path (rows shared out by bdf_layout_build, every rank holding its rows' observations only, in-place
     exchange of the sampled rows inside bdf_gibbs_sweep, test ratings split over the ranks, RMSE all-reduced) gives the chain
     of the single-process run of the same workload.  Two ranks on the one GPU of the box: RCCL needs a GPU per rank, so the
@@ -527,11 +565,12 @@ def test_two_ranks_match_one(B):
     env["BDF_DIST_BACKEND"] = "gloo"
     c5_sizes = "3000,16,60,40,120000,30000,400,8"
     # `python bench.py --gpus 2` as typed: bench.py starts its two ranks itself (torch's launcher, as a child process)
-    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6",
+    two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6", "--dump-state", str(tmp_path / "two"),
                           "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64", "--c5-sizes", c5_sizes, "--c5-sweeps", "6"],
                          env=env, capture_output=True, text=True, timeout=600)
     assert two.returncode == 0, two.stdout[-2000:] + two.stderr[-2000:]
     one = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--replicas", "2", "--steps", "4", "--warmup", "6", "--no-cpu-baseline", "--no-c3", "--no-mref",
+                          "--dump-state", str(tmp_path / "one"),
                           "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64", "--c5-sizes", c5_sizes, "--c5-sweeps", "6"],
                          capture_output=True, text=True, timeout=600)
     assert one.returncode == 0, one.stdout[-2000:] + one.stderr[-2000:]
@@ -550,6 +589,22 @@ def test_two_ranks_match_one(B):
     assert "error" not in d2["c5"] and "error" not in d1["c5"], (d2["c5"], d1["c5"])
     assert d2["c5"]["n_gpus"] == 2 and d2["c5"]["beta_columns_per_rank"] == 16 and d2["c5"]["native_iteration"] and d1["c5"]["native_iteration"]
     assert abs(d2["c5"]["test_rmse"] - d1["c5"]["test_rmse"]) < 1e-5, (d2["c5"], d1["c5"])
+    # ... and the chains themselves, element by element: every entity's sampled factor (the reference's row order), mu, Lambda
+    # (and beta) of the three blocks -- the two ranks' replicas bit for bit after the exchange, the two-rank chain against the
+    # single process's to 1e-9 (the hyperprior's sums are added in another order: rounding, carried through ten iterations)
+    _compare_dumped_states(tmp_path, ("main", "c4", "c5"))
+
+
+def _compare_dumped_states(tmp_path, blocks, rtol=1e-9):
+    for block in blocks:
+        r0, r1 = np.load(tmp_path / f"two.{block}.rank0.npz"), np.load(tmp_path / f"two.{block}.rank1.npz")
+        o = np.load(tmp_path / f"one.{block}.rank0.npz")
+        assert sorted(r0.files) == sorted(o.files) and len(r0.files) >= 6, (block, r0.files, o.files)
+        for k in r0.files:
+            assert np.array_equal(r0[k], r1[k]), (block, k)                  # one replica on every rank
+            assert np.isfinite(r0[k]).all() and r0[k].shape == o[k].shape, (block, k)
+            scale = max(1.0, float(np.abs(o[k]).max()))
+            assert float(np.abs(r0[k] - o[k]).max()) <= rtol * scale, (block, k, float(np.abs(r0[k] - o[k]).max()), scale)
 
 
 def test_two_ranks_match_one_with_four_rows_per_wave():

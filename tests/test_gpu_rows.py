@@ -861,3 +861,77 @@ def test_lowrank_row_moments(B, O, ctx, D, n):
     exp1 = O.sample_row_lowrank(D, [ot], 3, mu, Lam, O.lowrank_normals(SEED, 1, 1, 3, D, n))
     np.testing.assert_allclose(draws[3], exp1, rtol=1e-8, atol=1e-9)
     dr.close()
+
+
+def _probe(tmp_path, env_extra, *args):
+    """tests/env_probe.py in a fresh process with the environment given (switches the library reads once per process)"""
+    import os, subprocess, sys
+    out = str(tmp_path / "probe.npz")
+    env = dict(os.environ)
+    env.update(env_extra)
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "env_probe.py"), args[0], out] +
+                       [str(a) for a in args[1:]], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return np.load(out)
+
+
+def test_lowrank_wave_per_row_kernel_with_a_padded_list(B, O, tmp_path):
+    """BDF_LR_WAVE=1: the wave-per-row form of the low-rank sampler (k_rows_lr, rows of at most 15 observations) over a list that is
+    padded to a multiple of four with row = -1 records -- which it must skip (round 5 ran it over them: stores before the factor
+    matrix) -- against the oracle's low-rank function at 1e-8, shared and per-row prior means, a guard buffer untouched."""
+    from env_probe import lowrank_problem
+    D = 24
+    lr = min(15, D // 2)
+    for n_rows in range(203, 220):      # a list whose length is no multiple of four (the problem is a function of the seed and n_rows)
+        ids, vals, facs, Lam, mu, mu_rows = lowrank_problem(515, [n_rows, 60], D)
+        cnt = np.bincount(ids[:, 0] - 1, minlength=n_rows)
+        if int((cnt <= lr).sum()) % 4 != 0:
+            break
+    dims = [n_rows, 60]
+    got = _probe(tmp_path, {"BDF_LR_WAVE": "1"}, "lowrank", 515, n_rows, D)
+    ot = O.Term(ids, vals, dims, 0, 1.7, float(vals.mean()), [None, facs[1]])
+    assert int((cnt <= lr).sum()) % 4 != 0 and int(got["lr_rows"][0]) == 2 * int((cnt <= lr).sum())     # (two launches under the one tag add up)
+    for name, m in (("shared", mu), ("per_row", mu_rows)):
+        exp = O.sample_rows_lowrank(D, n_rows, [ot], m, Lam, lr, SEED, 7, 5)
+        np.testing.assert_allclose(got[name], exp, rtol=1e-8, atol=1e-9)
+        assert not got[name + "_guard"].any()
+
+
+def test_normal_wishart_draw_moments(B, O, ctx):
+    """Sampled moments of the device's Normal-Wishart draw (bdf_hyper_sample, the default map of the mean normals) over 12,000
+    draws at D = 6 against rand(::NormalWishart)'s law (/root/reference/src/normal_wishart.jl:38-42):
+    E[Lambda] = nu_N T_N with Var[Lambda_ij] = nu_N (T_ij^2 + T_ii T_jj), E[mu] = mu_N, Cov[mu] = inv(T_N) / (beta_N (nu_N - D - 1)).
+    Means within 5 standard errors; the mean's covariance within 8 % (Frobenius)."""
+    from bdf_amd._lib import check, lib
+    D, N, n = 6, 40, 12000
+    rng = np.random.default_rng(909)
+    U = rng.standard_normal((N, D)) * 0.8 + rng.standard_normal(D) * 0.3
+    mu0 = rng.standard_normal(D) * 0.1
+    A = rng.standard_normal((D, D))
+    Tinv = A @ A.T / D + np.eye(D)
+    b0, nu = 2.0, D + 4.0
+    S_t = ctx.tensor(U)
+    sumU, UUt = ctx.zeros(D), ctx.zeros(D, D)
+    check(lib().bdf_hyper_sums(ctx.handle, D, N, _p(S_t), None, _p(sumU), _p(UUt)))
+    mu0_t, Tinv_t = ctx.tensor(mu0), ctx.tensor(Tinv)
+    mus, Lams = ctx.zeros(n, D), ctx.zeros(n, D * D)
+    for s in range(n):
+        ctx.set_sweep(s + 1)
+        check(lib().bdf_hyper_sample(ctx.handle, D, N, _p(sumU), _p(UUt), _p(mu0_t), b0, _p(Tinv_t), nu, 3,
+                                     C.c_void_p(mus.data_ptr() + 8 * D * s), C.c_void_p(Lams.data_ptr() + 8 * D * D * s), None, None, None))
+    ctx.sync()
+    mu_N, beta_N, T_N, nu_N = O.hyper_params(U, mu0, b0, Tinv, nu)
+    m = mus.cpu().numpy()
+    L = Lams.cpu().numpy().reshape(n, D, D)
+    assert np.isfinite(m).all() and np.isfinite(L).all()
+    # one draw against the oracle on the same streams (the map), the rest by their moments (the law)
+    mu_e, Lam_e = O.hyper_draw(mu_N, beta_N, T_N, nu_N, SEED, 17, 3)
+    np.testing.assert_allclose(m[16], mu_e, rtol=1e-7, atol=1e-9)
+    np.testing.assert_allclose(L[16], Lam_e, rtol=1e-7, atol=1e-9)
+    EL = nu_N * T_N
+    seL = np.sqrt(nu_N * (T_N ** 2 + np.outer(np.diag(T_N), np.diag(T_N))) / n)
+    assert np.all(np.abs(L.mean(0) - EL) < 5 * seL)
+    cov_mu = np.linalg.inv(T_N) / (beta_N * (nu_N - D - 1))
+    assert np.all(np.abs(m.mean(0) - mu_N) < 5 * np.sqrt(np.diag(cov_mu) / n))
+    emp = np.cov(m.T)
+    assert np.linalg.norm(emp - cov_mu) / np.linalg.norm(cov_mu) < 0.08

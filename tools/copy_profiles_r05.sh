@@ -7,7 +7,6 @@ for f in kernel_stats.csv kernel_stats_driver_cmd.csv hbm_traffic.json pmc_k_row
          c3_cg_kernel_stats.csv c4_kernel_stats.csv c5_kernel_stats.csv mref_kernel_stats.csv k1_alone.txt; do
   [ -f $S/$f ] && cp $S/$f $P/r05_$f
 done
-[ -f $S/bench_driver_full.json ] && grep '^{' $S/bench_driver_full.json | tail -1 > $P/r05_bench_driver_form.json
 cat $S/bench_driver_cmd_1.json $S/bench_driver_cmd_2.json $S/bench_driver_cmd_3.json 2>/dev/null | grep '^{' > $P/r05_bench_driver_cmd_repeats.jsonl
 [ -f $S/timeline.txt ] && cp $S/timeline.txt $P/r05_timeline_final.txt
 ls -la $P | grep r05_ | wc -l
