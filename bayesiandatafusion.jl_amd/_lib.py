@@ -180,6 +180,7 @@ _SIGS = {
     "bdf_comm_create_host": (C.c_int, [C.c_void_p, C.c_int, C.c_int, EXCHANGE_FN, C.c_void_p, C.POINTER(C.c_void_p)]),
     "bdf_comm_enable_peer": (C.c_int, [C.c_void_p, EXCHANGE_FN, C.c_void_p, C.c_size_t]),
     "bdf_comm_disable_peer": (C.c_int, [C.c_void_p]),
+    "bdf_comm_peer_selftest": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "bdf_comm_peer_stats": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "bdf_comm_destroy": (C.c_int, [C.c_void_p]),
     "bdf_comm_size": (C.c_int, [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]),

@@ -1191,11 +1191,13 @@ class Comm:
 
     def _enable_peer(self, ctx, rank, world, on_device):
         """large exchanges (>= BDF_COMM_PEER_MIN_BYTES per rank, default 4 MiB) by direct all-pairs copies over IPC mappings
-        (bdf_comm_enable_peer) -- after a collective self-test: every rank pulls a small block from every other one and checks it;
-        if any rank fails (no peer access, IPC refused) all of them stay on the communicator's own transport.  BDF_COMM_PEER=0: off."""
+        (bdf_comm_enable_peer; ordered on the device by interprocess events) -- after a collective self-test: every rank pulls a
+        small block from every other one and checks it; if any rank fails (no peer access, IPC refused) all of them stay on the
+        communicator's own transport.  Off unless BDF_COMM_PEER=1: unmeasured on a node with several GPUs."""
         import torch.distributed as dist
         self.peer_min_bytes = None
-        if world <= 1 or os.environ.get("BDF_COMM_PEER", "1") == "0":
+        # (opt-in until it has run on a node with several GPUs: BDF_COMM_PEER=1)
+        if world <= 1 or os.environ.get("BDF_COMM_PEER", "0") != "1":
             return
         self._peer_cb = _lib.EXCHANGE_FN(self._make_exchange(ctx, world, on_device))
         min_bytes = int(os.environ.get("BDF_COMM_PEER_MIN_BYTES", str(4 << 20)))
@@ -1205,7 +1207,7 @@ class Comm:
             probe = torch.full((world, 64), -1.0, dtype=torch.float64, device=ctx.device)
             probe[rank] = float(rank + 1)
             torch.cuda.synchronize(ctx.device)
-            check(lib().bdf_allgather_block(ctx.handle, self.handle, C.c_void_p(probe.data_ptr()), 64 * 8))
+            check(lib().bdf_comm_peer_selftest(ctx.handle, self.handle, C.c_void_p(probe.data_ptr()), 64 * 8))
             torch.cuda.synchronize(ctx.device)
             want = torch.arange(1, world + 1, dtype=torch.float64, device=ctx.device)[:, None].expand(world, 64)
             if not torch.equal(probe, want):
@@ -1221,8 +1223,8 @@ class Comm:
             return
         check(lib().bdf_comm_enable_peer(self.handle, self._peer_cb, None, min_bytes))
         self.peer_min_bytes = min_bytes
-        self.transport += (f"; exchanges of >= {min_bytes} bytes per rank by direct all-pairs peer copies over IPC mappings "
-                           f"(bdf_comm_enable_peer: one copy per xGMI link at once instead of the ring)")
+        self.transport += (f"; row exchanges of >= {min_bytes} bytes per rank by direct all-pairs peer copies over IPC mappings, "
+                           f"ordered on the device by interprocess events (bdf_comm_enable_peer: one copy per xGMI link at once instead of the ring)")
 
     def peer_stats(self):
         n, b = C.c_int64(0), C.c_int64(0)

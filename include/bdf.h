@@ -395,13 +395,18 @@ int bdf_comm_size(const bdf_comm *comm, int *rank, int *world);
  * the reference shipping the whole sample matrix to every worker (src/sampling.jl:155-171): every rank exports the allocation its
  * block lives in (hipIpcGetMemHandle), opens its peers', and an exchange of bytes_per_rank >= min_bytes is world - 1 concurrent
  * device-to-device copies, one per link, pulled from the owners' mappings (configuration C4 on 8 GPUs: 640 MB per link per users'
- * half-sweep, ~4.2 ms, where a ring moves 7 x 640 MB through one link after the other).  `fn` is the host's all-gather (as for
- * bdf_comm_create_host): it carries the 88-byte control message per rank and is the barrier that orders the copies; such an
- * exchange is synchronous for the host (~0.1 ms), which is why small exchanges keep the communicator's own transport.  Added to a
- * communicator of either kind; bdf_comm_disable_peer takes it off again (collectively: every rank or none).  Exchanges made this
- * way and the bytes this rank pulled: bdf_comm_peer_stats.  Unmeasured on several GPUs; tested with two processes on one. */
+ * half-sweep, ~4.2 ms, where a ring moves 7 x 640 MB through one link after the other).  ORDERED ON THE DEVICE: the owner records
+ * an interprocess event behind its row kernel, every peer's copy stream waits for it, the caller's stream waits for the copies in
+ * bdf_allgather_join -- no stream is synchronised, the next chunk's rows run beside the copies.  `fn` is the host's all-gather
+ * (as for bdf_comm_create_host): it carries a control message per rank and exchange (handle, offset, an error code the ranks
+ * agree on) and orders the host CALLS (record before wait), nothing else.  Taken by bdf_allgather_rows only (rotating buffers:
+ * bdf_comm.hip); added to a communicator of either kind; bdf_comm_disable_peer takes it off again (collectively: every rank or
+ * none).  bdf_comm_peer_selftest (collective): one exchange this way whatever its size, complete on return -- what a host runs
+ * before it lets the rows take the path.  Exchanges made this way and the bytes this rank pulled: bdf_comm_peer_stats.
+ * Unmeasured on several GPUs; tested with two processes on one. */
 int bdf_comm_enable_peer(bdf_comm *comm, bdf_exchange_fn fn, void *user, size_t min_bytes);
 int bdf_comm_disable_peer(bdf_comm *comm);
+int bdf_comm_peer_selftest(bdf_ctx *ctx, bdf_comm *comm, void *buf, size_t bytes_per_rank);
 int bdf_comm_peer_stats(const bdf_comm *comm, int64_t *exchanges, int64_t *bytes_pulled);
 /* Exchange of chunk `chunk` of the N x D factor matrix `sample` (dev; N = chunks * world * cmax rows, the layout above): an
  * in-place all-gather of the ranks' blocks (ncclAllGather), ordered after the work enqueued so far on ctx's stream, run on

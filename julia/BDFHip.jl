@@ -343,6 +343,9 @@ workers): it carries the control messages and orders the copies"""
 enable_peer!(m::Comm, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL, min_bytes::Integer=4 << 20) =
     check(ccall((:bdf_comm_enable_peer, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), m.h, fn, user, min_bytes))
 disable_peer!(m::Comm) = check(ccall((:bdf_comm_disable_peer, lib), Cint, (Ptr{Cvoid},), m.h))
+"(collective) one exchange by peer copies whatever its size, complete on return: `buf` (device) holds world blocks of `bytes`, this rank's filled in"
+peer_selftest!(c::Context, m::Comm, buf::Ptr{Cvoid}, bytes::Integer) =
+    check(ccall((:bdf_comm_peer_selftest, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Csize_t), c.h, m.h, buf, bytes))
 function peer_stats(m::Comm)
     n = Ref{Int64}(0); b = Ref{Int64}(0)
     check(ccall((:bdf_comm_peer_stats, lib), Cint, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), m.h, n, b))

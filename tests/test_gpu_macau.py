@@ -563,6 +563,7 @@ def test_two_ranks_match_one(B, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
     env["BDF_DIST_BACKEND"] = "gloo"
+    env["BDF_COMM_PEER"] = "1"          # (opt-in: unmeasured on a node with several GPUs)
     c5_sizes = "3000,16,60,40,120000,30000,400,8"
     # `python bench.py --gpus 2` as typed: bench.py starts its two ranks itself (torch's launcher, as a child process)
     two = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "6", "--dump-state", str(tmp_path / "two"),
@@ -593,6 +594,18 @@ def test_two_ranks_match_one(B, tmp_path):
     # (and beta) of the three blocks -- the two ranks' replicas bit for bit after the exchange, the two-rank chain against the
     # single process's to 1e-9 (the hyperprior's sums are added in another order: rounding, carried through ten iterations)
     _compare_dumped_states(tmp_path, ("main", "c4", "c5"))
+    # ... and the transport changes nothing: the same two ranks with the blocks staged through the host (BDF_COMM_PEER unset)
+    # leave the C4-shaped block's factors bit for bit
+    env.pop("BDF_COMM_PEER")
+    host = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "2", "--dump-state", str(tmp_path / "host"),
+                           "--no-c5", "--c4-rows", "20000", "--c4-cols", "3000", "--c4-nnz", "300000", "--c4-latent", "64"],
+                          env=env, capture_output=True, text=True, timeout=600)
+    assert host.returncode == 0, host.stdout[-2000:] + host.stderr[-2000:]
+    dh = json.loads([l for l in host.stdout.splitlines() if l.startswith("{")][-1])
+    assert "peer copies" not in dh["c4"]["exchange"]["transport"] and dh["c4"]["exchange"]["peer_exchanges"] == 0, dh["c4"]["exchange"]
+    a, b = np.load(tmp_path / "two.c4.rank0.npz"), np.load(tmp_path / "host.c4.rank1.npz")
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), ("c4", k)
 
 
 def _compare_dumped_states(tmp_path, blocks, rtol=1e-9):
