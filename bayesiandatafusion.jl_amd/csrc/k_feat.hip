@@ -11,6 +11,7 @@
 //   (cg_AtA, src/parallel_cg.jl:63-94: stop when ||r|| < tol ||b||, checked before an iteration; maxiter).
 //   lambda_beta ~ Gamma                                sample_lambda_beta, src/sampling.jl:136-142
 #include "bdf_common.h"
+#include <chrono>
 #include "wave_linalg.h"
 #include "dpp_rows16.h"
 #include <algorithm>
@@ -425,6 +426,105 @@ __global__ __launch_bounds__(256) void k_spmm_rm16(int64_t m, int ncol, const in
     }
 }
 
+// The column panels of a product in ONE launch (round 6; until then one launch of the kernel above per panel, the rows' running
+// sums carried through Y: 5 + 9 launches per F'(F p) on configuration C5, and Y -- 25.6 MB -- written and read back between them).
+// A PERSISTENT grid, one workgroup per resident slot: workgroup w owns the row blocks w, w + G, ... (KB of them, sixteen rows
+// each), walks the panels in order and inside a panel its row blocks, and keeps every row's two running sums in registers from the
+// first panel to the last -- Y is written once.  Nothing synchronises the workgroups: they start together and do the same amount of
+// work per panel, so the chip is inside one panel (two at the edges) at any moment and every XCD's L2 holds the 3 MiB of the operand
+// its gathers want.  A row's entries are taken in the order of k_spmm_rm16 (column order: panel after panel): the same sums to the
+// last bit.  The walk is pipelined over the units (row block, panel): the unit after the next one's bounds and the next one's
+// first sixteen indices are loaded before this unit's gathers are issued -- a unit of ~10 entries per row is ONE dependent round
+// trip, its gathers.
+template <bool HASV>
+__global__ __launch_bounds__(256, 4) void k_spmm_rm16p(int64_t m, int ncol, const int32_t *__restrict__ colind, const double *__restrict__ vals,
+                                                       const double *__restrict__ B, int64_t ldb, double *__restrict__ Y, int64_t ldy,
+                                                       const double *__restrict__ bias, double *__restrict__ Y2, const int *skip,
+                                                       const int64_t *__restrict__ panel_ptr, int np, int KB, int64_t rb0, int64_t nblocks)
+{
+    // the rows' running sums: KB pairs per thread, in LDS (in registers they cost the kernel its fourth wave per SIMD -- and a grid
+    // sized for four that holds three runs its last quarter as a second generation, out of step with the panels)
+    extern __shared__ __attribute__((aligned(16))) double spmm_acc[];
+    // (A counter the workgroups add to after every panel and briefly wait on was tried as a hint to keep them in step: its ~900
+    // pollers on one word starve the arrivals -- every wait ran into its bound, 510 us per product instead of 120.  Not kept.)
+    if (skip && *skip == 0) return;
+    const int l = threadIdx.x & 15;
+    const int c = 2 * l;
+    const bool cv = c < ncol;
+    const int64_t G = gridDim.x;
+    spd2 *acc = (spd2 *)spmm_acc + threadIdx.x;                   // pair k of this thread: acc[k * 256]
+    for (int k = 0; k < KB; k++) acc[k * 256] = spd2{0.0, 0.0};
+    // unit u = p * KB + k: row block rb0 + blockIdx.x + k G, panel p
+    auto row_of = [&](int k) -> int64_t {
+        const int64_t rb = rb0 + blockIdx.x + (int64_t)k * G;
+        const int64_t r = rb * 16 + (threadIdx.x >> 4);
+        return (rb < nblocks && r < m) ? r : -1;
+    };
+    const int n_units = np * KB;
+    // the pipeline's registers: bounds two units ahead, bounds + first indices one unit ahead
+    int64_t b2 = 0, e2 = 0, b1 = 0, e1 = 0;
+    int32_t i1 = 0;
+    double v1 = 0.0;
+    int k2 = 0, p2 = 0;                                           // (k, p) of the unit whose bounds are loaded next
+    auto bounds = [&](int64_t &b, int64_t &e) {
+        b = e = 0;
+        if (p2 < np) {
+            const int64_t r = row_of(k2);
+            if (r >= 0) { const int64_t *pp = panel_ptr + (int64_t)p2 * m + r; b = pp[0]; e = pp[m]; }
+        }
+        if (++k2 == KB) { k2 = 0; p2++; }
+    };
+    bounds(b1, e1);
+    bounds(b2, e2);
+    i1 = b1 + l < e1 ? colind[b1 + l] : 0;
+    if (HASV) v1 = b1 + l < e1 ? vals[b1 + l] : 0.0;
+    (void)n_units;
+#pragma unroll 1
+    for (int p = 0; p < np; p++) {
+#pragma unroll 1
+        for (int k = 0; k < KB; k++) {
+            const int64_t beg = b1, end = e1;
+            int32_t myi = i1;
+            double myv = v1;
+            // the next unit's first indices and the one after's bounds: in flight under this unit's gathers
+            b1 = b2; e1 = e2;
+            i1 = b1 + l < e1 ? colind[b1 + l] : 0;
+            if (HASV) v1 = b1 + l < e1 ? vals[b1 + l] : 0.0;
+            bounds(b2, e2);
+            int64_t nq = end - beg;
+            nq = max(nq, __shfl_xor(nq, 16));
+            nq = max(nq, __shfl_xor(nq, 32));
+            nq = __builtin_amdgcn_readfirstlane((int)nq);
+            if (nq <= 0) continue;
+            spd2 av = acc[k * 256];
+            double a0 = av[0], a1 = av[1];
+            for (int64_t o = 0; o < nq; o += 16) {
+                const int left = (int)min((int64_t)16, end - beg - o);
+                const int64_t qn = beg + o + 16 + l;
+                int32_t nxi = 0;
+                double nxv = 0.0;
+                if (o + 16 < nq) {                                   // (rare: a row with more than sixteen entries in one panel)
+                    nxi = qn < end ? colind[qn] : 0;
+                    if (HASV) nxv = qn < end ? vals[qn] : 0.0;
+                }
+                spd2 g[16];
+                spmm_gather16<0>(g, myi, left, B, ldb, c, cv);
+                spmm_acc16<HASV, 0>(g, myv, left, a0, a1);
+                myi = nxi; myv = nxv;
+            }
+            acc[k * 256] = spd2{a0, a1};
+        }
+    }
+    for (int k = 0; k < KB; k++) {
+        const int64_t r = row_of(k);
+        if (r >= 0 && cv) {
+            const spd2 av = acc[k * 256];
+            *(spd2 *)(Y + r * ldy + c) = av;
+            if (Y2) *(spd2 *)(Y2 + r * ldy + c) = spd2{av[0] + bias[c], av[1] + bias[c + 1]};
+        }
+    }
+}
+
 // out[i*ncol + c] = in[i*irs + c*ics]  (32 x 32 tiles through LDS: coalesced on both sides for a column-major `in`)
 __global__ __launch_bounds__(256) void k_to_rowmajor(int64_t n, int ncol, const double *__restrict__ in, int64_t irs, int64_t ics,
                                                      double *__restrict__ out, const int *skip)
@@ -505,6 +605,45 @@ int spmm(bdf_ctx *ctx, const SpmmArgs &s)
         const int np = (panels_ok && s.panel_ptr && s.n_panels >= 2 && s.n_panels <= max_panels &&
                         (size_t)s.kin * s.ncol * sizeof(double) >= ((size_t)8 << 20)) ? s.n_panels : 1;
         const dim3 grid((unsigned)((s.m + 15) / 16));
+        // ... all panels in ONE launch of a persistent grid (k_spmm_rm16p; BDF_SPMM_FUSED=0: a launch per panel, the rows' running sums
+        // carried through Y).  Measured on configuration C5 (profiles/r06_c5_fused_panels.txt, rocprofv3): F p -- 6,250 row blocks,
+        // 5 panels -- 5 x 23.7 = 118 us panel by panel, 117 fused; F't -- 3,125 row blocks, 9 panels, every panel launch 2.4
+        // generations of workgroups ending on a half-empty chip -- 9 x 15.8 = 142 us against 125-130 fused: 241 us per F'(F p)
+        // instead of 260, 1.28 GB of gathered rows per product at 10-11 TB/s (between the Infinity Cache's 8.6 and an L2-resident
+        // table's 23: the workgroups drift out of step by a panel or two).
+        static const bool fused_ok = !(getenv("BDF_SPMM_FUSED") && atoi(getenv("BDF_SPMM_FUSED")) == 0);
+        if (np > 1 && fused_ok) {
+            // the panels in one launch: a persistent grid of as many workgroups as the stream's CUs hold (k_spmm_rm16p), every one
+            // with KB row blocks' running sums in LDS (4 KB each): the smallest KB whose grid is resident at once
+            static int cus = 0;
+            if (!cus) {
+                hipDeviceProp_t prop;
+                BDF_HIP(hipGetDeviceProperties(&prop, ctx->device));
+                cus = prop.multiProcessorCount;
+            }
+            const int avail = ctx->on_reserved ? std::max(1, ctx->reserve_cus) : std::max(1, cus - ctx->reserve_cus);
+            const int64_t nblocks = (s.m + 15) / 16;
+            const double *bias = y_rm ? s.bias : nullptr;
+            double *Y2 = y_rm ? s.Y2 : nullptr;
+            for (int64_t rb0 = 0; rb0 < nblocks;) {
+                const int64_t left = nblocks - rb0;
+                int kb = 1;
+                int64_t G = 1;
+                for (;; kb++) {
+                    int occ = 0;
+                    if (s.vals) BDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmm_rm16p<true>, 256, (size_t)kb * 4096));
+                    else BDF_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, k_spmm_rm16p<false>, 256, (size_t)kb * 4096));
+                    G = (int64_t)avail * std::max(1, occ);
+                    if (G * kb >= left || kb == 12) break;
+                }
+                const dim3 pg((unsigned)std::min<int64_t>(G, (left + kb - 1) / kb));
+                if (s.vals) hipLaunchKernelGGL(k_spmm_rm16p<true>, pg, dim3(256), (size_t)kb * 4096, ctx->stream, s.m, s.ncol, s.colind, s.vals, B, ldb, Y, ldy,
+                                               bias, Y2, ctx->skip_flag, s.panel_ptr, np, kb, rb0, nblocks);
+                else hipLaunchKernelGGL(k_spmm_rm16p<false>, pg, dim3(256), (size_t)kb * 4096, ctx->stream, s.m, s.ncol, s.colind, s.vals, B, ldb, Y, ldy,
+                                        bias, Y2, ctx->skip_flag, s.panel_ptr, np, kb, rb0, nblocks);
+                rb0 += (int64_t)pg.x * kb;
+            }
+        } else
         for (int p = 0; p < np; p++) {
             const int64_t *pb = np > 1 ? s.panel_ptr + (size_t)p * s.m : nullptr, *pe = np > 1 ? s.panel_ptr + (size_t)(p + 1) * s.m : nullptr;
             const bool last = p == np - 1;
