@@ -1042,6 +1042,13 @@ struct CgResident {
     unsigned *bar;                    // zeroed before the launch
 };
 
+#ifdef BDF_CG_STAMPS      // diagnostic build (tools/c3_cg_stamps.py): workgroup 0's clock (s_memrealtime, 100 MHz) at eight points of every iteration
+__device__ unsigned long long g_cgstamps[64 * 8];
+#define CGSTAMP(it, k) do { if (blockIdx.x == 0 && threadIdx.x == 0 && (it) < 64) g_cgstamps[(it) * 8 + (k)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define CGSTAMP(it, k) do { } while (0)
+#endif
+
 __device__ __forceinline__ void cg_grid_sync(unsigned *bar, unsigned target, int *flag)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this thread's write-through stores have completed
@@ -1102,6 +1109,7 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
     unsigned sync_no = 0;
     for (int iter = 1; iter <= c.maxiter; iter++) {
         if (__hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;      // (the same value in every workgroup: read after a hand-over)
+        CGSTAMP(iter, 0);
         // ---- Z[rows of w, :] = FF[rows of w, :] P
         fd4 acc[CB];
 #pragma unroll
@@ -1122,6 +1130,7 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[cb][t], acc[cb], 0, 0, 0);
         }
+        CGSTAMP(iter, 1);                  // P loaded (128 KB past the L2, agent scope), the matrix instructions issued
         if (wave > 0) {
 #pragma unroll
             for (int cb = 0; cb < CB; cb++)
@@ -1140,7 +1149,9 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
                     if (zr < n && col < D) __hip_atomic_store(s.Z + zr + (int64_t)col * n, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
         }
+        CGSTAMP(iter, 2);                  // the waves' sums added, Z's rows stored (write-through, not yet drained)
         cg_grid_sync(c.bar, ++sync_no * (unsigned)c.nwg, s.flag);
+        CGSTAMP(iter, 3);                  // first hand-over passed: every workgroup's rows of Z are in memory
         // ---- the step of column w: bottom of iteration `iter`, top of iteration `iter + 1` (k_cg_step_short's arithmetic)
         if (owner && active && iters_d == iter) {           // (workgroup-uniform)
             double z[EPT];
@@ -1183,7 +1194,9 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
                 __syncthreads();                          // (`go` is rewritten in the next iteration)
             }
         }
+        CGSTAMP(iter, 4);                  // column w's step: Z's column read, two block sums, p stored
         cg_grid_sync(c.bar, ++sync_no * (unsigned)c.nwg, s.flag);
+        CGSTAMP(iter, 5);                  // second hand-over passed: every column's new p is in memory
     }
     if (owner) {
 #pragma unroll
@@ -1194,6 +1207,15 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
         if (tid == 0) { s.active[d] = active ? 1 : 0; s.iters[d] = iters_d; s.bknum[d] = bknum_d; s.bkden[d] = bkden_d; }
     }
 }
+
+#ifdef BDF_CG_STAMPS
+extern "C" int bdf_debug_cg_stamps(unsigned long long *host512)
+{
+    BDF_HIP(hipDeviceSynchronize());
+    BDF_HIP(hipMemcpyFromSymbol(host512, HIP_SYMBOL(g_cgstamps), sizeof(unsigned long long) * 64 * 8));
+    return BDF_OK;
+}
+#endif
 
 // k_cg_step for long columns (n > 2048): one workgroup per column is one CU's bandwidth per column (82 us per iteration at
 // n = 50,000, D = 32: 32 CUs moving 100 MB).  Here a column is cut into G chunks, grid (D, G), and the step becomes three

@@ -13,7 +13,8 @@ nnz = int(N * M * 0.01)
 key = np.unique(rng.integers(0, N * M, size=int(nnz * 1.01)))[:nnz]
 ids = np.stack([key // M + 1, key % M + 1], axis=1)
 vals = rng.random(len(key))
-for D in (10, 30):
+# MREF_D=10 or 30: one D per process (a profile of the run then names THAT configuration's dominant kernel)
+for D in ([int(os.environ['MREF_D'])] if os.environ.get('MREF_D') else (10, 30)):
     t0 = time.time()
     rel = B.Relation((ids, vals), "r", [B.Entity("rows"), B.Entity("cols")], dims=[N, M])
     B.assignToTest(rel, np.arange(1, 51))
