@@ -1070,6 +1070,9 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
     __shared__ double red[3][CB][4][64];
     __shared__ double sred[16];
     __shared__ int go;
+    // P staged for the product: column c at Pl + c * PSTR (517: an odd stride, the sixteen columns of a matrix operand in sixteen banks)
+    constexpr int PSTR = 517, PLD = 32 * CB;               // n <= 512 rows, 16 CB columns: at most 32 CB elements per thread
+    __shared__ double Pl[16 * CB * PSTR + 2];
     const CgState &s = c.s;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, i = lane & 15, h = lane >> 4;
     const int w = blockIdx.x;
@@ -1111,24 +1114,48 @@ __global__ __launch_bounds__(256) void k_cg_resident(CgResident c)
         if (__hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) break;      // (the same value in every workgroup: read after a hand-over)
         CGSTAMP(iter, 0);
         // ---- Z[rows of w, :] = FF[rows of w, :] P
+        // P -- n x D, the columns one after the other: 128 KB at n = 500, D = 32, written by the other workgroups a moment ago -- comes
+        // into LDS by COALESCED loads past the L2, all of them in flight at once (a thread's elements are 256 apart), and the matrix
+        // operands are read from there.  (Until round 6 every lane fetched its operands itself, 8 bytes at a stride of a column:
+        // sixty-four cache lines per instruction -- 7.25 us of an iteration's 12.9, profiles/r06_c3_cg_handover.txt.)  Same operand
+        // values into the same matrix instructions in the same order: the iterates are unchanged to the last bit.
+        {
+            const int64_t total = n * (int64_t)D;
+            double pv[PLD];
+            // (no branches: an element beyond the end reads the last one again and is not stored)
+#pragma unroll
+            for (int q = 0; q < PLD; q++) {
+                const int64_t e = tid + 256 * q;
+                pv[q] = __hip_atomic_load(s.P + (e < total ? e : total - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            int col = 0;
+            int k = tid;
+#pragma unroll
+            for (int q = 0; q < PLD; q++) {
+                // (n >= 128 -- cg_solve takes this kernel for no smaller operator -- : at most two columns' ends per 256 elements)
+                const bool w1 = k >= (int)n;
+                k -= w1 ? (int)n : 0; col += w1 ? 1 : 0;
+                const bool w2 = k >= (int)n;
+                k -= w2 ? (int)n : 0; col += w2 ? 1 : 0;
+                Pl[col < D ? col * PSTR + k : 16 * CB * PSTR] = pv[q];               // (beyond the end: a spare slot)
+                k += 256;
+            }
+        }
+        __syncthreads();
         fd4 acc[CB];
 #pragma unroll
         for (int cb = 0; cb < CB; cb++) acc[cb] = fd4{0.0, 0.0, 0.0, 0.0};
         {
-            double b[CB][KS];
 #pragma unroll
             for (int t = 0; t < KS; t++) {
                 const int64_t k = kb + 16 * (t >> 2) + 4 * h + (t & 3);
 #pragma unroll
                 for (int cb = 0; cb < CB; cb++) {
                     const int col = 16 * cb + i;
-                    b[cb][t] = (k < ke && col < D) ? __hip_atomic_load(s.P + k + (int64_t)col * n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+                    const double b = (k < ke && col < D) ? Pl[col * PSTR + k] : 0.0;
+                    acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b, acc[cb], 0, 0, 0);
                 }
             }
-#pragma unroll
-            for (int t = 0; t < KS; t++)
-#pragma unroll
-                for (int cb = 0; cb < CB; cb++) acc[cb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[t], b[cb][t], acc[cb], 0, 0, 0);
         }
         CGSTAMP(iter, 1);                  // P loaded (128 KB past the L2, agent scope), the matrix instructions issued
         if (wave > 0) {
@@ -1624,7 +1651,7 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     const dim3 cgb(numF >= 8192 ? 1024 : 256);      // threads per column
     // a small resident operator: the whole solve in one launch (k_cg_resident; BDF_CG_RESIDENT=0: the two launches per iteration)
     static const bool resident_ok = !(getenv("BDF_CG_RESIDENT") && atoi(getenv("BDF_CG_RESIDENT")) == 0);
-    bool resident = resident_ok && use_ff && numF <= 512 && D <= 32 && D <= (numF + 15) / 16;
+    bool resident = resident_ok && use_ff && numF >= 128 && numF <= 512 && D <= 32 && D <= (numF + 15) / 16;
     if (resident) {
         // its workgroups hand over through a counter they all poll: ALL ceil(numF / 16) of them must be resident at once.  One
         // workgroup per CU is what the kernel's registers and LDS allow for certain (asked of the runtime below), so the stream
