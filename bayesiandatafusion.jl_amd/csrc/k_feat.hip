@@ -1337,6 +1337,187 @@ __global__ __launch_bounds__(256) void k_cg_long_c(CgState s, CgChunks c, int it
     }
 }
 
+// ---- the same solve with its state ROW-MAJOR (element (i, d) at [i * D + d]) -- sparse features (round 6).  The sparse products gather
+// ROWS of their dense operand (256 contiguous bytes at D = 32), so with the state column-major, as the reference's matrices are,
+// every F'(F p) was wrapped in two tiled transposes (k_to_rowmajor / k_from_rowmajor: 912 + 912 launches per sweep of configuration
+// C5).  Here P, Z, R, X live row-major from the solve's first launch to its last: the products take and leave them as they are, and
+// the three vector steps take a chunk of rows per workgroup, a thread per (row, column) with the column fastest: 32 lanes read one
+// row.  A column's dot products are summed over the chunk's rows in row order by the eight row lanes of a column, then over the
+// chunks in chunk order (another order than the column-major kernels': the iterates agree to rounding, not to the bit).
+//   rm_init: R = P = b (row-major copy made by k_to_rowmajor), X = 0, partial |b|^2        rm_start: tol |b|, bknum = bkden = |b|^2, iters = 1
+//   rm_a / rm_b / rm_c: k_cg_long_a / _b / _c's arithmetic
+struct CgRm { int G; int64_t len; double *partA, *partB, *bkden0, *zp, *rrs; };
+#define BDF_CG_RM_MAXG 1024
+
+__device__ __forceinline__ double rm_colsum(double v, double (*red)[32], int d, int rl)
+{
+    // the eight row lanes of column d, added in row-lane order (every thread gets the sum)
+    __syncthreads();
+    red[rl][d] = v;
+    __syncthreads();
+    double sum = 0.0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) sum += red[q][d];
+    return sum;
+}
+
+// this workgroup's per-column partial to part[d * G + g]; the workgroup that finishes LAST adds the G partials of every column --
+// row lane rl those of chunks rl, rl + 8, ..., then the eight row lanes in order: a fixed order whichever workgroup it is -- and
+// returns true in it (with the column's sum in `total`)
+__device__ __forceinline__ bool rm_reduce(const CgState &s, const CgRm &c, double *part, double v, bool keep, double (*red)[32], int d, int rl, double &total)
+{
+    __shared__ int last;
+    const double mine = rm_colsum(v, red, d, rl);
+    if (rl == 0 && keep) __hip_atomic_store(part + d * c.G + blockIdx.x, mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) last = __hip_atomic_fetch_add(s.done_blocks, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == c.G - 1;
+    __syncthreads();
+    if (!last) return false;
+    if (threadIdx.x == 0) __hip_atomic_store(s.done_blocks, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the partials were written through by the other workgroups: one acquire, then plain loads -- many in flight; taken one by one
+    // past the L2 the ~50 loads of a row lane were ~50 round trips: 55 us per iteration)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    double acc = 0.0;
+    if (keep) {
+        const double *pp = part + d * c.G;
+#pragma unroll 8
+        for (int q = rl; q < c.G; q += 8) acc += pp[q];
+    }
+    total = rm_colsum(acc, red, d, rl);
+    return true;
+}
+
+// the G partials of every column added by THIS workgroup (row lane rl those of chunks rl, rl + 8, ..., then the row lanes in order: the
+// same fixed order in every workgroup) -- the vector steps read their dot products this way: a kernel boundary lies between the
+// partials' writers and their readers, nothing to wait for
+__device__ __forceinline__ double rm_sum_parts(const CgRm &c, const double *part, bool keep, double (*red)[32], int d, int rl)
+{
+    double acc = 0.0;
+    if (keep) {
+        const double *pp = part + d * c.G;
+#pragma unroll 8
+        for (int q = rl; q < c.G; q += 8) acc += pp[q];
+    }
+    return rm_colsum(acc, red, d, rl);
+}
+
+__global__ __launch_bounds__(256) void k_cg_rm_init(CgState s, CgRm c, double tol)
+{
+    __shared__ double red[8][32];
+    const int d = threadIdx.x & 31, rl = threadIdx.x >> 5, g = blockIdx.x;
+    const bool dok = d < s.D;
+    const int64_t i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+    double nb = 0.0;
+    if (dok)
+        for (int64_t i = i0 + rl; i < i1; i += 8) {
+            const double b = s.R[i * s.D + d];
+            s.P[i * s.D + d] = b; s.X[i * s.D + d] = 0.0;
+            nb = fma(b, b, nb);
+        }
+    double tot = 0.0;
+    if (!rm_reduce(s, c, c.partA, nb, dok, red, d, rl, tot)) return;
+    if (rl == 0 && dok) {
+        s.tolb[d] = tol * sqrt(tot);                     // tol = tol * norm(b), parallel_cg.jl:65
+        const bool go = !(sqrt(tot) < s.tolb[d]);        // top of iteration 1 (cg_pre): the residual is b
+        s.active[d] = go ? 1 : 0; s.iters[d] = go ? 1 : 0;
+        s.bkden[d] = tot; s.bknum[d] = tot;
+        if (!go) atomicSub(s.nactive, 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_cg_rm_a(CgState s, CgRm c, const double *lambda_p, int iter)
+{
+    __shared__ double red[8][32];
+    if (cg_all_stopped(s, iter)) return;
+    const int d = threadIdx.x & 31, rl = threadIdx.x >> 5, g = blockIdx.x;
+    const bool act = d < s.D && s.active[d] && s.iters[d] == iter;
+    const double lambda = *lambda_p;
+    const int64_t i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+    double zp = 0.0;
+    if (act)
+#pragma unroll 4
+        for (int64_t i = i0 + rl; i < i1; i += 8) {
+            const double p = s.P[i * s.D + d];
+            const double z = fma(lambda, p, s.Z[i * s.D + d]);
+            s.Z[i * s.D + d] = z;
+            zp = fma(z, p, zp);
+        }
+    zp = rm_colsum(zp, red, d, rl);
+    if (rl == 0 && act) c.partA[d * c.G + g] = zp;
+}
+
+__global__ __launch_bounds__(256) void k_cg_rm_b(CgState s, CgRm c, int iter)
+{
+    __shared__ double red[8][32];
+    if (*s.nactive == 0) return;
+    const int d = threadIdx.x & 31, rl = threadIdx.x >> 5, g = blockIdx.x;
+    const bool act = d < s.D && s.active[d] && s.iters[d] == iter;
+    double rr = 0.0;
+    const double zp = rm_sum_parts(c, c.partA, act, red, d, rl);
+    if (act) {
+        const double ak = s.bknum[d] / zp;
+        const int64_t i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+#pragma unroll 4
+        for (int64_t i = i0 + rl; i < i1; i += 8) {
+            const int64_t e = i * s.D + d;
+            s.X[e] = fma(ak, s.P[e], s.X[e]);
+            const double r = fma(-ak, s.Z[e], s.R[e]);
+            s.R[e] = r;
+            rr = fma(r, r, rr);
+        }
+    }
+    rr = rm_colsum(rr, red, d, rl);
+    if (rl == 0 && act) c.partB[d * c.G + g] = rr;
+}
+
+__global__ __launch_bounds__(256) void k_cg_rm_c(CgState s, CgRm c, int iter, int maxiter)
+{
+    if (*s.nactive == 0) return;                          // (a) has reported
+    const int d = threadIdx.x & 31, rl = threadIdx.x >> 5, g = blockIdx.x;
+    const bool act = d < s.D && s.active[d] && s.iters[d] == iter;
+    if (act && iter >= maxiter && g == 0 && rl == 0) atomicOr_system(s.flag, (int)BDF_WARN_CG_MAXITER);
+    bool go = false;
+    __shared__ double red[8][32];
+    const double rr = rm_sum_parts(c, c.partB, act && iter < maxiter, red, d, rl);
+    if (act && iter < maxiter) {                          // top of iteration iter + 1 (cg_pre)
+        go = !(sqrt(rr) < s.tolb[d]);
+        if (go) {
+            const double bk = rr / s.bkden[d];
+            const int64_t i0 = g * c.len, i1 = (i0 + c.len < s.n) ? i0 + c.len : s.n;
+    #pragma unroll 4
+        for (int64_t i = i0 + rl; i < i1; i += 8) { const int64_t e = i * s.D + d; s.P[e] = fma(bk, s.P[e], s.R[e]); }
+        }
+    }
+    // the columns' bookkeeping by the workgroup that FINISHES LAST (every other one has read active / iters / bkden by then)
+    __shared__ int last;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        last = atomicAdd(s.done_blocks, 1) == c.G - 1;
+    }
+    __syncthreads();
+    if (!last) return;
+    if (rl == 0 && act && iter < maxiter) {
+        if (!go) { s.active[d] = 0; atomicSub(s.nactive, 1); }
+        else { s.bkden[d] = rr; s.bknum[d] = rr; s.iters[d] = iter + 1; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        *s.done_blocks = 0;
+        __threadfence();
+        const int na = __hip_atomic_load(s.nactive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s.status[1] = (uint64_t)(iter < maxiter ? na : 0);
+        __threadfence_system();
+        s.status[0] = ((uint64_t)s.gen << 32) | (uint32_t)iter;
+    }
+}
+
+__global__ void k_cg_rm_zero(CgState s)
+{
+    if (threadIdx.x == 0) { *s.nactive = s.D; *s.done_blocks = 0; }
+}
+
 // ---- beta' beta, trace(beta'beta Lambda), lambda_beta ~ Gamma ----------------------------------------------------
 // G = beta' beta (D x D) by one block
 __global__ __launch_bounds__(256) void k_btb(int D, int64_t numF, const double *beta, double *G)
@@ -1629,9 +1810,12 @@ extern "C" int bdf_hyper_feature_terms(bdf_ctx *ctx, int D, int64_t numF, const 
 
 // D simultaneous cg_AtA solves of (F'F + lambda I) X = rhs (solve_cg2, parallel_matrix.jl:488-507); with use_ff the operator
 // is the precomputed F'F.  R, P, Z: numF x D; Tm: N x D; scal: 3 D doubles; ints: 2 D + 1 ints.
+// ctx->cg_part: the partial dot products of the chunked steps -- the column-major kernels' (2 x BDF_MAX_D x 64 + BDF_MAX_D) or the
+// row-major ones' (2 x 32 x BDF_CG_RM_MAXG + 128)
+constexpr size_t CG_PART_DOUBLES = (size_t)2 * 32 * BDF_CG_RM_MAXG + 128 > (size_t)2 * BDF_MAX_D * 64 + BDF_MAX_D ? (size_t)2 * 32 * BDF_CG_RM_MAXG + 128 : (size_t)2 * BDF_MAX_D * 64 + BDF_MAX_D;
 static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double *lambda_beta_dev, const double *rhs,
                     double *beta_out, double tol, int maxiter, double *R, double *P, double *Z, double *Tm, double *scal,
-                    int *ints, int **iters_dev)
+                    int *ints, int **iters_dev, double *Xrm = nullptr /* numF x D spare (the row-major solve's X), or NULL */)
 {
     const int64_t N = f->m, numF = f->n;
     int rc;
@@ -1670,9 +1854,30 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
         resident = (int64_t)per_cu * avail >= (numF + 15) / 16;
     }
     if (resident && !ctx->cg_bar) BDF_HIP(hipMalloc((void **)&ctx->cg_bar, sizeof(unsigned)));
+    // sparse features, long columns: the state ROW-MAJOR from the first launch to the last (k_cg_rm_*): no transposes around the products
+    static const bool rm_ok = !(getenv("BDF_CG_ROWMAJOR") && atoi(getenv("BDF_CG_ROWMAJOR")) == 0);
+    static const bool long_ok_ = !(getenv("BDF_CG_LONG") && atoi(getenv("BDF_CG_LONG")) == 0);
+    const bool rm = rm_ok && long_ok_ && Xrm && !use_ff && f->kind != 0 && numF > 2048 && D <= 32;
+    CgRm cr;
+    cr.len = 256;                                             // rows per workgroup: thirty-two per row lane (G ~ 200 at 50,000 rows: every workgroup adds G partials per column)
+    cr.G = (int)((numF + cr.len - 1) / cr.len);
+    if (cr.G > BDF_CG_RM_MAXG) { cr.G = BDF_CG_RM_MAXG; cr.len = (numF + cr.G - 1) / cr.G; cr.G = (int)((numF + cr.len - 1) / cr.len); }
+    cr.partA = cr.partB = cr.bkden0 = cr.zp = cr.rrs = nullptr;
+    if (rm) {
+        if (!ctx->cg_part) BDF_HIP(hipMalloc((void **)&ctx->cg_part, CG_PART_DOUBLES * sizeof(double)));
+        cr.partA = ctx->cg_part; cr.partB = cr.partA + (size_t)32 * BDF_CG_RM_MAXG; cr.zp = cr.partB + (size_t)32 * BDF_CG_RM_MAXG; cr.rrs = cr.zp + 64;
+        // (X row-major in the caller's spare buffer: beta_out is column-major and receives the solution at the end)
+        hipLaunchKernelGGL(k_cg_rm_zero, dim3(1), dim3(64), 0, ctx->stream, s);
+        hipLaunchKernelGGL(k_to_rowmajor, dim3((unsigned)((numF + 31) / 32), (unsigned)((D + 31) / 32)), dim3(256), 0, ctx->stream, numF, D, rhs, (int64_t)1, numF, R,
+                           (const int *)nullptr);
+        s.X = Xrm;
+        hipLaunchKernelGGL(k_cg_rm_init, dim3(cr.G), dim3(256), 0, ctx->stream, s, cr, tol);
+        BDF_HIP(hipGetLastError());
+    } else {
     hipLaunchKernelGGL(k_cg_init, dim3(D), cgb, 0, ctx->stream, s, (const double *)rhs, tol, resident ? ctx->cg_bar : (unsigned *)nullptr);
     BDF_HIP(hipGetLastError());
     hipLaunchKernelGGL(k_cg_pre, dim3(D), cgb, 0, ctx->stream, s, 1);
+    }
     // The host enqueues iterations AHEAD of the device (no stream synchronisation: the device never idles between
     // iterations) and reads the (iteration, active columns) word the device writes to host-mapped memory after every
     // iteration.  Run-ahead is bounded to CG_AHEAD iterations; once every column has stopped, the launches already enqueued
@@ -1685,8 +1890,7 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     ch.len = (numF + ch.G - 1) / ch.G;
     ch.partA = ch.partB = ch.bkden0 = nullptr;
     if (long_cols) {
-        constexpr size_t PART = (size_t)2 * BDF_MAX_D * 64 + BDF_MAX_D;     // (the scratch buffers are reused by the products inside the loop)
-        if (!ctx->cg_part) BDF_HIP(hipMalloc((void **)&ctx->cg_part, PART * sizeof(double)));
+        if (!ctx->cg_part) BDF_HIP(hipMalloc((void **)&ctx->cg_part, CG_PART_DOUBLES * sizeof(double)));     // (the scratch buffers are reused by the products inside the loop)
         ch.partA = ctx->cg_part; ch.partB = ch.partA + (size_t)BDF_MAX_D * 64; ch.bkden0 = ch.partB + (size_t)BDF_MAX_D * 64;
     }
     if (resident) {
@@ -1724,14 +1928,23 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
             if ((rc = gemm(ctx, g))) return rc;
         } else {
             // the N x D intermediate row-major: contiguous writes of the first product, contiguous operand rows of the second
-            if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, D, 1))) return rc;
-            if ((rc = feat_apply(ctx, f, true, Tm, D, 1, D, Z, 1, numF))) return rc;
+            if (rm) {
+                if ((rc = feat_apply(ctx, f, false, P, D, 1, D, Tm, D, 1))) return rc;
+                if ((rc = feat_apply(ctx, f, true, Tm, D, 1, D, Z, D, 1))) return rc;
+            } else {
+                if ((rc = feat_apply(ctx, f, false, P, 1, numF, D, Tm, D, 1))) return rc;
+                if ((rc = feat_apply(ctx, f, true, Tm, D, 1, D, Z, 1, numF))) return rc;
+            }
         }
         // bottom of this iteration and top of the next in one launch
         if (numF <= 512) hipLaunchKernelGGL(k_cg_step_short<2>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         else if (numF <= 1024) hipLaunchKernelGGL(k_cg_step_short<4>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
         else if (numF <= 2048) hipLaunchKernelGGL(k_cg_step_short<8>, dim3(D), dim3(256), 0, ctx->stream, s, (const double *)lambda_beta_dev, iter, maxiter);
-        else if (long_cols) {
+        else if (rm) {
+            hipLaunchKernelGGL(k_cg_rm_a, dim3(cr.G), dim3(256), 0, ctx->stream, s, cr, (const double *)lambda_beta_dev, iter);
+            hipLaunchKernelGGL(k_cg_rm_b, dim3(cr.G), dim3(256), 0, ctx->stream, s, cr, iter);
+            hipLaunchKernelGGL(k_cg_rm_c, dim3(cr.G), dim3(256), 0, ctx->stream, s, cr, iter, maxiter);
+        } else if (long_cols) {
             hipLaunchKernelGGL(k_cg_long_a, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, (const double *)lambda_beta_dev, iter);
             hipLaunchKernelGGL(k_cg_long_b, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, iter);
             hipLaunchKernelGGL(k_cg_long_c, dim3(D, ch.G), dim3(256), 0, ctx->stream, s, ch, iter, maxiter);
@@ -1739,6 +1952,12 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
         BDF_HIP(hipGetLastError());
     }
     ctx->skip_flag = nullptr;
+    if (rm) {
+        // the solution, row-major in s.X, into the caller's column-major beta_out
+        hipLaunchKernelGGL(k_from_rowmajor, dim3((unsigned)((numF + 31) / 32), (unsigned)((D + 31) / 32)), dim3(256), 0, ctx->stream, numF, D,
+                           (const double *)s.X, beta_out, (int64_t)1, numF, (const double *)nullptr, (double *)nullptr, (const int *)nullptr);
+        BDF_HIP(hipGetLastError());
+    }
     *iters_dev = s.iters;
     return BDF_OK;
 }
@@ -2003,7 +2222,7 @@ extern "C" int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_fea
         int rank = 0, world = 1;
         if (comm && (rc = bdf_comm_size(comm, &rank, &world))) return rc;
         if (world <= 1) {
-            if ((rc = cg_solve(ctx, f, ff_op, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+            if ((rc = cg_solve(ctx, f, ff_op, D, lambda_beta_dev, rhs, beta_out, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters, E2s))) return rc;      // (E2s: free once rhs is formed)
             if (iters_out) BDF_HIP(hipMemcpyAsync(iters_out, cg_iters, D * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
         } else {
             // this rank's block of columns, solved into its place of a gather buffer of world blocks (>= D columns), then the
@@ -2022,7 +2241,7 @@ extern "C" int bdf_sample_beta_ranks(bdf_ctx *ctx, bdf_comm *comm, const bdf_fea
             int32_t *my_iters = (int32_t *)(gb + (size_t)rank * blk + (size_t)nc * numF * sizeof(double));
             BDF_HIP(hipMemsetAsync(my_beta, 0, blk, ctx->stream));
             if (mine > 0) {
-                if ((rc = cg_solve(ctx, f, ff_op, mine, lambda_beta_dev, rhs + (size_t)c0 * numF, my_beta, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters))) return rc;
+                if ((rc = cg_solve(ctx, f, ff_op, mine, lambda_beta_dev, rhs + (size_t)c0 * numF, my_beta, tol, maxiter, R, P, Z, Tm, scal, ints, &cg_iters, E2s))) return rc;
                 BDF_HIP(hipMemcpyAsync(my_iters, cg_iters, (size_t)mine * sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
             }
             if ((rc = bdf_allgather_block(ctx, comm, gb, blk)) || (rc = bdf_allgather_join(ctx, comm))) return rc;

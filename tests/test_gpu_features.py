@@ -120,6 +120,39 @@ def test_sample_beta_cg_and_direct_match_oracle(B, O, ctx, kind, D):
     op.close()
 
 
+@pytest.mark.parametrize("kind,D", [("csr", 32), ("bin", 6), ("csr", 17)])
+def test_sample_beta_cg_long_columns_row_major_state(B, O, ctx, kind, D):
+    """Sparse features with more than 2,048 columns and no F'F: the conjugate-gradient state lives ROW-major from the solve's first
+    launch to its last (k_cg_rm_*: the sparse products take and leave it as it is -- no transposes around them) -- 3,000 x 2,600
+    features, 9 entries per row, real-valued (CSR) and binary, D = 32 (sixteen 16-byte lanes per gathered row), 6 and 17 (an odd
+    row length: the general sparse kernel): rhs and beta against the oracle's literal cg_AtA (src/parallel_cg.jl:63-94) on the same
+    noise streams, beta against the direct solve of the same system, the per-column iteration counts within one."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(2600 + D)
+    N, numF, per = 3000, 2600, 9
+    rows = np.repeat(np.arange(N), per)
+    cols = np.concatenate([np.sort(rng.choice(numF, per, replace=False)) for _ in range(N)])
+    vals = np.ones(len(rows)) if kind == "bin" else rng.standard_normal(len(rows))
+    A = sp.csr_matrix((vals, (rows, cols)), shape=(N, numF))
+    op = B.FeatOperator(ctx, B.SparseBinMatrix(N, numF, rows + 1, cols + 1) if kind == "bin" else B.sparse_csr(rows + 1, cols + 1, vals, N, numF))
+    sample = rng.standard_normal((N, D))
+    mu = rng.standard_normal(D) * 0.1
+    M = rng.standard_normal((D, D))
+    Lam = M @ M.T / D + np.eye(D)
+    lb = 2.5
+    ctx.set_sweep(8)
+    ofeat = O.Feat.from_csr(rows, cols, vals, N, numF)
+    beta_e, rhs_e, it_e = O.sample_beta(ofeat, sample, mu, Lam, lb, False, 1e-10, SEED, 8, 3)
+    beta, rhs, iters, _ = _sample_beta(B, ctx, op, D, sample, mu, Lam, lb, False, 1e-10)
+    np.testing.assert_allclose(rhs, rhs_e, rtol=1e-9, atol=1e-9)
+    scale = np.abs(beta_e).max()
+    np.testing.assert_allclose(beta, beta_e, rtol=1e-7, atol=1e-8 * scale)
+    direct = np.linalg.solve((A.T @ A).toarray() + lb * np.eye(numF), rhs_e)
+    np.testing.assert_allclose(beta, direct, rtol=1e-6, atol=1e-7 * scale)
+    assert np.all(np.abs(iters - it_e) <= 1), (iters, it_e)
+    op.close()
+
+
 @pytest.mark.parametrize("kind", ["dense", "csr"])
 def test_cg_out_of_iterations_is_reported_not_raised(B, ctx, kind):
     """cg_AtA (parallel_cg.jl:73-93) returns a column that ran out of iterations as it stands; the library does the same and
