@@ -58,7 +58,7 @@ extern "C" int bdf_ctx_create(int device, void *stream, uint64_t seed, bdf_ctx *
     c->sweep_host = 0;
     c->rows_span = nullptr;
     c->rows_ready = nullptr; c->rows_ready_want = 0; c->hyper_ready = nullptr; c->hyper_ready_value = 0;
-    c->rows_done = nullptr; c->rows_done_added = -1; c->rows_begun = nullptr; c->hyper_wait = nullptr; c->hyper_wait_target = 0;
+    c->rows_done = nullptr; c->rows_done_added = -1; c->hyper_wait = nullptr; c->hyper_wait_target = 0;
     c->warnings = 0;
     c->reserve_cus = 0;
     c->on_reserved = 0;
@@ -745,9 +745,7 @@ extern "C" int bdf_sample_rows(bdf_ctx *ctx, int D, int64_t N, int n_terms, cons
     a.span = ctx->rows_span;
     ctx->rows_span = nullptr;
     a.done = ctx->rows_done;
-    a.begun = ctx->rows_begun;
     ctx->rows_done = nullptr;
-    ctx->rows_begun = nullptr;
     ctx->rows_done_added = -1;
 #ifdef BDF_K1_SPANS
     {   // diagnostic build only: a ring of 1024 launches x 8192 waves x {start, end, wait} (bdf_debug_spans)

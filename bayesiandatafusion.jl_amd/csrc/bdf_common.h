@@ -71,7 +71,6 @@ struct bdf_ctx {
     // 64 words (16 words apart), and rows_done_added says how many will; else rows_done_added stays -1 and the caller uses the event
     uint32_t *rows_done;
     int64_t rows_done_added;
-    uint32_t *rows_begun;                  // ... and 64 more words the same waves add to when they START (the prediction update's gate: bdf_gibbs.hip)
     const uint32_t *hyper_wait;            // (library-internal) ... and the next one-launch chain (k_hyper_chain) polls their sum for this target
     uint32_t hyper_wait_target;
     uint32_t *hyper_ready;                 // (library-internal) word the next bdf_hyper_sample sets to hyper_ready_value once its pack is written, then cleared
@@ -381,7 +380,6 @@ struct SampleArgs {
     // nullable (bdf_gibbs_sweep, k_rows_col only): 64 counters, 16 words apart; a wave that has written its rows (write-through, drained)
     // adds 1 to counter (wave % 64): what the hyperprior chain polls instead of waiting for the launch's completion event
     uint32_t *done;
-    uint32_t *begun;           // nullable: the same shards, added to by every wave as it starts
 };
 #define BDF_DONE_SHARDS 64
 #define BDF_DONE_STRIDE 16         // words between two shards

@@ -39,11 +39,6 @@ struct bdf_gibbs {
         // this entity enqueued so far has completed (wraps; compared as a difference)
         uint32_t *done_dev = nullptr;
         uint32_t done_target = 0;
-        // ... and the waves that have STARTED (k_pred_gate's second condition): the sum begun_dev reaches when every launch enqueued
-        // so far has begun; last_waves: the waves of the entity's latest launch by counter (what the gate expects of the next one)
-        uint32_t *begun_dev = nullptr;
-        uint32_t begun_target = 0;
-        int64_t last_waves = 0;
         hipEvent_t t_start = nullptr, t_stop = nullptr;      // bdf_gibbs_time_rows: attached to the next row launch of this entity
         unsigned long long *span = nullptr;                  // bdf_gibbs_span_rows: SampleArgs::span of the next row launch of this entity
     };
@@ -54,11 +49,6 @@ struct bdf_gibbs {
     double *stats_dev;
     hipEvent_t ev_pred[3] = {nullptr, nullptr, nullptr};   // prediction update number k complete: ev_pred[k % 3]
     uint64_t pred_at[3] = {0, 0, 0};     // ... and the iteration count (n_iter) at which it was enqueued
-    // k_pred_gate's second condition: the gate enqueued last expects entity gate_entity's begun-count to reach gate_target; the
-    // entity's next row launch provides it -- or, if that launch adds less (another kernel, a timed launch) or never comes
-    // (bdf_gibbs_sync), the library adds the rest itself (k_bump)
-    int gate_entity = -1;
-    uint32_t gate_target = 0;
     uint64_t n_pred;                     // prediction updates enqueued so far
     uint64_t n_iter = 0;                 // iterations enqueued so far (with or without a prediction update)
     bdf_comm *comm;                      // nullable: exchange of the sampled rows between the ranks after every entity
@@ -99,36 +89,6 @@ __global__ void k_wait_flag(const uint32_t *flag, long long max_ticks, uint32_t 
     }
 }
 __global__ void k_set_flag(uint32_t *flag) { __hip_atomic_store(flag, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }
-
-// One wave, enqueued on the prediction stream IN FRONT of the update, in place of a wait for the last row launch's completion event
-// (an event on the dispatch costs the row stream ~5 us between that launch and the next: 0.0 us without one).  It ends when
-//   1. the row waves' done-counters (SampleArgs::done: 64 shards) have reached `done_target`: the update's inputs are in memory; and
-//   2. the NEXT iteration's first row launch holds its slots (SampleArgs::begun reached `begun_target`): the update's workgroups then
-//      fill that launch's tail -- let onto an empty chip they take the slots the row waves need, and the launch runs 41-44 us
-//      instead of 35-38 (profiles/r06_predict_gate.txt).  This one is a hint: bounded at ~10 ms without an error (no further
-//      iteration: bdf_gibbs_sync releases it by adding the missing count itself).
-// Bounded spin on the first (flag 16).
-__global__ __launch_bounds__(64) void k_pred_gate(const uint32_t *done, uint32_t done_target, const uint32_t *begun, uint32_t begun_target, int *flag)
-{
-    int spins = 0;
-    for (;;) {
-        uint32_t v = __hip_atomic_load(done + BDF_DONE_STRIDE * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((int32_t)(v - done_target) >= 0) break;
-        __builtin_amdgcn_s_sleep(16);
-        if (++spins > (1 << 22)) { if (threadIdx.x == 0) atomicOr_system(flag, 16); break; }
-    }
-    if (!begun) return;
-    for (spins = 0; spins < 8000; spins++) {
-        uint32_t v = __hip_atomic_load(begun + BDF_DONE_STRIDE * threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
-        if ((int32_t)(v - begun_target) >= 0) break;
-        __builtin_amdgcn_s_sleep(8);
-    }
-}
-__global__ void k_bump(uint32_t *word, uint32_t by) { __hip_atomic_fetch_add(word, by, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 int streams_concurrent(hipStream_t a, hipStream_t b, bool *yes)
 {
@@ -327,8 +287,6 @@ extern "C" int bdf_gibbs_create(bdf_ctx *rows_ctx, int D, int n_entities, const 
         for (int j = 0; j < n_entities; j++) {
             BDF_HIP(hipMalloc((void **)&g->ent[(size_t)j].done_dev, bytes));
             BDF_HIP(hipMemsetAsync(g->ent[(size_t)j].done_dev, 0, bytes, rows_ctx->stream));
-            BDF_HIP(hipMalloc((void **)&g->ent[(size_t)j].begun_dev, bytes));
-            BDF_HIP(hipMemsetAsync(g->ent[(size_t)j].begun_dev, 0, bytes, rows_ctx->stream));
         }
         BDF_HIP(hipStreamSynchronize(rows_ctx->stream));
     }
@@ -349,7 +307,6 @@ extern "C" int bdf_gibbs_destroy(bdf_gibbs *g)
         if (E.ev_hyper) (void)hipEventDestroy(E.ev_hyper);
         if (E.ev_beta) (void)hipEventDestroy(E.ev_beta);
         if (E.done_dev) (void)hipFree(E.done_dev);
-        if (E.begun_dev) (void)hipFree(E.begun_dev);
     }
     for (int k = 0; k < 3; k++)
         if (g->ev_pred[k]) (void)hipEventDestroy(g->ev_pred[k]);
@@ -753,30 +710,20 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         for (int c = 0; c < nch; c++) {
             R->time_start = (c == 0) ? E.t_start : nullptr;
             R->rows_span = E.span;
-            R->time_stop = (c == nch - 1 && !g->comm && !counter) ? done : nullptr;
+            R->time_stop = (c == nch - 1 && !g->comm && !(counter && !pred_waits)) ? done : nullptr;
             if (poll) { R->rows_ready = g->ready_dev + j; R->rows_ready_want = E.epoch; }
-            if (counter) { R->rows_done = E.done_dev; R->rows_begun = E.begun_dev; }
+            if (counter) R->rows_done = E.done_dev;
             if ((rc = bdf_sample_rows(R, D, e.N, e.n_terms, terms, e.feat ? e.mu_matrix : e.mu, e.feat ? 1 : 0, e.Lambda, e.tag, c, nch,
                                       e.sample[nxt], (E.hyper_recorded && !e.feat) ? e.prior_pack : nullptr)))
                 return rc;
-            if (counter && R->rows_done_added >= 0) {
-                by_counter = true;
-                E.done_target += (uint32_t)R->rows_done_added; E.begun_target += (uint32_t)R->rows_done_added; E.last_waves = R->rows_done_added;
-            }
+            if (counter && R->rows_done_added >= 0) { by_counter = true; E.done_target += (uint32_t)R->rows_done_added; }
             if (g->comm && (rc = bdf_allgather_rows(R, g->comm, D, e.N, e.sample[nxt], c, nch))) return rc;
         }
         if (g->comm) {
             if ((rc = bdf_allgather_join(R, g->comm))) return rc;       // the row stream continues after the last chunk's exchange
             BDF_HIP(hipEventRecord(done, R->stream));
-        } else if (counter && !by_counter) {
+        } else if (counter && !pred_waits && !by_counter) {
             BDF_HIP(hipEventRecord(done, R->stream));                   // (the launch took another kernel: the event after all)
-        }
-        if (g->gate_entity == j) {
-            // a gate of the prediction stream waits for this launch to hold its slots: if its waves will not add up to what the
-            // gate expects, the rest is added here (behind the launch: the gate passes when the launch ends, at the latest)
-            const uint32_t missing = g->gate_target - E.begun_target;
-            if ((int32_t)missing > 0) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, R->stream, E.begun_dev, missing); E.begun_target += missing; }
-            g->gate_entity = -1;
         }
         E.t_start = E.t_stop = nullptr;
         E.span = nullptr;
@@ -803,20 +750,7 @@ extern "C" int bdf_gibbs_sweep(bdf_gibbs *g, uint32_t sweep, int predict_phase)
         if ((rc = bdf_hyper_sample(H, D, e.n_real, e.sumU, e.UUt, e.mu0, e.b0, Tinv, hyper_nu(e), e.tag, e.mu, e.Lambda, e.params, e.prior_pack, e.draws)))
             return rc;
         E.hyper_recorded = true;
-        if (pred_waits) {
-            // the prediction update needs this entity's rows: the event, or -- rows handed over by counter -- a one-wave gate kernel
-            if (by_counter) {
-                // (the next iteration's first row launch: entity 0's, expected to bring as many waves as its last one)
-                auto &N0 = g->ent[0];
-                static const bool gate2 = !(getenv("BDF_PRED_GATE_BEGUN") && atoi(getenv("BDF_PRED_GATE_BEGUN")) == 0);
-                const bool wait_begun = gate2 && n > 1 && N0.begun_dev && N0.last_waves > 0;
-                // (most of them: the launch may have a few more waves than the stream has slots -- those start when slots come free)
-                const uint32_t bt = N0.begun_target + (uint32_t)(N0.last_waves * 85 / 100);
-                hipLaunchKernelGGL(k_pred_gate, dim3(1), dim3(64), 0, P->stream, (const uint32_t *)E.done_dev, E.done_target,
-                                   (const uint32_t *)(wait_begun ? N0.begun_dev : nullptr), bt, R->flag_dev);
-                if (wait_begun) { g->gate_entity = 0; g->gate_target = bt; }
-            } else BDF_HIP(hipStreamWaitEvent(P->stream, done, 0));
-        }
+        if (j == n - 1 && g->test && predict_phase >= 0) BDF_HIP(hipStreamWaitEvent(P->stream, done, 0));
     }
     // side information: beta of every entity that has it, from this iteration's rows and (mu, Lambda) (macau.jl:138-140)
     for (int j = 0; j < n; j++) {
@@ -857,12 +791,6 @@ extern "C" int bdf_gibbs_sync(bdf_gibbs *g)
 {
     BDF_REQUIRE(g, BDF_ERR_ARG, "bdf_gibbs_sync: NULL argument");
     int rc;
-    if (g->gate_entity >= 0) {          // no further iteration is coming for now: let the prediction update's gate pass
-        auto &E = g->ent[(size_t)g->gate_entity];
-        const uint32_t missing = g->gate_target - E.begun_target;
-        if ((int32_t)missing > 0) { hipLaunchKernelGGL(k_bump, dim3(1), dim3(1), 0, g->rows->stream, E.begun_dev, missing); E.begun_target += missing; }
-        g->gate_entity = -1;
-    }
     if ((rc = bdf_ctx_sync(g->pred)) || (rc = bdf_ctx_sync(g->hyper))) return rc;
     return bdf_ctx_sync(g->rows);
 }

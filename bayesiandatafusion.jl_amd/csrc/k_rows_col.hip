@@ -156,8 +156,6 @@ __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in,
     // (64 shards: two thousand waves on ONE word are served one after the other, ~12 ns each, and a wave's first loads queue behind
     // its own atomic -- measured: the launch 60 us instead of 39)
     if (a_in.span && threadIdx.x == 0) atomicMin(a_in.span + 2 * (w & 63), (unsigned long long)__builtin_amdgcn_s_memrealtime());
-    // (this wave holds its slot: what the prediction update's gate counts before it lets the update's workgroups onto the chip)
-    if (a_in.begun && threadIdx.x == 0) __hip_atomic_fetch_add(a_in.begun + BDF_DONE_STRIDE * (w & (BDF_DONE_SHARDS - 1)), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CSTAMP_DECL;
 #pragma nounroll
     for (int rd = p_in.wave_round[w]; rd < r_end; rd++) {

@@ -1245,7 +1245,6 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         if (no_coded) ac.t[0].packed = nullptr;
         // the rows' hand-over by counter (SampleArgs::done): only when this launch is ALL of the call's rows
         if (more || plan->n_lr > 0 || plan->n_small > 0) ac.done = nullptr;
-        if (!ac.done) ac.begun = nullptr;
         if (ac.done) ctx->rows_done_added = plan->col.n_waves;
         int rc = bdf_col_launch(ctx, ac, plan->col, M_other, ctx->time_start, more ? nullptr : ctx->time_stop);
         if (rc) return rc;
