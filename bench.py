@@ -665,8 +665,9 @@ def main():
                          # launch from the committed counters, the launch's flops by the reference's map against the 78.6 TF peak, and the
                          # counters' HBM traffic over the algorithmic bytes (<< 1: the gathered factor is L2-resident, nothing re-read)
                          "fp64_valu_busy_frac": None if pipe is None else pipe["frac"],
-                         "fp64_flops_frac": round(k1_flops / n_launch / (launch_us * 1e-6) / (FP64_PEAK_TFLOPS * 1e12), 4),
-                         "traffic_over_algorithmic": None if traffic is None else round(traffic / (k1_bytes / n_launch), 3),
+                         "fp64_flops_frac": (round(k1_flops / n_launch / (launch_us * 1e-6) / (FP64_PEAK_TFLOPS * 1e12), 4)
+                                             if n_launch and launch_us > 0 else None),
+                         "traffic_over_algorithmic": None if traffic is None or not k1_bytes else round(traffic / (k1_bytes / n_launch), 3),
                          "counters_schedule": "the committed PMC passes ran with BDF_RESERVE_CUS=0 BDF_NO_POLL=1 (rocprofv3 serialises the streams; CU-masked "
                                               "streams crash its teardown): all 1,024 SIMDs, event hand-overs -- the launch time they are divided by is this run's",
                          "algorithmic_bytes_per_launch": int(k1_bytes / n_launch),
