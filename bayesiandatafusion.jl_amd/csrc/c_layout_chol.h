@@ -12,7 +12,7 @@
 #define BDF_K1_WPB 4
 #endif
 #ifndef BDF_K1_WPB64
-#define BDF_K1_WPB64 1            // ... at D > 32: one (a wave's 18 KB of LDS come free with it: with two, a finished wave's slot idled until its partner ended -- C4 42.7 -> 39.1 ms)
+#define BDF_K1_WPB64 1            // ... at D > 32: one (a wave's LDS comes free with it: with two, a finished wave's slot idled until its partner ended -- C4 42.7 -> 39.1 ms)
 #endif
 #ifndef BDF_K1_WAVES32M
 #define BDF_K1_WAVES32M 6         // ... its variant for two-mode relations (78 registers)
@@ -21,13 +21,19 @@
 #define BDF_K1_WAVES32 5          // waves per SIMD the D <= 32 kernel is compiled for
 #endif
 #ifndef BDF_K1_WAVES64
-#define BDF_K1_WAVES64 2          // waves per SIMD the D > 32 kernel is compiled for
+#define BDF_K1_WAVES64 3          // waves per SIMD the D > 32 kernel is compiled for (round 6: 168 registers, 8.6 KB of LDS per wave -- GeoL below; 2: round 5's build)
 #endif
 #ifndef BDF_K1_WAVES32C
 #define BDF_K1_WAVES32C 7         // ... its variant for one two-mode relation with coded values (70 registers)
 #endif
 
 namespace {
+
+// f(std::integral_constant<int, 0>{}), ..., f(std::integral_constant<int, N - 1>{}): a loop whose index is a constant expression
+template <class F, int... Is>
+__device__ __forceinline__ void static_for_impl(F &&f, std::integer_sequence<int, Is...>) { (f(std::integral_constant<int, Is>{}), ...); }
+template <int N, class F>
+__device__ __forceinline__ void static_for(F &&f) { static_for_impl(f, std::make_integer_sequence<int, N>{}); }
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
@@ -329,6 +335,23 @@ struct PanelLanes {             // per-lane constants of the blocked variant (op
 template <int DP>
 struct GeoB { static constexpr int T_OFF = Geo<DP>::TRI_D; };       // the extra row's entries of one panel sit behind the packed factor
 
+// LOCAL = true (k_rows at DP = 64 since round 6: three waves per SIMD need <= 13 KB of LDS per wave where the whole packed factor
+// is 17.9 KB): LDS holds ONE panel at a time -- panel K at the offsets of the packed layout minus col_base(16 K), every panel from
+// offset 0 on -- because the only reader of the packed factor during the factorisation is the panel's own trailing update.  The
+// finished columns stay in the registers (blocked variant: the lanes of finished columns take a zero multiplier), and the backward
+// solve (backward_rows) puts them to LDS again one BLOCK ROW at a time, in the order it walks the rows.
+template <int DP>
+struct GeoL {
+    using GG = Geo<DP>;
+    static constexpr int PANEL0 = GG::col_base(16 < DP ? 16 : DP - 1);   // doubles of panel 0, the largest (944 at DP = 64)
+    static constexpr int RS = DP + 1;                                    // row stride of the backward solve's block row (odd: lane = column reads, no bank conflicts)
+    static constexpr int ROWS = 16 * RS;                                 // one block row: 16 rows x DP columns
+    static constexpr int T_OFF = PANEL0;                                 // the extra row's entries of the panel being finished
+    static constexpr int PIV = (ROWS > PANEL0 + 16 ? ROWS : PANEL0 + 16);   // the DP pivots, behind both
+    static constexpr int WAVE_LDS = PIV + DP;                            // 1,104 doubles at DP = 64 (8.6 KB)
+    __host__ __device__ static constexpr int base(int K) { return GG::col_base(16 * K); }
+};
+
 // the multiplier of block column K for step k (column k is final; the block column has unfinished columns)
 template <int DP, int k>
 __device__ __forceinline__ void prep_b(const double (&A)[Geo<DP>::NB * 4], const PanelLanes &pl, double &nmK)
@@ -348,13 +371,13 @@ __device__ __forceinline__ void prep_b(const double (&A)[Geo<DP>::NB * 4], const
 
 // panel K to the packed factor: the diagonal block (rows from each column's first stored row), the blocks below it, the
 // extra row's entries of the panel (lane j: t of column 16 K + j)
-template <int DP, int K>
+template <int DP, int K, bool LOCAL = false>
 __device__ __forceinline__ void panel_store(const double (&A)[Geo<DP>::NB * 4], const double (&bv)[Geo<DP>::DB], double *tri, int j, int h)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB;
     const typename GG::ColRT cr = GG::col_rt(16 * K + j);
-    double *dst = tri + cr.cbase + h * cr.nr4 - cr.q;          // row 16 I + h + 4 r of column 16 K + j at dst[4 I + r]
+    double *dst = tri + cr.cbase + h * cr.nr4 - cr.q - (LOCAL ? GeoL<DP>::base(K) : 0);   // row 16 I + h + 4 r of column 16 K + j at dst[4 I + r]
     const int r0 = j >> 2;                                      // the column stores rows 16 K + 4 (j >> 2) and on
 #pragma unroll
     for (int r = 0; r < 4; r++)
@@ -363,19 +386,19 @@ __device__ __forceinline__ void panel_store(const double (&A)[Geo<DP>::NB * 4], 
     for (int I = K + 1; I < DB; I++)
 #pragma unroll
         for (int r = 0; r < 4; r++) dst[4 * I + r] = A[GG::blk(I, K) * 4 + r];
-    if (h == 0) tri[GeoB<DP>::T_OFF + j] = bv[K];
+    if (h == 0) tri[(LOCAL ? GeoL<DP>::T_OFF : GeoB<DP>::T_OFF) + j] = bv[K];
 }
 
 // panel K is complete: to the packed factor, then the trailing update of the block columns J > K and of the extra row's
 // entries there
-template <int DP, int K>
+template <int DP, int K, bool LOCAL = false>
 __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, int j, int h,
                                  const PanelLanes &pl)
 {
     using GG = Geo<DP>;
     constexpr int DB = GG::DB;
     static_assert(K + 1 < DB, "the last panel has nothing to its right");
-    panel_store<DP, K>(A, bv, tri, j, h);
+    panel_store<DP, K, LOCAL>(A, bv, tri, j, h);
     wave_sync();
     // operands: lane (i, kk), k-step s: row 16 I + i of column c = 16 K + 4 s + kk, at
     //     col_base(c) + (i & 3) R / 4 + 4 (I - K) - s + (i >> 2),  R = DP - 16 K - 4 s rows stored, col_base(c) = col_base(c - kk) + kk (R + 1);
@@ -387,13 +410,13 @@ __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (
 #pragma unroll
     for (int s = 0; s < 4; s++) {
         const int R = DP - 16 * K - 4 * s;
-        const int base = GG::col_base(16 * K + 4 * s);
+        const int base = GG::col_base(16 * K + 4 * s) - (LOCAL ? GeoL<DP>::base(K) : 0);
         const double *src = tri + (base - s) + pl.kk * (R + 1) + pl.i3 * (R / 4) + pl.i2;
         double a[DB], as[DB];
 #pragma unroll
         for (int I = K + 1; I < DB; I++) a[I] = src[4 * (I - K)];
         const double nr = -fast_rcp(tri[base + pl.kk * (R + 1 + R / 4)]);
-        const double tc = tri[GeoB<DP>::T_OFF + 4 * s + pl.kk];
+        const double tc = tri[(LOCAL ? GeoL<DP>::T_OFF : GeoB<DP>::T_OFF) + 4 * s + pl.kk];
 #pragma unroll
         for (int I = K + 1; I < DB; I++) as[I] = a[I] * nr;
 #pragma unroll
@@ -421,7 +444,7 @@ __device__ __forceinline__ void panel_end(double (&A)[Geo<DP>::NB * 4], double (
     asm volatile("s_nop 15\n\ts_nop 3" ::: "memory");
 }
 
-template <int DP, int k>
+template <int DP, int k, bool LOCAL = false>
 __device__ __forceinline__ void factor_step_b(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double *tri, const PanelLanes &pl,
                                      int j, int h, double &nmK)
 {
@@ -440,7 +463,7 @@ __device__ __forceinline__ void factor_step_b(double (&A)[Geo<DP>::NB * 4], doub
         }
         nmK = nm_next;
     } else {
-        if constexpr (K + 1 < DB) panel_end<DP, K>(A, bv, tri, j, h, pl);
+        if constexpr (K + 1 < DB) panel_end<DP, K, LOCAL>(A, bv, tri, j, h, pl);
         prep_b<DP, k + 1>(A, pl, nmK);
     }
 }
@@ -466,6 +489,31 @@ __device__ __forceinline__ void factor_all_blocked(double (&A)[Geo<DP>::NB * 4],
     // the extra row's entries stopped changing when their columns finished: they are the forward solve
 #pragma unroll
     for (int J = 0; J < GG::DB; J++) ts[J] = bv[J];
+}
+
+// LOCAL variant (GeoL): one panel in LDS at a time; at the end the factor is in the registers (A) and the pivots in tri[GeoL::PIV + c]
+template <int DP, int... Ks>
+__device__ __forceinline__ void factor_all_blocked_local(double (&A)[Geo<DP>::NB * 4], double (&bv)[Geo<DP>::DB], double (&ts)[Geo<DP>::DB],
+                                                double *tri, int j, int h, int D, std::integer_sequence<int, Ks...>)
+{
+    using GG = Geo<DP>;
+    PanelLanes pl;
+    pl.kk = h; pl.i3 = j & 3; pl.i2 = j >> 2; pl.j4 = 4 * j;
+    asm volatile("" : "+v"(pl.kk), "+v"(pl.i3), "+v"(pl.i2), "+v"(pl.j4));
+    double nmK = 0.0;
+    prep_b<DP, 0>(A, pl, nmK);
+    (void)(... && ((Ks + 1 < D) && (factor_step_b<DP, Ks, true>(A, bv, tri, pl, j, h, nmK), true)));
+#pragma unroll
+    for (int J = 0; J < GG::DB; J++) ts[J] = bv[J];
+    // the pivots: element (c, c), c = 16 K + j, is register j >> 2 of block (K, K) in the lane of row class h == j & 3
+    const int r = j >> 2;
+    static_for<GG::DB>([&](auto Kc) {
+        constexpr int K = decltype(Kc)::value;
+        constexpr int b4 = GG::blk(K, K) * 4;
+        const double d01 = r == 0 ? A[b4] : A[b4 + 1], d23 = r == 2 ? A[b4 + 2] : A[b4 + 3];
+        const double d = r < 2 ? d01 : d23;
+        if (h == (j & 3)) tri[GeoL<DP>::PIV + 16 * K + j] = d;
+    });
 }
 
 // ---- backward solve Lt' x = yh with lane = column: lane c < i subtracts Lt[i][c] x_i, read from the packed factor ----
@@ -532,5 +580,53 @@ __device__ __forceinline__ void backward_all(double &yh, double rdv, const unsig
     constexpr int N = 16;                             // rows per batch (32 registers of entries in flight)
     (backward_batch<DP, DP - 1 - N * Bs, N>(yh, rdv, colq, std::make_integer_sequence<int, N>{}), ...);
 }
+
+// ---- backward solve for the LOCAL variant: Lt' x = yh, lane = column, the factor coming from the REGISTERS one block row at a time:
+// block row I (rows 16 I .. 16 I + 15 of every column up to the diagonal block) goes to LDS row-major with stride DP + 1, then the
+// sixteen steps of those rows run as in backward_batch -- all sixteen rows' entries of the lane's column loaded first, then per step
+// one multiply, one v_readlane, one masked fma.  Same operations in the same order as backward_all: the same bits.
+template <int i, int RS>
+__device__ __forceinline__ void backward_load_row(double &L, unsigned addr)
+{
+    unsigned long long save;
+    asm volatile("s_mov_b64 %1, exec\n\t"
+                 "s_mov_b32 exec_lo, %3\n\t"
+                 "s_mov_b32 exec_hi, %4\n\t"
+                 "ds_read_b64 %0, %2 offset:%5\n\t"
+                 "s_mov_b64 exec, %1"
+                 : "=v"(L), "=&s"(save) : "v"(addr), "n"(BwMask<i>::LO), "n"(BwMask<i>::HI), "n"((i & 15) * RS * 8) : "memory");
+}
+
+template <int DP, int I, int... Ns>
+__device__ __forceinline__ void backward_block_row(const double (&A)[Geo<DP>::NB * 4], double &yh, double rdv, double *rows, unsigned addr,
+                                          int j, int h, std::integer_sequence<int, Ns...>)
+{
+    using GG = Geo<DP>;
+    constexpr int RS = GeoL<DP>::RS;
+    // (LDS operations of a wave execute in order: these writes cannot pass the previous block row's reads)
+#pragma unroll
+    for (int J = 0; J <= I; J++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) rows[(h + 4 * r) * RS + 16 * J + j] = A[GG::blk(I, J) * 4 + r];
+    wave_sync();
+    double L[16];
+    (((16 * I + 15 - Ns >= 1) ? backward_load_row<(16 * I + 15 - Ns >= 1 ? 16 * I + 15 - Ns : 1), RS>(L[Ns], addr) : (void)0), ...);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    (((16 * I + 15 - Ns >= 1)
+          ? backward_fma<(16 * I + 15 - Ns >= 1 ? 16 * I + 15 - Ns : 1)>(yh, L[Ns], readlane_f64(yh * rdv, (16 * I + 15 - Ns >= 1 ? 16 * I + 15 - Ns : 1)))
+          : (void)0), ...);
+}
+
+template <int DP>
+__device__ __forceinline__ void backward_rows(const double (&A)[Geo<DP>::NB * 4], double &yh, double rdv, double *tri, int lane)
+{
+    const int j = lane & 15, h = lane >> 4;
+    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + lane);
+    if constexpr (Geo<DP>::DB >= 4) backward_block_row<DP, 3>(A, yh, rdv, tri, addr, j, h, std::make_integer_sequence<int, 16>{});
+    if constexpr (Geo<DP>::DB >= 3) backward_block_row<DP, 2>(A, yh, rdv, tri, addr, j, h, std::make_integer_sequence<int, 16>{});
+    if constexpr (Geo<DP>::DB >= 2) backward_block_row<DP, 1>(A, yh, rdv, tri, addr, j, h, std::make_integer_sequence<int, 16>{});
+    backward_block_row<DP, 0>(A, yh, rdv, tri, addr, j, h, std::make_integer_sequence<int, 16>{});
+}
+
 
 }  // namespace

@@ -58,6 +58,9 @@
 #ifndef BDF_K1_KS
 #define BDF_K1_KS 2               // k-steps (4 observations each) per pipelined trip, matrix relations
 #endif
+#ifndef BDF_K1_KS64
+#define BDF_K1_KS64 2             // ... at D > 32
+#endif
 
 #ifdef BDF_K1_SPANS      // diagnostic build: per wave of every launch {start, end, wait for the prior} (s_memrealtime: the 100 MHz clock all XCDs share -- s_memtime is per XCD; plain stores)
 #define SPAN_BEGIN() do { if (lane == 0 && a.b_dump && wid < 8192) ((unsigned long long *)a.b_dump)[wid * 3] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -76,6 +79,11 @@
 
 namespace {
 
+#ifndef BDF_K1_LOCAL64
+#define BDF_K1_LOCAL64 1          // D > 32: 8.6 KB of LDS per wave instead of 17.9 (c_layout_chol.h: GeoL)
+#endif
+template <int DP>
+struct K1Local { static constexpr bool value = (DP == 64) && BDF_K1_LOCAL64 && BDF_CHOL_BLOCKED; };
 
 struct Item {             // one wave's accumulation work
     int32_t row;          // entity row: where the sample is written (the row's position in the factor matrix)
@@ -220,7 +228,7 @@ __device__ __forceinline__ void accumulate_lean(const SampleArgs &a, const Item 
 {
     static_assert(!CODED || (NO == 1 && !WIDE), "coded values: one two-mode relation, 32-bit row offsets");
     constexpr int DB = Geo<DP>::DB, NB = Geo<DP>::NB;
-    constexpr int KS = (NO == 1) ? BDF_K1_KS : 1;
+    constexpr int KS = (NO == 1) ? (DP == 64 ? BDF_K1_KS64 : BDF_K1_KS) : 1;
     const TermDev &T = a.t[it.term];
     const int D = FULL ? DP : a.D;
     const int j = lane & 15, h = lane >> 4;
@@ -361,10 +369,10 @@ __device__ __forceinline__ void accumulate_any(const SampleArgs &a, const Item &
     if constexpr (DP == 64) {
         if (a.t[it.term].lean == 2) {        // a factor matrix of 4 GiB or more (e.g. 10M rows at D = 64): 64-bit row offsets
             if (a.D == DP) {
-                if (no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
+                if (MATRIX || no == 1) accumulate_lean<DP, 1, true, true>(a, it, lane, acc, bred);
                 else accumulate_lean<DP, 2, true, true>(a, it, lane, acc, bred);
             } else {
-                if (no == 1) accumulate_lean<DP, 1, false, true>(a, it, lane, acc, bred);
+                if (MATRIX || no == 1) accumulate_lean<DP, 1, false, true>(a, it, lane, acc, bred);
                 else accumulate_lean<DP, 2, false, true>(a, it, lane, acc, bred);
             }
             return;
@@ -433,6 +441,19 @@ __global__ __launch_bounds__(256) void k_prior(int D, int DP, int64_t nrows, con
     out_c[e * 64 + lane] = v;
 }
 
+// the sums of blocks b - 4 .. b are made before any later load is issued (a compiler fence that also pins the sums: at DP = 64 the
+// 40 or 44 loads of a prior image / a partial slot all in flight beside the 80-register matrix are the kernel's register peak)
+template <int NB>
+__device__ __forceinline__ void batch_fence(d4 (&acc)[NB], int b)
+{
+#pragma unroll
+    for (int q = 0; q < NB; q++)
+        if (q <= b && q + 5 > b) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) { double t = acc[q][r]; asm volatile("" : "+v"(t) : : "memory"); acc[q][r] = t; }
+        }
+}
+
 // ---- sum the partials of a split row in slot order (fixed order: the result does not depend on which wave does it) ---
 template <int DP>
 __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &sr, int lane, d4 (&acc)[Geo<DP>::NB],
@@ -444,6 +465,27 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
     for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < DB; I++) bred[I] = 0.0;
+    if constexpr (DP == 64) {
+        // a slot in two halves of 22 doubles (44 at once plus the 80-register matrix would leave nothing of a 168-register budget);
+        // the same additions in the same order
+        for (int s = 0; s < sr.n_slots; s++) {
+            const double *src = p.partials + (int64_t)(sr.slot_begin + s) * PSZ;
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                double v[NB * 2 + DB / 2];
+#pragma unroll
+                for (int e = 0; e < NB * 2; e++) v[e] = src[(half * NB * 2 + e) * 64 + lane];
+#pragma unroll
+                for (int I = 0; I < DB / 2; I++) v[NB * 2 + I] = src[NB * 4 * 64 + (half * (DB / 2) + I) * 16 + (lane & 15)];
+#pragma unroll
+                for (int e = 0; e < NB * 2; e++) acc[(half * NB * 2 + e) >> 2][(half * NB * 2 + e) & 3] += v[e];
+#pragma unroll
+                for (int I = 0; I < DB / 2; I++) bred[half * (DB / 2) + I] += v[NB * 2 + I];
+                batch_fence<NB>(acc, half * (NB / 2) + NB / 2 - 1);
+            }
+        }
+        return;
+    }
     for (int s0 = 0; s0 < sr.n_slots; s0 += U) {
         double v[U][NB * 4 + DB];
 #pragma unroll
@@ -551,11 +593,14 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
             if (++spins > (1 << 22)) { if (lane == 0) atomicOr_system(a.flag, 16); break; }      // bounded: ~seconds
         }
         SPAN_WAIT(t_poll);
+        // (DP = 64: the image's 40 loads in batches of 20, so that no more than 40 registers of it are in flight beside the matrix)
 #pragma unroll
-        for (int b = 0; b < NB; b++)
+        for (int b = 0; b < NB; b++) {
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 acc[b][r] += __hip_atomic_load(a.prior_c + (b * 4 + r) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (DP == 64 && b % 5 == 4) batch_fence<NB>(acc, b);
+        }
 #pragma unroll
         for (int J = 0; J < DB; J++) {
             const int ec = D - 1 - (16 * J + j);
@@ -563,9 +608,11 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         }
     } else {
 #pragma unroll
-        for (int b = 0; b < NB; b++)
+        for (int b = 0; b < NB; b++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[b][r] += a.prior_c[(b * 4 + r) * 64 + lane];
+            if (DP == 64 && b % 5 == 4) batch_fence<NB>(acc, b);
+        }
 #pragma unroll
         for (int J = 0; J < DB; J++) {
             const int ec = D - 1 - (16 * J + j);
@@ -608,11 +655,23 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) A[b * 4 + r] = acc[b][r];
+    if constexpr (DP == 64) {
+        // a boundary for the register allocator: the values that live through the factorisation start new live ranges here, so that
+        // what the load phases above may have to keep in scratch under a three-wave budget is in registers again for the steps
+#pragma unroll
+        for (int b = 0; b < NB * 4; b++) asm volatile("" : "+v"(A[b]));
+#pragma unroll
+        for (int J = 0; J < DB; J++) asm volatile("" : "+v"(bv[J]));
+        asm volatile("" : "+v"(z));
+    }
     double ts[DB];                                // ts[J] in lane j: t_(16 J + j) once its step has passed; the last column's
 #pragma unroll                                    // (and any column's before its step) is still in bv
     for (int J = 0; J < DB; J++) ts[J] = 0.0;
-    if (D < DP) zero_packed_factor<DP>(tri, lane);
-    if constexpr (BDF_CHOL_BLOCKED)
+    constexpr bool LOCAL = K1Local<DP>::value;    // DP = 64: one panel of the factor in LDS at a time, the backward solve fed from the registers
+    if (D < DP && !LOCAL) zero_packed_factor<DP>(tri, lane);
+    if constexpr (LOCAL)
+        factor_all_blocked_local<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
+    else if constexpr (BDF_CHOL_BLOCKED)
         factor_all_blocked<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
     else
         factor_all<DP>(A, bv, ts, tri, j, h, D, std::make_integer_sequence<int, DP - 1>{});
@@ -623,18 +682,22 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     const typename GG::ColRT cr = GG::col_rt(lane < DP ? lane : 0);       // this lane's column of the packed factor
     wave_sync();
     double dv = 1.0, tv = 0.0;
-    if (lane < D) dv = tri[cr.cbase + (lane & 3) * cr.nr4];      // the diagonal entry is the first of its row class
+    if (lane < D) dv = LOCAL ? tri[GeoL<DP>::PIV + lane] : tri[cr.cbase + (lane & 3) * cr.nr4];      // the diagonal entry is the first of its row class
     if (!(dv > 0.0)) atomicOr_system(a.flag, 1);                      // a pivot that is not positive (or NaN): not positive definite
 #pragma unroll
     for (int J = 0; J < DB; J++) tv = (lane < D && cK == J) ? ts[J] : tv;
     const double rdv = fast_rcp(dv);
     // L w = b, y = w + z carried as yh = y sqrt(d) = t + z sqrt(d);  then Lt' x = yh
     double yh = fma(z, dv * fast_rsqrt(dv), tv);
-    unsigned colq[4];                              // LDS byte addresses: row i of this lane's column at colq[i & 3] + 8 (i >> 2)
+    if constexpr (LOCAL) {
+        backward_rows<DP>(A, yh, rdv, tri, lane);
+    } else {
+        unsigned colq[4];                          // LDS byte addresses: row i of this lane's column at colq[i & 3] + 8 (i >> 2)
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-        colq[q] = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + cr.cbase + q * cr.nr4 - cr.q);
-    backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
+        for (int q = 0; q < 4; q++)
+            colq[q] = (unsigned)(size_t)(__attribute__((address_space(3))) double *)(tri + cr.cbase + q * cr.nr4 - cr.q);
+        backward_all<DP>(yh, rdv, colq, std::make_integer_sequence<int, DP / 16>{});
+    }
     if (lane < D) a.out[row * D + (D - 1 - lane)] = yh * rdv;
     STAMP(8);
     SPAN_END();
@@ -646,11 +709,12 @@ void k_rows(SampleArgs a, PlanDev p)
 {
     using GG = Geo<DP>;
     constexpr int WPB = GG::WPB;
-    __shared__ __attribute__((aligned(16))) double lds[WPB * GG::WAVE_LDS];
+    constexpr int WLDS = K1Local<DP>::value ? GeoL<DP>::WAVE_LDS : GG::WAVE_LDS;
+    __shared__ __attribute__((aligned(16))) double lds[WPB * WLDS];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int64_t w = (int64_t)blockIdx.x * WPB + wave;
     if (w < (int64_t)p.n_split + p.n_direct)
-        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * GG::WAVE_LDS);
+        process_item<DP, DUMP, MATRIX, CODED>(a, p, p.order[w], lane, lds + wave * WLDS);
 }
 
 // ---- D <= 16, short rows of ONE two-mode relation: FOUR ROWS PER WAVE -------------------------------------------------
@@ -948,14 +1012,14 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
 
 // which k_rows variant a launch takes: every term a two-mode relation on the lean gather path (matrix), and of those the
 // launches with ONE relation whose values are coded (ratings)
-void launch_kind(const SampleArgs &a, bool dump, bool &matrix, bool &coded)
+void launch_kind(const SampleArgs &a, bool dump, bool &matrix, bool &coded, bool wide_ok = false)
 {
-    matrix = true;
-    for (int r = 0; r < a.n_terms; r++) matrix = matrix && a.t[r].lean == 1 && a.t[r].n_other == 1;
+    matrix = true;             // (wide_ok: D > 32, where the two-mode variant also takes factor matrices of 4 GiB or more -- lean == 2)
+    for (int r = 0; r < a.n_terms; r++) matrix = matrix && (a.t[r].lean == 1 || (wide_ok && a.t[r].lean == 2)) && a.t[r].n_other == 1;
     static const bool no_matrix = getenv("BDF_K1_GENERAL_KERNEL") != nullptr;      // test hook: the general variant
     matrix = matrix && !no_matrix;
     static const bool no_coded = getenv("BDF_K1_NO_CODED") != nullptr;               // test hook: the uncoded two-mode variant
-    coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
+    coded = matrix && !dump && !no_coded && a.n_terms == 1 && a.t[0].lean == 1 && a.t[0].packed != nullptr && a.t[0].n_codes <= BDF_K1_CODES;
 }
 
 template <int DP>
@@ -964,7 +1028,7 @@ int launch(bdf_ctx *ctx, const SampleArgs &a, Plan &plan, bool dump)
     constexpr int WPB = Geo<DP>::WPB;
     PlanDev p = plan.dev;
     bool matrix, coded;
-    launch_kind(a, dump, matrix, coded);
+    launch_kind(a, dump, matrix, coded, DP == 64);
     const int64_t waves = (int64_t)p.n_split + p.n_direct;
     if (waves > 0) {
         const dim3 grid((unsigned)((waves + WPB - 1) / WPB)), block(64 * WPB);
