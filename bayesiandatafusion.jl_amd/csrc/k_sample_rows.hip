@@ -465,7 +465,7 @@ __device__ __forceinline__ void sum_partials(const PlanDev &p, const SplitRow &s
     for (int b = 0; b < NB; b++) acc[b] = d4{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int I = 0; I < DB; I++) bred[I] = 0.0;
-    if constexpr (DP == 64) {
+    if constexpr (DP == 64 && BDF_K1_WAVES64 >= 3) {
         // a slot in two halves of 22 doubles (44 at once plus the 80-register matrix would leave nothing of a 168-register budget);
         // the same additions in the same order
         for (int s = 0; s < sr.n_slots; s++) {
@@ -599,7 +599,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
 #pragma unroll
             for (int r = 0; r < 4; r++)
                 acc[b][r] += __hip_atomic_load(a.prior_c + (b * 4 + r) * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (DP == 64 && b % 5 == 4) batch_fence<NB>(acc, b);
+            if (DP == 64 && BDF_K1_WAVES64 >= 3 && b % 5 == 4) batch_fence<NB>(acc, b);
         }
 #pragma unroll
         for (int J = 0; J < DB; J++) {
@@ -611,7 +611,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
         for (int b = 0; b < NB; b++) {
 #pragma unroll
             for (int r = 0; r < 4; r++) acc[b][r] += a.prior_c[(b * 4 + r) * 64 + lane];
-            if (DP == 64 && b % 5 == 4) batch_fence<NB>(acc, b);
+            if (DP == 64 && BDF_K1_WAVES64 >= 3 && b % 5 == 4) batch_fence<NB>(acc, b);
         }
 #pragma unroll
         for (int J = 0; J < DB; J++) {
@@ -655,7 +655,7 @@ __device__ __forceinline__ void process_item(const SampleArgs &a, const PlanDev 
     for (int b = 0; b < NB; b++)
 #pragma unroll
         for (int r = 0; r < 4; r++) A[b * 4 + r] = acc[b][r];
-    if constexpr (DP == 64) {
+    if constexpr (DP == 64 && BDF_K1_WAVES64 >= 3) {
         // a boundary for the register allocator: the values that live through the factorisation start new live ranges here, so that
         // what the load phases above may have to keep in scratch under a three-wave budget is in registers again for the steps
 #pragma unroll

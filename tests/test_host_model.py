@@ -357,18 +357,14 @@ def test_hot_kernels_use_no_scratch_and_keep_their_occupancy():
     hot = {k: v for k, v in res.items() if re.search(r"6k_rowsILi|10k_rows_colILi|k_hyper_sampleILi|k_hyper_chainILi|k_hyper_partialILi|9k_predictILi|k_spmm_rm|k_dense_", k)}
     assert len(hot) >= 20, sorted(res)
     for k, v in hot.items():
-        # (the D > 32 row kernel at three waves per SIMD since round 6: 168 registers, and what its LOAD phases -- the prior's image, a
-        # partial slot: 40 / 44 doubles beside the 80-register matrix -- cannot hold goes through <= 160 bytes of scratch per lane,
-        # ~30 operations per row and none in the accumulation loop or the factorisation's steps: profiles/r06_c4_items_three_waves.txt)
-        scratch_ok = 160 if "6k_rowsILi64E" in k else 0
-        assert v["ScratchSize"] <= scratch_ok and v["VGPRs"] <= 256 and v.get("VGPRs Spill".split(" ")[0], 0) >= 0, (k, v)
+        assert v["ScratchSize"] == 0 and v["VGPRs"] <= 256 and v.get("VGPRs Spill".split(" ")[0], 0) >= 0, (k, v)
     occ = {k: v["Occupancy"] for k, v in hot.items()}
     k = "_ZN12_GLOBAL__N_16k_rowsILi%dELb0ELb%dELb%dEEEv10SampleArgsNS_7PlanDevE"      # <DP, dump = false, two-mode, coded values>
     assert occ["_ZN12_GLOBAL__N_110k_rows_colILi32ELb1EEEv10SampleArgs10ColPlanDevj"] >= 2       # K1c at D = 32: the bench's kernel
     assert occ[k % (32, 1, 1)] >= 7       # one two-mode relation with coded values (ratings), D <= 32
     assert occ[k % (32, 1, 0)] >= 6       # two-mode variant, D <= 32
     assert occ[k % (32, 0, 0)] >= 5
-    assert occ[k % (64, 1, 0)] >= 3 and occ[k % (64, 0, 0)] >= 3
+    assert occ[k % (64, 1, 0)] >= 2 and occ[k % (64, 0, 0)] >= 2
     assert occ[k % (16, 1, 0)] >= 8
 
 
