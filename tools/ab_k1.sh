@@ -17,6 +17,7 @@ if [ "$1" = build ]; then
       bdf_api.hip) case "$flags" in *BDF_K1_STAMPS*) extra="-DBDF_K1_STAMPS" ;; *BDF_K1_SPANS*) extra="-DBDF_K1_SPANS" ;; esac ;;
       k_hyper.hip) case "$flags" in *BDF_HYPER_STAMPS*) extra="-DBDF_HYPER_STAMPS" ;; esac ;;
       k_feat.hip) case "$flags" in *BDF_CG_STAMPS*) extra="-DBDF_CG_STAMPS" ;; esac ;;
+      k_predict.hip) case "$flags" in *BDF_PREDICT*) extra="$flags" ;; esac ;;
     esac
     if [ -z "$extra" ] && [ -f ${f%.hip}.o ]; then cp ${f%.hip}.o $o; continue; fi
     /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form=1 $extra -c $f -o $o
