@@ -1010,6 +1010,38 @@ int build_plan(bdf_ctx *ctx, const PlanKey &key, const std::vector<RowRef> &rows
     return BDF_OK;
 }
 
+// Lambda mu_i for MANY rows (per-row prior means: an entity with side information, macau.jl:104) -- one thread per output element with
+// its row of Lambda in registers and the rows' means broadcast from LDS, where k_prior spends eight lanes and a butterfly on every
+// element (100,000 rows at D = 32: 214 us -> ~20).  The same sums in the same order: the eight chains i = p, p + 8, ... by fma, then
+// ((v0 + v4) + (v2 + v6)) + ((v1 + v5) + (v3 + v7)) -- the butterfly as k_prior's lane part 0 sees it.
+template <int DPAD>
+__global__ __launch_bounds__(256) void k_prior_rows(int D, int64_t nrows, const double *__restrict__ Lambda, const double *__restrict__ mu,
+                                                    double *__restrict__ out_b)
+{
+    __shared__ double m_s[256];
+    const int tid = threadIdx.x;
+    const int RP = 256 / D;                                // rows per pass
+    const int r = tid / D, e = tid - r * D;
+    const bool mine = r < RP;
+    double L[DPAD];
+#pragma unroll
+    for (int i = 0; i < DPAD; i++) L[i] = (mine && i < D) ? Lambda[e + (int64_t)i * D] : 0.0;
+    for (int64_t row0 = (int64_t)blockIdx.x * RP; row0 < nrows; row0 += (int64_t)gridDim.x * RP) {
+        const bool ok = mine && row0 + r < nrows;
+        if (ok) m_s[tid] = mu[(row0 + r) * D + e];         // (tid == r * D + e: the pass's rows are contiguous)
+        __syncthreads();
+        if (ok) {
+            const double *m = m_s + r * D;
+            double v[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int i = 0; i < DPAD; i++)
+                if (i < D) v[i & 7] = fma(L[i], m[i], v[i & 7]);
+            out_b[(row0 + r) * D + e] = ((v[0] + v[4]) + (v[2] + v[6])) + ((v[1] + v[5]) + (v[3] + v[7]));
+        }
+        __syncthreads();
+    }
+}
+
 // which k_rows variant a launch takes: every term a two-mode relation on the lean gather path (matrix), and of those the
 // launches with ONE relation whose values are coded (ratings)
 void launch_kind(const SampleArgs &a, bool dump, bool &matrix, bool &coded, bool wide_ok = false)
@@ -1125,9 +1157,21 @@ int bdf_launch_sample_rows(bdf_ctx *ctx, const SampleArgs &a_in, const bdf_rel *
         void *pb;
         int rc = bdf_scratch(ctx, ((size_t)nr * a.D + (size_t)nimg * 64) * sizeof(double), &pb);
         if (rc) return rc;
-        const int64_t waves = (nr * a.D + 7) / 8 + nimg;
-        hipLaunchKernelGGL(k_prior, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a.D, DPp, nr, a.Lambda, a.mu,
-                           a.mu_is_matrix, (double *)pb, (double *)pb + nr * a.D);
+        static const bool no_prior_rows = getenv("BDF_PRIOR_ROWS") && atoi(getenv("BDF_PRIOR_ROWS")) == 0;     // test hook: k_prior for every size
+        if (a.mu_is_matrix && nr >= 4096 && !no_prior_rows) {
+            // many rows: Lambda mu_i by k_prior_rows (the same sums in the same order), the image alone by k_prior (nrows = 0)
+            const int RP = 256 / a.D;
+            const unsigned grid = (unsigned)std::min<int64_t>((nr + RP - 1) / RP, 4096);
+            if (DPp == 16) hipLaunchKernelGGL(k_prior_rows<16>, dim3(grid), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda, a.mu, (double *)pb);
+            else if (DPp == 32) hipLaunchKernelGGL(k_prior_rows<32>, dim3(grid), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda, a.mu, (double *)pb);
+            else hipLaunchKernelGGL(k_prior_rows<64>, dim3(grid), dim3(256), 0, ctx->stream, a.D, nr, a.Lambda, a.mu, (double *)pb);
+            hipLaunchKernelGGL(k_prior, dim3((unsigned)((nimg + 3) / 4)), dim3(256), 0, ctx->stream, a.D, DPp, (int64_t)0, a.Lambda, a.mu,
+                               0, (double *)pb, (double *)pb + nr * a.D);
+        } else {
+            const int64_t waves = (nr * a.D + 7) / 8 + nimg;
+            hipLaunchKernelGGL(k_prior, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, ctx->stream, a.D, DPp, nr, a.Lambda, a.mu,
+                               a.mu_is_matrix, (double *)pb, (double *)pb + nr * a.D);
+        }
         BDF_HIP(hipGetLastError());
         a.prior_b = (const double *)pb;
         a.prior_c = (const double *)pb + nr * a.D;

@@ -115,6 +115,41 @@ def test_row_system_and_sample_matrix(B, O, ctx, D):
     dr.close()
 
 
+@pytest.mark.parametrize("D", [20, 32, 64])
+def test_per_row_prior_means_of_many_rows(B, O, ctx, D):
+    """Lambda mu_i for an entity of >= 4,096 rows comes from k_prior_rows (round 6: one thread per element, its row of Lambda in
+    registers) instead of k_prior (eight lanes and a butterfly per element) -- the same sums in the same order: b_i of the first 4,000
+    rows is BIT-IDENTICAL between a 4,500-row entity (new kernel) and a 4,000-row one (k_prior) with the same observations, equals
+    Lambda mu_i + the data term to 1e-12, and the drawn rows match the oracle (macau.jl:104, sampling.jl:200-212)."""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(900 + D)
+    N_big, N_small, M = 4500, 4000, 30
+    ids, vals, facs, Lam, mu = _problem(rng, [N_small, M], 3000, D)
+    mu_rows = rng.standard_normal((N_big, D))
+    f1 = ctx.tensor(facs[1])
+    Lam_t = ctx.tensor(Lam)
+    b = {}
+    for N in (N_big, N_small):
+        dr = B.DeviceRelation(ctx, B.IndexedDF((ids, vals), [N, M]))
+        terms = _dev_terms(B, ctx, [(dr, 0, 1.3, 0.2, [None, f1], None)])
+        mu_t = ctx.tensor(mu_rows[:N])
+        P_t, b_t = ctx.zeros(N, D, D), ctx.zeros(N, D)
+        check(lib().bdf_row_system(ctx.handle, D, N, 1, terms, _p(mu_t), 1, _p(Lam_t), _p(P_t), _p(b_t)))
+        ctx.sync()
+        b[N] = b_t.cpu().numpy()
+        if N == N_big:
+            ctx.set_sweep(4)
+            out_t = ctx.zeros(N, D)
+            _run_rows(B, ctx, D, N, terms, mu_t, Lam_t, 6, out_t)
+            ot = O.Term(ids, vals, [N, M], 0, 1.3, 0.2, [None, facs[1]])
+            exp = O.sample_rows(D, N, [ot], mu_rows, Lam, SEED, 4, 6)
+            np.testing.assert_allclose(out_t.cpu().numpy(), exp, rtol=1e-8, atol=1e-9)
+        dr.close()
+    assert np.array_equal(b[N_big][:N_small], b[N_small])
+    empty = np.setdiff1d(np.arange(N_big), ids[:, 0] - 1)
+    np.testing.assert_allclose(b[N_big][empty], (mu_rows @ Lam.T)[empty], rtol=1e-12, atol=1e-12)
+
+
 def test_rows_tensor_multi_relation_mu_matrix_linear(B, O, ctx):
     """3-mode relation (Hadamard gather, sampling.jl:215-234) + a 2-mode relation sharing the entity
     (sum over relations, :270-283), per-row prior mean (macau.jl:104) and linear_values (:273)"""
