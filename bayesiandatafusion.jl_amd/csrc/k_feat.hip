@@ -1860,6 +1860,7 @@ static int cg_solve(bdf_ctx *ctx, bdf_feat *f, bool use_ff, int D, const double 
     const bool rm = rm_ok && long_ok_ && Xrm && !use_ff && f->kind != 0 && numF > 2048 && D <= 32;
     CgRm cr;
     cr.len = 256;                                             // rows per workgroup: thirty-two per row lane (G ~ 200 at 50,000 rows: every workgroup adds G partials per column)
+    if (const char *ev = getenv("BDF_CG_RM_LEN")) { const int v = atoi(ev); if (v >= 8 && v % 8 == 0) cr.len = v; }      // A/B hook (the dots' order follows it)
     cr.G = (int)((numF + cr.len - 1) / cr.len);
     if (cr.G > BDF_CG_RM_MAXG) { cr.G = BDF_CG_RM_MAXG; cr.len = (numF + cr.G - 1) / cr.G; cr.G = (int)((numF + cr.len - 1) / cr.len); }
     cr.partA = cr.partB = cr.bkden0 = cr.zp = cr.rrs = nullptr;
