@@ -16,7 +16,7 @@ if [ "$1" = build ]; then
       k_sample_rows.hip|k_rows_col.hip) extra="$flags" ;;
       bdf_api.hip) case "$flags" in *BDF_K1_STAMPS*) extra="-DBDF_K1_STAMPS" ;; *BDF_K1_SPANS*) extra="-DBDF_K1_SPANS" ;; esac ;;
       k_hyper.hip) case "$flags" in *BDF_HYPER_STAMPS*) extra="-DBDF_HYPER_STAMPS" ;; esac ;;
-      k_feat.hip) case "$flags" in *BDF_CG_STAMPS*) extra="-DBDF_CG_STAMPS" ;; esac ;;
+      k_feat.hip) case "$flags" in *BDF_CG_STAMPS*) extra="-DBDF_CG_STAMPS" ;; *BDF_CG_RM*) extra="$flags" ;; esac ;;
       k_predict.hip) case "$flags" in *BDF_PREDICT*) extra="$flags" ;; esac ;;
     esac
     if [ -z "$extra" ] && [ -f ${f%.hip}.o ]; then cp ${f%.hip}.o $o; continue; fi
