@@ -149,6 +149,7 @@ _SIGS = {
     "bdf_pairs_create": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_int, c_dp, C.POINTER(C.c_void_p)]),
     "bdf_pairs_destroy": (C.c_int, [C.c_void_p]),
     "bdf_predict": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),
+    "bdf_predict_all": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(C.c_int64), C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_void_p]),
     "bdf_predict_update": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.c_double, C.c_int, C.c_double,
                                      C.c_double, C.c_double, C.c_void_p]),
     "bdf_pairs_state": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), c_i64p]),

@@ -290,6 +290,79 @@ int fill(const char *who, bdf_ctx *ctx, const bdf_pairs *p, int D, const double 
 
 }  // namespace
 
+// ---- pred_all (sampling.jl:91-97): every cell of the relation.  A workgroup takes a TILE of 16 rows of the first mode x 16 cells of
+// the others (their flattened index): the first mode's rows sit in LDS, every thread owns one cell and walks the latent dimension
+// in order.  (A reporting path -- predictions_full of macau.jl:145-147 -- not the sweep: plain fp64, no matrix cores.)
+namespace {
+struct PredAllArgs {
+    int D, n_modes;
+    int64_t dims[BDF_MAX_MODES];
+    const double *fac[BDF_MAX_MODES];
+    double mean;
+    double *out;
+    int64_t rest;                  // cells of the modes behind the first: dims[1] * ... * dims[n - 1]
+};
+__global__ __launch_bounds__(256) void k_predict_all(PredAllArgs a)
+{
+    __shared__ double u[16][BDF_MAX_D + 1];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t i0 = (int64_t)blockIdx.y * 16, c = (int64_t)blockIdx.x * 16 + tx;
+    for (int e = threadIdx.x; e < 16 * a.D; e += 256) {
+        const int r = e / a.D, d = e - r * a.D;
+        u[r][d] = i0 + r < a.dims[0] ? a.fac[0][(i0 + r) * a.D + d] : 0.0;
+    }
+    __syncthreads();
+    if (c >= a.rest || i0 + ty >= a.dims[0]) return;
+    // the cell's indices in the modes behind the first (the last one fastest)
+    const double *row[BDF_MAX_MODES];
+    int64_t q = c;
+#pragma unroll
+    for (int k = BDF_MAX_MODES - 1; k >= 1; k--)
+        if (k < a.n_modes) { row[k] = a.fac[k] + (q % a.dims[k]) * a.D; q /= a.dims[k]; }
+    double s = 0.0;
+    for (int d = 0; d < a.D; d++) {
+        double pr = u[ty][d];
+#pragma unroll
+        for (int k = 1; k < BDF_MAX_MODES; k++)
+            if (k < a.n_modes) pr *= row[k][d];
+        s += pr;
+    }
+    a.out[(i0 + ty) * a.rest + c] = s + a.mean;
+}
+}  // namespace
+
+extern "C" int bdf_predict_all(bdf_ctx *ctx, int n_modes, const int64_t *dims, int D, const double *const *factors,
+                               double mean_value, double *out)
+{
+    BDF_REQUIRE(ctx && dims && factors && out, BDF_ERR_ARG, "bdf_predict_all: NULL argument");
+    BDF_REQUIRE(n_modes >= 2 && n_modes <= BDF_MAX_MODES, BDF_ERR_ARG, "bdf_predict_all: n_modes=%d must be in 2..%d", n_modes, BDF_MAX_MODES);
+    BDF_REQUIRE(D >= 1 && D <= BDF_MAX_D, BDF_ERR_ARG, "bdf_predict_all: num_latent=%d must be in 1..%d", D, BDF_MAX_D);
+    PredAllArgs a;
+    memset(&a, 0, sizeof(a));
+    a.D = D; a.n_modes = n_modes; a.mean = mean_value; a.out = out; a.rest = 1;
+    for (int k = 0; k < n_modes; k++) {
+        BDF_REQUIRE(dims[k] >= 0 && factors[k] != nullptr, BDF_ERR_ARG, "bdf_predict_all: dims[%d] < 0 or factors[%d] NULL", k, k);
+        a.dims[k] = dims[k]; a.fac[k] = factors[k];
+        if (k >= 1) a.rest *= dims[k];
+    }
+    if (a.dims[0] == 0 || a.rest == 0) return BDF_OK;
+    const int64_t gx = (a.rest + 15) / 16, gy = (a.dims[0] + 15) / 16;
+    BDF_REQUIRE(gx < (int64_t)0x7fffffff && gy <= 65535 * (int64_t)1024, BDF_ERR_BOUNDS, "bdf_predict_all: %lld x %lld cells are too many for one launch",
+                (long long)a.dims[0], (long long)a.rest);
+    BDF_HIP(hipSetDevice(ctx->device));
+    // (grid.y is limited to 65,535 blocks: the first mode in slabs of that many tiles)
+    for (int64_t y0 = 0; y0 < gy; y0 += 65535) {
+        PredAllArgs b = a;
+        const int64_t ny = std::min<int64_t>(65535, gy - y0);
+        b.fac[0] = a.fac[0] + y0 * 16 * D;
+        b.dims[0] = std::min<int64_t>(a.dims[0] - y0 * 16, ny * 16);
+        b.out = a.out + y0 * 16 * a.rest;
+        hipLaunchKernelGGL(k_predict_all, dim3((unsigned)gx, (unsigned)ny), dim3(256), 0, ctx->stream, b);
+    }
+    BDF_HIP(hipGetLastError());
+    return BDF_OK;
+}
+
 extern "C" int bdf_pairs_create(bdf_ctx *ctx, int n_modes, int64_t n, const void *ids, int id_bytes,
                                 const double *values, bdf_pairs **out)
 {

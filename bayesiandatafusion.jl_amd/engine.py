@@ -1042,17 +1042,19 @@ class GibbsEngine:
         return [self.ent[self._entity_index(e)].sample for e in r.entities]
 
     def pred_all(self, r):
-        """pred_all(r) (sampling.jl:91-97): udot over every cell + mean_value, as one library GEMM / einsum on the device"""
+        """pred_all(r) (sampling.jl:91-97): udot over every cell + mean_value (bdf_predict_all: k_predict.hip)"""
         S = []
         for e in r.entities:
             st = self.ent[self._entity_index(e)]
             S.append(st.sample if st.layout.pos is None else st.sample[torch.as_tensor(st.layout.pos.astype(np.int64), device=st.sample.device)])
+        dims = [int(x.shape[0]) for x in S]
         with torch.cuda.stream(self.ctx.stream):
-            if len(S) == 2:
-                return torch.mm(S[0], S[1].T) + r.model.mean_value
-            letters = "abcdefg"[:len(S)]
-            expr = ",".join(f"{c}z" for c in letters) + "->" + letters
-            return torch.einsum(expr, *S) + r.model.mean_value
+            S = [x.contiguous() for x in S]
+            out = torch.empty(dims, dtype=torch.float64, device=S[0].device)
+        fp = (C.c_void_p * len(S))(*[x.data_ptr() for x in S])
+        check(lib().bdf_predict_all(self.ctx.handle, len(S), (C.c_int64 * len(S))(*dims), self.D, fp, float(r.model.mean_value),
+                                    C.c_void_p(out.data_ptr())))
+        return out
 
     def _pairs(self, ctx, r, ids, values):
         """test_vec / the training table as device pairs, ids at the entities' internal positions"""

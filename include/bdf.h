@@ -310,6 +310,11 @@ int bdf_pairs_destroy(bdf_pairs *p);
 /* pred(r, test_vec) = udot + mean_value -> out (dev n) */
 int bdf_predict(bdf_ctx *ctx, const bdf_pairs *p, int D, const double *const *factors,
                 double mean_value, double *out);
+/* pred_all(r) (src/sampling.jl:91-97; macau.jl:145-147 accumulates it into predictions_full): udot over EVERY cell of the relation
+ * + mean_value.  dims: n_modes (2 .. 4) sizes; factors[k]: dims[k] x D row-major (dev); out (dev): prod(dims) doubles, the cell
+ * (i_1, ..., i_n) at ((i_1 dims[1] + i_2) dims[2] + ...) + i_n -- the last mode fastest. */
+int bdf_predict_all(bdf_ctx *ctx, int n_modes, const int64_t *dims, int D, const double *const *factors,
+                    double mean_value, double *out);
 /* one macau.jl:142-203 reporting step: p = pred; phase 0 (burn-in): avg = p; phase 1 (first
  * posterior sample): avg = p, sq = p^2, count = 1; phase 2: running mean / sum of squares.
  * stats_out (dev 4 doubles): sum (y-clamp(avg))^2, sum (y-clamp(p))^2, #correct(avg), #correct(p).

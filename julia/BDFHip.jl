@@ -431,6 +431,12 @@ function predict!(c::Context, p::DevPairs, D, factors::Vector{<:DevArray}, mean_
     fp = Ptr{Cvoid}[f.p for f in factors]
     check(ccall((:bdf_predict, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}, Cint, Ptr{Ptr{Cvoid}}, Float64, Ptr{Cvoid}), c.h, p.h, D, fp, mean_value, out.p))
 end
+"pred_all(r) (sampling.jl:91-97): every cell of the relation, the last mode fastest -> out (device, prod(dims) doubles)"
+function predict_all!(c::Context, dims::Vector{Int64}, D, factors::Vector{<:DevArray}, mean_value, out::DevArray{Float64})
+    fp = Ptr{Cvoid}[f.p for f in factors]
+    check(ccall((:bdf_predict_all, lib), Cint, (Ptr{Cvoid}, Cint, Ptr{Int64}, Cint, Ptr{Ptr{Cvoid}}, Float64, Ptr{Cvoid}),
+                c.h, length(dims), dims, D, fp, mean_value, out.p))
+end
 "per-pair baseline replacing mean_value: mean_value + F_test beta of pred(r, probe_vec, F) (sampling.jl:9-14); `nothing` clears it"
 set_baseline!(p::DevPairs, baseline) =
     check(ccall((:bdf_pairs_set_baseline, lib), Cint, (Ptr{Cvoid}, Ptr{Cvoid}), p.h, baseline === nothing ? C_NULL : baseline.p))

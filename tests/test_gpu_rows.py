@@ -485,6 +485,27 @@ def test_predict_every_kernel_variant_ragged_counts(B, O, ctx, n_modes, D):
             pairs.close()
 
 
+@pytest.mark.parametrize("dims,D", [([37, 21], 32), ([6040 // 40, 99], 10), ([19, 5, 7], 12), ([9, 4, 3, 5], 64), ([1, 1], 1), ([33, 0], 8)])
+def test_predict_all_cells(B, ctx, dims, D):
+    """bdf_predict_all = pred_all(r) (sampling.jl:91-97): udot over every cell + mean_value, the last mode fastest; sizes that are
+    no multiple of the 16 x 16 tile, two to four modes, an empty mode"""
+    from bdf_amd._lib import check, lib
+    rng = np.random.default_rng(sum(dims) + D)
+    facs = [rng.standard_normal((d, D)) * 0.7 for d in dims]
+    ft = [ctx.tensor(f) if f.size else ctx.zeros(1, D) for f in facs]
+    out = ctx.zeros(*[max(d, 1) for d in dims])
+    out.fill_(-7.0)
+    fp = (C.c_void_p * len(dims))(*[t.data_ptr() for t in ft])
+    check(lib().bdf_predict_all(ctx.handle, len(dims), (C.c_int64 * len(dims))(*dims), D, fp, 0.35, _p(out)))
+    ctx.sync()
+    if 0 in dims:
+        assert float(out.min()) == -7.0                     # nothing written
+        return
+    letters = "abcd"[:len(dims)]
+    exp = np.einsum(",".join(f"{c}z" for c in letters) + "->" + letters, *facs) + 0.35
+    np.testing.assert_allclose(out.cpu().numpy(), exp, rtol=1e-12, atol=1e-12)
+
+
 def test_hyper_sums_large_entity(B, ctx):
     """more than 2048 x 128 rows: every workgroup of the sums kernel takes several 128-row chunks"""
     from bdf_amd._lib import check, lib
