@@ -72,14 +72,16 @@ __device__ __forceinline__ void col_gather4(double (&b)[4][2], __amdgpu_buffer_r
         uint32_t id;
         if (q == 0) id = row_bcast_u32<K0>(idw); else if (q == 1) id = row_bcast_u32<K0 + 1>(idw);
         else if (q == 2) id = row_bcast_u32<K0 + 2>(idw); else id = row_bcast_u32<K0 + 3>(idw);
+        // (idw holds the observations' ROW OFFSETS, id x row bytes, made once per chunk of sixteen: the broadcast and the addition of the
+        // lane's element offset are then ONE v_add_u32_dpp per observation where broadcast, multiply and add were three instructions)
         if constexpr (FULL) {
             // eo: byte offset of element D-17-j; element D-1-j sits 128 bytes further
-            const uint32_t base = __umul24(id, 256u) + eo;
+            const uint32_t base = id + eo;
             b[q][1] = col_ld(rs, base);
             b[q][0] = col_ld(rs, base + 128u);
         } else {
             // eo: byte offset of element D-1-j; the padded columns (D-17-j < 0) read beyond the matrix: zero
-            const uint32_t base = __umul24(id, rowb) + eo;
+            const uint32_t base = id + eo;
             b[q][0] = col_ld(rs, base);
             b[q][1] = col_ld(rs, ok1 ? base - 128u : 0xffffffffu);
         }
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(64, BDF_COL_WAVES) void k_rows_col(SampleArgs a_in,
                     if (coded) { const uint32_t pw_ = packed[o_]; IDW = pw_; R = table[pw_ >> 24] - mean; } \
                     else { IDW = (uint32_t)colidx[o_]; R = vals[o_] - mean; }                     \
                 }                                                                                 \
+                IDW = __umul24(IDW, rowb);      /* the row's byte offset (the low 24 bits of a packed word are the id) */ \
             }
             uint32_t idw_c, idw_n;
             double r_c, r_n;
