@@ -350,6 +350,8 @@ def recorded_pipe(launch_us):
         k = next(v for kk, v in d["kernels"].items() if "k_rows_col" in kk)
         valu = 4.0 * k["SQ_ACTIVE_INST_VALU"]["mean"]
         mfma = k.get("SQ_VALU_MFMA_BUSY_CYCLES", {"mean": 0.0})["mean"]
+        if not launch_us or launch_us <= 0:           # (--k1-min-launches 0: no launch was timed)
+            return None
         cyc = launch_us * 1e-6 * 2.4e9 * 1024
         return {"valu_busy_cycles_per_launch": round(valu), "mfma_busy_cycles_per_launch": round(mfma),
                 "valu_instructions_per_launch": round(k["SQ_INSTS_VALU"]["mean"]) if "SQ_INSTS_VALU" in k else None,
